@@ -1,0 +1,179 @@
+"""Headline benchmark: timesteps decoded / second, 1440 states, batch 512 (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE decode (forward recurrence + final argmax + backtrace) of a synthetic batch
+of 512 sequences x 500 frames x 1440 states (BASELINE configs[2]) that is already resident
+in HBM.  With N GPUs every rank decodes its own such batch (weak scaling, batch items are
+independent) and the decoded indices are all-gathered over RCCL inside the timed region.
+Rank 0 prints one JSON line; see DESIGN.md "Measurement" for every field.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import torbi_amd
+from torbi_amd import distributed, synth, viterbi
+
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz lane-instructions/s
+
+
+def algorithmic_bytes_per_timestep(S):
+    """4S observation read + 4S int32 backpointer write + 8 (backtrace)."""
+    return 8 * S + 8
+
+
+def cpu_baseline(obs_dev, trans_dev, init_dev, gpu_indices, budget_s=15.0):
+    """Time the CPU path on this host's cores on a bounded sample of the SAME workload and
+    check the GPU's indices against it.  Uses the reference's own operator (oracle/_ref)
+    when that build is present, else the reference-shaped C port (oracle mode 0)."""
+    import oracle
+    cores = os.cpu_count() or 1
+    T = obs_dev.shape[1]
+    trans = trans_dev.cpu().numpy()
+    init = init_dev.cpu().numpy()
+    try:
+        use_ref = oracle.ref_available()
+        if use_ref:
+            oracle.ref_decode(np.zeros((1, 2, 2), np.float32), [2], np.zeros((2, 2), np.float32),
+                              np.zeros(2, np.float32))
+    except Exception:
+        use_ref = False
+
+    def run(items):
+        obs = obs_dev[:items].cpu().numpy()
+        frames = np.full((items,), T, np.int32)
+        t0 = time.perf_counter()
+        if use_ref:
+            idx = oracle.ref_decode(obs, frames, trans, init, num_threads=cores).numpy()
+        else:
+            idx = oracle.decode(obs, frames, trans, init, num_threads=cores, mode=0)
+        return time.perf_counter() - t0, idx
+
+    dt, idx = run(1)
+    items = int(max(1, min(obs_dev.shape[0], budget_s / max(dt, 1e-3))))
+    if items > 1:
+        dt, idx = run(items)
+    match = bool(np.array_equal(idx, gpu_indices[:items].cpu().numpy()))
+    return {
+        'value': items * T / dt, 'unit': 'timesteps/s', 'cores': cores,
+        'kind': 'reference' if use_ref else 'port',
+        'sample': f'first {items} of 512 items x {T} frames x {obs_dev.shape[2]} states, '
+                  f'{cores} threads, {dt:.1f} s',
+        'gpu_matches_cpu': match,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=512)
+    ap.add_argument('--frames', type=int, default=500)
+    ap.add_argument('--states', type=int, default=1440)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank, size, local = distributed.init_from_env()
+    assert size == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={size}'
+    dev = torch.device('cuda', torch.cuda.current_device())
+    B, T, S = args.batch, args.frames, args.states
+
+    # synthetic inputs generated in HBM (rank-specific observation stream; shared transition)
+    obs = viterbi.fill_synthetic((B, T, S), synth.STREAM_OBSERVATION, seed=rank, device=dev)
+    trans = viterbi.fill_synthetic((S, S), synth.STREAM_TRANSITION, seed=0, device=dev)
+    init = viterbi.fill_synthetic((S,), synth.STREAM_INITIAL, seed=0, device=dev)
+    frames = torch.full((B,), T, dtype=torch.int32, device=dev)
+    ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+
+    def step():
+        idx = torbi_amd.decode(obs, frames, trans, init, workspace=ws)
+        if size > 1:
+            idx = distributed.gather_indices(idx, B * size)
+        return idx
+
+    def fence():
+        if size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        indices = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if size > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    timesteps = float(B) * T * args.steps * size
+    value = timesteps / elapsed
+
+    # dominant kernel: the forward-recurrence step kernel; average launch duration measured with
+    # hipEvents on the launch stream around the whole chain of launches (one launch = one
+    # timestep of the whole batch), averaged over a few profiled decodes
+    prof, fwd_ms, bt_ms, launches = [], 0.0, 0.0, 1
+    for _ in range(3):
+        torbi_amd.decode(obs, frames, trans, init, workspace=ws, _profile=prof)
+        fwd_ms += prof[0] / 3
+        bt_ms += prof[1] / 3
+        launches = max(int(prof[2]), 1)
+    per_launch_s = fwd_ms * 1e-3 / launches
+    bytes_per_launch = B * algorithmic_bytes_per_timestep(S)
+    achieved = bytes_per_launch / per_launch_s / 1e9
+    cells_per_launch = float(B) * S * S
+    result = {
+        'metric': 'timesteps decoded/sec, 1440 states batch=512',
+        'value': value, 'unit': 'timesteps/s', 'n_gpus': size, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': f'{S} states, {T} frames, batch={B} per GPU, fp32, dense '
+                               f'transition (BASELINE configs[2]); decode = forward + argmax + '
+                               f'backtrace, inputs resident in HBM',
+                   'parallelism': f'batch-sharded x{size}' if size > 1 else 'single GPU'},
+        'roofline': {
+            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+            'kernel': 'forward step (one timestep of the whole batch per launch)',
+            'launch_us': per_launch_s * 1e6, 'launches_per_decode': launches,
+            'algorithmic_bytes_per_launch': bytes_per_launch,
+            'note': 'dense (max,+) recurrence is VALU-bound (S/4 = 360 op/B); see valu',
+        },
+        'valu': {
+            'cells_per_s': cells_per_launch / per_launch_s,
+            'lane_instr_peak_per_s': VALU_LANE_OPS,
+            'frac_at_1_instr_per_cell': cells_per_launch / per_launch_s / VALU_LANE_OPS,
+        },
+        'phases_ms': {'forward': fwd_ms, 'argmax_backtrace': bt_ms},
+        'hbm_roofline_frac_whole_decode':
+            value / size * algorithmic_bytes_per_timestep(S) / (HBM_PEAK_GBS * 1e9),
+    }
+    if rank == 0 and size == 1 and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline(obs, trans, init, indices)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

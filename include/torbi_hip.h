@@ -1,0 +1,120 @@
+/*
+ * torbi_hip.h -- C ABI of libtorbi_hip.so, the MI355X (gfx950) batched Viterbi decoder.
+ *
+ * This is the drop-in boundary for ONE path of maxrmorrison/torbi: the operator
+ *
+ *     torbi::viterbi_decode(Tensor observation, Tensor batch_frames,
+ *                           Tensor transition, Tensor initial) -> Tensor
+ *
+ * declared at reference torbi/csrc/ops.cpp:16-18, implemented for CUDA at
+ * torbi/csrc/cuda/viterbi.cu:309-362 (viterbi_decode_cuda) and called from
+ * torbi/viterbi.py:53.  The entry points below are what a binding for that operator
+ * binds; INTEGRATION.md shows the ctypes stub and the torch.library registration.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / ATen types
+ *   - all pointers are DEVICE pointers on HIP device `device` unless stated otherwise
+ *   - tensors are contiguous row-major (the reference calls .contiguous() itself,
+ *     viterbi.cu:325-328)
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     device's default stream), performs no allocation, keeps no pointer after return, and
+ *     is re-entrant across devices/streams
+ *   - return value: 0 = success, < 0 = argument error (TORBI_HIP_E*), > 0 = a hipError_t
+ *     reported by the runtime (launch failure etc.)
+ *
+ * Result contract (what "same results as the reference" means; reference CPU path,
+ * torbi/csrc/viterbi.cpp, line numbers in DESIGN.md):
+ *   - transition is indexed [next, prev]; candidate(j,i) = fl(post[i] + transition[j*S+i])
+ *   - post'[j] = fl(observation[t,j] + max_i candidate(j,i)); t = 0: fl(obs[0,i]+initial[i])
+ *   - backpointer = LOWEST index attaining the maximum; final state = lowest index attaining
+ *     the maximum of the last posterior row; every output position t >= batch_frames[b]-1
+ *     holds that final state
+ *   - decoded indices are bit-identical to the reference CPU operator for inputs without
+ *     NaN (-inf is allowed).  batch_frames[b] outside [1, T] is clamped on the device
+ *     (the reference reads out of bounds for 0, viterbi.cpp:153).
+ */
+#ifndef TORBI_HIP_H
+#define TORBI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TORBI_HIP_ABI_VERSION 1
+
+#define TORBI_HIP_OK 0
+#define TORBI_HIP_EINVAL (-1)      /* null pointer / non-positive dimension            */
+#define TORBI_HIP_EWORKSPACE (-2)  /* workspace smaller than torbi_hip_workspace_bytes */
+#define TORBI_HIP_ERANGE (-3)      /* dimension too large for this build               */
+#define TORBI_HIP_ENODEVICE (-4)   /* no usable HIP device / wrong architecture        */
+
+/* Build/ABI version of the loaded library (== TORBI_HIP_ABI_VERSION). */
+int torbi_hip_abi_version(void);
+
+/* Human-readable text for a return code of this library (static storage). */
+const char *torbi_hip_error_string(int code);
+
+/* Number of visible HIP devices (0 if none or the runtime failed to initialise). */
+int torbi_hip_device_count(void);
+
+/*
+ * Bytes of device scratch `torbi_hip_viterbi_decode` needs for a (B,T,S) problem.
+ * Replaces the reference's internal at::zeros trellis (B,T,S) int32 + posterior (B,S)
+ * fp32 allocations (viterbi.cu:331-336): the CALLER owns the scratch (e.g. a torch uint8
+ * tensor from the caching allocator).  Contents need no initialisation.
+ */
+size_t torbi_hip_workspace_bytes(int B, int T, int S);
+
+/*
+ * The operator.  Replaces viterbi_decode_cuda (viterbi.cu:309-362) = forward trellis
+ * kernel (:48-130) + argmax/repeat fill (:347-350) + backtrace kernel (:150-176).
+ *
+ *   observation   (B,T,S) fp32, log space          batch_frames (B) int32
+ *   transition    (S,S)   fp32, [next, prev]       initial      (S) fp32
+ *   indices_out   (B,T)   int32  -- fully overwritten
+ *   workspace     >= torbi_hip_workspace_bytes(B,T,S) bytes, 256-byte aligned
+ */
+int torbi_hip_viterbi_decode(const float *observation, const int32_t *batch_frames,
+                             const float *transition, const float *initial,
+                             int32_t *indices_out, void *workspace, size_t workspace_bytes,
+                             int B, int T, int S, int device, void *stream);
+
+/*
+ * Same operator, instrumented for bench.py: brackets the forward recurrence and the
+ * final-argmax + backtrace with hipEvents on `stream`, SYNCHRONISES the stream, and
+ * returns the phases in milliseconds:
+ *   phase_ms[0] = forward recurrence (all timesteps)   phase_ms[1] = argmax + backtrace
+ *   phase_ms[2] = number of forward kernel launches     phase_ms[3] = reserved (0)
+ * `phase_ms` is a HOST pointer to 4 floats.
+ */
+int torbi_hip_viterbi_decode_profiled(const float *observation, const int32_t *batch_frames,
+                                      const float *transition, const float *initial,
+                                      int32_t *indices_out, void *workspace,
+                                      size_t workspace_bytes, int B, int T, int S, int device,
+                                      void *stream, float *phase_ms);
+
+/*
+ * Test/diagnostic access to the final posterior rows the forward pass produced by the last
+ * decode that used `workspace` (reference: the `posterior` tensor, viterbi.cu:334-336).
+ * Copies (B,S) fp32 into `posterior_out` (device pointer) on `stream`.
+ */
+int torbi_hip_read_posterior(const void *workspace, size_t workspace_bytes,
+                             const int32_t *batch_frames, float *posterior_out,
+                             int B, int T, int S, int device, void *stream);
+
+/*
+ * Measurement helper (not part of the reference interface): fills dst[0..count) with the
+ * deterministic synthetic scores of torbi_amd/synth.py -- value(k) = 0 - u24(hash(stream_id,
+ * seed, start + k)) * 2^-20 -- so bench.py can build the 1.5 GB headline input in HBM
+ * without a host round trip.  Bit-identical to the numpy definition (tested).
+ */
+int torbi_hip_fill_synthetic(float *dst, uint64_t count, uint64_t start, int stream_id,
+                             int seed, int device, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TORBI_HIP_H */

@@ -1,0 +1,151 @@
+"""Host-side logic and the C-ABI surface, without a GPU (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import torbi_amd
+from torbi_amd import _lib, synth, distributed
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'torbi_hip.h')).read()
+    declared = set(re.findall(r'\b(torbi_hip_\w+)\s*\(', header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.torbi_hip_abi_version() == _lib.ABI_VERSION
+
+
+def test_workspace_bytes_and_error_strings():
+    lib = _lib.load()
+    need = lib.torbi_hip_workspace_bytes(512, 500, 1440)
+    assert need >= 512 * 500 * 1440 * 4 + 2 * 512 * 1440 * 4
+    assert need % 256 == 0
+    assert lib.torbi_hip_workspace_bytes(0, 0, 0) > 0
+    assert b'success' in lib.torbi_hip_error_string(0)
+    assert b'workspace' in lib.torbi_hip_error_string(-2)
+
+
+def test_argument_errors_without_touching_a_device():
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    assert lib.torbi_hip_viterbi_decode(null, null, null, null, null, null, 0, 1, 1, 1, 0, null) == -1
+    assert lib.torbi_hip_viterbi_decode(null, null, null, null, null, null, 0, 1, 0, 1, 0, null) == -1
+    buf = (ctypes.c_char * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.torbi_hip_viterbi_decode(p, p, p, p, p, p, 64, 4, 4, 4, 0, null) == -2
+    assert lib.torbi_hip_viterbi_decode(null, null, null, null, null, null, 0, 0, 1, 1, 0, null) == 0
+
+
+def test_decode_validates_like_the_reference_operator():
+    obs = torch.zeros(1, 3, 3)
+    trans = torch.zeros(3, 3)
+    init = torch.zeros(3)
+    with pytest.raises(RuntimeError, match='batch_frames'):   # int64 lengths are rejected upstream too
+        torbi_amd.decode(obs, torch.tensor([3]), trans, init)
+    with pytest.raises(RuntimeError, match='observation'):
+        torbi_amd.decode(obs.double(), torch.tensor([3], dtype=torch.int32), trans, init)
+    with pytest.raises(RuntimeError, match='shape'):
+        torbi_amd.decode(obs[0], torch.tensor([3], dtype=torch.int32), trans, init)
+    with pytest.raises(RuntimeError, match='transition'):
+        torbi_amd.decode(obs, torch.tensor([3], dtype=torch.int32), torch.zeros(3, 4), init)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_no_gpu_fails_loudly_instead_of_falling_back():
+    obs = torch.full((1, 3, 3), 1 / 3)
+    with pytest.raises(RuntimeError, match='no CPU'):
+        torbi_amd.from_probabilities(obs)
+    with pytest.raises(RuntimeError, match='HIP device'):
+        torbi_amd.decode(torch.zeros(1, 3, 3), torch.tensor([3], dtype=torch.int32),
+                         torch.zeros(3, 3), torch.zeros(3))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'torbi_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(import|from)\s+oracle\b', text, re.M), f
+                assert 'libviterbi_oracle' not in text, f
+
+
+def test_synth_is_deterministic_and_exact():
+    a = synth.scores(1, (3, 5), seed=0)
+    b = synth.scores(1, (15,), seed=0).reshape(3, 5)
+    assert np.array_equal(a, b) and a.dtype == np.float32
+    assert (a <= 0).all() and (a > -16).all()
+    # values are 24-bit integers times 2**-20
+    assert np.array_equal(a * 2 ** 20, np.round(a * 2 ** 20))
+    # windows of one stream agree
+    assert np.array_equal(synth.scores(2, (10,), start=5), synth.scores(2, (15,))[5:])
+    lens = synth.lengths(1000, 100, 900)
+    assert lens.min() >= 100 and lens.max() <= 900
+
+
+def test_synth_golden_values():
+    """Frozen hash outputs: guards the generator the committed goldens depend on."""
+    assert synth.hash_u24(1, 0, 4).tolist() == [14819496, 9505325, 9918517, 1903380]
+    assert synth.hash_u24(2, 7, 3, seed=5).tolist() == [6252287, 11286206, 8102033]
+    assert synth.scores(3, (3,)).tolist() == [
+        -0.4229402542114258, -15.536043167114258, -9.530208587646484]
+
+
+def test_collate_pads_and_separate_rejoins(tmp_path):
+    """reference torbi/data/collate.py:9-45"""
+    items = [(torch.arange(6, dtype=torch.float32).reshape(3, 2), 'a'),
+             (torch.ones(5, 2), 'b'), (torch.full((1, 2), 7.), 'c')]
+    obs, frames, chunks, files = torbi_amd.data.collate(items)
+    assert obs.shape == (3, 5, 2) and frames.tolist() == [3, 5, 1]
+    assert chunks == [1, 1, 1] and files == ('a', 'b', 'c')
+    assert torch.equal(obs[0, :3], items[0][0]) and (obs[0, 3:] == 0).all() and (obs[2, 1:] == 0).all()
+    with pytest.raises(ValueError):
+        torbi_amd.data.collate([])
+    idx = torch.arange(15).reshape(3, 5)
+    parts = torbi_amd.data.separate(idx, [2, 1], torch.tensor([3, 5, 1]))
+    assert parts[0].tolist() == [0, 1, 2, 5, 6, 7, 8, 9] and parts[1].tolist() == [10]
+
+
+def test_loader_batches_in_order(tmp_path):
+    files = []
+    for k in range(5):
+        f = tmp_path / f'{k}.pt'
+        torch.save(torch.full((k + 1, 3), float(k)), f)
+        files.append(f)
+    batches = list(torbi_amd.data.loader(files, batch_size=2))
+    assert [len(b[3]) for b in batches] == [2, 2, 1]
+    assert batches[1][1].tolist() == [3, 4] and batches[1][0].shape == (2, 4, 3)
+
+
+def test_save_masked(tmp_path):
+    """reference torbi/core.py:471-473"""
+    f = tmp_path / 'o.pt'
+    torbi_amd.save_masked(torch.arange(10, dtype=torch.int32), f, torch.tensor(4))
+    assert torch.load(f).tolist() == [0, 1, 2, 3]
+
+
+def test_shard_bounds_cover_everything():
+    for count in (0, 1, 7, 512, 513):
+        for size in (1, 2, 3, 8):
+            spans = [distributed.shard_bounds(count, size, r) for r in range(size)]
+            assert spans[0][0] == 0 and spans[-1][1] == count
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_assign_batches_is_a_partition():
+    lengths = synth.lengths(2000, 100, 900).tolist()
+    plan = distributed.assign_batches(lengths, 512, 3)
+    flat = sorted(i for rank in plan for batch in rank for i in batch)
+    assert flat == list(range(2000))
+    for rank in plan:
+        for batch in rank:
+            assert batch == list(range(batch[0], batch[0] + len(batch))) and len(batch) <= 512

@@ -1,0 +1,97 @@
+"""ctypes binding of libtorbi_hip.so (C ABI declared in include/torbi_hip.h).
+
+The library is built IN-TREE by `torbi_amd._lib.build()` (hipcc --offload-arch=gfx950) and is
+the only compute path of this package: there is no CPU or eager-PyTorch fallback.  A missing
+library, a missing symbol or an ABI mismatch raises at first use.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+SOURCE = os.path.join(_HERE, 'csrc', 'torbi_hip.hip')
+INCLUDE = os.path.join(ROOT, 'include')
+LIBRARY = os.path.join(_HERE, 'libtorbi_hip.so')
+ABI_VERSION = 1
+
+# every symbol include/torbi_hip.h declares: name -> (restype, argtypes)
+_c = ctypes
+SYMBOLS = {
+    'torbi_hip_abi_version': (_c.c_int, []),
+    'torbi_hip_error_string': (_c.c_char_p, [_c.c_int]),
+    'torbi_hip_device_count': (_c.c_int, []),
+    'torbi_hip_workspace_bytes': (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int]),
+    'torbi_hip_viterbi_decode': (_c.c_int, [
+        _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+        _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+    'torbi_hip_viterbi_decode_profiled': (_c.c_int, [
+        _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+        _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
+        _c.POINTER(_c.c_float)]),
+    'torbi_hip_read_posterior': (_c.c_int, [
+        _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p,
+        _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+    'torbi_hip_fill_synthetic': (_c.c_int, [
+        _c.c_void_p, _c.c_uint64, _c.c_uint64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+}
+
+_LIB = None
+
+
+class TorbiHipError(RuntimeError):
+    """A non-zero return code from libtorbi_hip.so."""
+
+
+def hipcc():
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise FileNotFoundError('hipcc not found (set HIPCC or install ROCm under /opt/rocm)')
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/torbi_hip.hip for gfx950 into torbi_amd/libtorbi_hip.so (in-tree)."""
+    header = os.path.join(INCLUDE, 'torbi_hip.h')
+    if not force and os.path.exists(LIBRARY):
+        newest = max(os.path.getmtime(SOURCE), os.path.getmtime(header))
+        if os.path.getmtime(LIBRARY) >= newest:
+            return LIBRARY
+    cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+           '-ffp-contract=off', f'-I{INCLUDE}', '-o', LIBRARY + '.tmp', SOURCE]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIBRARY + '.tmp', LIBRARY)
+    global _LIB
+    _LIB = None
+    return LIBRARY
+
+
+def load():
+    """Load the library and bind every declared symbol; raises if anything is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIBRARY):
+        raise FileNotFoundError(
+            f'{LIBRARY} is missing: the HIP extension has not been built. Run '
+            '`python -c "import __graft_entry__ as g; g.build()"` (or torbi_amd._lib.build()). '
+            'torbi_amd has no CPU fallback.')
+    lib = ctypes.CDLL(LIBRARY)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the export is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = lib.torbi_hip_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f'libtorbi_hip.so ABI version {got}, expected {ABI_VERSION}: rebuild')
+    _LIB = lib
+    return lib
+
+
+def check(code, what='torbi_hip call'):
+    if code != 0:
+        msg = load().torbi_hip_error_string(code)
+        raise TorbiHipError(f'{what} failed with code {code}: {msg.decode() if msg else "?"}')

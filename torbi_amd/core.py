@@ -1,0 +1,259 @@
+"""Tensor and file API: the host-side mirror of reference torbi/core.py:110-473.
+
+Same function names, argument order, defaults and return conventions as the reference; the
+decode itself runs on an MI355X through `torbi_amd.decode` (C ABI, include/torbi_hip.h).
+Differences that follow from "GPU only" are stated in each docstring and in INTEGRATION.md.
+"""
+import math
+import os
+from typing import Dict, List, Optional, Union
+
+import torch
+
+from . import data as _data
+from .viterbi import decode
+
+# reference torbi/config/defaults.py:80,83
+BATCH_SIZE = 512
+NUM_WORKERS = 0
+
+
+def _compute_device(gpu, observation):
+    if gpu is None:
+        if observation.is_cuda:
+            return observation.device
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                'torbi_amd has no CPU decoder: from_probabilities(gpu=None) decodes on the '
+                'current HIP device and needs one (the reference would run its CPU operator)')
+        return torch.device('cuda', torch.cuda.current_device())
+    if gpu == 'mps':
+        raise RuntimeError('the MPS backend of the reference is out of scope on MI355X')
+    return torch.device(f'cuda:{gpu}')
+
+
+def from_probabilities(
+    observation: torch.Tensor,
+    batch_frames: Optional[torch.Tensor] = None,
+    transition: Optional[torch.Tensor] = None,
+    initial: Optional[torch.Tensor] = None,
+    log_probs: bool = False,
+    gpu: Optional[int] = None,
+    num_threads: Optional[int] = 1
+) -> torch.Tensor:
+    """Decode a time-varying categorical distribution
+
+    Mirrors reference torbi/core.py:110-208 step for step: default `batch_frames` (all
+    frames, int32), default uniform `initial` = log(1/S + tiny) and `transition` = log(1/S),
+    `log()` of the inputs unless `log_probs`, fp32 cast + device move, the in-place epsilon
+    round trip `log(exp(x) + tiny)`, then `decode`.
+
+    Arguments
+        observation
+            Time-varying categorical distribution
+            shape=(batch, frames, states)
+        batch_frames
+            Number of frames in each batch item; defaults to all
+            shape=(batch,)
+        transition
+            Categorical transition matrix; defaults to uniform
+            shape=(states, states)
+        initial
+            Categorical initial distribution; defaults to uniform
+            shape=(states,)
+        log_probs
+            Whether inputs are in (natural) log space
+        gpu
+            GPU index to use for decoding. The reference decodes on the CPU when this is
+            None; here None means "the HIP device the observation lives on, else the
+            current one", and the result is returned on the CPU in that case, as the
+            reference does.
+        num_threads
+            Ignored (CPU thread count in the reference)
+
+    Returns
+        indices
+            The decoded bin indices
+            shape=(batch, frames)
+    """
+    batch, frames, states = observation.shape
+    device = _compute_device(gpu, observation)
+    to_host = gpu is None and not observation.is_cuda
+    tiny = torch.finfo(torch.float32).tiny
+
+    if batch_frames is None:
+        batch_frames = torch.full((batch,), frames, dtype=torch.int32, device=device)
+    batch_frames = batch_frames.to(dtype=torch.int32, device=device)
+
+    # Default to uniform initial probabilities (core.py:161-166)
+    if initial is None:
+        initial = torch.full(
+            (states,), math.log((1. / states) + tiny), dtype=torch.float32, device=device)
+    else:
+        if not log_probs:
+            initial = torch.log(initial)
+        initial = initial.to(device)
+
+    # Default to uniform transition probabilities (core.py:175-180)
+    if transition is None:
+        transition = torch.full(
+            (states, states), math.log(1. / states), dtype=torch.float32, device=device)
+    else:
+        if not log_probs:
+            transition = torch.log(transition)
+        transition = transition.to(device)
+
+    # Ensure observation probabilities are in log space (core.py:189-191)
+    if not log_probs:
+        observation = torch.log(observation)
+    observation = observation.to(device=device, dtype=torch.float32)
+
+    # Add epsilon for stability (core.py:193-197; in place, like the reference)
+    torch.exp_(observation)
+    observation += tiny
+    torch.log_(observation)
+
+    indices = decode(observation, batch_frames, transition, initial, num_threads=num_threads)
+    return indices.cpu() if to_host else indices
+
+
+def from_file(
+    input_file: Union[str, os.PathLike],
+    transition_file: Optional[Union[str, os.PathLike]] = None,
+    initial_file: Optional[Union[str, os.PathLike]] = None,
+    log_probs: bool = False,
+    gpu: Optional[int] = None,
+    num_threads: Optional[int] = 1
+) -> torch.Tensor:
+    """Decode a time-varying categorical distribution file (reference core.py:211-267)
+
+    Arguments
+        input_file
+            Time-varying categorical distribution file
+            shape=(frames, states)
+        transition_file
+            Categorical transition matrix file; defaults to uniform
+            shape=(states, states)
+        initial_file
+            Categorical initial distribution file; defaults to uniform
+            shape=(states,)
+        log_probs
+            Whether inputs are in (natural) log space
+        gpu
+            GPU index to use for decoding (None = current HIP device, result on CPU)
+        num_threads
+            Ignored
+
+    Returns
+        indices
+            The decoded bin indices
+            shape=(1, frames)
+    """
+    observation = torch.load(input_file).unsqueeze(dim=0)
+
+    if transition_file:
+        transition = torch.load(transition_file)
+        if log_probs:
+            transition = torch.log(transition)   # core.py:246-247: files hold probabilities
+    else:
+        transition = None
+
+    initial = torch.load(initial_file) if initial_file else None
+
+    return from_probabilities(
+        observation=observation,
+        transition=transition,
+        initial=initial,
+        log_probs=log_probs,
+        gpu=gpu,
+        num_threads=num_threads)
+
+
+def from_file_to_file(
+    input_file: Union[str, os.PathLike],
+    output_file: Union[str, os.PathLike],
+    transition_file: Optional[Union[str, os.PathLike]] = None,
+    initial_file: Optional[Union[str, os.PathLike]] = None,
+    log_probs: bool = False,
+    gpu: Optional[int] = None,
+    num_threads: Optional[int] = None
+) -> None:
+    """Decode a time-varying categorical distribution file and save (core.py:270-307)"""
+    indices = from_file(
+        input_file, transition_file, initial_file, log_probs, gpu=gpu, num_threads=num_threads)
+    torch.save(indices, output_file)
+
+
+def from_files_to_files(
+    input_files: List[Union[str, os.PathLike]],
+    output_files: List[Union[str, os.PathLike]],
+    transition_file: Optional[Union[str, os.PathLike]] = None,
+    initial_file: Optional[Union[str, os.PathLike]] = None,
+    log_probs: bool = False,
+    gpu: Optional[int] = None,
+    num_threads: Optional[int] = None
+) -> None:
+    """Decode time-varying categorical distribution files and save (core.py:310-368)
+
+    Files are batched `BATCH_SIZE` (512) at a time in the given order, zero-padded to the
+    longest item of the batch (reference torbi/data/collate.py:24-33) and each output holds
+    the first `frames` indices of its item (core.py:449-457).
+    """
+    if transition_file:
+        transition = torch.load(transition_file)
+        if log_probs:
+            transition = torch.log(transition + torch.finfo(transition.dtype).tiny)  # :341-347
+    else:
+        transition = None
+
+    initial = torch.load(initial_file) if initial_file else None
+
+    mapping = {
+        input_file: output_file for input_file, output_file in zip(input_files, output_files)}
+
+    from_dataloader(
+        dataloader=_data.loader(input_files),
+        output_files=mapping,
+        transition=transition,
+        initial=initial,
+        log_probs=log_probs,
+        gpu=gpu,
+        num_threads=num_threads)
+
+
+def from_dataloader(
+    dataloader: torch.utils.data.DataLoader,
+    output_files: Dict[
+        Union[str, bytes, os.PathLike],
+        Union[str, bytes, os.PathLike]],
+    transition: Optional[torch.Tensor] = None,
+    initial: Optional[torch.Tensor] = None,
+    log_probs: bool = False,
+    gpu: Optional[int] = None,
+    num_threads: Optional[int] = 1
+) -> None:
+    """Decode time-varying categorical distributions from dataloader (core.py:376-463)"""
+    for observation, batch_frames, batch_chunks, input_filenames in dataloader:
+        indices = from_probabilities(
+            observation=observation,
+            batch_frames=batch_frames,
+            transition=transition,
+            initial=initial,
+            log_probs=log_probs,
+            gpu=gpu,
+            num_threads=num_threads)
+
+        filenames = [output_files[file] for file in input_filenames]
+
+        for item, filename, frames in zip(indices.cpu().detach(), filenames, batch_frames.cpu()):
+            save_masked(item, filename, frames)
+
+
+def save(tensor, file):
+    """Save tensor (core.py:466-468)"""
+    torch.save(tensor.clone(), file)
+
+
+def save_masked(tensor, file, length):
+    """Save masked tensor (core.py:471-473)"""
+    torch.save(tensor[..., :length].clone(), file)

@@ -1,0 +1,491 @@
+// torbi_hip.hip -- MI355X (gfx950 / CDNA4) batched Viterbi decoder behind a plain C ABI.
+//
+// Written from scratch for wave64 / LDS / 256-CU CDNA4; not derived from the reference's
+// CUDA kernels.  The reference functions each piece replaces are cited by file:line
+// (paths relative to /root/reference/torbi/csrc/).
+//
+//   forward recurrence   viterbi.cpp:65-108 (oracle semantics) / cuda/viterbi.cu:48-130
+//   final argmax + fill  viterbi.cpp:218-221                   / cuda/viterbi.cu:347-350
+//   backtrace            viterbi.cpp:140-160                   / cuda/viterbi.cu:150-176
+//   orchestration        viterbi.cpp:182-234                   / cuda/viterbi.cu:309-362
+//
+// The forward recurrence is a (max,+) matrix product per timestep,
+//     post'[b,j] = obs[b,t,j] + max_i ( post[b,i] + trans[j,i] ),   bp[b,t,j] = first argmax_i
+// i.e. a GEMM-shaped contraction over i with M = batch, N = K = states, in the (max,+)
+// semiring: VALU work (MFMA cannot evaluate it), 2 fp32 roundings per cell in a fixed order.
+// See DESIGN.md for the roofline analysis and kernel inventory.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <math.h>
+
+#include "torbi_hip.h"
+
+namespace {
+
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------
+
+__host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Workspace {
+    float *post[2];     // (B,S) ping-pong posterior rows
+    int32_t *trellis;   // (B,T,S) backpointers; rows t >= 1 of valid frames are written
+    size_t bytes;
+};
+
+inline Workspace carve(void *base, int B, int T, int S) {
+    Workspace w;
+    char *p = static_cast<char *>(base);
+    const size_t post_bytes = align_up(sizeof(float) * (size_t)B * S, 256);
+    w.post[0] = reinterpret_cast<float *>(p);
+    w.post[1] = reinterpret_cast<float *>(p + post_bytes);
+    w.trellis = reinterpret_cast<int32_t *>(p + 2 * post_bytes);
+    w.bytes = 2 * post_bytes + align_up(sizeof(int32_t) * (size_t)B * T * S, 256);
+    return w;
+}
+
+// (value, index) comparator of the reference CPU scan (viterbi.cpp:94-100): a candidate
+// replaces the incumbent only if strictly greater; among equal values the lower index wins.
+__device__ __forceinline__ void take_better(float &v, int &i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+__device__ __forceinline__ void wave_argmax(float &v, int &i) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        const float ov = __shfl_down(v, off, kWave);
+        const int oi = __shfl_down(i, off, kWave);
+        take_better(v, i, ov, oi);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// t = 0 : post[b,i] = obs[b,0,i] + initial[i]                       (viterbi.cpp:72-76)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void init_posterior_kernel(
+    const float *__restrict__ obs, const float *__restrict__ initial, float *__restrict__ post0,
+    int B, int T, int S) {
+    const size_t n = (size_t)B * S;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(e / S);
+        const int i = (int)(e - (size_t)b * S);
+        post0[e] = obs[(size_t)b * T * S + i] + initial[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// One timestep for all batch items as a tiled (max,+) GEMM.        (viterbi.cpp:78-108)
+//   tile = BM batch items x BN next-states, contraction over prev-state i in chunks of BK
+//   256 threads as 16 (ty: batch) x 16 (tx: state); each thread owns 4 x 4 outputs:
+//     b = b0 + 4*ty + bb,   j = j0 + tx + 16*jj
+//   LDS images keep the global orientation ([row][k], k contiguous, +4 pad): fragment reads
+//   are ds_read_b128 along k, conflict-free for the 16 distinct transition rows of a lane
+//   group (row stride 36 dwords -> 16 distinct 4-bank slots) and broadcast for the batch rows.
+//   The running (max, argmax) per output is the reference's own scan: k ascends, strict '>'.
+// ---------------------------------------------------------------------------------------
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void step_tile_kernel(
+    const float *__restrict__ obs, const int32_t *__restrict__ frames,
+    const float *__restrict__ trans, const float *__restrict__ pcur, float *__restrict__ pnext,
+    int32_t *__restrict__ trellis, int B, int T, int S, int t) {
+    static_assert(BM == 64 && BN == 64 && BK % 4 == 0, "thread map assumes 64x64 tiles");
+    constexpr int LD = BK + 4;
+    __shared__ __attribute__((aligned(16))) float Ps[BM * LD];
+    __shared__ __attribute__((aligned(16))) float Ts[BN * LD];
+    __shared__ int any_live;
+
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int b0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+
+    // skip tiles whose batch items have all ended (t >= batch_frames[b])
+    if (tid == 0) any_live = 0;
+    __syncthreads();
+    if (tid < BM && b0 + tid < B && t < frames[b0 + tid]) any_live = 1;
+    __syncthreads();
+    if (!any_live) return;
+
+    float best[4][4];
+    int arg[4][4];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { best[bb][jj] = -INFINITY; arg[bb][jj] = 0; }
+
+    for (int k0 = 0; k0 < S; k0 += BK) {
+        // stage: BM x BK posterior values and BN x BK transition values, k contiguous
+#pragma unroll
+        for (int r = 0; r < BM * BK / 256; ++r) {
+            const int e = tid + 256 * r;
+            const int row = e / BK, col = e % BK;
+            const int k = k0 + col;
+            const int b = b0 + row;
+            float v = -INFINITY;                       // k >= S: can never win a strict '>'
+            if (k < S) v = (b < B) ? pcur[(size_t)b * S + k] : 0.0f;
+            Ps[row * LD + col] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < BN * BK / 256; ++r) {
+            const int e = tid + 256 * r;
+            const int row = e / BK, col = e % BK;
+            const int k = k0 + col;
+            const int j = j0 + row;
+            Ts[row * LD + col] = (k < S && j < S) ? trans[(size_t)j * S + k] : 0.0f;
+        }
+        __syncthreads();
+
+#pragma unroll 2
+        for (int kk = 0; kk < BK; kk += 4) {
+            float4 p[4], q[4];
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+                p[bb] = *reinterpret_cast<const float4 *>(&Ps[(4 * ty + bb) * LD + kk]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                q[jj] = *reinterpret_cast<const float4 *>(&Ts[(tx + 16 * jj) * LD + kk]);
+            const int k = k0 + kk;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    float c;
+                    c = p[bb].x + q[jj].x; if (c > best[bb][jj]) { best[bb][jj] = c; arg[bb][jj] = k; }
+                    c = p[bb].y + q[jj].y; if (c > best[bb][jj]) { best[bb][jj] = c; arg[bb][jj] = k + 1; }
+                    c = p[bb].z + q[jj].z; if (c > best[bb][jj]) { best[bb][jj] = c; arg[bb][jj] = k + 2; }
+                    c = p[bb].w + q[jj].w; if (c > best[bb][jj]) { best[bb][jj] = c; arg[bb][jj] = k + 3; }
+                }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+        const int b = b0 + 4 * ty + bb;
+        if (b >= B || t >= frames[b]) continue;
+        const size_t row = ((size_t)b * T + t) * S;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = j0 + tx + 16 * jj;
+            if (j >= S) continue;
+            trellis[row + j] = arg[bb][jj];
+            pnext[(size_t)b * S + j] = obs[row + j] + best[bb][jj];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// One timestep, small-batch form: grid = (state tiles, batch items); each wave owns 4
+// next-states, its 64 lanes stride the prev-state axis (coalesced transition-row reads,
+// posterior row staged once in LDS), then a wave (value,index) reduction that keeps the
+// lowest index among equal maxima.
+// ---------------------------------------------------------------------------------------
+constexpr int kRowsPerWave = 4;
+constexpr int kRowsPerBlock = 16;
+
+__global__ __launch_bounds__(256) void step_rows_kernel(
+    const float *__restrict__ obs, const int32_t *__restrict__ frames,
+    const float *__restrict__ trans, const float *__restrict__ pcur, float *__restrict__ pnext,
+    int32_t *__restrict__ trellis, int B, int T, int S, int t) {
+    extern __shared__ __attribute__((aligned(16))) float pl[];
+    const int b = blockIdx.y;
+    if (t >= frames[b]) return;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < S; i += 256) pl[i] = pcur[(size_t)b * S + i];
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int jb = blockIdx.x * kRowsPerBlock + wave * kRowsPerWave;
+    if (jb >= S) return;
+    const float *rows[kRowsPerWave];
+    float best[kRowsPerWave];
+    int arg[kRowsPerWave];
+#pragma unroll
+    for (int r = 0; r < kRowsPerWave; ++r) {
+        const int j = min(jb + r, S - 1);
+        rows[r] = trans + (size_t)j * S;
+        best[r] = -INFINITY;
+        arg[r] = 0x7fffffff;   // lanes that saw no candidate must lose index ties
+    }
+    for (int i = lane; i < S; i += kWave) {
+        const float p = pl[i];
+#pragma unroll
+        for (int r = 0; r < kRowsPerWave; ++r) {
+            const float c = p + rows[r][i];
+            if (c > best[r]) { best[r] = c; arg[r] = i; }
+            else if (arg[r] == 0x7fffffff) { arg[r] = i; best[r] = c; }  // first candidate, incl. -inf
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kRowsPerWave; ++r) wave_argmax(best[r], arg[r]);
+    if (lane == 0) {
+        const size_t row = ((size_t)b * T + t) * S;
+#pragma unroll
+        for (int r = 0; r < kRowsPerWave; ++r) {
+            const int j = jb + r;
+            if (j < S) {
+                trellis[row + j] = arg[r];
+                pnext[(size_t)b * S + j] = obs[row + j] + best[r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Final state + tail fill + backtrace, one wave per batch item.
+//   final = first argmax of the item's last posterior row           (viterbi.cpp:218)
+//   out[b, t] = final for t >= frames-1                               (viterbi.cpp:219-221)
+//   for t = frames-1 .. 1: idx = bp[b,t,idx]; out[b,t-1] = idx        (viterbi.cpp:153-157)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void finalize_kernel(
+    const float *__restrict__ post0, const float *__restrict__ post1,
+    const int32_t *__restrict__ frames, const int32_t *__restrict__ trellis,
+    int32_t *__restrict__ out, int B, int T, int S) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    int f = frames[b];
+    f = f < 1 ? 1 : (f > T ? T : f);
+    const float *post = (((f - 1) & 1) ? post1 : post0) + (size_t)b * S;
+
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int i = lane; i < S; i += kWave) {
+        const float v = post[i];
+        if (v > best) { best = v; arg = i; }
+        else if (arg == 0x7fffffff) { arg = i; best = v; }
+    }
+    wave_argmax(best, arg);
+    const int fin = __shfl(arg, 0, kWave);
+
+    int32_t *o = out + (size_t)b * T;
+    for (int tt = f - 1 + lane; tt < T; tt += kWave) o[tt] = fin;
+    if (lane == 0) {
+        const int32_t *tr = trellis + (size_t)b * T * S;
+        int idx = fin;
+        for (int tt = f - 1; tt >= 1; --tt) {
+            idx = tr[(size_t)tt * S + idx];
+            o[tt - 1] = idx;
+        }
+    }
+}
+
+// posterior read-back for tests (each item's last row lives in buffer (frames-1)&1)
+__global__ __launch_bounds__(256) void gather_posterior_kernel(
+    const float *__restrict__ post0, const float *__restrict__ post1,
+    const int32_t *__restrict__ frames, float *__restrict__ dst, int B, int T, int S) {
+    const size_t n = (size_t)B * S;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(e / S);
+        int f = frames[b];
+        f = f < 1 ? 1 : (f > T ? T : f);
+        dst[e] = (((f - 1) & 1) ? post1 : post0)[e];
+    }
+}
+
+// deterministic synthetic scores, same function as torbi_amd/synth.py::scores
+__global__ __launch_bounds__(256) void fill_synthetic_kernel(float *__restrict__ dst,
+                                                             uint64_t count, uint64_t start,
+                                                             uint64_t stream_key) {
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count;
+         e += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t z = (start + e) + stream_key;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        const uint32_t u = (uint32_t)(z >> 40);
+        dst[e] = 0.0f - (float)u * 0x1p-20f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) err = hipSetDevice(device);
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+int check_args(const void *a, const void *b, const void *c, const void *d, const void *e,
+               const void *ws, size_t ws_bytes, int B, int T, int S) {
+    if (B < 0 || T < 1 || S < 1) return TORBI_HIP_EINVAL;
+    if (B == 0) return TORBI_HIP_OK;
+    if (!a || !b || !c || !d || !e || !ws) return TORBI_HIP_EINVAL;
+    if ((size_t)B * T * S > (size_t)1 << 40) return TORBI_HIP_ERANGE;
+    if (ws_bytes < torbi_hip_workspace_bytes(B, T, S)) return TORBI_HIP_EWORKSPACE;
+    return TORBI_HIP_OK;
+}
+
+// launches the forward recurrence; returns the number of step launches through *launches
+hipError_t launch_forward(const float *obs, const int32_t *frames, const float *trans,
+                          const float *init, const Workspace &w, int B, int T, int S,
+                          hipStream_t stream, int *launches) {
+    {
+        const size_t n = (size_t)B * S;
+        const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+        hipLaunchKernelGGL(init_posterior_kernel, dim3(grid), dim3(256), 0, stream, obs, init,
+                           w.post[0], B, T, S);
+    }
+    const bool tiled = B >= 24;
+    int n = 0;
+    for (int t = 1; t < T; ++t) {
+        const float *pc = w.post[(t - 1) & 1];
+        float *pn = w.post[t & 1];
+        if (tiled) {
+            dim3 grid((S + 63) / 64, (B + 63) / 64);
+            hipLaunchKernelGGL((step_tile_kernel<64, 64, 32>), grid, dim3(256), 0, stream, obs,
+                               frames, trans, pc, pn, w.trellis, B, T, S, t);
+        } else {
+            dim3 grid((S + kRowsPerBlock - 1) / kRowsPerBlock, B);
+            hipLaunchKernelGGL(step_rows_kernel, grid, dim3(256), sizeof(float) * (size_t)S,
+                               stream, obs, frames, trans, pc, pn, w.trellis, B, T, S, t);
+        }
+        ++n;
+    }
+    if (launches) *launches = n;
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(const int32_t *frames, const Workspace &w, int32_t *out, int B, int T,
+                           int S, hipStream_t stream) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(64), 0, stream, w.post[0], w.post[1],
+                       frames, w.trellis, out, B, T, S);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+int torbi_hip_abi_version(void) { return TORBI_HIP_ABI_VERSION; }
+
+const char *torbi_hip_error_string(int code) {
+    switch (code) {
+        case TORBI_HIP_OK: return "success";
+        case TORBI_HIP_EINVAL: return "invalid argument (null pointer or non-positive dimension)";
+        case TORBI_HIP_EWORKSPACE: return "workspace smaller than torbi_hip_workspace_bytes()";
+        case TORBI_HIP_ERANGE: return "problem dimensions out of range for this build";
+        case TORBI_HIP_ENODEVICE: return "no usable HIP device";
+        default: break;
+    }
+    if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
+    return "unknown torbi_hip error";
+}
+
+int torbi_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+size_t torbi_hip_workspace_bytes(int B, int T, int S) {
+    if (B <= 0 || T <= 0 || S <= 0) return 256;
+    Workspace w = carve(nullptr, B, T, S);
+    return w.bytes;
+}
+
+int torbi_hip_viterbi_decode(const float *observation, const int32_t *batch_frames,
+                             const float *transition, const float *initial,
+                             int32_t *indices_out, void *workspace, size_t workspace_bytes,
+                             int B, int T, int S, int device, void *stream) {
+    const int rc = check_args(observation, batch_frames, transition, initial, indices_out,
+                              workspace, workspace_bytes, B, T, S);
+    if (rc != TORBI_HIP_OK || B == 0) return rc;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return (int)guard.err;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Workspace w = carve(workspace, B, T, S);
+    hipError_t e = launch_forward(observation, batch_frames, transition, initial, w, B, T, S, s,
+                                  nullptr);
+    if (e != hipSuccess) return (int)e;
+    e = launch_finalize(batch_frames, w, indices_out, B, T, S, s);
+    return (int)e;
+}
+
+int torbi_hip_viterbi_decode_profiled(const float *observation, const int32_t *batch_frames,
+                                      const float *transition, const float *initial,
+                                      int32_t *indices_out, void *workspace,
+                                      size_t workspace_bytes, int B, int T, int S, int device,
+                                      void *stream, float *phase_ms) {
+    if (!phase_ms) return TORBI_HIP_EINVAL;
+    phase_ms[0] = phase_ms[1] = phase_ms[2] = phase_ms[3] = 0.0f;
+    const int rc = check_args(observation, batch_frames, transition, initial, indices_out,
+                              workspace, workspace_bytes, B, T, S);
+    if (rc != TORBI_HIP_OK || B == 0) return rc;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return (int)guard.err;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Workspace w = carve(workspace, B, T, S);
+    hipEvent_t ev[3];
+    for (auto &x : ev) {
+        hipError_t e = hipEventCreate(&x);
+        if (e != hipSuccess) return (int)e;
+    }
+    int launches = 0;
+    (void)hipEventRecord(ev[0], s);
+    hipError_t e = launch_forward(observation, batch_frames, transition, initial, w, B, T, S, s,
+                                  &launches);
+    (void)hipEventRecord(ev[1], s);
+    if (e == hipSuccess) e = launch_finalize(batch_frames, w, indices_out, B, T, S, s);
+    (void)hipEventRecord(ev[2], s);
+    hipError_t es = hipEventSynchronize(ev[2]);
+    if (e == hipSuccess) e = es;
+    if (e == hipSuccess) {
+        (void)hipEventElapsedTime(&phase_ms[0], ev[0], ev[1]);
+        (void)hipEventElapsedTime(&phase_ms[1], ev[1], ev[2]);
+        phase_ms[2] = (float)launches;
+    }
+    for (auto &x : ev) (void)hipEventDestroy(x);
+    return (int)e;
+}
+
+int torbi_hip_read_posterior(const void *workspace, size_t workspace_bytes,
+                             const int32_t *batch_frames, float *posterior_out, int B, int T,
+                             int S, int device, void *stream) {
+    if (B < 0 || T < 1 || S < 1) return TORBI_HIP_EINVAL;
+    if (B == 0) return TORBI_HIP_OK;
+    if (!workspace || !batch_frames || !posterior_out) return TORBI_HIP_EINVAL;
+    if (workspace_bytes < torbi_hip_workspace_bytes(B, T, S)) return TORBI_HIP_EWORKSPACE;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return (int)guard.err;
+    const Workspace w = carve(const_cast<void *>(workspace), B, T, S);
+    const size_t n = (size_t)B * S;
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(gather_posterior_kernel, dim3(grid), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w.post[0], w.post[1], batch_frames,
+                       posterior_out, B, T, S);
+    return (int)hipGetLastError();
+}
+
+int torbi_hip_fill_synthetic(float *dst, uint64_t count, uint64_t start, int stream_id, int seed,
+                             int device, void *stream) {
+    if (count == 0) return TORBI_HIP_OK;
+    if (!dst) return TORBI_HIP_EINVAL;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return (int)guard.err;
+    const uint64_t key =
+        ((uint64_t)(uint32_t)stream_id + (uint64_t)(uint32_t)seed * 1000003ull) * 0x9E3779B97F4A7C15ull;
+    const uint64_t blocks = (count + 255) / 256;
+    const int grid = (int)(blocks < 8192 ? blocks : 8192);
+    hipLaunchKernelGGL(fill_synthetic_kernel, dim3(grid), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), dst, count, start, key);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

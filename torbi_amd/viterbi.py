@@ -1,0 +1,141 @@
+"""Operator wrapper: the host-side mirror of reference torbi/viterbi.py:5-53.
+
+`decode` keeps the reference's name, argument order and meaning, and calls the MI355X HIP
+implementation through the C ABI (include/torbi_hip.h) instead of
+`torch.ops.torbi.viterbi_decode` (reference torbi/csrc/ops.cpp:17).
+"""
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            'torbi_amd.decode needs a HIP device (PyTorch-ROCm reports none). This package has '
+            'no CPU compute path; the reference CPU implementation is only restated under '
+            'oracle/ as a test oracle.')
+
+
+def _check_inputs(observation, batch_frames, transition, initial):
+    if observation.dim() != 3:
+        raise RuntimeError(
+            f'observation must have shape (batch, frames, states); got {tuple(observation.shape)}')
+    B, T, S = observation.shape
+    if T < 1 or S < 1:
+        raise RuntimeError('observation needs at least one frame and one state')
+    # dtype errors mirror what ATen's data_ptr<T>() raises in the reference operator
+    # (torbi/csrc/cuda/viterbi.cu:203-215): fp32 scores, int32 lengths
+    for name, tensor, dtype in (('observation', observation, torch.float32),
+                                ('transition', transition, torch.float32),
+                                ('initial', initial, torch.float32),
+                                ('batch_frames', batch_frames, torch.int32)):
+        if tensor.dtype != dtype:
+            raise RuntimeError(
+                f'expected scalar type {dtype} for {name} but found {tensor.dtype}')
+    if tuple(batch_frames.shape) != (B,):
+        raise RuntimeError(f'batch_frames must have shape ({B},); got {tuple(batch_frames.shape)}')
+    if tuple(transition.shape) != (S, S):
+        raise RuntimeError(f'transition must have shape ({S}, {S}); got {tuple(transition.shape)}')
+    if tuple(initial.shape) != (S,):
+        raise RuntimeError(f'initial must have shape ({S},); got {tuple(initial.shape)}')
+    return B, T, S
+
+
+def workspace_bytes(batch: int, frames: int, states: int) -> int:
+    """Scratch bytes one decode of this shape needs (trellis + posterior rows)."""
+    return int(_lib.load().torbi_hip_workspace_bytes(batch, frames, states))
+
+
+def decode(
+    observation: torch.Tensor,
+    batch_frames: torch.Tensor,
+    transition: torch.Tensor,
+    initial: torch.Tensor,
+    num_threads: Optional[int] = 0,
+    workspace: Optional[torch.Tensor] = None,
+    _profile: Optional[list] = None,
+) -> torch.Tensor:
+    """Decode a time-varying categorical distribution (log space) on an MI355X
+
+    Args:
+        observation: :math:`(N, T, S)` float32 log-probabilities
+        batch_frames: :math:`(N)` int32 sequence length of each batch item
+        transition: :math:`(S, S)` float32 log transition matrix, indexed [next, prev]
+            (reference torbi/csrc/viterbi.cpp:81-86)
+        initial: :math:`(S)` float32 log initial distribution
+        num_threads: accepted for signature compatibility (reference torbi/viterbi.py:51-52
+            sets the CPU thread count); ignored -- there is no CPU path here
+        workspace: optional uint8 scratch tensor on the compute device with at least
+            `workspace_bytes(N, T, S)` bytes; allocated from torch's caching allocator if None
+
+    Return:
+        indices: :math:`(N, T)` int32 decoded bin indices, on the device of `observation`
+
+    Tensors on the CPU are moved to the current HIP device, decoded there, and the indices
+    are returned on the CPU (the reference returns on the input device as well).
+    """
+    B, T, S = _check_inputs(observation, batch_frames, transition, initial)
+    _require_gpu()
+    lib = _lib.load()
+
+    home = observation.device
+    device = home if home.type == 'cuda' else torch.device('cuda', torch.cuda.current_device())
+    obs = observation.to(device).contiguous()
+    frames = batch_frames.to(device).contiguous()
+    trans = transition.to(device).contiguous()
+    init = initial.to(device).contiguous()
+
+    indices = torch.empty((B, T), dtype=torch.int32, device=device)
+    if B == 0:
+        return indices.to(home)
+    need = lib.torbi_hip_workspace_bytes(B, T, S)
+    if workspace is None:
+        workspace = torch.empty((need,), dtype=torch.uint8, device=device)
+    elif (workspace.device != device or workspace.dtype != torch.uint8
+          or workspace.numel() < need or not workspace.is_contiguous()):
+        raise RuntimeError(f'workspace must be a contiguous uint8 tensor of >= {need} bytes on {device}')
+
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    args = (obs.data_ptr(), frames.data_ptr(), trans.data_ptr(), init.data_ptr(),
+            indices.data_ptr(), workspace.data_ptr(), workspace.numel(), B, T, S, index,
+            ctypes.c_void_p(stream))
+    if _profile is None:
+        _lib.check(lib.torbi_hip_viterbi_decode(*args), 'torbi_hip_viterbi_decode')
+    else:
+        phases = (ctypes.c_float * 4)()
+        _lib.check(lib.torbi_hip_viterbi_decode_profiled(*args, phases),
+                   'torbi_hip_viterbi_decode_profiled')
+        _profile[:] = list(phases)
+    return indices if home == device else indices.to(home)
+
+
+def read_posterior(workspace, batch_frames, batch, frames, states):
+    """Final posterior rows (N, S) of the last decode that used `workspace` (diagnostic)."""
+    lib = _lib.load()
+    device = workspace.device
+    out = torch.empty((batch, states), dtype=torch.float32, device=device)
+    bf = batch_frames.to(device=device, dtype=torch.int32).contiguous()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    _lib.check(lib.torbi_hip_read_posterior(
+        workspace.data_ptr(), workspace.numel(), bf.data_ptr(), out.data_ptr(),
+        batch, frames, states, device.index or 0, ctypes.c_void_p(stream)),
+        'torbi_hip_read_posterior')
+    return out
+
+
+def fill_synthetic(shape, stream_id, seed=0, device=None, start=0):
+    """Device-side torbi_amd.synth.scores(): deterministic fp32 scores in (-16, 0]."""
+    _require_gpu()
+    lib = _lib.load()
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    _lib.check(lib.torbi_hip_fill_synthetic(
+        out.data_ptr(), out.numel(), start, stream_id, seed, device.index or 0,
+        ctypes.c_void_p(stream)), 'torbi_hip_fill_synthetic')
+    return out
