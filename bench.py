@@ -38,11 +38,14 @@ def algorithmic_bytes_per_timestep(S):
 
 def cpu_baseline(obs_dev, trans_dev, init_dev, gpu_indices, budget_s=15.0):
     """Time the CPU path on this host's cores on a bounded sample of the SAME workload and
-    check the GPU's indices against it.  Uses the reference's own operator (oracle/_ref)
-    when that build is present, else the reference-shaped C port (oracle mode 0)."""
+    check the GPU's indices against it.  Uses the reference's own operator (oracle/_ref,
+    kind "reference") when that build is present, else the reference-shaped C port (oracle
+    mode 0, kind "port").  The thread count is calibrated on a 16-frame prefix (the
+    reference's at::parallel_for over states gets SLOWER with hundreds of threads) and the
+    sample is sized to about `budget_s` seconds."""
     import oracle
-    cores = os.cpu_count() or 1
-    T = obs_dev.shape[1]
+    host = os.cpu_count() or 1
+    T, S = obs_dev.shape[1], obs_dev.shape[2]
     trans = trans_dev.cpu().numpy()
     init = init_dev.cpu().numpy()
     try:
@@ -53,26 +56,36 @@ def cpu_baseline(obs_dev, trans_dev, init_dev, gpu_indices, budget_s=15.0):
     except Exception:
         use_ref = False
 
-    def run(items):
-        obs = obs_dev[:items].cpu().numpy()
-        frames = np.full((items,), T, np.int32)
+    def run(obs, frames, threads):
         t0 = time.perf_counter()
         if use_ref:
-            idx = oracle.ref_decode(obs, frames, trans, init, num_threads=cores).numpy()
+            idx = oracle.ref_decode(obs, frames, trans, init, num_threads=threads).numpy()
         else:
-            idx = oracle.decode(obs, frames, trans, init, num_threads=cores, mode=0)
+            idx = oracle.decode(obs, frames, trans, init, num_threads=threads, mode=0)
         return time.perf_counter() - t0, idx
 
-    dt, idx = run(1)
-    items = int(max(1, min(obs_dev.shape[0], budget_s / max(dt, 1e-3))))
-    if items > 1:
-        dt, idx = run(items)
+    item0 = obs_dev[:1].cpu().numpy()
+    cal = np.ascontiguousarray(item0[:, :16])
+    best_threads, best_dt = 1, None
+    for threads in (1, 2, 4, 8, 16, 32, 64, 128):
+        if threads > host:
+            break
+        dt, _ = run(cal, np.array([16], np.int32), threads)
+        if best_dt is None or dt < best_dt:
+            best_threads, best_dt = threads, dt
+        elif dt > 2 * best_dt:
+            break
+    per_item = best_dt / 15.0 * (T - 1)            # 15 recurrence steps in the prefix
+    items = int(max(1, min(obs_dev.shape[0], budget_s / max(per_item, 1e-3))))
+    obs = obs_dev[:items].cpu().numpy()
+    dt, idx = run(obs, np.full((items,), T, np.int32), best_threads)
     match = bool(np.array_equal(idx, gpu_indices[:items].cpu().numpy()))
     return {
-        'value': items * T / dt, 'unit': 'timesteps/s', 'cores': cores,
+        'value': items * T / dt, 'unit': 'timesteps/s', 'cores': best_threads,
         'kind': 'reference' if use_ref else 'port',
-        'sample': f'first {items} of 512 items x {T} frames x {obs_dev.shape[2]} states, '
-                  f'{cores} threads, {dt:.1f} s',
+        'sample': f'first {items} of {obs_dev.shape[0]} items x {T} frames x {S} states, '
+                  f'{best_threads} threads (best of a 16-frame calibration; host has {host} '
+                  f'logical CPUs), {dt:.1f} s',
         'gpu_matches_cpu': match,
     }
 

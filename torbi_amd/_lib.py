@@ -53,13 +53,15 @@ def hipcc():
 
 def build(force=False, verbose=False):
     """Compile csrc/torbi_hip.hip for gfx950 into torbi_amd/libtorbi_hip.so (in-tree)."""
-    header = os.path.join(INCLUDE, 'torbi_hip.h')
+    csrc = os.path.dirname(SOURCE)
+    deps = [os.path.join(INCLUDE, 'torbi_hip.h')] + [
+        os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(('.hip', '.hpp', '.h'))]
     if not force and os.path.exists(LIBRARY):
-        newest = max(os.path.getmtime(SOURCE), os.path.getmtime(header))
+        newest = max(os.path.getmtime(d) for d in deps)
         if os.path.getmtime(LIBRARY) >= newest:
             return LIBRARY
     cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-ffp-contract=off', f'-I{INCLUDE}', '-o', LIBRARY + '.tmp', SOURCE]
+           '-ffp-contract=off', '-fno-slp-vectorize', f'-I{INCLUDE}', '-o', LIBRARY + '.tmp', SOURCE]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

@@ -21,6 +21,8 @@
 #include <math.h>
 
 #include "torbi_hip.h"
+#include "dense_forward.hpp"
+#include "lazy_backtrace.hpp"
 
 namespace {
 
@@ -288,6 +290,21 @@ __global__ __launch_bounds__(256) void gather_posterior_kernel(
     }
 }
 
+// dense path: each item's last posterior row is history row frames-1
+__global__ __launch_bounds__(256) void gather_history_kernel(const float *__restrict__ hist,
+                                                             const int32_t *__restrict__ frames,
+                                                             float *__restrict__ dst, int B, int T, int S) {
+    const size_t n = (size_t)B * S;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(e / S);
+        const int i = (int)(e - (size_t)b * S);
+        int f = frames[b];
+        f = f < 1 ? 1 : (f > T ? T : f);
+        dst[e] = hist[((size_t)b * T + (f - 1)) * S + i];
+    }
+}
+
 // deterministic synthetic scores, same function as torbi_amd/synth.py::scores
 __global__ __launch_bounds__(256) void fill_synthetic_kernel(float *__restrict__ dst,
                                                              uint64_t count, uint64_t start,
@@ -319,6 +336,35 @@ struct DeviceGuard {
     }
 };
 
+constexpr int kNumCUs = 256;   // MI355X; the tiling plan is a pure function of (B, S)
+
+// Path selection.  Large batches run the value-only (max,+) GEMM + lazy backtrace
+// (dense_forward.hpp / lazy_backtrace.hpp); small batches and tiny state spaces run the generic
+// kernels above, which materialise the int32 trellis like the reference does.
+inline bool use_dense(int B, int S) { return B >= 32 && S >= 64; }
+
+struct DenseWorkspace {
+    dense::Plan plan;
+    float *panel[2];   // [n_bt][Kp][64] posterior panels (ping-pong)
+    float *trp;        // [n_jt][Kp][W]  packed transition panels
+    float *hist;       // [B][T][S]      posterior history (replaces the int32 trellis)
+    size_t bytes;
+};
+
+inline DenseWorkspace carve_dense(void *base, int B, int T, int S) {
+    DenseWorkspace w;
+    w.plan = dense::make_plan(B, S, kNumCUs);
+    char *p = static_cast<char *>(base);
+    const size_t panel_bytes = align_up(sizeof(float) * (size_t)w.plan.n_bt * w.plan.Kp * dense::kBT, 256);
+    const size_t trp_bytes = align_up(sizeof(float) * (size_t)w.plan.n_jt * w.plan.Kp * w.plan.W, 256);
+    w.panel[0] = reinterpret_cast<float *>(p);
+    w.panel[1] = reinterpret_cast<float *>(p + panel_bytes);
+    w.trp = reinterpret_cast<float *>(p + 2 * panel_bytes);
+    w.hist = reinterpret_cast<float *>(p + 2 * panel_bytes + trp_bytes);
+    w.bytes = 2 * panel_bytes + trp_bytes + align_up(sizeof(float) * (size_t)B * T * S, 256);
+    return w;
+}
+
 int check_args(const void *a, const void *b, const void *c, const void *d, const void *e,
                const void *ws, size_t ws_bytes, int B, int T, int S) {
     if (B < 0 || T < 1 || S < 1) return TORBI_HIP_EINVAL;
@@ -329,7 +375,7 @@ int check_args(const void *a, const void *b, const void *c, const void *d, const
     return TORBI_HIP_OK;
 }
 
-// launches the forward recurrence; returns the number of step launches through *launches
+// ---- generic path ---------------------------------------------------------------------
 hipError_t launch_forward(const float *obs, const int32_t *frames, const float *trans,
                           const float *init, const Workspace &w, int B, int T, int S,
                           hipStream_t stream, int *launches) {
@@ -366,6 +412,82 @@ hipError_t launch_finalize(const int32_t *frames, const Workspace &w, int32_t *o
     return hipGetLastError();
 }
 
+// ---- dense path -----------------------------------------------------------------------
+template <int JL>
+hipError_t launch_dense_steps(const float *obs, const int32_t *frames, const DenseWorkspace &w,
+                              int B, int T, int S, hipStream_t stream, int *launches) {
+    const dense::Plan &pl = w.plan;
+    const size_t lds = dense::lds_bytes<JL>();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense::step_dense_kernel<JL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int ntiles = pl.n_bt * pl.n_jt;
+    const int grid = 8 * ((ntiles + 7) / 8);
+    int n = 0;
+    for (int t = 1; t < T; ++t) {
+        hipLaunchKernelGGL((dense::step_dense_kernel<JL>), dim3(grid), dim3(512), lds, stream, obs,
+                           frames, w.trp, w.panel[(t - 1) & 1], w.panel[t & 1], w.hist, B, T, S, t,
+                           pl.n_bt, pl.n_jt, pl.JT, pl.KS, pl.Kp);
+        ++n;
+    }
+    if (launches) *launches = n;
+    return hipGetLastError();
+}
+
+hipError_t launch_dense_forward(const float *obs, const int32_t *frames, const float *trans,
+                                const float *init, const DenseWorkspace &w, int B, int T, int S,
+                                hipStream_t stream, int *launches) {
+    const dense::Plan &pl = w.plan;
+    hipLaunchKernelGGL(dense::pack_transition_kernel, dim3((pl.Kp + 63) / 64, pl.n_jt), dim3(256), 0,
+                       stream, trans, w.trp, S, pl.JT, pl.W, pl.Kp);
+    {
+        const size_t n = (size_t)pl.n_bt * dense::kBT * pl.Kp;
+        const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipLaunchKernelGGL(dense::init_panels_kernel, dim3(grid), dim3(256), 0, stream, obs, init,
+                           w.panel[0], w.panel[1], w.hist, B, T, S, pl.n_bt, pl.Kp);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    switch (pl.JL) {
+        case 6: return launch_dense_steps<6>(obs, frames, w, B, T, S, stream, launches);
+        case 4: return launch_dense_steps<4>(obs, frames, w, B, T, S, stream, launches);
+        default: return launch_dense_steps<2>(obs, frames, w, B, T, S, stream, launches);
+    }
+}
+
+hipError_t launch_dense_backtrace(const float *trans, const int32_t *frames, const DenseWorkspace &w,
+                                  int32_t *out, int B, int T, int S, hipStream_t stream) {
+    const bool vec = (S % 4 == 0) && ((reinterpret_cast<uintptr_t>(trans) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(lazy::backtrace_kernel<4>, dim3(B), dim3(64), 0, stream, w.hist, trans,
+                           frames, out, B, T, S);
+    else
+        hipLaunchKernelGGL(lazy::backtrace_kernel<1>, dim3(B), dim3(64), 0, stream, w.hist, trans,
+                           frames, out, B, T, S);
+    return hipGetLastError();
+}
+
+// one decode on `s`; optional events bracket the forward and backtrace phases
+hipError_t run_decode(const float *obs, const int32_t *frames, const float *trans, const float *init,
+                      int32_t *out, void *workspace, int B, int T, int S, hipStream_t s,
+                      hipEvent_t *ev, int *launches) {
+    hipError_t e;
+    if (ev) (void)hipEventRecord(ev[0], s);
+    if (use_dense(B, S)) {
+        const DenseWorkspace w = carve_dense(workspace, B, T, S);
+        e = launch_dense_forward(obs, frames, trans, init, w, B, T, S, s, launches);
+        if (ev) (void)hipEventRecord(ev[1], s);
+        if (e == hipSuccess) e = launch_dense_backtrace(trans, frames, w, out, B, T, S, s);
+    } else {
+        const Workspace w = carve(workspace, B, T, S);
+        e = launch_forward(obs, frames, trans, init, w, B, T, S, s, launches);
+        if (ev) (void)hipEventRecord(ev[1], s);
+        if (e == hipSuccess) e = launch_finalize(frames, w, out, B, T, S, s);
+    }
+    if (ev) (void)hipEventRecord(ev[2], s);
+    return e;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
@@ -396,8 +518,8 @@ int torbi_hip_device_count(void) {
 
 size_t torbi_hip_workspace_bytes(int B, int T, int S) {
     if (B <= 0 || T <= 0 || S <= 0) return 256;
-    Workspace w = carve(nullptr, B, T, S);
-    return w.bytes;
+    if (use_dense(B, S)) return carve_dense(nullptr, B, T, S).bytes;
+    return carve(nullptr, B, T, S).bytes;
 }
 
 int torbi_hip_viterbi_decode(const float *observation, const int32_t *batch_frames,
@@ -409,13 +531,8 @@ int torbi_hip_viterbi_decode(const float *observation, const int32_t *batch_fram
     if (rc != TORBI_HIP_OK || B == 0) return rc;
     DeviceGuard guard(device);
     if (guard.err != hipSuccess) return (int)guard.err;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const Workspace w = carve(workspace, B, T, S);
-    hipError_t e = launch_forward(observation, batch_frames, transition, initial, w, B, T, S, s,
-                                  nullptr);
-    if (e != hipSuccess) return (int)e;
-    e = launch_finalize(batch_frames, w, indices_out, B, T, S, s);
-    return (int)e;
+    return (int)run_decode(observation, batch_frames, transition, initial, indices_out, workspace,
+                           B, T, S, static_cast<hipStream_t>(stream), nullptr, nullptr);
 }
 
 int torbi_hip_viterbi_decode_profiled(const float *observation, const int32_t *batch_frames,
@@ -431,25 +548,21 @@ int torbi_hip_viterbi_decode_profiled(const float *observation, const int32_t *b
     DeviceGuard guard(device);
     if (guard.err != hipSuccess) return (int)guard.err;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const Workspace w = carve(workspace, B, T, S);
     hipEvent_t ev[3];
     for (auto &x : ev) {
         hipError_t e = hipEventCreate(&x);
         if (e != hipSuccess) return (int)e;
     }
     int launches = 0;
-    (void)hipEventRecord(ev[0], s);
-    hipError_t e = launch_forward(observation, batch_frames, transition, initial, w, B, T, S, s,
-                                  &launches);
-    (void)hipEventRecord(ev[1], s);
-    if (e == hipSuccess) e = launch_finalize(batch_frames, w, indices_out, B, T, S, s);
-    (void)hipEventRecord(ev[2], s);
+    hipError_t e = run_decode(observation, batch_frames, transition, initial, indices_out,
+                              workspace, B, T, S, s, ev, &launches);
     hipError_t es = hipEventSynchronize(ev[2]);
     if (e == hipSuccess) e = es;
     if (e == hipSuccess) {
         (void)hipEventElapsedTime(&phase_ms[0], ev[0], ev[1]);
         (void)hipEventElapsedTime(&phase_ms[1], ev[1], ev[2]);
         phase_ms[2] = (float)launches;
+        phase_ms[3] = use_dense(B, S) ? 1.0f : 0.0f;
     }
     for (auto &x : ev) (void)hipEventDestroy(x);
     return (int)e;
@@ -464,12 +577,19 @@ int torbi_hip_read_posterior(const void *workspace, size_t workspace_bytes,
     if (workspace_bytes < torbi_hip_workspace_bytes(B, T, S)) return TORBI_HIP_EWORKSPACE;
     DeviceGuard guard(device);
     if (guard.err != hipSuccess) return (int)guard.err;
-    const Workspace w = carve(const_cast<void *>(workspace), B, T, S);
     const size_t n = (size_t)B * S;
     const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(gather_posterior_kernel, dim3(grid), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), w.post[0], w.post[1], batch_frames,
-                       posterior_out, B, T, S);
+    if (use_dense(B, S)) {
+        const DenseWorkspace w = carve_dense(const_cast<void *>(workspace), B, T, S);
+        hipLaunchKernelGGL(gather_history_kernel, dim3(grid), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), w.hist, batch_frames, posterior_out, B,
+                           T, S);
+    } else {
+        const Workspace w = carve(const_cast<void *>(workspace), B, T, S);
+        hipLaunchKernelGGL(gather_posterior_kernel, dim3(grid), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), w.post[0], w.post[1], batch_frames,
+                           posterior_out, B, T, S);
+    }
     return (int)hipGetLastError();
 }
 
