@@ -25,54 +25,72 @@
 #include <stdint.h>
 #include <math.h>
 
+#ifndef DENSE_ABLATE
+#define DENSE_ABLATE 0   // tools/step_bench.hip only: 1 = no global loads after chunk 1, 3 = no merge/finalize
+#endif
+
 namespace dense {
 
-constexpr int kBT = 64;   // batch items per tile (= posterior panel row width)
 constexpr int kNW = 8;    // waves per workgroup = contraction slices
 constexpr int kKC = 12;   // prev-state rows staged per chunk
 
 struct Plan {
-    int JL;     // next-states per lane (2, 4 or 6); panel row width W = 8*JL
+    int BL;     // batch items per lane (8 or 4); batch tile width BT = 8*BL
+    int BT;
+    int JL;     // next-states per lane (2, 4 or 6); state panel row width W = 8*JL
     int W;
     int n_bt;   // batch tiles
     int n_jt;   // state tiles
     int JT;     // next-states per tile (<= W)
     int KS;     // prev-states per wave slice (multiple of kKC)
     int Kp;     // padded contraction length = kNW*KS >= S
+    int RB;     // XCD region: RB batch tiles x RJ state tiles per XCD (L2 locality only)
 };
 
-inline Plan make_plan(int B, int S, int num_cus) {
+// Tiling plan: a pure function of (B, S).  One workgroup computes a BT x JT output tile.
+//  * BT = 32 doubles the number of workgroups (two co-resident per CU, 4 waves per SIMD): a
+//    wave can issue one VALU instruction per ~4 cycles but a SIMD retires two, so stalls of
+//    one wave are only hidden when >= 3-4 waves share the SIMD.  BT = 64 halves the L2->LDS
+//    operand traffic instead.  `bl_override` (0 = heuristic) exists for experiments.
+//  * JL is chosen to minimise rounds * W (every workgroup computes all W state slots).
+inline Plan make_plan(int B, int S, int num_cus, int bl_override = 0) {
     Plan best{};
-    long best_cost = -1;
-    const int n_bt = (B + kBT - 1) / kBT;
     const int cus = num_cus > 0 ? num_cus : 256;
+    const int BL = bl_override ? bl_override : 8;   // measured: 40.6 us/step (BL=8) vs 43.2 (BL=4) at B=512,S=1440
+    const int BT = 8 * BL;
+    const int per_cu = BL == 4 ? 2 : 1;         // co-resident workgroups per CU
+    const int n_bt = (B + BT - 1) / BT;
+    long best_cost = -1;
     for (int JL = 6; JL >= 2; JL -= 2) {
         const int W = 8 * JL;
         const int min_jt = (S + W - 1) / W;
         const long tiles = (long)n_bt * min_jt;
-        const long rounds = (tiles + cus - 1) / cus;
-        const long cost = rounds * W;           // every workgroup computes W slots per round
+        const long slots = (long)cus * per_cu;
+        const long rounds = (tiles + slots - 1) / slots;
+        const long cost = rounds * W;
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
-            int n_jt = (int)(rounds * cus / n_bt);      // spread the states over the whole round
+            int n_jt = (int)(rounds * slots / n_bt);    // spread the states over the whole round
             if (n_jt < min_jt) n_jt = min_jt;
             if (n_jt > S) n_jt = S;
             best.JL = JL;
             best.W = W;
-            best.n_bt = n_bt;
-            best.n_jt = n_jt;
             best.JT = (S + n_jt - 1) / n_jt;
             best.n_jt = (S + best.JT - 1) / best.JT;
         }
     }
+    best.BL = BL;
+    best.BT = BT;
+    best.n_bt = n_bt;
     const int per_wave = (S + kNW - 1) / kNW;
     best.KS = (per_wave + kKC - 1) / kKC * kKC;
     best.Kp = best.KS * kNW;
+    best.RB = n_bt >= 2 ? (n_bt + 1) / 2 : 1;
     return best;
 }
 
 // panel addressing
-//   posterior panel  pt[bt][i][64]   : value of batch item 64*bt + s at prev-state i; rows i >= S
+//   posterior panel  pt[bt][i][BT]   : value of batch item BT*bt + s at prev-state i; rows i >= S
 //                                      hold -inf (a -inf candidate never raises a maximum)
 //   transition panel trp[jt][i][W]   : trans[(jt*JT + s) * S + i]; 0 outside the matrix
 
@@ -103,21 +121,21 @@ __global__ __launch_bounds__(256) void pack_transition_kernel(const float *__res
 
 // ---------------------------------------------------------------------------------------
 // t = 0: posterior = obs[b,0,:] + initial  (viterbi.cpp:72-76) into panel 0 and history row 0;
-// pad rows of BOTH panels are set to -inf.   grid-stride over n_bt*Kp*64 panel elements.
+// pad rows of BOTH panels are set to -inf.   grid-stride over n_bt*BT*Kp elements.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void init_panels_kernel(const float *__restrict__ obs,
                                                           const float *__restrict__ initial,
                                                           float *__restrict__ p0, float *__restrict__ p1,
                                                           float *__restrict__ hist, int B, int T, int S,
-                                                          int n_bt, int Kp) {
+                                                          int n_bt, int BT, int Kp) {
     // one thread per (b, i): reads coalesced along i
-    const size_t n = (size_t)n_bt * kBT * Kp;
+    const size_t n = (size_t)n_bt * BT * Kp;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
          e += (size_t)gridDim.x * blockDim.x) {
         const int b = (int)(e / Kp);
         const int i = (int)(e - (size_t)b * Kp);
-        const int bt = b >> 6, s = b & 63;
-        const size_t pe = ((size_t)bt * Kp + i) * kBT + s;
+        const int bt = b / BT, s = b - bt * BT;
+        const size_t pe = ((size_t)bt * Kp + i) * BT + s;
         if (i >= S) {
             p0[pe] = -INFINITY;
             p1[pe] = -INFINITY;
@@ -139,141 +157,247 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
     return __builtin_fmaxf(__builtin_fmaxf(a, b), c);
 }
 
-// ---------------------------------------------------------------------------------------
-// one timestep:  post'[b,j] = obs[b,t,j] + max_i ( post[b,i] + trans[j,i] )     (viterbi.cpp:78-108)
-// grid = 8 * ceil(n_bt*n_jt / 8) workgroups of 512 threads; dynamic LDS = lds_bytes(JL)
-// ---------------------------------------------------------------------------------------
-template <int JL>
+template <int BL, int JL>
 struct StepShape {
+    static constexpr int BT = 8 * BL;
     static constexpr int W = 8 * JL;
-    static constexpr int CHP = kKC * kBT;                 // floats per posterior chunk
+    static constexpr int CHP = kKC * BT;                  // floats per posterior chunk
     static constexpr int CHT = kKC * W;                   // floats per transition chunk
-    static constexpr int NP4 = CHP / 4 / 64;              // float4 per lane per posterior chunk (3)
+    static constexpr int NP4 = (CHP / 4 + 63) / 64;       // float4 per lane per posterior chunk
     static constexpr int NT4 = (CHT / 4 + 63) / 64;       // float4 per lane per transition chunk
-    static constexpr int MS = 8 * JL + 4;                 // merge row stride per lane (bank-spread)
-    static constexpr int STAGE_FLOATS = kNW * (CHP + CHT);
+    static constexpr int STAGE = CHP + CHT;               // floats per wave per stage
+    static constexpr int MS = BL * JL + 4;                // merge row stride per lane (bank-spread)
+    static constexpr int STAGE_FLOATS = kNW * 2 * STAGE;  // two stages per wave (ping-pong)
     static constexpr int MERGE_FLOATS = kNW * 64 * MS;
     static constexpr int LDS_FLOATS = STAGE_FLOATS > MERGE_FLOATS ? STAGE_FLOATS : MERGE_FLOATS;
 };
 
-template <int JL>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void step_dense_kernel(
-    const float *__restrict__ obs, const int32_t *__restrict__ frames,
-    const float *__restrict__ trp, const float *__restrict__ pcur, float *__restrict__ pnext,
-    float *__restrict__ hist, int B, int T, int S, int t, int n_bt, int n_jt, int JT, int KS, int Kp) {
-    using Sh = StepShape<JL>;
-    constexpr int W = Sh::W;
+// operand fragment of one prev-state pair (i, i+1) for this lane's BL x JL register tile
+template <int BL, int JL>
+struct Frag {
+    float p0[BL], p1[BL], t0[JL], t1[JL];
+};
+
+template <int BL, int JL>
+__device__ __forceinline__ void load_frag(Frag<BL, JL> &f, const float *lp, const float *lt, int ip,
+                                          int bg, int jg) {
+    constexpr int BT = 8 * BL, W = 8 * JL;
+#pragma unroll
+    for (int h = 0; h < BL / 4; ++h) {
+        const float4 a = *reinterpret_cast<const float4 *>(&lp[ip * BT + 32 * h + 4 * bg]);
+        const float4 b = *reinterpret_cast<const float4 *>(&lp[(ip + 1) * BT + 32 * h + 4 * bg]);
+        f.p0[4 * h] = a.x; f.p0[4 * h + 1] = a.y; f.p0[4 * h + 2] = a.z; f.p0[4 * h + 3] = a.w;
+        f.p1[4 * h] = b.x; f.p1[4 * h + 1] = b.y; f.p1[4 * h + 2] = b.z; f.p1[4 * h + 3] = b.w;
+    }
+    // state slots of lane jg: JL = 6: {4jg..4jg+3} U {32+2jg, 33+2jg}; JL = 4: {4jg..4jg+3};
+    // JL = 2: {2jg, 2jg+1}  -> one ds_read_b128 (+ one ds_read_b64) per row, never ds_read2_b64
+    if (JL >= 4) {
+        const float4 u = *reinterpret_cast<const float4 *>(&lt[ip * W + 4 * jg]);
+        const float4 v = *reinterpret_cast<const float4 *>(&lt[(ip + 1) * W + 4 * jg]);
+        f.t0[0] = u.x; f.t0[1] = u.y; f.t0[2] = u.z; f.t0[3] = u.w;
+        f.t1[0] = v.x; f.t1[1] = v.y; f.t1[2] = v.z; f.t1[3] = v.w;
+    }
+    if (JL == 6 || JL == 2) {
+        constexpr int off = JL == 6 ? 32 : 0, k = JL == 6 ? 4 : 0;
+        const float2 u = *reinterpret_cast<const float2 *>(&lt[ip * W + off + 2 * jg]);
+        const float2 v = *reinterpret_cast<const float2 *>(&lt[(ip + 1) * W + off + 2 * jg]);
+        f.t0[k] = u.x; f.t0[k + 1] = u.y;
+        f.t1[k] = v.x; f.t1[k + 1] = v.y;
+    }
+}
+
+template <int BL, int JL>
+__device__ __forceinline__ void cells(float (&acc)[BL][JL], const Frag<BL, JL> &f) {
+#pragma unroll
+    for (int bb = 0; bb < BL; ++bb)
+#pragma unroll
+        for (int jj = 0; jj < JL; ++jj)
+            acc[bb][jj] = max3(acc[bb][jj], f.p0[bb] + f.t0[jj], f.p1[bb] + f.t1[jj]);
+}
+
+// ---------------------------------------------------------------------------------------
+// one timestep:  post'[b,j] = obs[b,t,j] + max_i ( post[b,i] + trans[j,i] )     (viterbi.cpp:78-108)
+// grid = 8 * ceil(n_bt*n_jt / 8) workgroups of 512 threads; dynamic LDS = lds_bytes<BL,JL>()
+//
+// lane map: bg = lane & 7 (batch group), jg = lane >> 3 (state group); the lane's register tile
+// is batch positions {4bg..4bg+3} (+32 for BL = 8) x the state slots listed in load_frag.
+// Wave w contracts prev-states [w*KS, (w+1)*KS); chunks of kKC rows go global -> registers ->
+// this wave's private LDS stage (two stages, ping-pong) -> ds_read fragments, with the next
+// fragment's reads issued before the current fragment's 2*BL*JL cells.
+// ---------------------------------------------------------------------------------------
+template <int BL, int JL>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BL == 4 ? 4 : 2, BL == 4 ? 4 : 2)))
+void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict__ frames,
+                       const float *__restrict__ trp, const float *__restrict__ pcur,
+                       float *__restrict__ pnext, float *__restrict__ hist, int B, int T, int S, int t,
+                       int n_bt, int n_jt, int JT, int KS, int Kp, int RB) {
+    using Sh = StepShape<BL, JL>;
+    constexpr int W = Sh::W, BT = Sh::BT;
     // all LDS is dynamic: a static __shared__ in front would shift the 16-byte alignment the
     // ds_read_b128 fragments rely on
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    // XCD-aware tile order: consecutive blocks land on different XCDs (block b -> XCD b % 8), so
-    // give each XCD a contiguous run of tiles (state-tile major: its transition panels stay in
-    // that XCD's L2 across timesteps)
+    // XCD-aware tile order (block b runs on XCD b % 8): XCD x owns a compact RB x RJ rectangle
+    // of tiles so that its transition panels and posterior panels stay in that XCD's L2.
+    // Pure speed choice; any mapping is correct (inputs come from the previous launch).
     const int ntiles = n_bt * n_jt;
-    const int per_xcd = (ntiles + 7) >> 3;
-    const int L = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (L >= ntiles) return;
-    const int jt = L / n_bt, bt = L - jt * n_bt;
-    const int b0 = bt * kBT, j0 = jt * JT;
+    int bt, jt;
+    {
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int nrb = (n_bt + RB - 1) / RB;                 // regions along the batch axis
+        const int nrj = (8 + nrb - 1) / nrb;                  // regions along the state axis
+        const int RJ = (n_jt + nrj - 1) / nrj;
+        const int rb = xcd % nrb, rj = xcd / nrb;
+        const int kb = k % RB, kj = k / RB;
+        bt = rb * RB + kb;
+        jt = rj * RJ + kj;
+        if (kj >= RJ || bt >= n_bt || jt >= n_jt) {
+            // tiles not covered by the rectangle map (uneven grids) are picked up linearly
+            if (nrb * nrj == 8 && n_bt % RB == 0 && n_jt % RJ == 0) return;
+            const int L = blockIdx.x;
+            if (L >= ntiles) return;
+            jt = L / n_bt;
+            bt = L - jt * n_bt;
+        } else if (!(nrb * nrj == 8 && n_bt % RB == 0 && n_jt % RJ == 0)) {
+            const int L = blockIdx.x;
+            if (L >= ntiles) return;
+            jt = L / n_bt;
+            bt = L - jt * n_bt;
+        }
+    }
+    const int b0 = bt * BT, j0 = jt * JT;
 
     const int tid = threadIdx.x;
     // skip tiles whose batch items have all ended (t >= batch_frames[b])
-    if (!__syncthreads_or(tid < kBT && b0 + tid < B && t < frames[b0 + tid])) return;
+    if (!__syncthreads_or(tid < BT && b0 + tid < B && t < frames[b0 + tid])) return;
 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bg = lane & 7, jg = lane >> 3;
 
-    float acc[8][JL];
+    // observation values of the outputs this lane finalises (wave w: batch rows BL*w .. BL*w+BL-1,
+    // lane l: state position l); issued now so that their latency hides under the contraction
+    float ob[BL];
+    const bool fin_lane = lane < JT && j0 + lane < S;
 #pragma unroll
-    for (int bb = 0; bb < 8; ++bb)
+    for (int u = 0; u < BL; ++u) {
+        const int b = b0 + BL * wave + u;
+        ob[u] = (fin_lane && b < B) ? obs[((size_t)b * T + t) * S + j0 + lane] : 0.0f;
+    }
+
+    float acc[BL][JL];
+#pragma unroll
+    for (int bb = 0; bb < BL; ++bb)
 #pragma unroll
         for (int jj = 0; jj < JL; ++jj) acc[bb][jj] = -INFINITY;
 
-    const float4 *gp = reinterpret_cast<const float4 *>(pcur + ((size_t)bt * Kp + (size_t)wave * KS) * kBT);
+    const float4 *gp = reinterpret_cast<const float4 *>(pcur + ((size_t)bt * Kp + (size_t)wave * KS) * BT);
     const float4 *gt = reinterpret_cast<const float4 *>(trp + ((size_t)jt * Kp + (size_t)wave * KS) * W);
-    float *lp = smem + wave * (Sh::CHP + Sh::CHT);
-    float *lt = lp + Sh::CHP;
-    float4 *lp4 = reinterpret_cast<float4 *>(lp);
-    float4 *lt4 = reinterpret_cast<float4 *>(lt);
+    float *stage = smem + wave * 2 * Sh::STAGE;
+
+    // staging registers.  A chunk is P4 + T4 float4; where that is not a multiple of 64 the
+    // surplus lanes re-copy an element another of their own copies already moves (same data to
+    // the same LDS address), so no lane is predicated off and nothing is branchy.
+    static_assert(Sh::NP4 >= 1 && Sh::NP4 <= 3 && Sh::NT4 >= 1 && Sh::NT4 <= 3, "staging layout");
+    constexpr int P4 = Sh::CHP / 4, T4 = Sh::CHT / 4;         // float4 per chunk
+    const int ip0 = lane < P4 ? lane : 0;
+    const int ip1 = lane + 64 < P4 ? lane + 64 : ip0;
+    const int ip2 = lane + 128 < P4 ? lane + 128 : ip1;
+    const int it0 = lane < T4 ? lane : 0;
+    const int it1 = lane + 64 < T4 ? lane + 64 : it0;
+    const int it2 = lane + 128 < T4 ? lane + 128 : it1;
+    float4 rp0, rp1, rp2, rt0, rt1, rt2;
+
+#define DENSE_LOAD_CHUNK()                                              \
+    do {                                                                \
+        rp0 = gp[ip0];                                                  \
+        if (Sh::NP4 > 1) rp1 = gp[ip1];                                 \
+        if (Sh::NP4 > 2) rp2 = gp[ip2];                                 \
+        rt0 = gt[it0];                                                  \
+        if (Sh::NT4 > 1) rt1 = gt[it1];                                 \
+        if (Sh::NT4 > 2) rt2 = gt[it2];                                 \
+        gp += P4;                                                       \
+        gt += T4;                                                       \
+    } while (0)
+#define DENSE_STORE_CHUNK(dst)                                          \
+    do {                                                                \
+        float4 *lp4_ = reinterpret_cast<float4 *>(dst);                 \
+        float4 *lt4_ = reinterpret_cast<float4 *>((dst) + Sh::CHP);     \
+        lp4_[ip0] = rp0;                                                \
+        if (Sh::NP4 > 1) lp4_[ip1] = rp1;                               \
+        if (Sh::NP4 > 2) lp4_[ip2] = rp2;                               \
+        lt4_[it0] = rt0;                                                \
+        if (Sh::NT4 > 1) lt4_[it1] = rt1;                               \
+        if (Sh::NT4 > 2) lt4_[it2] = rt2;                               \
+    } while (0)
 
     const int nch = KS / kKC;
-    // staging registers: NP4 + NT4 float4 per lane, the last transition one only on the lanes
-    // that have an element (CHT/4 is not a multiple of 64 for W = 48).  Named scalars, no
-    // conditional array writes: those would be demoted to scratch memory.
-    static_assert(Sh::NP4 == 3 && Sh::NT4 >= 1 && Sh::NT4 <= 3, "staging register layout");
-    constexpr bool kTail = (Sh::CHT / 4) % 64 != 0;           // last transition float4 is partial
-    const bool tail_lane = lane + 64 * (Sh::NT4 - 1) < Sh::CHT / 4;
-    float4 rp0 = gp[lane], rp1 = gp[lane + 64], rp2 = gp[lane + 128];
-    float4 rt0 = make_float4(0, 0, 0, 0), rt1 = rt0, rt2 = rt0;
-    if (Sh::NT4 > 1 || !kTail || tail_lane) rt0 = gt[lane];
-    if (Sh::NT4 > 1 && (Sh::NT4 > 2 || !kTail || tail_lane)) rt1 = gt[lane + 64];
-    if (Sh::NT4 > 2 && (!kTail || tail_lane)) rt2 = gt[lane + 128];
+    DENSE_LOAD_CHUNK();                 // chunk 0 -> registers
+    DENSE_STORE_CHUNK(stage);           // -> stage 0
+    if (nch > 1) DENSE_LOAD_CHUNK();    // chunk 1 -> registers
 
+    Frag<BL, JL> fa, fb;
     for (int c = 0; c < nch; ++c) {
-        // registers -> this wave's private LDS stage (same wave wrote/reads it: program order)
-        lp4[lane] = rp0; lp4[lane + 64] = rp1; lp4[lane + 128] = rp2;
-        if (Sh::NT4 > 1 || !kTail || tail_lane) lt4[lane] = rt0;
-        if (Sh::NT4 > 1 && (Sh::NT4 > 2 || !kTail || tail_lane)) lt4[lane + 64] = rt1;
-        if (Sh::NT4 > 2 && (!kTail || tail_lane)) lt4[lane + 128] = rt2;
-        if (c + 1 < nch) {
-            gp += Sh::CHP / 4;
-            gt += Sh::CHT / 4;
-            rp0 = gp[lane]; rp1 = gp[lane + 64]; rp2 = gp[lane + 128];
-            if (Sh::NT4 > 1 || !kTail || tail_lane) rt0 = gt[lane];
-            if (Sh::NT4 > 1 && (Sh::NT4 > 2 || !kTail || tail_lane)) rt1 = gt[lane + 64];
-            if (Sh::NT4 > 2 && (!kTail || tail_lane)) rt2 = gt[lane + 128];
-        }
+        const float *cur = stage + (c & 1) * Sh::STAGE;
+        float *nxt = stage + ((c + 1) & 1) * Sh::STAGE;
+        // Fragment reads of this chunk are issued first; then chunk c+1 goes registers -> the other
+        // stage (its previous contents, chunk c-1, were fully read before this point: same wave,
+        // program order) and chunk c+2 global -> registers.  No fragment is carried across the
+        // loop back-edge, so every wait in the body is a counted lgkmcnt(N), never a full drain.
+        load_frag<BL, JL>(fa, cur, cur + Sh::CHP, 0, bg, jg);
+        load_frag<BL, JL>(fb, cur, cur + Sh::CHP, 2, bg, jg);
+        if (c + 1 < nch) DENSE_STORE_CHUNK(nxt);
+        if (DENSE_ABLATE != 1 && c + 2 < nch) DENSE_LOAD_CHUNK();
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ip = 0; ip < kKC; ip += 2) {
-            float p0[8], p1[8], t0[JL], t1[JL];
-            {
-                const float4 a = *reinterpret_cast<const float4 *>(&lp[ip * kBT + 4 * bg]);
-                const float4 b = *reinterpret_cast<const float4 *>(&lp[ip * kBT + 32 + 4 * bg]);
-                const float4 c4 = *reinterpret_cast<const float4 *>(&lp[(ip + 1) * kBT + 4 * bg]);
-                const float4 d = *reinterpret_cast<const float4 *>(&lp[(ip + 1) * kBT + 32 + 4 * bg]);
-                p0[0] = a.x; p0[1] = a.y; p0[2] = a.z; p0[3] = a.w;
-                p0[4] = b.x; p0[5] = b.y; p0[6] = b.z; p0[7] = b.w;
-                p1[0] = c4.x; p1[1] = c4.y; p1[2] = c4.z; p1[3] = c4.w;
-                p1[4] = d.x; p1[5] = d.y; p1[6] = d.z; p1[7] = d.w;
-            }
-#pragma unroll
-            for (int q = 0; q < JL / 2; ++q) {
-                const float2 u = *reinterpret_cast<const float2 *>(&lt[ip * W + 16 * q + 2 * jg]);
-                const float2 v = *reinterpret_cast<const float2 *>(&lt[(ip + 1) * W + 16 * q + 2 * jg]);
-                t0[2 * q] = u.x; t0[2 * q + 1] = u.y;
-                t1[2 * q] = v.x; t1[2 * q + 1] = v.y;
-            }
-#pragma unroll
-            for (int bb = 0; bb < 8; ++bb)
-#pragma unroll
-                for (int jj = 0; jj < JL; ++jj)
-                    acc[bb][jj] = max3(acc[bb][jj], p0[bb] + t0[jj], p1[bb] + t1[jj]);
+        for (int ip = 0; ip < kKC; ip += 4) {
+            // cells of fragment A while fragment B (and the staging traffic) is in flight, then
+            // refill A and run B
+            cells<BL, JL>(acc, fa);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ip + 4 < kKC) load_frag<BL, JL>(fa, cur, cur + Sh::CHP, ip + 4, bg, jg);
+            __builtin_amdgcn_sched_barrier(0);
+            cells<BL, JL>(acc, fb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ip + 6 < kKC) load_frag<BL, JL>(fb, cur, cur + Sh::CHP, ip + 6, bg, jg);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+#undef DENSE_LOAD_CHUNK
+#undef DENSE_STORE_CHUNK
 
+#if DENSE_ABLATE == 3
+    {   // keep the accumulators live, skip merge + finalize
+        float sink = 0.f;
+#pragma unroll
+        for (int bb = 0; bb < BL; ++bb)
+#pragma unroll
+            for (int jj = 0; jj < JL; ++jj) sink += acc[bb][jj];
+        if (sink == 12345.678f) pnext[tid] = sink + ob[0];
+        return;
+    }
+#endif
     // merge the 8 contraction slices through LDS (aliases the staging area)
     __syncthreads();
     {
         float *m = smem + ((size_t)wave * 64 + lane) * Sh::MS;
 #pragma unroll
-        for (int bb = 0; bb < 8; ++bb)
+        for (int bb = 0; bb < BL; ++bb)
 #pragma unroll
             for (int jj = 0; jj < JL; ++jj) m[bb * JL + jj] = acc[bb][jj];
     }
     __syncthreads();
 
-    // finalize: wave w owns tile rows (batch positions) 8w .. 8w+7, lane l owns state position l
-    if (lane < JT && j0 + lane < S) {
+    // finalize: wave w owns tile rows (batch positions) BL*w .. BL*w+BL-1, lane l state position l
+    if (fin_lane) {
         const int p = lane;
-        const int src_jg = (p & 15) >> 1;
-        const int jj = 2 * (p >> 4) + (p & 1);
+        const int src_jg = JL == 2 ? (p >> 1) : (p < 32 ? (p >> 2) : ((p - 32) >> 1));
+        const int jj = JL == 2 ? (p & 1) : (p < 32 ? (p & 3) : 4 + (p & 1));
         const int j = j0 + p;
-        float out[8];
+        float out[BL];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int r = 8 * wave + u;
+        for (int u = 0; u < BL; ++u) {
+            const int r = BL * wave + u;
             const int src_bg = (r & 31) >> 2;
             const int bb = (r & 3) + 4 * (r >> 5);
             const float *m = smem + (size_t)(src_jg * 8 + src_bg) * Sh::MS + bb * JL + jj;
@@ -281,21 +405,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int w = 1; w < kNW; ++w) v = fmaxf(v, m[(size_t)w * 64 * Sh::MS]);
             const int b = b0 + r;
-            float o = 0.0f;
-            if (b < B) {
-                const size_t e = ((size_t)b * T + t) * S + j;
-                o = obs[e] + v;
-                if (t < frames[b]) hist[e] = o;
-            }
-            out[u] = o;
+            const float o = ob[u] + v;
+            if (b < B && t < frames[b]) hist[((size_t)b * T + t) * S + j] = o;
+            out[u] = b < B ? o : 0.0f;
         }
-        float4 *dst = reinterpret_cast<float4 *>(pnext + ((size_t)bt * Kp + j) * kBT + 8 * wave);
-        dst[0] = make_float4(out[0], out[1], out[2], out[3]);
-        dst[1] = make_float4(out[4], out[5], out[6], out[7]);
+        float4 *dst = reinterpret_cast<float4 *>(pnext + ((size_t)bt * Kp + j) * BT + BL * wave);
+#pragma unroll
+        for (int h = 0; h < BL / 4; ++h)
+            dst[h] = make_float4(out[4 * h], out[4 * h + 1], out[4 * h + 2], out[4 * h + 3]);
     }
 }
 
-template <int JL>
-constexpr size_t lds_bytes() { return sizeof(float) * (size_t)StepShape<JL>::LDS_FLOATS; }
+template <int BL, int JL>
+constexpr size_t lds_bytes() { return sizeof(float) * (size_t)StepShape<BL, JL>::LDS_FLOATS; }
 
 }  // namespace dense

@@ -89,4 +89,86 @@ __global__ __launch_bounds__(64) void backtrace_kernel(const float *__restrict__
     }
 }
 
+// Register-resident form for S % 4 == 0 and S <= 256*NQ: the posterior row of the NEXT path step
+// does not depend on the state being resolved, so it is prefetched into registers while the current
+// step's transition row (which does) is in flight; one wave per batch item, lanes own 4 consecutive
+// prev-states per 256-wide stripe (ascending per lane, as the reference scan).
+template <int NQ>
+__global__ __launch_bounds__(64) void backtrace_prefetch_kernel(const float *__restrict__ hist,
+                                                                const float *__restrict__ trans,
+                                                                const int32_t *__restrict__ frames,
+                                                                int32_t *__restrict__ out, int B, int T, int S) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    int f = frames[b];
+    f = f < 1 ? 1 : (f > T ? T : f);
+    const float *h = hist + (size_t)b * T * S;
+    int32_t *o = out + (size_t)b * T;
+    const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+
+    float4 cur[NQ], nxt[NQ];
+    {
+        const float *row = h + (size_t)(f - 1) * S;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = 4 * lane + 256 * q;
+            cur[q] = i < S ? *reinterpret_cast<const float4 *>(row + i) : ninf;
+        }
+    }
+    if (f >= 2) {
+        const float *row = h + (size_t)(f - 2) * S;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = 4 * lane + 256 * q;
+            nxt[q] = i < S ? *reinterpret_cast<const float4 *>(row + i) : ninf;
+        }
+    }
+    float best = -INFINITY;
+    int arg = kSentinel;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i = 4 * lane + 256 * q;
+        if (i < S) {
+            scan1(cur[q].x, i, best, arg); scan1(cur[q].y, i + 1, best, arg);
+            scan1(cur[q].z, i + 2, best, arg); scan1(cur[q].w, i + 3, best, arg);
+        }
+    }
+    int j = wave_first_argmax(best, arg);
+    for (int tt = f - 1 + lane; tt < T; tt += 64) o[tt] = j;
+
+    for (int tt = f - 1; tt >= 1; --tt) {
+        // transition row of the state just resolved (depends on j) ...
+        const float *tr = trans + (size_t)j * S;
+        float4 q4[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = 4 * lane + 256 * q;
+            q4[q] = i < S ? *reinterpret_cast<const float4 *>(tr + i) : ninf;
+        }
+        // ... posterior row tt-1 is already in registers; fetch row tt-2 for the next step
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) cur[q] = nxt[q];
+        if (tt >= 2) {
+            const float *row = h + (size_t)(tt - 2) * S;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int i = 4 * lane + 256 * q;
+                nxt[q] = i < S ? *reinterpret_cast<const float4 *>(row + i) : ninf;
+            }
+        }
+        best = -INFINITY;
+        arg = kSentinel;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = 4 * lane + 256 * q;
+            if (i < S) {
+                scan1(cur[q].x + q4[q].x, i, best, arg); scan1(cur[q].y + q4[q].y, i + 1, best, arg);
+                scan1(cur[q].z + q4[q].z, i + 2, best, arg); scan1(cur[q].w + q4[q].w, i + 3, best, arg);
+            }
+        }
+        j = wave_first_argmax(best, arg);
+        if (lane == 0) o[tt - 1] = j;
+    }
+}
+
 }  // namespace lazy

@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "torbi_hip.h"
 #include "dense_forward.hpp"
@@ -345,17 +346,27 @@ inline bool use_dense(int B, int S) { return B >= 32 && S >= 64; }
 
 struct DenseWorkspace {
     dense::Plan plan;
-    float *panel[2];   // [n_bt][Kp][64] posterior panels (ping-pong)
+    float *panel[2];   // [n_bt][Kp][BT] posterior panels (ping-pong)
     float *trp;        // [n_jt][Kp][W]  packed transition panels
     float *hist;       // [B][T][S]      posterior history (replaces the int32 trellis)
     size_t bytes;
 };
 
+// TORBI_HIP_BL=4|8 forces the batch-tile width of the dense path (experiments; default heuristic)
+inline int bl_override() {
+    static const int v = [] {
+        const char *e = getenv("TORBI_HIP_BL");
+        const int x = e ? atoi(e) : 0;
+        return (x == 4 || x == 8) ? x : 0;
+    }();
+    return v;
+}
+
 inline DenseWorkspace carve_dense(void *base, int B, int T, int S) {
     DenseWorkspace w;
-    w.plan = dense::make_plan(B, S, kNumCUs);
+    w.plan = dense::make_plan(B, S, kNumCUs, bl_override());
     char *p = static_cast<char *>(base);
-    const size_t panel_bytes = align_up(sizeof(float) * (size_t)w.plan.n_bt * w.plan.Kp * dense::kBT, 256);
+    const size_t panel_bytes = align_up(sizeof(float) * (size_t)w.plan.n_bt * w.plan.Kp * w.plan.BT, 256);
     const size_t trp_bytes = align_up(sizeof(float) * (size_t)w.plan.n_jt * w.plan.Kp * w.plan.W, 256);
     w.panel[0] = reinterpret_cast<float *>(p);
     w.panel[1] = reinterpret_cast<float *>(p + panel_bytes);
@@ -413,21 +424,21 @@ hipError_t launch_finalize(const int32_t *frames, const Workspace &w, int32_t *o
 }
 
 // ---- dense path -----------------------------------------------------------------------
-template <int JL>
+template <int BL, int JL>
 hipError_t launch_dense_steps(const float *obs, const int32_t *frames, const DenseWorkspace &w,
                               int B, int T, int S, hipStream_t stream, int *launches) {
     const dense::Plan &pl = w.plan;
-    const size_t lds = dense::lds_bytes<JL>();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense::step_dense_kernel<JL>),
+    const size_t lds = dense::lds_bytes<BL, JL>();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense::step_dense_kernel<BL, JL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int ntiles = pl.n_bt * pl.n_jt;
     const int grid = 8 * ((ntiles + 7) / 8);
     int n = 0;
     for (int t = 1; t < T; ++t) {
-        hipLaunchKernelGGL((dense::step_dense_kernel<JL>), dim3(grid), dim3(512), lds, stream, obs,
+        hipLaunchKernelGGL((dense::step_dense_kernel<BL, JL>), dim3(grid), dim3(512), lds, stream, obs,
                            frames, w.trp, w.panel[(t - 1) & 1], w.panel[t & 1], w.hist, B, T, S, t,
-                           pl.n_bt, pl.n_jt, pl.JT, pl.KS, pl.Kp);
+                           pl.n_bt, pl.n_jt, pl.JT, pl.KS, pl.Kp, pl.RB);
         ++n;
     }
     if (launches) *launches = n;
@@ -441,23 +452,40 @@ hipError_t launch_dense_forward(const float *obs, const int32_t *frames, const f
     hipLaunchKernelGGL(dense::pack_transition_kernel, dim3((pl.Kp + 63) / 64, pl.n_jt), dim3(256), 0,
                        stream, trans, w.trp, S, pl.JT, pl.W, pl.Kp);
     {
-        const size_t n = (size_t)pl.n_bt * dense::kBT * pl.Kp;
+        const size_t n = (size_t)pl.n_bt * pl.BT * pl.Kp;
         const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
         hipLaunchKernelGGL(dense::init_panels_kernel, dim3(grid), dim3(256), 0, stream, obs, init,
-                           w.panel[0], w.panel[1], w.hist, B, T, S, pl.n_bt, pl.Kp);
+                           w.panel[0], w.panel[1], w.hist, B, T, S, pl.n_bt, pl.BT, pl.Kp);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    switch (pl.JL) {
-        case 6: return launch_dense_steps<6>(obs, frames, w, B, T, S, stream, launches);
-        case 4: return launch_dense_steps<4>(obs, frames, w, B, T, S, stream, launches);
-        default: return launch_dense_steps<2>(obs, frames, w, B, T, S, stream, launches);
-    }
+#define TORBI_DENSE_CASE(BL_, JL_) \
+    if (pl.BL == BL_ && pl.JL == JL_) return launch_dense_steps<BL_, JL_>(obs, frames, w, B, T, S, stream, launches)
+    TORBI_DENSE_CASE(4, 6);
+    TORBI_DENSE_CASE(4, 4);
+    TORBI_DENSE_CASE(4, 2);
+    TORBI_DENSE_CASE(8, 6);
+    TORBI_DENSE_CASE(8, 4);
+    TORBI_DENSE_CASE(8, 2);
+#undef TORBI_DENSE_CASE
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_dense_backtrace(const float *trans, const int32_t *frames, const DenseWorkspace &w,
                                   int32_t *out, int B, int T, int S, hipStream_t stream) {
     const bool vec = (S % 4 == 0) && ((reinterpret_cast<uintptr_t>(trans) & 15) == 0);
+    if (vec && S <= 256 * 16) {
+#define TORBI_BT_CASE(NQ_)                                                                          \
+    if (S <= 256 * NQ_) {                                                                           \
+        hipLaunchKernelGGL(lazy::backtrace_prefetch_kernel<NQ_>, dim3(B), dim3(64), 0, stream, w.hist, \
+                           trans, frames, out, B, T, S);                                            \
+        return hipGetLastError();                                                                   \
+    }
+        TORBI_BT_CASE(2)
+        TORBI_BT_CASE(6)
+        TORBI_BT_CASE(16)
+#undef TORBI_BT_CASE
+    }
     if (vec)
         hipLaunchKernelGGL(lazy::backtrace_kernel<4>, dim3(B), dim3(64), 0, stream, w.hist, trans,
                            frames, out, B, T, S);
