@@ -104,6 +104,7 @@ def main():
     rank, size, local = distributed.init_from_env()
     assert size == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={size}'
     dev = torch.device('cuda', torch.cuda.current_device())
+    collective = dist.is_available() and dist.is_initialized()
     B, T, S = args.batch, args.frames, args.states
 
     # synthetic inputs generated in HBM (rank-specific observation stream; shared transition)
@@ -115,12 +116,12 @@ def main():
 
     def step():
         idx = torbi_amd.decode(obs, frames, trans, init, workspace=ws)
-        if size > 1:
-            idx = distributed.gather_indices(idx, B * size)
+        if collective:
+            idx = distributed.gather_indices(idx, B * size, force=True)
         return idx
 
     def fence():
-        if size > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -132,7 +133,7 @@ def main():
         indices = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if size > 1:
+    if collective:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -184,7 +185,7 @@ def main():
         result['cpu_baseline'] = cpu_baseline(obs, trans, init, indices)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if size > 1:
+    if collective:
         dist.destroy_process_group()
 
 

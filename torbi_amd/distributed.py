@@ -33,7 +33,8 @@ def init_from_env(backend: Optional[str] = None):
     local = int(os.environ.get('LOCAL_RANK', str(rank)))
     if torch.cuda.is_available():
         torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
-    if size > 1 and not dist.is_initialized():
+    force = os.environ.get('TORBI_FORCE_DIST') == '1'    # exercise the RCCL path with one rank
+    if (size > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -52,14 +53,14 @@ def shard_bounds(count: int, size: int, rank: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_indices(local: torch.Tensor, count: int, group=None) -> torch.Tensor:
+def gather_indices(local: torch.Tensor, count: int, group=None, force: bool = False) -> torch.Tensor:
     """All-gather the per-rank (n_r, T) int32 index blocks into the full (count, T) tensor.
 
     Shards may differ by one row, so blocks are padded to the largest shard for the
     collective and trimmed afterwards.
     """
     rank, size = world(group)
-    if size == 1:
+    if size == 1 and not (force and dist.is_available() and dist.is_initialized()):
         return local
     frames = local.shape[1]
     widest = (count + size - 1) // size
