@@ -33,6 +33,13 @@ void run(int B, int T, int S, int reps) {
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense::step_dense_kernel<BL, JL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int ntiles = pl.n_bt * pl.n_jt, grid = 8 * ((ntiles + 7) / 8);
+    {
+        int nb = 0;
+        CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dense::step_dense_kernel<BL, JL>, 512, lds));
+        hipFuncAttributes fa;
+        CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&dense::step_dense_kernel<BL, JL>)));
+        printf("   occupancy API: %d blocks/CU, numRegs %d, static LDS %zu, dyn LDS %zu\n", nb, fa.numRegs, fa.sharedSizeBytes, lds);
+    }
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     auto go = [&](int n) {
         for (int t = 1; t <= n; ++t)
@@ -49,7 +56,43 @@ void run(int B, int T, int S, int reps) {
     }
     printf("ablate=%d BL=%d JL=%d grid=%d lds=%zu: %.2f us/step  (%.2f Tcell/s useful)\n", DENSE_ABLATE, BL, JL, grid, lds,
            best * 1e3 / reps, (double)B * S * S / (best * 1e-3 / reps) / 1e12);
-    hipFree(p0); hipFree(p1); hipFree(tr); hipFree(hist); hipFree(obs); hipFree(frames);
+#if DENSE_TIMING
+    {
+        go(1); CHECK(hipDeviceSynchronize());
+        std::vector<unsigned long long> tb(4096 * 8);
+        CHECK(hipMemcpyFromSymbol(tb.data(), HIP_SYMBOL(dense::timing_buf), tb.size() * 8));
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long tmin = ~0ull, tmax = 0;
+        const int nw = grid * dense::kNW;
+        for (int w = 0; w < nw; ++w) {
+            const unsigned long long *t = &tb[w * 8];
+            acc[0] += (double)(t[1] - t[0]);   // setup
+            acc[1] += (double)(t[5] - t[1]);   // first chunk landed
+            acc[2] += (double)(t[2] - t[5]);   // contraction loop
+            acc[3] += (double)(t[3] - t[2]);   // merge write + barriers
+            acc[4] += (double)(t[4] - t[3]);   // finalize
+            if (t[0] < tmin) tmin = t[0];
+            if (t[4] > tmax) tmax = t[4];
+        }
+        {   // per-XCD span (clocks differ between XCDs): blocks b with b % 8 == 0
+            unsigned long long lo = ~0ull, hi = 0, late = 0; int n = 0;
+            for (int blk = 0; blk < grid; blk += 8) {
+                const unsigned long long *t = &tb[(blk * dense::kNW) * 8];
+                if (t[0] < lo) lo = t[0];
+                if (t[4] > hi) hi = t[4];
+            }
+            for (int blk = 0; blk < grid; blk += 8) {
+                const unsigned long long *t = &tb[(blk * dense::kNW) * 8];
+                if (t[0] - lo > 5000) ++late;
+                ++n;
+            }
+            printf("   XCD0: first start -> last end %llu ticks; %llu of %d blocks started > 5000 ticks after the first\n", hi - lo, late, n);
+        }
+        printf("   timing (s_memtime ticks, mean per wave): setup %.0f | first chunk %.0f | K loop %.0f | merge %.0f | finalize %.0f | first start -> last end %llu\n",
+               acc[0] / nw, acc[1] / nw, acc[2] / nw, acc[3] / nw, acc[4] / nw, tmax - tmin);
+    }
+#endif
+    (void)hipFree(p0); (void)hipFree(p1); (void)hipFree(tr); (void)hipFree(hist); (void)hipFree(obs); (void)hipFree(frames);
 }
 
 int main(int argc, char **argv) {

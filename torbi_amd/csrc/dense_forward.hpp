@@ -29,10 +29,24 @@
 #define DENSE_ABLATE 0   // tools/step_bench.hip only: 1 = no global loads after chunk 1, 3 = no merge/finalize
 #endif
 
+#ifndef DENSE_TIMING
+#define DENSE_TIMING 0    // tools/step_bench.hip only: per-wave s_memtime stamps into dense::timing_buf
+#endif
+
 namespace dense {
 
+#if DENSE_TIMING
+__device__ unsigned long long timing_buf[4096 * 8];
+#define DENSE_STAMP(k) do { if (lane == 0) timing_buf[(blockIdx.x * kNW + wave) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DENSE_STAMP(k) do { } while (0)
+#endif
+
 constexpr int kNW = 8;    // waves per workgroup = contraction slices
-constexpr int kKC = 12;   // prev-state rows staged per chunk
+#ifndef DENSE_KC
+#define DENSE_KC 12
+#endif
+constexpr int kKC = DENSE_KC;   // prev-state rows staged per chunk (multiple of 4)
 
 struct Plan {
     int BL;     // batch items per lane (8 or 4); batch tile width BT = 8*BL
@@ -206,13 +220,67 @@ __device__ __forceinline__ void load_frag(Frag<BL, JL> &f, const float *lp, cons
     }
 }
 
+#ifndef DENSE_SKEW
+#define DENSE_SKEW 1   // 1: issue the two adds of cell k+1 before the max3 of cell k
+#endif
+
 template <int BL, int JL>
 __device__ __forceinline__ void cells(float (&acc)[BL][JL], const Frag<BL, JL> &f) {
+#if DENSE_SKEW
+    // software-pipelined by one cell so that a v_max3_f32 never directly follows the v_add_f32
+    // pair it consumes
+    float c0 = f.p0[0] + f.t0[0], c1 = f.p1[0] + f.t1[0];
+#pragma unroll
+    for (int k = 1; k < BL * JL; ++k) {
+        const int bb = k / JL, jj = k % JL, pb = (k - 1) / JL, pj = (k - 1) % JL;
+        const float n0 = f.p0[bb] + f.t0[jj], n1 = f.p1[bb] + f.t1[jj];
+        acc[pb][pj] = max3(acc[pb][pj], c0, c1);
+        c0 = n0;
+        c1 = n1;
+    }
+    acc[BL - 1][JL - 1] = max3(acc[BL - 1][JL - 1], c0, c1);
+#else
 #pragma unroll
     for (int bb = 0; bb < BL; ++bb)
 #pragma unroll
         for (int jj = 0; jj < JL; ++jj)
             acc[bb][jj] = max3(acc[bb][jj], f.p0[bb] + f.t0[jj], f.p1[bb] + f.t1[jj]);
+#endif
+}
+
+#ifndef DENSE_USE_DMA
+#define DENSE_USE_DMA 1   // 1: global -> LDS by LDS-DMA (global_load_lds_dwordx4), 0: through registers
+#endif
+
+// One chunk (kKC prev-state rows of the posterior panel + of the transition panel) global -> this
+// wave's LDS stage by LDS-DMA: the LDS image equals the global image, 1 KiB per wave instruction
+// (destination = M0 = wave-uniform LDS byte address, + lane*16 B), no VGPRs, no ds_write.
+// Written as inline asm on purpose: hipcc orders every later ds_read behind a pending builtin
+// LDS-DMA with s_waitcnt vmcnt(0), which would serialise the copy of chunk c+1 with the cells of
+// chunk c.  Here the issuing wave is the only reader of its stage and waits with its own
+// s_waitcnt vmcnt(0) one chunk later.  M0 is saved/restored inside the statement.
+__device__ __forceinline__ void glds16(const float *gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_byte_addr)
+                 : "memory");
+}
+
+template <int P4, int T4>
+__device__ __forceinline__ void dma_chunk(const float *gp, const float *gt, float *dst, int chp_floats,
+                                          int lane) {
+    const unsigned base = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)dst);
+#pragma unroll
+    for (int q = 0; q < (P4 + 63) / 64; ++q) {
+        if ((q + 1) * 64 <= P4 || lane + 64 * q < P4) glds16(gp + 4 * (lane + 64 * q), base + 1024 * q);
+    }
+#pragma unroll
+    for (int q = 0; q < (T4 + 63) / 64; ++q) {
+        if ((q + 1) * 64 <= T4 || lane + 64 * q < T4)
+            glds16(gt + 4 * (lane + 64 * q), base + 4 * chp_floats + 1024 * q);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -285,6 +353,7 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
         ob[u] = (fin_lane && b < B) ? obs[((size_t)b * T + t) * S + j0 + lane] : 0.0f;
     }
 
+    DENSE_STAMP(0);
     float acc[BL][JL];
 #pragma unroll
     for (int bb = 0; bb < BL; ++bb)
@@ -295,11 +364,12 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
     const float4 *gt = reinterpret_cast<const float4 *>(trp + ((size_t)jt * Kp + (size_t)wave * KS) * W);
     float *stage = smem + wave * 2 * Sh::STAGE;
 
+    constexpr int P4 = Sh::CHP / 4, T4 = Sh::CHT / 4;         // float4 per chunk
+#if !DENSE_USE_DMA
     // staging registers.  A chunk is P4 + T4 float4; where that is not a multiple of 64 the
     // surplus lanes re-copy an element another of their own copies already moves (same data to
     // the same LDS address), so no lane is predicated off and nothing is branchy.
     static_assert(Sh::NP4 >= 1 && Sh::NP4 <= 3 && Sh::NT4 >= 1 && Sh::NT4 <= 3, "staging layout");
-    constexpr int P4 = Sh::CHP / 4, T4 = Sh::CHT / 4;         // float4 per chunk
     const int ip0 = lane < P4 ? lane : 0;
     const int ip1 = lane + 64 < P4 ? lane + 64 : ip0;
     const int ip2 = lane + 128 < P4 ? lane + 128 : ip1;
@@ -331,24 +401,48 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
         if (Sh::NT4 > 2) lt4_[it2] = rt2;                               \
     } while (0)
 
+#endif
     const int nch = KS / kKC;
+    Frag<BL, JL> fa, fb;
+    DENSE_STAMP(1);
+#if DENSE_USE_DMA
+    const float *gpf = reinterpret_cast<const float *>(gp);
+    const float *gtf = reinterpret_cast<const float *>(gt);
+    dma_chunk<P4, T4>(gpf, gtf, stage, Sh::CHP, lane);          // chunk 0 -> stage 0
+    for (int c = 0; c < nch; ++c) {
+        const float *cur = stage + (c & 1) * Sh::STAGE;
+        float *nxt = stage + ((c + 1) & 1) * Sh::STAGE;
+        // chunk c has landed (it was issued one whole chunk of cells ago); chunk c+1 -> the other
+        // stage, whose previous contents (chunk c-1) were consumed before this point
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (c == 0) DENSE_STAMP(5);
+        __builtin_amdgcn_sched_barrier(0);
+        if (DENSE_ABLATE != 1 && c + 1 < nch) {
+            gpf += Sh::CHP;
+            gtf += Sh::CHT;
+            dma_chunk<P4, T4>(gpf, gtf, nxt, Sh::CHP, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_frag<BL, JL>(fa, cur, cur + Sh::CHP, 0, bg, jg);
+        load_frag<BL, JL>(fb, cur, cur + Sh::CHP, 2, bg, jg);
+        __builtin_amdgcn_sched_barrier(0);
+#else
     DENSE_LOAD_CHUNK();                 // chunk 0 -> registers
     DENSE_STORE_CHUNK(stage);           // -> stage 0
     if (nch > 1) DENSE_LOAD_CHUNK();    // chunk 1 -> registers
-
-    Frag<BL, JL> fa, fb;
     for (int c = 0; c < nch; ++c) {
         const float *cur = stage + (c & 1) * Sh::STAGE;
         float *nxt = stage + ((c + 1) & 1) * Sh::STAGE;
         // Fragment reads of this chunk are issued first; then chunk c+1 goes registers -> the other
         // stage (its previous contents, chunk c-1, were fully read before this point: same wave,
         // program order) and chunk c+2 global -> registers.  No fragment is carried across the
-        // loop back-edge, so every wait in the body is a counted lgkmcnt(N), never a full drain.
+        // loop back-edge.
         load_frag<BL, JL>(fa, cur, cur + Sh::CHP, 0, bg, jg);
         load_frag<BL, JL>(fb, cur, cur + Sh::CHP, 2, bg, jg);
         if (c + 1 < nch) DENSE_STORE_CHUNK(nxt);
         if (DENSE_ABLATE != 1 && c + 2 < nch) DENSE_LOAD_CHUNK();
         __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int ip = 0; ip < kKC; ip += 4) {
             // cells of fragment A while fragment B (and the staging traffic) is in flight, then
@@ -363,9 +457,12 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+#if !DENSE_USE_DMA
 #undef DENSE_LOAD_CHUNK
 #undef DENSE_STORE_CHUNK
+#endif
 
+    DENSE_STAMP(2);
 #if DENSE_ABLATE == 3
     {   // keep the accumulators live, skip merge + finalize
         float sink = 0.f;
@@ -377,18 +474,25 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
         return;
     }
 #endif
-    // merge the 8 contraction slices through LDS (aliases the staging area)
+    // merge the 8 contraction slices through LDS (aliases the staging area).  Slot order is
+    // state-major (jj*BL + bb): the batch rows one finalising lane needs are then contiguous, so
+    // both the writes and the reads are ds_*_b128.
     __syncthreads();
     {
         float *m = smem + ((size_t)wave * 64 + lane) * Sh::MS;
 #pragma unroll
-        for (int bb = 0; bb < BL; ++bb)
+        for (int jj = 0; jj < JL; ++jj)
 #pragma unroll
-            for (int jj = 0; jj < JL; ++jj) m[bb * JL + jj] = acc[bb][jj];
+            for (int h = 0; h < BL / 4; ++h)
+                *reinterpret_cast<float4 *>(&m[jj * BL + 4 * h]) =
+                    make_float4(acc[4 * h][jj], acc[4 * h + 1][jj], acc[4 * h + 2][jj], acc[4 * h + 3][jj]);
     }
     __syncthreads();
+    DENSE_STAMP(3);
 
-    // finalize: wave w owns tile rows (batch positions) BL*w .. BL*w+BL-1, lane l state position l
+    // finalize: wave w owns tile rows (batch positions) BL*w .. BL*w+BL-1, lane l state position l.
+    // Row r lives in lane group bg = (r & 31) >> 2 at register row bb = (r & 3) + 4*(r >> 5); for
+    // the 4-row group g of this wave (rows BL*w + 4g .. +3) bg and bb & ~3 are constant.
     if (fin_lane) {
         const int p = lane;
         const int src_jg = JL == 2 ? (p >> 1) : (p < 32 ? (p >> 2) : ((p - 32) >> 1));
@@ -396,16 +500,23 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
         const int j = j0 + p;
         float out[BL];
 #pragma unroll
-        for (int u = 0; u < BL; ++u) {
-            const int r = BL * wave + u;
-            const int src_bg = (r & 31) >> 2;
-            const int bb = (r & 3) + 4 * (r >> 5);
-            const float *m = smem + (size_t)(src_jg * 8 + src_bg) * Sh::MS + bb * JL + jj;
-            float v = m[0];
+        for (int g = 0; g < BL / 4; ++g) {
+            const int r0 = BL * wave + 4 * g;
+            const int src_bg = (r0 & 31) >> 2;
+            const int bb0 = 4 * (r0 >> 5);
+            const float *m = smem + (size_t)(src_jg * 8 + src_bg) * Sh::MS + jj * BL + bb0;
+            float4 v = *reinterpret_cast<const float4 *>(m);
 #pragma unroll
-            for (int w = 1; w < kNW; ++w) v = fmaxf(v, m[(size_t)w * 64 * Sh::MS]);
-            const int b = b0 + r;
-            const float o = ob[u] + v;
+            for (int w = 1; w < kNW; ++w) {
+                const float4 x = *reinterpret_cast<const float4 *>(m + (size_t)w * 64 * Sh::MS);
+                v.x = fmaxf(v.x, x.x); v.y = fmaxf(v.y, x.y); v.z = fmaxf(v.z, x.z); v.w = fmaxf(v.w, x.w);
+            }
+            out[4 * g] = v.x; out[4 * g + 1] = v.y; out[4 * g + 2] = v.z; out[4 * g + 3] = v.w;
+        }
+#pragma unroll
+        for (int u = 0; u < BL; ++u) {
+            const int b = b0 + BL * wave + u;
+            const float o = ob[u] + out[u];
             if (b < B && t < frames[b]) hist[((size_t)b * T + t) * S + j] = o;
             out[u] = b < B ? o : 0.0f;
         }
@@ -414,6 +525,7 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
         for (int h = 0; h < BL / 4; ++h)
             dst[h] = make_float4(out[4 * h], out[4 * h + 1], out[4 * h + 2], out[4 * h + 3]);
     }
+    DENSE_STAMP(4);
 }
 
 template <int BL, int JL>
