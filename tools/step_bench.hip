@@ -13,6 +13,12 @@
 template <int BL, int JL>
 void run(int B, int T, int S, int reps) {
     dense::Plan pl = dense::make_plan(B, S, 256, BL);
+    if (getenv("NJT")) {           // experiment: force the number of state tiles
+        pl.n_jt = atoi(getenv("NJT"));
+        pl.JT = (S + pl.n_jt - 1) / pl.n_jt;
+        pl.n_jt = (S + pl.JT - 1) / pl.JT;
+    }
+    if (getenv("RB")) pl.RB = atoi(getenv("RB"));
     if (pl.JL != JL) { printf("plan JL %d != %d, skip\n", pl.JL, JL); return; }
     const size_t panel = (size_t)pl.n_bt * pl.Kp * pl.BT, trp = (size_t)pl.n_jt * pl.Kp * pl.W;
     float *p0, *p1, *tr, *hist, *obs; int *frames;

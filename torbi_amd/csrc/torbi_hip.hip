@@ -239,6 +239,48 @@ __global__ __launch_bounds__(256) void step_rows_kernel(
     }
 }
 
+// Small-batch timestep, vector form (S % 4 == 0, 16-byte aligned rows): one next-state per wave,
+// 4 per block, so a batch-1 step spreads over S/4 workgroups; each lane owns 4 consecutive
+// prev-states per 256-wide stripe (ascending per lane, like the reference scan) and loads the
+// transition row as float4.
+__global__ __launch_bounds__(256) void step_rows4_kernel(
+    const float *__restrict__ obs, const int32_t *__restrict__ frames,
+    const float *__restrict__ trans, const float *__restrict__ pcur, float *__restrict__ pnext,
+    int32_t *__restrict__ trellis, int B, int T, int S, int t) {
+    extern __shared__ __attribute__((aligned(16))) float pl[];
+    const int b = blockIdx.y;
+    if (t >= frames[b]) return;
+    const int tid = threadIdx.x;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(pcur + (size_t)b * S);
+        float4 *dst = reinterpret_cast<float4 *>(pl);
+        for (int i = tid; i < S / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = blockIdx.x * 4 + wave;
+    if (j >= S) return;
+    const float *row = trans + (size_t)j * S;
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int i = 4 * lane; i < S; i += 256) {
+        const float4 q = *reinterpret_cast<const float4 *>(row + i);
+        const float4 p = *reinterpret_cast<const float4 *>(pl + i);
+        const float c[4] = {p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (c[u] > best) { best = c[u]; arg = i + u; }
+            else if (arg == 0x7fffffff) { arg = i + u; best = c[u]; }
+        }
+    }
+    wave_argmax(best, arg);
+    if (lane == 0) {
+        const size_t e = ((size_t)b * T + t) * S + j;
+        trellis[e] = arg;
+        pnext[(size_t)b * S + j] = obs[e] + best;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Final state + tail fill + backtrace, one wave per batch item.
 //   final = first argmax of the item's last posterior row           (viterbi.cpp:218)
@@ -405,6 +447,10 @@ hipError_t launch_forward(const float *obs, const int32_t *frames, const float *
             dim3 grid((S + 63) / 64, (B + 63) / 64);
             hipLaunchKernelGGL((step_tile_kernel<64, 64, 32>), grid, dim3(256), 0, stream, obs,
                                frames, trans, pc, pn, w.trellis, B, T, S, t);
+        } else if (S % 4 == 0 && S >= 256 && (reinterpret_cast<uintptr_t>(trans) & 15) == 0) {
+            dim3 grid((S + 3) / 4, B);
+            hipLaunchKernelGGL(step_rows4_kernel, grid, dim3(256), sizeof(float) * (size_t)S,
+                               stream, obs, frames, trans, pc, pn, w.trellis, B, T, S, t);
         } else {
             dim3 grid((S + kRowsPerBlock - 1) / kRowsPerBlock, B);
             hipLaunchKernelGGL(step_rows_kernel, grid, dim3(256), sizeof(float) * (size_t)S,
