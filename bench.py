@@ -99,6 +99,11 @@ def main():
     ap.add_argument('--frames', type=int, default=500)
     ap.add_argument('--states', type=int, default=1440)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--transition', choices=['dense', 'banded'], default='dense',
+                    help="dense = headline workload; banded = the reference's pitch transition "
+                         '(torbi/evaluate/core.py:24-33), secondary structured-transition line')
+    ap.add_argument('--half-width', type=float, default=87.2,
+                    help='band half width in states for --transition banded (penn: 87.2)')
     args = ap.parse_args()
 
     rank, size, local = distributed.init_from_env()
@@ -110,6 +115,8 @@ def main():
     # synthetic inputs generated in HBM (rank-specific observation stream; shared transition)
     obs = viterbi.fill_synthetic((B, T, S), synth.STREAM_OBSERVATION, seed=rank, device=dev)
     trans = viterbi.fill_synthetic((S, S), synth.STREAM_TRANSITION, seed=0, device=dev)
+    if args.transition == 'banded':
+        trans = torch.from_numpy(synth.banded_transition(S, args.half_width)).to(dev)
     init = viterbi.fill_synthetic((S,), synth.STREAM_INITIAL, seed=0, device=dev)
     frames = torch.full((B,), T, dtype=torch.int32, device=dev)
     ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
@@ -162,7 +169,10 @@ def main():
         'data': 'synthetic',
         'config': {'workload': f'{S} states, {T} frames, batch={B} per GPU, fp32, dense '
                                f'transition (BASELINE configs[2]); decode = forward + argmax + '
-                               f'backtrace, inputs resident in HBM',
+                               f'backtrace, inputs resident in HBM'
+                               if args.transition == 'dense' else
+                               f'{S} states, {T} frames, batch={B} per GPU, fp32, BANDED transition '
+                               f'(half width {args.half_width}, -inf outside; secondary workload)',
                    'parallelism': f'batch-sharded x{size}' if size > 1 else 'single GPU'},
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -61,6 +61,35 @@ def test_random_shapes_against_oracle(shape, ties):
     assert np.array_equal(gpu_decode(obs, frames, trans, init), want)
 
 
+@pytest.mark.parametrize('kind', ['banded', 'diagonal', 'blocks', 'dead_rows', 'dead_everything'])
+@pytest.mark.parametrize('shape', [(64, 25, 360), (40, 12, 1440), (96, 9, 131)])
+def test_dense_path_skips_minus_inf_blocks_exactly(kind, shape):
+    """-inf-structured transitions on the large-batch path: chunks of prev-states whose
+    transition values are all -inf are skipped (build_chunk_lists_kernel); results must not
+    change.  'banded' is the reference's own pitch transition (torbi/evaluate/core.py:24-33)."""
+    B, T, S = shape
+    obs, trans, init = synth.problem(B, T, S, seed=S + len(kind))
+    rng = np.random.default_rng(S)
+    if kind == 'banded':
+        trans = synth.banded_transition(S, max(3, S // 16))
+    elif kind == 'diagonal':
+        d = np.full((S, S), -np.inf, np.float32)
+        np.fill_diagonal(d, trans.diagonal())
+        trans = d
+    elif kind == 'blocks':
+        mask = rng.random((S // 8 + 1, S // 8 + 1)) < 0.7
+        trans = np.where(np.kron(mask, np.ones((8, 8), bool))[:S, :S], -np.inf, trans).astype(np.float32)
+    elif kind == 'dead_rows':
+        trans = trans.copy()
+        trans[rng.random(S) < 0.3] = -np.inf
+    else:
+        trans = np.full((S, S), -np.inf, np.float32)
+    frames = np.clip(synth.lengths(B, 1, T, seed=3), 1, T)
+    frames[0] = T
+    want = oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())
+    assert np.array_equal(gpu_decode(obs, frames, trans, init), want)
+
+
 def test_posterior_rows_match_oracle_bitwise():
     B, T, S = 5, 23, 300
     obs, trans, init = synth.problem(B, T, S, seed=77)

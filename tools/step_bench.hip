@@ -21,10 +21,11 @@ void run(int B, int T, int S, int reps) {
     if (getenv("RB")) pl.RB = atoi(getenv("RB"));
     if (pl.JL != JL) { printf("plan JL %d != %d, skip\n", pl.JL, JL); return; }
     const size_t panel = (size_t)pl.n_bt * pl.Kp * pl.BT, trp = (size_t)pl.n_jt * pl.Kp * pl.W;
-    float *p0, *p1, *tr, *hist, *obs; int *frames;
+    float *p0, *p1, *tr, *hist, *obs; int *frames; int *chunks;
     CHECK(hipMalloc(&p0, panel * 4)); CHECK(hipMalloc(&p1, panel * 4)); CHECK(hipMalloc(&tr, trp * 4));
     CHECK(hipMalloc(&hist, (size_t)B * T * S * 4)); CHECK(hipMalloc(&obs, (size_t)B * T * S * 4));
     CHECK(hipMalloc(&frames, B * 4));
+    CHECK(hipMalloc(&chunks, (size_t)pl.n_jt * (pl.NCH + 1) * 4));
     std::vector<float> h(panel);
     for (size_t i = 0; i < panel; ++i) h[i] = -(float)(rand() % 16000) / 1000.f;
     CHECK(hipMemcpy(p0, h.data(), panel * 4, hipMemcpyHostToDevice));
@@ -33,6 +34,8 @@ void run(int B, int T, int S, int reps) {
     for (size_t i = 0; i < trp; ++i) ht[i] = -(float)(rand() % 16000) / 1000.f;
     CHECK(hipMemcpy(tr, ht.data(), trp * 4, hipMemcpyHostToDevice));
     CHECK(hipMemset(obs, 0, (size_t)B * T * S * 4));
+    hipLaunchKernelGGL(dense::build_chunk_lists_kernel, dim3(pl.n_jt), dim3(256), sizeof(int) * (size_t)pl.NCH, 0, tr, chunks, S,
+                       pl.JT, pl.W, pl.Kp, pl.NCH);
     std::vector<int> hf(B, T);
     CHECK(hipMemcpy(frames, hf.data(), B * 4, hipMemcpyHostToDevice));
     const size_t lds = dense::lds_bytes<BL, JL>();
@@ -50,8 +53,8 @@ void run(int B, int T, int S, int reps) {
     auto go = [&](int n) {
         for (int t = 1; t <= n; ++t)
             hipLaunchKernelGGL((dense::step_dense_kernel<BL, JL>), dim3(grid), dim3(512), lds, 0, obs, frames, tr,
-                               (t & 1) ? p0 : p1, (t & 1) ? p1 : p0, hist, B, T, S, 1 + (t % (T - 1)), pl.n_bt, pl.n_jt,
-                               pl.JT, pl.KS, pl.Kp, pl.RB);
+                               (t & 1) ? p0 : p1, (t & 1) ? p1 : p0, hist, chunks, B, T, S, 1 + (t % (T - 1)), pl.n_bt,
+                               pl.n_jt, pl.JT, pl.Kp, pl.NCH, pl.RB);
     };
     go(20); CHECK(hipDeviceSynchronize());
     float best = 1e30f;

@@ -56,8 +56,8 @@ struct Plan {
     int n_bt;   // batch tiles
     int n_jt;   // state tiles
     int JT;     // next-states per tile (<= W)
-    int KS;     // prev-states per wave slice (multiple of kKC)
-    int Kp;     // padded contraction length = kNW*KS >= S
+    int Kp;     // padded contraction length (multiple of kKC) >= S
+    int NCH;    // chunks of kKC prev-state rows per panel = Kp / kKC
     int RB;     // XCD region: RB batch tiles x RJ state tiles per XCD (L2 locality only)
 };
 
@@ -96,9 +96,8 @@ inline Plan make_plan(int B, int S, int num_cus, int bl_override = 0) {
     best.BL = BL;
     best.BT = BT;
     best.n_bt = n_bt;
-    const int per_wave = (S + kNW - 1) / kNW;
-    best.KS = (per_wave + kKC - 1) / kKC * kKC;
-    best.Kp = best.KS * kNW;
+    best.NCH = (S + kKC - 1) / kKC;
+    best.Kp = best.NCH * kKC;
     best.RB = n_bt >= 2 ? (n_bt + 1) / 2 : 1;
     return best;
 }
@@ -130,6 +129,41 @@ __global__ __launch_bounds__(256) void pack_transition_kernel(const float *__res
         const int ii = e / W, s = e - ii * W;
         const int i = i0 + ii;
         if (i < Kp) trp[((size_t)jt * Kp + i) * W + s] = tile[s][ii];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// once per decode: for every state tile, the ascending list of chunks (kKC prev-state rows) that
+// hold at least one transition value other than -inf.  A candidate post[i] + (-inf) = -inf can
+// never raise a maximum, so the forward pass skips the other chunks EXACTLY: banded / diagonal /
+// sparse transition matrices (e.g. the reference's own pitch transition,
+// torbi/evaluate/core.py:24-33) cost only their non-(-inf) blocks; a dense matrix lists every chunk.
+// chunks[jt][0] = count, chunks[jt][1..count] = chunk ids.   grid = n_jt, block = 256
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void build_chunk_lists_kernel(const float *__restrict__ trp,
+                                                                int32_t *__restrict__ chunks, int S, int JT,
+                                                                int W, int Kp, int NCH) {
+    extern __shared__ int flags[];
+    const int jt = blockIdx.x;
+    const float *panel = trp + (size_t)jt * Kp * W;
+    for (int c = threadIdx.x; c < NCH; c += blockDim.x) {
+        int any = 0;
+        for (int r = 0; r < kKC && !any; ++r) {
+            const int i = c * kKC + r;
+            if (i >= S) break;
+            const float *row = panel + (size_t)i * W;
+            for (int q = 0; q < JT; ++q)
+                if (!(row[q] == -INFINITY)) { any = 1; break; }
+        }
+        flags[c] = any;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t *list = chunks + (size_t)jt * (NCH + 1);
+        int n = 0;
+        for (int c = 0; c < NCH; ++c)
+            if (flags[c]) list[1 + n++] = c;
+        list[0] = n;
     }
 }
 
@@ -248,10 +282,6 @@ __device__ __forceinline__ void cells(float (&acc)[BL][JL], const Frag<BL, JL> &
 #endif
 }
 
-#ifndef DENSE_USE_DMA
-#define DENSE_USE_DMA 1   // 1: global -> LDS by LDS-DMA (global_load_lds_dwordx4), 0: through registers
-#endif
-
 // One chunk (kKC prev-state rows of the posterior panel + of the transition panel) global -> this
 // wave's LDS stage by LDS-DMA: the LDS image equals the global image, 1 KiB per wave instruction
 // (destination = M0 = wave-uniform LDS byte address, + lane*16 B), no VGPRs, no ds_write.
@@ -289,16 +319,17 @@ __device__ __forceinline__ void dma_chunk(const float *gp, const float *gt, floa
 //
 // lane map: bg = lane & 7 (batch group), jg = lane >> 3 (state group); the lane's register tile
 // is batch positions {4bg..4bg+3} (+32 for BL = 8) x the state slots listed in load_frag.
-// Wave w contracts prev-states [w*KS, (w+1)*KS); chunks of kKC rows go global -> registers ->
-// this wave's private LDS stage (two stages, ping-pong) -> ds_read fragments, with the next
+// Wave w contracts every 8th listed chunk of kKC prev-state rows; a chunk goes global -> this
+// wave's private LDS stage by LDS-DMA (two stages, ping-pong) -> ds_read fragments, with the next
 // fragment's reads issued before the current fragment's 2*BL*JL cells.
 // ---------------------------------------------------------------------------------------
 template <int BL, int JL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BL == 4 ? 4 : 2, BL == 4 ? 4 : 2)))
 void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict__ frames,
                        const float *__restrict__ trp, const float *__restrict__ pcur,
-                       float *__restrict__ pnext, float *__restrict__ hist, int B, int T, int S, int t,
-                       int n_bt, int n_jt, int JT, int KS, int Kp, int RB) {
+                       float *__restrict__ pnext, float *__restrict__ hist,
+                       const int32_t *__restrict__ chunks, int B, int T, int S, int t, int n_bt, int n_jt,
+                       int JT, int Kp, int NCH, int RB) {
     using Sh = StepShape<BL, JL>;
     constexpr int W = Sh::W, BT = Sh::BT;
     // all LDS is dynamic: a static __shared__ in front would shift the 16-byte alignment the
@@ -343,6 +374,21 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bg = lane & 7, jg = lane >> 3;
 
+    // This wave contracts a contiguous eighth of the tile's chunk list (build_chunk_lists_kernel):
+    // entries [first, first + nch); lane l keeps the id of the wave's l-th chunk.  Panels with
+    // more than 512 chunks (S > 6144) are walked densely instead.  Loaded first: nothing below
+    // depends on it until the contraction starts.
+    // A dense panel (every chunk listed) is walked arithmetically: the id lookup below costs
+    // ~1.3 us per launch at 15 chunks per wave.
+    const int32_t *list = chunks + (size_t)jt * (NCH + 1);
+    const int count = NCH <= 64 * kNW ? __builtin_amdgcn_readfirstlane(list[0]) : NCH;
+    const bool listed = count != NCH;
+    const int per = (count + kNW - 1) / kNW;
+    const int first = wave * per;
+    const int nch = count - first < per ? (count - first > 0 ? count - first : 0) : per;
+    int ids = 0;
+    if (listed && lane < nch) ids = list[1 + first + lane];
+
     // observation values of the outputs this lane finalises (wave w: batch rows BL*w .. BL*w+BL-1,
     // lane l: state position l); issued now so that their latency hides under the contraction
     float ob[BL];
@@ -360,55 +406,18 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
 #pragma unroll
         for (int jj = 0; jj < JL; ++jj) acc[bb][jj] = -INFINITY;
 
-    const float4 *gp = reinterpret_cast<const float4 *>(pcur + ((size_t)bt * Kp + (size_t)wave * KS) * BT);
-    const float4 *gt = reinterpret_cast<const float4 *>(trp + ((size_t)jt * Kp + (size_t)wave * KS) * W);
+    const float *gp_base = pcur + (size_t)bt * Kp * BT;
+    const float *gt_base = trp + (size_t)jt * Kp * W;
+#define DENSE_CHUNK_ID(c) (listed ? __builtin_amdgcn_readlane(ids, (c)) : first + (c))
     float *stage = smem + wave * 2 * Sh::STAGE;
-
     constexpr int P4 = Sh::CHP / 4, T4 = Sh::CHT / 4;         // float4 per chunk
-#if !DENSE_USE_DMA
-    // staging registers.  A chunk is P4 + T4 float4; where that is not a multiple of 64 the
-    // surplus lanes re-copy an element another of their own copies already moves (same data to
-    // the same LDS address), so no lane is predicated off and nothing is branchy.
-    static_assert(Sh::NP4 >= 1 && Sh::NP4 <= 3 && Sh::NT4 >= 1 && Sh::NT4 <= 3, "staging layout");
-    const int ip0 = lane < P4 ? lane : 0;
-    const int ip1 = lane + 64 < P4 ? lane + 64 : ip0;
-    const int ip2 = lane + 128 < P4 ? lane + 128 : ip1;
-    const int it0 = lane < T4 ? lane : 0;
-    const int it1 = lane + 64 < T4 ? lane + 64 : it0;
-    const int it2 = lane + 128 < T4 ? lane + 128 : it1;
-    float4 rp0, rp1, rp2, rt0, rt1, rt2;
 
-#define DENSE_LOAD_CHUNK()                                              \
-    do {                                                                \
-        rp0 = gp[ip0];                                                  \
-        if (Sh::NP4 > 1) rp1 = gp[ip1];                                 \
-        if (Sh::NP4 > 2) rp2 = gp[ip2];                                 \
-        rt0 = gt[it0];                                                  \
-        if (Sh::NT4 > 1) rt1 = gt[it1];                                 \
-        if (Sh::NT4 > 2) rt2 = gt[it2];                                 \
-        gp += P4;                                                       \
-        gt += T4;                                                       \
-    } while (0)
-#define DENSE_STORE_CHUNK(dst)                                          \
-    do {                                                                \
-        float4 *lp4_ = reinterpret_cast<float4 *>(dst);                 \
-        float4 *lt4_ = reinterpret_cast<float4 *>((dst) + Sh::CHP);     \
-        lp4_[ip0] = rp0;                                                \
-        if (Sh::NP4 > 1) lp4_[ip1] = rp1;                               \
-        if (Sh::NP4 > 2) lp4_[ip2] = rp2;                               \
-        lt4_[it0] = rt0;                                                \
-        if (Sh::NT4 > 1) lt4_[it1] = rt1;                               \
-        if (Sh::NT4 > 2) lt4_[it2] = rt2;                               \
-    } while (0)
-
-#endif
-    const int nch = KS / kKC;
     Frag<BL, JL> fa, fb;
     DENSE_STAMP(1);
-#if DENSE_USE_DMA
-    const float *gpf = reinterpret_cast<const float *>(gp);
-    const float *gtf = reinterpret_cast<const float *>(gt);
-    dma_chunk<P4, T4>(gpf, gtf, stage, Sh::CHP, lane);          // chunk 0 -> stage 0
+    if (nch > 0) {
+        const int ci = DENSE_CHUNK_ID(0);
+        dma_chunk<P4, T4>(gp_base + (size_t)ci * Sh::CHP, gt_base + (size_t)ci * Sh::CHT, stage, Sh::CHP, lane);
+    }
     for (int c = 0; c < nch; ++c) {
         const float *cur = stage + (c & 1) * Sh::STAGE;
         float *nxt = stage + ((c + 1) & 1) * Sh::STAGE;
@@ -418,31 +427,13 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
         if (c == 0) DENSE_STAMP(5);
         __builtin_amdgcn_sched_barrier(0);
         if (DENSE_ABLATE != 1 && c + 1 < nch) {
-            gpf += Sh::CHP;
-            gtf += Sh::CHT;
-            dma_chunk<P4, T4>(gpf, gtf, nxt, Sh::CHP, lane);
+            const int ci = DENSE_CHUNK_ID(c + 1);
+            dma_chunk<P4, T4>(gp_base + (size_t)ci * Sh::CHP, gt_base + (size_t)ci * Sh::CHT, nxt, Sh::CHP, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
         load_frag<BL, JL>(fa, cur, cur + Sh::CHP, 0, bg, jg);
         load_frag<BL, JL>(fb, cur, cur + Sh::CHP, 2, bg, jg);
         __builtin_amdgcn_sched_barrier(0);
-#else
-    DENSE_LOAD_CHUNK();                 // chunk 0 -> registers
-    DENSE_STORE_CHUNK(stage);           // -> stage 0
-    if (nch > 1) DENSE_LOAD_CHUNK();    // chunk 1 -> registers
-    for (int c = 0; c < nch; ++c) {
-        const float *cur = stage + (c & 1) * Sh::STAGE;
-        float *nxt = stage + ((c + 1) & 1) * Sh::STAGE;
-        // Fragment reads of this chunk are issued first; then chunk c+1 goes registers -> the other
-        // stage (its previous contents, chunk c-1, were fully read before this point: same wave,
-        // program order) and chunk c+2 global -> registers.  No fragment is carried across the
-        // loop back-edge.
-        load_frag<BL, JL>(fa, cur, cur + Sh::CHP, 0, bg, jg);
-        load_frag<BL, JL>(fb, cur, cur + Sh::CHP, 2, bg, jg);
-        if (c + 1 < nch) DENSE_STORE_CHUNK(nxt);
-        if (DENSE_ABLATE != 1 && c + 2 < nch) DENSE_LOAD_CHUNK();
-        __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
         for (int ip = 0; ip < kKC; ip += 4) {
             // cells of fragment A while fragment B (and the staging traffic) is in flight, then
@@ -457,10 +448,7 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-#if !DENSE_USE_DMA
-#undef DENSE_LOAD_CHUNK
-#undef DENSE_STORE_CHUNK
-#endif
+#undef DENSE_CHUNK_ID
 
     DENSE_STAMP(2);
 #if DENSE_ABLATE == 3

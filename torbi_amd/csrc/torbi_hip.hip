@@ -390,6 +390,7 @@ struct DenseWorkspace {
     dense::Plan plan;
     float *panel[2];   // [n_bt][Kp][BT] posterior panels (ping-pong)
     float *trp;        // [n_jt][Kp][W]  packed transition panels
+    int32_t *chunks;   // [n_jt][NCH+1]  per-tile lists of chunks that are not all -inf
     float *hist;       // [B][T][S]      posterior history (replaces the int32 trellis)
     size_t bytes;
 };
@@ -413,8 +414,10 @@ inline DenseWorkspace carve_dense(void *base, int B, int T, int S) {
     w.panel[0] = reinterpret_cast<float *>(p);
     w.panel[1] = reinterpret_cast<float *>(p + panel_bytes);
     w.trp = reinterpret_cast<float *>(p + 2 * panel_bytes);
-    w.hist = reinterpret_cast<float *>(p + 2 * panel_bytes + trp_bytes);
-    w.bytes = 2 * panel_bytes + trp_bytes + align_up(sizeof(float) * (size_t)B * T * S, 256);
+    const size_t list_bytes = align_up(sizeof(int32_t) * (size_t)w.plan.n_jt * (w.plan.NCH + 1), 256);
+    w.chunks = reinterpret_cast<int32_t *>(p + 2 * panel_bytes + trp_bytes);
+    w.hist = reinterpret_cast<float *>(p + 2 * panel_bytes + trp_bytes + list_bytes);
+    w.bytes = 2 * panel_bytes + trp_bytes + list_bytes + align_up(sizeof(float) * (size_t)B * T * S, 256);
     return w;
 }
 
@@ -483,8 +486,8 @@ hipError_t launch_dense_steps(const float *obs, const int32_t *frames, const Den
     int n = 0;
     for (int t = 1; t < T; ++t) {
         hipLaunchKernelGGL((dense::step_dense_kernel<BL, JL>), dim3(grid), dim3(512), lds, stream, obs,
-                           frames, w.trp, w.panel[(t - 1) & 1], w.panel[t & 1], w.hist, B, T, S, t,
-                           pl.n_bt, pl.n_jt, pl.JT, pl.KS, pl.Kp, pl.RB);
+                           frames, w.trp, w.panel[(t - 1) & 1], w.panel[t & 1], w.hist, w.chunks, B, T, S,
+                           t, pl.n_bt, pl.n_jt, pl.JT, pl.Kp, pl.NCH, pl.RB);
         ++n;
     }
     if (launches) *launches = n;
@@ -497,6 +500,8 @@ hipError_t launch_dense_forward(const float *obs, const int32_t *frames, const f
     const dense::Plan &pl = w.plan;
     hipLaunchKernelGGL(dense::pack_transition_kernel, dim3((pl.Kp + 63) / 64, pl.n_jt), dim3(256), 0,
                        stream, trans, w.trp, S, pl.JT, pl.W, pl.Kp);
+    hipLaunchKernelGGL(dense::build_chunk_lists_kernel, dim3(pl.n_jt), dim3(256),
+                       sizeof(int) * (size_t)pl.NCH, stream, w.trp, w.chunks, S, pl.JT, pl.W, pl.Kp, pl.NCH);
     {
         const size_t n = (size_t)pl.n_bt * pl.BT * pl.Kp;
         const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
