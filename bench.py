@@ -99,7 +99,7 @@ def main():
     ap.add_argument('--frames', type=int, default=500)
     ap.add_argument('--states', type=int, default=1440)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--transition', choices=['dense', 'banded'], default='dense',
+    ap.add_argument('--transition', choices=['dense', 'banded', 'uniform'], default='dense',
                     help="dense = headline workload; banded = the reference's pitch transition "
                          '(torbi/evaluate/core.py:24-33), secondary structured-transition line')
     ap.add_argument('--half-width', type=float, default=87.2,
@@ -121,8 +121,14 @@ def main():
     frames = torch.full((B,), T, dtype=torch.int32, device=dev)
     ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
 
+    import math
+    uniform_c = float(torch.tensor(math.log(1.0 / S), dtype=torch.float32))
+
     def step():
-        idx = torbi_amd.decode(obs, frames, trans, init, workspace=ws)
+        if args.transition == 'uniform':
+            idx = torbi_amd.decode_uniform(obs, frames, uniform_c, init)
+        else:
+            idx = torbi_amd.decode(obs, frames, trans, init, workspace=ws)
         if collective:
             idx = distributed.gather_indices(idx, B * size, force=True)
         return idx
@@ -152,6 +158,28 @@ def main():
     # hipEvents on the launch stream around the whole chain of launches (one launch = one
     # timestep of the whole batch), averaged over a few profiled decodes
     prof, fwd_ms, bt_ms, launches = [], 0.0, 0.0, 1
+    if args.transition == 'uniform':
+        # one kernel per decode, HBM-bound: 4S observation bytes + 4 index bytes per timestep
+        per = elapsed / args.steps
+        nbytes = float(B) * T * (4 * S + 4)
+        result = {
+            'metric': 'timesteps decoded/sec, 1440 states batch=512', 'value': value,
+            'unit': 'timesteps/s', 'n_gpus': size, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': per * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{S} states, {T} frames, batch={B} per GPU, fp32, UNIFORM '
+                                   f'transition (the reference default, transition=None; secondary '
+                                   f'workload)'},
+            'roofline': {'bound': 'hbm', 'achieved': nbytes / per / 1e9, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': nbytes / per / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                         'kernel': 'uniform_decode_kernel (whole decode, host-timed incl. launch)',
+                         'algorithmic_bytes_per_launch': nbytes},
+        }
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        if collective:
+            dist.destroy_process_group()
+        return
     for _ in range(3):
         torbi_amd.decode(obs, frames, trans, init, workspace=ws, _profile=prof)
         fwd_ms += prof[0] / 3

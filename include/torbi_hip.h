@@ -43,13 +43,14 @@
 extern "C" {
 #endif
 
-#define TORBI_HIP_ABI_VERSION 1
+#define TORBI_HIP_ABI_VERSION 2
 
 #define TORBI_HIP_OK 0
 #define TORBI_HIP_EINVAL (-1)      /* null pointer / non-positive dimension            */
 #define TORBI_HIP_EWORKSPACE (-2)  /* workspace smaller than torbi_hip_workspace_bytes */
 #define TORBI_HIP_ERANGE (-3)      /* dimension too large for this build               */
 #define TORBI_HIP_ENODEVICE (-4)   /* no usable HIP device / wrong architecture        */
+#define TORBI_HIP_EUNSUPPORTED (-5) /* shape not covered by this specialised entry point */
 
 /* Build/ABI version of the loaded library (== TORBI_HIP_ABI_VERSION). */
 int torbi_hip_abi_version(void);
@@ -81,6 +82,21 @@ int torbi_hip_viterbi_decode(const float *observation, const int32_t *batch_fram
                              const float *transition, const float *initial,
                              int32_t *indices_out, void *workspace, size_t workspace_bytes,
                              int B, int T, int S, int device, void *stream);
+
+/*
+ * The operator for a UNIFORM transition matrix (every entry == log_transition), i.e. the
+ * reference's default when from_probabilities() is called without a transition
+ * (torbi/core.py:175-180 builds torch.full((S,S), log(1/S)) and runs the generic recurrence).
+ * With identical rows the backpointer is the same for every next state, so the decode is O(S)
+ * per timestep, needs no scratch and streams the observations once (HBM-bound).  Results are
+ * bit-identical to torbi_hip_viterbi_decode on the materialised matrix.
+ * Covers S % 4 == 0, S <= 4096, 16-byte aligned observation/initial; otherwise returns
+ * TORBI_HIP_EUNSUPPORTED and the caller materialises the matrix.
+ */
+int torbi_hip_viterbi_decode_uniform(const float *observation, const int32_t *batch_frames,
+                                     float log_transition, const float *initial,
+                                     int32_t *indices_out, int B, int T, int S, int device,
+                                     void *stream);
 
 /*
  * Same operator, instrumented for bench.py: brackets the forward recurrence and the

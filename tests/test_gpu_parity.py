@@ -90,6 +90,29 @@ def test_dense_path_skips_minus_inf_blocks_exactly(kind, shape):
     assert np.array_equal(gpu_decode(obs, frames, trans, init), want)
 
 
+@pytest.mark.parametrize('shape', [(3, 40, 1440), (70, 9, 360), (5, 1, 64), (2, 33, 4096), (9, 7, 132),
+                                   (4, 6, 63), (130, 5, 256)])
+@pytest.mark.parametrize('ties', [False, True])
+def test_uniform_transition_entry_equals_materialised_matrix(shape, ties):
+    """torbi_hip_viterbi_decode_uniform vs the oracle run on torch.full((S,S), c), the matrix the
+    reference builds for transition=None (torbi/core.py:175-180)."""
+    import math
+    B, T, S = shape
+    obs, _, init = synth.problem(B, T, S, seed=S + T)
+    if ties:
+        obs, init = np.round(obs / 4), np.round(init / 4)
+    c = np.float32(math.log(1. / S))
+    frames = np.clip(synth.lengths(B, 1, T, seed=7), 1, T)
+    frames[0] = T
+    want = oracle.decode(obs, frames, np.full((S, S), c, np.float32), init,
+                         num_threads=oracle.max_threads())
+    dev = torch.device('cuda:0')
+    got = torbi_amd.decode_uniform(torch.tensor(obs, device=dev), torch.tensor(frames, device=dev),
+                                   float(c), torch.tensor(init, device=dev))
+    assert got.dtype == torch.int32
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
 def test_posterior_rows_match_oracle_bitwise():
     B, T, S = 5, 23, 300
     obs, trans, init = synth.problem(B, T, S, seed=77)

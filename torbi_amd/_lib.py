@@ -14,7 +14,7 @@ ROOT = os.path.dirname(_HERE)
 SOURCE = os.path.join(_HERE, 'csrc', 'torbi_hip.hip')
 INCLUDE = os.path.join(ROOT, 'include')
 LIBRARY = os.path.join(_HERE, 'libtorbi_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/torbi_hip.h declares: name -> (restype, argtypes)
 _c = ctypes
@@ -26,6 +26,9 @@ SYMBOLS = {
     'torbi_hip_viterbi_decode': (_c.c_int, [
         _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
         _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+    'torbi_hip_viterbi_decode_uniform': (_c.c_int, [
+        _c.c_void_p, _c.c_void_p, _c.c_float, _c.c_void_p, _c.c_void_p,
+        _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     'torbi_hip_viterbi_decode_profiled': (_c.c_int, [
         _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
         _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,

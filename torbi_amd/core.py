@@ -11,7 +11,7 @@ from typing import Dict, List, Optional, Union
 import torch
 
 from . import data as _data
-from .viterbi import decode
+from .viterbi import decode, decode_uniform
 
 # reference torbi/config/defaults.py:80,83
 BATCH_SIZE = 512
@@ -94,10 +94,12 @@ def from_probabilities(
             initial = torch.log(initial)
         initial = initial.to(device)
 
-    # Default to uniform transition probabilities (core.py:175-180)
+    # Default to uniform transition probabilities (core.py:175-180).  The reference
+    # materialises torch.full((S, S), log(1/S)); a matrix of identical entries is decoded by the
+    # O(S)-per-timestep entry point instead, with identical results (decode_uniform).
+    uniform = None
     if transition is None:
-        transition = torch.full(
-            (states, states), math.log(1. / states), dtype=torch.float32, device=device)
+        uniform = float(torch.tensor(math.log(1. / states), dtype=torch.float32))
     else:
         if not log_probs:
             transition = torch.log(transition)
@@ -113,7 +115,10 @@ def from_probabilities(
     observation += tiny
     torch.log_(observation)
 
-    indices = decode(observation, batch_frames, transition, initial, num_threads=num_threads)
+    if uniform is not None:
+        indices = decode_uniform(observation, batch_frames, uniform, initial)
+    else:
+        indices = decode(observation, batch_frames, transition, initial, num_threads=num_threads)
     return indices.cpu() if to_host else indices
 
 

@@ -24,6 +24,7 @@
 #include "torbi_hip.h"
 #include "dense_forward.hpp"
 #include "lazy_backtrace.hpp"
+#include "uniform_decode.hpp"
 
 namespace {
 
@@ -583,6 +584,7 @@ const char *torbi_hip_error_string(int code) {
         case TORBI_HIP_EWORKSPACE: return "workspace smaller than torbi_hip_workspace_bytes()";
         case TORBI_HIP_ERANGE: return "problem dimensions out of range for this build";
         case TORBI_HIP_ENODEVICE: return "no usable HIP device";
+        case TORBI_HIP_EUNSUPPORTED: return "shape not covered by this specialised entry point";
         default: break;
     }
     if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
@@ -612,6 +614,32 @@ int torbi_hip_viterbi_decode(const float *observation, const int32_t *batch_fram
     if (guard.err != hipSuccess) return (int)guard.err;
     return (int)run_decode(observation, batch_frames, transition, initial, indices_out, workspace,
                            B, T, S, static_cast<hipStream_t>(stream), nullptr, nullptr);
+}
+
+int torbi_hip_viterbi_decode_uniform(const float *observation, const int32_t *batch_frames,
+                                     float log_transition, const float *initial,
+                                     int32_t *indices_out, int B, int T, int S, int device,
+                                     void *stream) {
+    if (B < 0 || T < 1 || S < 1) return TORBI_HIP_EINVAL;
+    if (B == 0) return TORBI_HIP_OK;
+    if (!observation || !batch_frames || !initial || !indices_out) return TORBI_HIP_EINVAL;
+    if (S % 4 != 0 || S > 4096 || (reinterpret_cast<uintptr_t>(observation) & 15) ||
+        (reinterpret_cast<uintptr_t>(initial) & 15))
+        return TORBI_HIP_EUNSUPPORTED;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return (int)guard.err;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define TORBI_UNIFORM_CASE(NQ_, DEPTH_)                                                             \
+    if (S <= 256 * NQ_) {                                                                           \
+        hipLaunchKernelGGL((uniform::uniform_decode_kernel<NQ_, DEPTH_>), dim3(B), dim3(64), 0, s,  \
+                           observation, batch_frames, initial, log_transition, indices_out, B, T, S); \
+        return (int)hipGetLastError();                                                              \
+    }
+    TORBI_UNIFORM_CASE(2, 4)
+    TORBI_UNIFORM_CASE(6, 4)
+    TORBI_UNIFORM_CASE(16, 2)
+#undef TORBI_UNIFORM_CASE
+    return TORBI_HIP_EUNSUPPORTED;
 }
 
 int torbi_hip_viterbi_decode_profiled(const float *observation, const int32_t *batch_frames,

@@ -1,0 +1,164 @@
+// uniform_decode.hpp -- exact decode for a UNIFORM transition matrix (every entry = c).
+//
+// This is the reference's default: from_probabilities(observation) with transition=None builds
+// torch.full((S, S), log(1/S)) (torbi/core.py:175-180) and runs the generic S*S recurrence on it.
+// With all rows identical the candidates fl(post[i] + c) do not depend on the next state j, so per
+// timestep (viterbi.cpp:78-108)
+//     m    = max_i fl(post[i] + c)            k = first i attaining it     (the backpointer of EVERY j)
+//     post'[j] = fl(obs[t,j] + m)
+// and the backtrace (viterbi.cpp:153-157) reads bp[t][anything] = k_t:  out[t-1] = k_t.
+// O(S) per timestep instead of O(S*S), no trellis, no posterior history: the decode streams the
+// observations once and is HBM-bound (4S + 4 bytes per timestep).  One wave per batch item; the
+// posterior row lives in registers; observation rows are prefetched DEPTH timesteps ahead.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+namespace uniform {
+
+// DPP controls: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror -- after the
+// four steps every lane holds the reduction of its 16-lane row; the four rows are combined from
+// readlane values.  All lanes end with the same result.
+template <typename Op>
+__device__ __forceinline__ float wave_reduce_f32(float x, Op op) {
+    x = op(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true)));
+    x = op(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true)));
+    x = op(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true)));
+    x = op(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, true)));
+    const int xi = __builtin_bit_cast(int, x);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
+    return op(op(r0, r1), op(r2, r3));
+}
+
+__device__ __forceinline__ int wave_min_i32(int x) {
+    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true));
+    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true));
+    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true));
+    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, true));
+    return min(min(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 16)),
+               min(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)));
+}
+
+struct MaxOp {
+    __device__ __forceinline__ float operator()(float a, float b) const { return __builtin_fmaxf(a, b); }
+};
+
+constexpr int kNone = 0x7fffffff;
+
+// first index (ascending) whose value equals m among this lane's 4*NQ elements, else kNone
+template <int NQ>
+__device__ __forceinline__ int first_equal(const float4 (&v)[NQ], float m, int lane, int S) {
+    int k = kNone;
+#pragma unroll
+    for (int q = NQ - 1; q >= 0; --q) {
+        const int i = 4 * lane + 256 * q;
+        if (i < S) {
+            k = v[q].w == m ? i + 3 : k;
+            k = v[q].z == m ? i + 2 : k;
+            k = v[q].y == m ? i + 1 : k;
+            k = v[q].x == m ? i : k;
+        }
+    }
+    return k;
+}
+
+template <int NQ>
+__device__ __forceinline__ float lane_max(const float4 (&v)[NQ], int lane, int S) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        if (4 * lane + 256 * q < S)
+            m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fmaxf(v[q].x, v[q].y)), __builtin_fmaxf(v[q].z, v[q].w));
+    return m;
+}
+
+template <int NQ>
+__device__ __forceinline__ void load_row(float4 (&r)[NQ], const float *row, int lane, int S) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i = 4 * lane + 256 * q;
+        r[q] = i < S ? *reinterpret_cast<const float4 *>(row + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// NQ float4 per lane per row (S <= 256*NQ, S % 4 == 0); DEPTH observation rows in flight
+template <int NQ, int DEPTH>
+__global__ __launch_bounds__(64) void uniform_decode_kernel(const float *__restrict__ obs,
+                                                            const int32_t *__restrict__ frames,
+                                                            const float *__restrict__ initial, float c,
+                                                            int32_t *__restrict__ out, int B, int T, int S) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    int f = frames[b];
+    f = f < 1 ? 1 : (f > T ? T : f);
+    const float *o = obs + (size_t)b * T * S;
+    int32_t *res = out + (size_t)b * T;
+
+    float4 post[NQ], cand[NQ], rows[DEPTH][NQ];
+    // t = 0: post = obs[0] + initial                                        (viterbi.cpp:72-76)
+    {
+        float4 a[NQ], i4[NQ];
+        load_row<NQ>(a, o, lane, S);
+        load_row<NQ>(i4, initial, lane, S);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            post[q] = make_float4(a[q].x + i4[q].x, a[q].y + i4[q].y, a[q].z + i4[q].z, a[q].w + i4[q].w);
+    }
+    // Observation rows are always fetched (row index clamped to T-1, valid memory), so the
+    // unrolled body has no conditional register-array writes (those would be demoted to scratch).
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        const int r = 1 + d < T ? 1 + d : T - 1;
+        load_row<NQ>(rows[d], o + (size_t)r * S, lane, S);
+    }
+
+    int t0 = 1;
+    for (; t0 + DEPTH <= f; t0 += DEPTH) {                    // whole groups: no per-step test
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int t = t0 + d;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                cand[q] = make_float4(post[q].x + c, post[q].y + c, post[q].z + c, post[q].w + c);
+            const float m = wave_reduce_f32(lane_max<NQ>(cand, lane, S), MaxOp());
+            const int k = wave_min_i32(first_equal<NQ>(cand, m, lane, S));
+            if (lane == 0) res[t - 1] = k;                    // the backpointer of every next state
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                post[q] = make_float4(rows[d][q].x + m, rows[d][q].y + m, rows[d][q].z + m, rows[d][q].w + m);
+            const int r = t + DEPTH < T ? t + DEPTH : T - 1;
+            load_row<NQ>(rows[d], o + (size_t)r * S, lane, S);
+        }
+    }
+    // remainder (< DEPTH steps): same body, the new posterior is committed with a select
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) {
+        const int t = t0 + d;
+        const bool live = t < f;                              // wave-uniform
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            cand[q] = make_float4(post[q].x + c, post[q].y + c, post[q].z + c, post[q].w + c);
+        const float m = wave_reduce_f32(lane_max<NQ>(cand, lane, S), MaxOp());
+        const int k = wave_min_i32(first_equal<NQ>(cand, m, lane, S));
+        if (live && lane == 0) res[t - 1] = k;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            post[q].x = live ? rows[d][q].x + m : post[q].x;
+            post[q].y = live ? rows[d][q].y + m : post[q].y;
+            post[q].z = live ? rows[d][q].z + m : post[q].z;
+            post[q].w = live ? rows[d][q].w + m : post[q].w;
+        }
+    }
+    // final state = first argmax of the last posterior row (viterbi.cpp:218); it fills every
+    // position t >= frames-1 (viterbi.cpp:219-221)
+    const float m = wave_reduce_f32(lane_max<NQ>(post, lane, S), MaxOp());
+    const int fin = wave_min_i32(first_equal<NQ>(post, m, lane, S));
+    for (int tt = f - 1 + lane; tt < T; tt += 64) res[tt] = fin;
+}
+
+}  // namespace uniform

@@ -114,6 +114,53 @@ def decode(
     return indices if home == device else indices.to(home)
 
 
+def uniform_supported(states: int) -> bool:
+    """Shapes the uniform-transition entry point covers (include/torbi_hip.h)."""
+    return states % 4 == 0 and states <= 4096
+
+
+def decode_uniform(
+    observation: torch.Tensor,
+    batch_frames: torch.Tensor,
+    log_transition: float,
+    initial: torch.Tensor,
+) -> torch.Tensor:
+    """`decode` for a transition matrix whose entries all equal `log_transition`
+
+    The reference's default (`from_probabilities` without a transition builds
+    `torch.full((S, S), log(1/S))`, torbi/core.py:175-180).  O(S) per timestep, no scratch,
+    HBM-bound; bit-identical to `decode` on the materialised matrix.  Falls back to
+    materialising the matrix for shapes `uniform_supported` rejects.
+    """
+    B, T, S = observation.shape
+    if not uniform_supported(S):
+        transition = torch.full((S, S), float(log_transition), dtype=torch.float32,
+                                device=observation.device)
+        return decode(observation, batch_frames, transition, initial)
+    _check_inputs(observation, batch_frames, torch.empty((S, S), dtype=torch.float32, device='meta'),
+                  initial)
+    _require_gpu()
+    lib = _lib.load()
+    home = observation.device
+    device = home if home.type == 'cuda' else torch.device('cuda', torch.cuda.current_device())
+    obs = observation.to(device).contiguous()
+    frames = batch_frames.to(device).contiguous()
+    init = initial.to(device).contiguous()
+    indices = torch.empty((B, T), dtype=torch.int32, device=device)
+    if B == 0:
+        return indices.to(home)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    code = lib.torbi_hip_viterbi_decode_uniform(
+        obs.data_ptr(), frames.data_ptr(), float(log_transition), init.data_ptr(),
+        indices.data_ptr(), B, T, S, index, ctypes.c_void_p(stream))
+    if code == -5:     # TORBI_HIP_EUNSUPPORTED (e.g. a misaligned view): materialise
+        transition = torch.full((S, S), float(log_transition), dtype=torch.float32, device=device)
+        return decode(observation, batch_frames, transition, initial)
+    _lib.check(code, 'torbi_hip_viterbi_decode_uniform')
+    return indices if home == device else indices.to(home)
+
+
 def read_posterior(workspace, batch_frames, batch, frames, states):
     """Final posterior rows (N, S) of the last decode that used `workspace` (diagnostic)."""
     lib = _lib.load()
