@@ -10,9 +10,10 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-template <int BL, int JL>
+template <int BL, int JL, int NW, int KC>
 void run(int B, int T, int S, int reps) {
-    dense::Plan pl = dense::make_plan(B, S, 256, BL);
+    dense::Plan pl = dense::make_plan(B, S, 256, BL, NW);
+    if (pl.NW != NW || pl.KC != KC) { printf("plan NW/KC %d/%d != %d/%d, skip\n", pl.NW, pl.KC, NW, KC); return; }
     if (getenv("NJT")) {           // experiment: force the number of state tiles
         pl.n_jt = atoi(getenv("NJT"));
         pl.JT = (S + pl.n_jt - 1) / pl.n_jt;
@@ -35,24 +36,24 @@ void run(int B, int T, int S, int reps) {
     CHECK(hipMemcpy(tr, ht.data(), trp * 4, hipMemcpyHostToDevice));
     CHECK(hipMemset(obs, 0, (size_t)B * T * S * 4));
     hipLaunchKernelGGL(dense::build_chunk_lists_kernel, dim3(pl.n_jt), dim3(256), sizeof(int) * (size_t)pl.NCH, 0, tr, chunks, S,
-                       pl.JT, pl.W, pl.Kp, pl.NCH);
+                       pl.JT, pl.W, pl.Kp, pl.NCH, pl.KC);
     std::vector<int> hf(B, T);
     CHECK(hipMemcpy(frames, hf.data(), B * 4, hipMemcpyHostToDevice));
-    const size_t lds = dense::lds_bytes<BL, JL>();
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense::step_dense_kernel<BL, JL>),
+    const size_t lds = dense::lds_bytes<BL, JL, NW, KC>();
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense::step_dense_kernel<BL, JL, NW, KC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int ntiles = pl.n_bt * pl.n_jt, grid = 8 * ((ntiles + 7) / 8);
     {
         int nb = 0;
-        CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dense::step_dense_kernel<BL, JL>, 512, lds));
+        CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dense::step_dense_kernel<BL, JL, NW, KC>, 64 * NW, lds));
         hipFuncAttributes fa;
-        CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&dense::step_dense_kernel<BL, JL>)));
+        CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&dense::step_dense_kernel<BL, JL, NW, KC>)));
         printf("   occupancy API: %d blocks/CU, numRegs %d, static LDS %zu, dyn LDS %zu\n", nb, fa.numRegs, fa.sharedSizeBytes, lds);
     }
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     auto go = [&](int n) {
         for (int t = 1; t <= n; ++t)
-            hipLaunchKernelGGL((dense::step_dense_kernel<BL, JL>), dim3(grid), dim3(512), lds, 0, obs, frames, tr,
+            hipLaunchKernelGGL((dense::step_dense_kernel<BL, JL, NW, KC>), dim3(grid), dim3(64 * NW), lds, 0, obs, frames, tr,
                                (t & 1) ? p0 : p1, (t & 1) ? p1 : p0, hist, chunks, B, T, S, 1 + (t % (T - 1)), pl.n_bt,
                                pl.n_jt, pl.JT, pl.Kp, pl.NCH, pl.RB);
     };
@@ -63,7 +64,7 @@ void run(int B, int T, int S, int reps) {
         float ms; CHECK(hipEventElapsedTime(&ms, a, b));
         if (ms < best) best = ms;
     }
-    printf("ablate=%d BL=%d JL=%d grid=%d lds=%zu: %.2f us/step  (%.2f Tcell/s useful)\n", DENSE_ABLATE, BL, JL, grid, lds,
+    printf("ablate=%d BL=%d JL=%d NW=%d KC=%d grid=%d lds=%zu: %.2f us/step  (%.2f Tcell/s useful)\n", DENSE_ABLATE, BL, JL, NW, KC, grid, lds,
            best * 1e3 / reps, (double)B * S * S / (best * 1e-3 / reps) / 1e12);
 #if DENSE_TIMING
     {
@@ -72,7 +73,7 @@ void run(int B, int T, int S, int reps) {
         CHECK(hipMemcpyFromSymbol(tb.data(), HIP_SYMBOL(dense::timing_buf), tb.size() * 8));
         double acc[6] = {0, 0, 0, 0, 0, 0};
         unsigned long long tmin = ~0ull, tmax = 0;
-        const int nw = grid * dense::kNW;
+        const int nw = grid * NW;
         for (int w = 0; w < nw; ++w) {
             const unsigned long long *t = &tb[w * 8];
             acc[0] += (double)(t[1] - t[0]);   // setup
@@ -86,12 +87,12 @@ void run(int B, int T, int S, int reps) {
         {   // per-XCD span (clocks differ between XCDs): blocks b with b % 8 == 0
             unsigned long long lo = ~0ull, hi = 0, late = 0; int n = 0;
             for (int blk = 0; blk < grid; blk += 8) {
-                const unsigned long long *t = &tb[(blk * dense::kNW) * 8];
+                const unsigned long long *t = &tb[(blk * NW) * 8];
                 if (t[0] < lo) lo = t[0];
                 if (t[4] > hi) hi = t[4];
             }
             for (int blk = 0; blk < grid; blk += 8) {
-                const unsigned long long *t = &tb[(blk * dense::kNW) * 8];
+                const unsigned long long *t = &tb[(blk * NW) * 8];
                 if (t[0] - lo > 5000) ++late;
                 ++n;
             }
@@ -106,7 +107,7 @@ void run(int B, int T, int S, int reps) {
 
 int main(int argc, char **argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 512, T = 8, S = argc > 2 ? atoi(argv[2]) : 1440;
-    run<8, 6>(B, T, S, 200);
-    run<4, 6>(B, T, S, 200);
+    run<8, 6, 8, 12>(B, T, S, 200);
+    run<8, 6, 16, 6>(B, T, S, 200);
     return 0;
 }

@@ -10,7 +10,14 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return __buil
 struct Frag { float4 p[4]; float4 t[3]; };
 
 template <int NP, int NT>
-__device__ __forceinline__ void load(Frag &f, const float *base, int it) {
+__device__ __forceinline__ void load(Frag &f, const float *base, int it, const float *pb = nullptr, const float *tb = nullptr) {
+    if (pb) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) f.p[n] = *reinterpret_cast<const float4 *>(pb + ((it + n) & 7) * 64 + (n & 1) * 32);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) f.t[n] = *reinterpret_cast<const float4 *>(tb + ((it + n) & 7) * 48);
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         if (n < NP) f.p[n] = *reinterpret_cast<const float4 *>(base + ((it + n) & 7) * 256);
@@ -34,27 +41,29 @@ __device__ __forceinline__ void cells(float (&acc)[8][6], const Frag &f) {
         for (int b = 0; b < 6; ++b) acc[a][b] = max3(acc[a][b], p0[a] + t0[b], p1[a] + t1[b]);
 }
 
-template <int NP, int NT>
+template <int NP, int NT, int PATTERN = 0>
 __global__ __launch_bounds__(1024) void k(float *out, int iters) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 16384; i += blockDim.x) sm[i] = (float)(i & 1023) * 1e-3f;
     __syncthreads();
     const float *base = sm + (wave & 3) * 4096 + lane * 4;
+    const float *pb = PATTERN ? sm + (wave & 7) * 1344 + 4 * (lane & 7) : nullptr;
+    const float *tb = PATTERN ? sm + (wave & 7) * 1344 + 768 + 4 * (lane >> 3) : nullptr;
     float acc[8][6];
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int b = 0; b < 6; ++b) acc[a][b] = -1e30f;
     Frag fa, fb;
-    load<4, 3>(fa, base, 0);
-    load<4, 3>(fb, base, 1);
+    load<4, 3>(fa, base, 0, pb, tb);
+    load<4, 3>(fb, base, 1, pb, tb);
     for (int it = 0; it < iters; it += 2) {
-        load<NP, NT>(fb, base, it);
+        load<NP, NT>(fb, base, it, pb, tb);
         __builtin_amdgcn_sched_barrier(0);
         cells(acc, fa);
         __builtin_amdgcn_sched_barrier(0);
-        load<NP, NT>(fa, base, it + 1);
+        load<NP, NT>(fa, base, it + 1, pb, tb);
         __builtin_amdgcn_sched_barrier(0);
         cells(acc, fb);
         __builtin_amdgcn_sched_barrier(0);
@@ -79,25 +88,20 @@ float time_ms(F f) {
     return best;
 }
 
-template <int NP, int NT>
+template <int NP, int NT, int PATTERN = 0>
 void run(float *out) {
     const int iters = 4000;
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k<NP, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k<NP, NT, PATTERN>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     for (int threads : {512, 768, 1024}) {
-        float ms = time_ms([&] { hipLaunchKernelGGL((k<NP, NT>), dim3(256), dim3(threads), 65536, 0, out, iters); });
+        float ms = time_ms([&] { hipLaunchKernelGGL((k<NP, NT, PATTERN>), dim3(256), dim3(threads), 65536, 0, out, iters); });
         const double cells = 256.0 * threads * 96 * iters;
-        printf("LDS float4/iter: P %d + T %d (%2d dwords) %2d waves/CU: %.3f ms  %.1f Tcell/s\n", NP, NT, 4 * (NP + NT), threads / 64, ms, cells / ms / 1e9);
+        printf("pattern %d LDS float4/iter: P %d + T %d (%2d dwords) %2d waves/CU: %.3f ms  %.1f Tcell/s\n", PATTERN, NP, NT, 4 * (NP + NT), threads / 64, ms, cells / ms / 1e9);
     }
 }
 
 int main() {
     float *out; CHECK(hipMalloc(&out, 1 << 24));
-    run<0, 0>(out);
-    run<1, 0>(out);
-    run<2, 0>(out);
-    run<4, 0>(out);
-    run<0, 3>(out);
-    run<2, 2>(out);
-    run<4, 3>(out);
+    run<4, 3, 0>(out);
+    run<4, 3, 1>(out);
     return 0;
 }

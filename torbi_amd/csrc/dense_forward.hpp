@@ -37,16 +37,11 @@ namespace dense {
 
 #if DENSE_TIMING
 __device__ unsigned long long timing_buf[4096 * 8];
-#define DENSE_STAMP(k) do { if (lane == 0) timing_buf[(blockIdx.x * kNW + wave) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define DENSE_STAMP(k) do { if (lane == 0) timing_buf[(blockIdx.x * NW + wave) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define DENSE_STAMP(k) do { } while (0)
 #endif
 
-constexpr int kNW = 8;    // waves per workgroup = contraction slices
-#ifndef DENSE_KC
-#define DENSE_KC 12
-#endif
-constexpr int kKC = DENSE_KC;   // prev-state rows staged per chunk (multiple of 4)
 
 struct Plan {
     int BL;     // batch items per lane (8 or 4); batch tile width BT = 8*BL
@@ -56,8 +51,10 @@ struct Plan {
     int n_bt;   // batch tiles
     int n_jt;   // state tiles
     int JT;     // next-states per tile (<= W)
-    int Kp;     // padded contraction length (multiple of kKC) >= S
-    int NCH;    // chunks of kKC prev-state rows per panel = Kp / kKC
+    int NW;     // waves per workgroup = contraction slices (8 or 16)
+    int KC;     // prev-state rows staged per chunk (12 with 8 waves, 6 with 16)
+    int Kp;     // padded contraction length (multiple of KC) >= S
+    int NCH;    // chunks of KC prev-state rows per panel = Kp / KC
     int RB;     // XCD region: RB batch tiles x RJ state tiles per XCD (L2 locality only)
 };
 
@@ -67,7 +64,7 @@ struct Plan {
 //    one wave are only hidden when >= 3-4 waves share the SIMD.  BT = 64 halves the L2->LDS
 //    operand traffic instead.  `bl_override` (0 = heuristic) exists for experiments.
 //  * JL is chosen to minimise rounds * W (every workgroup computes all W state slots).
-inline Plan make_plan(int B, int S, int num_cus, int bl_override = 0) {
+inline Plan make_plan(int B, int S, int num_cus, int bl_override = 0, int nw_override = 0) {
     Plan best{};
     const int cus = num_cus > 0 ? num_cus : 256;
     const int BL = bl_override ? bl_override : 8;   // measured: 40.6 us/step (BL=8) vs 43.2 (BL=4) at B=512,S=1440
@@ -96,8 +93,14 @@ inline Plan make_plan(int B, int S, int num_cus, int bl_override = 0) {
     best.BL = BL;
     best.BT = BT;
     best.n_bt = n_bt;
-    best.NCH = (S + kKC - 1) / kKC;
-    best.Kp = best.NCH * kKC;
+    // 8 waves x 12-row chunks.  A 16-wave / 6-row variant (4 waves per SIMD, two-round merge) was
+    // measured: its waves finish the contraction staggered (mean 48.7K ticks instead of 66.5K) but
+    // the workgroup ends no earlier (42.1 vs 40.4 us/step) -- the SIMD's VALU throughput for this
+    // instruction mix does not improve with occupancy.  `nw_override` = 16 still selects it.
+    best.NW = (nw_override == 16 && BL == 8 && best.JL == 6) ? 16 : 8;
+    best.KC = best.NW == 16 ? 6 : 12;
+    best.NCH = (S + best.KC - 1) / best.KC;
+    best.Kp = best.NCH * best.KC;
     best.RB = n_bt >= 2 ? (n_bt + 1) / 2 : 1;
     return best;
 }
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) void pack_transition_kernel(const float *__res
 }
 
 // ---------------------------------------------------------------------------------------
-// once per decode: for every state tile, the ascending list of chunks (kKC prev-state rows) that
+// once per decode: for every state tile, the ascending list of chunks (KC prev-state rows) that
 // hold at least one transition value other than -inf.  A candidate post[i] + (-inf) = -inf can
 // never raise a maximum, so the forward pass skips the other chunks EXACTLY: banded / diagonal /
 // sparse transition matrices (e.g. the reference's own pitch transition,
@@ -142,14 +145,14 @@ __global__ __launch_bounds__(256) void pack_transition_kernel(const float *__res
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void build_chunk_lists_kernel(const float *__restrict__ trp,
                                                                 int32_t *__restrict__ chunks, int S, int JT,
-                                                                int W, int Kp, int NCH) {
+                                                                int W, int Kp, int NCH, int KC) {
     extern __shared__ int flags[];
     const int jt = blockIdx.x;
     const float *panel = trp + (size_t)jt * Kp * W;
     for (int c = threadIdx.x; c < NCH; c += blockDim.x) {
         int any = 0;
-        for (int r = 0; r < kKC && !any; ++r) {
-            const int i = c * kKC + r;
+        for (int r = 0; r < KC && !any; ++r) {
+            const int i = c * KC + r;
             if (i >= S) break;
             const float *row = panel + (size_t)i * W;
             for (int q = 0; q < JT; ++q)
@@ -205,18 +208,17 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
     return __builtin_fmaxf(__builtin_fmaxf(a, b), c);
 }
 
-template <int BL, int JL>
+template <int BL, int JL, int NW, int KC>
 struct StepShape {
+    static_assert(KC % 2 == 0 && KC >= 4, "fragments are prev-state pairs, two in flight");
     static constexpr int BT = 8 * BL;
     static constexpr int W = 8 * JL;
-    static constexpr int CHP = kKC * BT;                  // floats per posterior chunk
-    static constexpr int CHT = kKC * W;                   // floats per transition chunk
-    static constexpr int NP4 = (CHP / 4 + 63) / 64;       // float4 per lane per posterior chunk
-    static constexpr int NT4 = (CHT / 4 + 63) / 64;       // float4 per lane per transition chunk
+    static constexpr int CHP = KC * BT;                   // floats per posterior chunk
+    static constexpr int CHT = KC * W;                    // floats per transition chunk
     static constexpr int STAGE = CHP + CHT;               // floats per wave per stage
     static constexpr int MS = BL * JL + 4;                // merge row stride per lane (bank-spread)
-    static constexpr int STAGE_FLOATS = kNW * 2 * STAGE;  // two stages per wave (ping-pong)
-    static constexpr int MERGE_FLOATS = kNW * 64 * MS;
+    static constexpr int STAGE_FLOATS = NW * 2 * STAGE;   // two stages per wave (ping-pong)
+    static constexpr int MERGE_FLOATS = 8 * 64 * MS;      // at most 8 partial tiles are in LDS at once
     static constexpr int LDS_FLOATS = STAGE_FLOATS > MERGE_FLOATS ? STAGE_FLOATS : MERGE_FLOATS;
 };
 
@@ -282,7 +284,7 @@ __device__ __forceinline__ void cells(float (&acc)[BL][JL], const Frag<BL, JL> &
 #endif
 }
 
-// One chunk (kKC prev-state rows of the posterior panel + of the transition panel) global -> this
+// One chunk (KC prev-state rows of the posterior panel + of the transition panel) global -> this
 // wave's LDS stage by LDS-DMA: the LDS image equals the global image, 1 KiB per wave instruction
 // (destination = M0 = wave-uniform LDS byte address, + lane*16 B), no VGPRs, no ds_write.
 // Written as inline asm on purpose: hipcc orders every later ds_read behind a pending builtin
@@ -315,23 +317,25 @@ __device__ __forceinline__ void dma_chunk(const float *gp, const float *gt, floa
 
 // ---------------------------------------------------------------------------------------
 // one timestep:  post'[b,j] = obs[b,t,j] + max_i ( post[b,i] + trans[j,i] )     (viterbi.cpp:78-108)
-// grid = 8 * ceil(n_bt*n_jt / 8) workgroups of 512 threads; dynamic LDS = lds_bytes<BL,JL>()
+// grid = 8 * ceil(n_bt*n_jt / 8) workgroups of 64*NW threads; dynamic LDS = lds_bytes<...>()
 //
 // lane map: bg = lane & 7 (batch group), jg = lane >> 3 (state group); the lane's register tile
 // is batch positions {4bg..4bg+3} (+32 for BL = 8) x the state slots listed in load_frag.
-// Wave w contracts every 8th listed chunk of kKC prev-state rows; a chunk goes global -> this
-// wave's private LDS stage by LDS-DMA (two stages, ping-pong) -> ds_read fragments, with the next
-// fragment's reads issued before the current fragment's 2*BL*JL cells.
+// The NW waves split the tile's chunk list NW ways; a chunk (KC prev-state rows) goes global ->
+// the wave's private LDS stage by LDS-DMA (two stages, ping-pong) -> ds_read fragments, with two
+// fragments (prev-state pairs) in flight while 2*BL*JL cells of a third are computed.
 // ---------------------------------------------------------------------------------------
-template <int BL, int JL>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BL == 4 ? 4 : 2, BL == 4 ? 4 : 2)))
+template <int BL, int JL, int NW, int KC>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4 * (BL == 4 ? 2 : 1), NW / 4 * (BL == 4 ? 2 : 1))))
 void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict__ frames,
                        const float *__restrict__ trp, const float *__restrict__ pcur,
                        float *__restrict__ pnext, float *__restrict__ hist,
                        const int32_t *__restrict__ chunks, int B, int T, int S, int t, int n_bt, int n_jt,
                        int JT, int Kp, int NCH, int RB) {
-    using Sh = StepShape<BL, JL>;
+    using Sh = StepShape<BL, JL, NW, KC>;
     constexpr int W = Sh::W, BT = Sh::BT;
+    constexpr int RW = BT / NW;                     // tile rows (batch positions) finalised per wave
+    static_assert(RW % 4 == 0 && RW >= 4, "each wave finalises whole groups of 4 batch rows");
     // all LDS is dynamic: a static __shared__ in front would shift the 16-byte alignment the
     // ds_read_b128 fragments rely on
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -346,18 +350,13 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
         const int nrb = (n_bt + RB - 1) / RB;                 // regions along the batch axis
         const int nrj = (8 + nrb - 1) / nrb;                  // regions along the state axis
         const int RJ = (n_jt + nrj - 1) / nrj;
-        const int rb = xcd % nrb, rj = xcd / nrb;
-        const int kb = k % RB, kj = k / RB;
-        bt = rb * RB + kb;
-        jt = rj * RJ + kj;
-        if (kj >= RJ || bt >= n_bt || jt >= n_jt) {
-            // tiles not covered by the rectangle map (uneven grids) are picked up linearly
-            if (nrb * nrj == 8 && n_bt % RB == 0 && n_jt % RJ == 0) return;
-            const int L = blockIdx.x;
-            if (L >= ntiles) return;
-            jt = L / n_bt;
-            bt = L - jt * n_bt;
-        } else if (!(nrb * nrj == 8 && n_bt % RB == 0 && n_jt % RJ == 0)) {
+        const bool rect = nrb * nrj == 8 && n_bt % RB == 0 && n_jt % RJ == 0;
+        if (rect) {
+            const int kb = k % RB, kj = k / RB;
+            if (kj >= RJ) return;
+            bt = (xcd % nrb) * RB + kb;
+            jt = (xcd / nrb) * RJ + kj;
+        } else {                                              // uneven grids: linear order
             const int L = blockIdx.x;
             if (L >= ntiles) return;
             jt = L / n_bt;
@@ -374,28 +373,27 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bg = lane & 7, jg = lane >> 3;
 
-    // This wave contracts a contiguous eighth of the tile's chunk list (build_chunk_lists_kernel):
-    // entries [first, first + nch); lane l keeps the id of the wave's l-th chunk.  Panels with
-    // more than 512 chunks (S > 6144) are walked densely instead.  Loaded first: nothing below
-    // depends on it until the contraction starts.
-    // A dense panel (every chunk listed) is walked arithmetically: the id lookup below costs
-    // ~1.3 us per launch at 15 chunks per wave.
+    // This wave contracts a contiguous 1/NW of the tile's chunk list (build_chunk_lists_kernel):
+    // entries [first, first + nch); lane l keeps the id of the wave's l-th chunk.  A dense panel
+    // (every chunk listed, or more than 64*NW chunks) is walked arithmetically: the id lookup
+    // costs ~1.3 us per launch at 15 chunks per wave.
     const int32_t *list = chunks + (size_t)jt * (NCH + 1);
-    const int count = NCH <= 64 * kNW ? __builtin_amdgcn_readfirstlane(list[0]) : NCH;
+    const int count = NCH <= 64 * NW ? __builtin_amdgcn_readfirstlane(list[0]) : NCH;
     const bool listed = count != NCH;
-    const int per = (count + kNW - 1) / kNW;
+    const int per = (count + NW - 1) / NW;
     const int first = wave * per;
     const int nch = count - first < per ? (count - first > 0 ? count - first : 0) : per;
     int ids = 0;
     if (listed && lane < nch) ids = list[1 + first + lane];
+#define DENSE_CHUNK_ID(c) (listed ? __builtin_amdgcn_readlane(ids, (c)) : first + (c))
 
-    // observation values of the outputs this lane finalises (wave w: batch rows BL*w .. BL*w+BL-1,
+    // observation values of the outputs this lane finalises (wave w: batch rows RW*w .. RW*w+RW-1,
     // lane l: state position l); issued now so that their latency hides under the contraction
-    float ob[BL];
+    float ob[RW];
     const bool fin_lane = lane < JT && j0 + lane < S;
 #pragma unroll
-    for (int u = 0; u < BL; ++u) {
-        const int b = b0 + BL * wave + u;
+    for (int u = 0; u < RW; ++u) {
+        const int b = b0 + RW * wave + u;
         ob[u] = (fin_lane && b < B) ? obs[((size_t)b * T + t) * S + j0 + lane] : 0.0f;
     }
 
@@ -408,11 +406,11 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
 
     const float *gp_base = pcur + (size_t)bt * Kp * BT;
     const float *gt_base = trp + (size_t)jt * Kp * W;
-#define DENSE_CHUNK_ID(c) (listed ? __builtin_amdgcn_readlane(ids, (c)) : first + (c))
     float *stage = smem + wave * 2 * Sh::STAGE;
     constexpr int P4 = Sh::CHP / 4, T4 = Sh::CHT / 4;         // float4 per chunk
+    constexpr int NF = KC / 2;                                // fragments (prev-state pairs) per chunk
 
-    Frag<BL, JL> fa, fb;
+    Frag<BL, JL> frag[2];
     DENSE_STAMP(1);
     if (nch > 0) {
         const int ci = DENSE_CHUNK_ID(0);
@@ -431,20 +429,17 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
             dma_chunk<P4, T4>(gp_base + (size_t)ci * Sh::CHP, gt_base + (size_t)ci * Sh::CHT, nxt, Sh::CHP, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
-        load_frag<BL, JL>(fa, cur, cur + Sh::CHP, 0, bg, jg);
-        load_frag<BL, JL>(fb, cur, cur + Sh::CHP, 2, bg, jg);
+        load_frag<BL, JL>(frag[0], cur, cur + Sh::CHP, 0, bg, jg);
+        load_frag<BL, JL>(frag[1], cur, cur + Sh::CHP, 2, bg, jg);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ip = 0; ip < kKC; ip += 4) {
-            // cells of fragment A while fragment B (and the staging traffic) is in flight, then
-            // refill A and run B
-            cells<BL, JL>(acc, fa);
+        for (int n = 0; n < NF; ++n) {
+            // cells of fragment n while fragment n+1 (and the DMA) is in flight, then refill
+            // this register set with fragment n+2; the sched_barriers keep hipcc from sinking
+            // the reads next to their first use
+            cells<BL, JL>(acc, frag[n & 1]);
             __builtin_amdgcn_sched_barrier(0);
-            if (ip + 4 < kKC) load_frag<BL, JL>(fa, cur, cur + Sh::CHP, ip + 4, bg, jg);
-            __builtin_amdgcn_sched_barrier(0);
-            cells<BL, JL>(acc, fb);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ip + 6 < kKC) load_frag<BL, JL>(fb, cur, cur + Sh::CHP, ip + 6, bg, jg);
+            if (n + 2 < NF) load_frag<BL, JL>(frag[n & 1], cur, cur + Sh::CHP, 2 * (n + 2), bg, jg);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -462,11 +457,37 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
         return;
     }
 #endif
-    // merge the 8 contraction slices through LDS (aliases the staging area).  Slot order is
+    // merge the NW contraction slices through LDS (aliases the staging area).  Slot order is
     // state-major (jj*BL + bb): the batch rows one finalising lane needs are then contiguous, so
-    // both the writes and the reads are ds_*_b128.
+    // both the writes and the reads are ds_*_b128.  With 16 waves the upper 8 first fold into the
+    // lower 8 (at most 8 partial tiles fit in LDS).
     __syncthreads();
-    {
+    if (NW == 16) {
+        float *m = smem + ((size_t)(wave & 7) * 64 + lane) * Sh::MS;
+        if (wave >= 8) {
+#pragma unroll
+            for (int jj = 0; jj < JL; ++jj)
+#pragma unroll
+                for (int h = 0; h < BL / 4; ++h)
+                    *reinterpret_cast<float4 *>(&m[jj * BL + 4 * h]) =
+                        make_float4(acc[4 * h][jj], acc[4 * h + 1][jj], acc[4 * h + 2][jj], acc[4 * h + 3][jj]);
+        }
+        __syncthreads();
+        if (wave < 8) {
+#pragma unroll
+            for (int jj = 0; jj < JL; ++jj)
+#pragma unroll
+                for (int h = 0; h < BL / 4; ++h) {
+                    const float4 x = *reinterpret_cast<const float4 *>(&m[jj * BL + 4 * h]);
+                    acc[4 * h][jj] = fmaxf(acc[4 * h][jj], x.x);
+                    acc[4 * h + 1][jj] = fmaxf(acc[4 * h + 1][jj], x.y);
+                    acc[4 * h + 2][jj] = fmaxf(acc[4 * h + 2][jj], x.z);
+                    acc[4 * h + 3][jj] = fmaxf(acc[4 * h + 3][jj], x.w);
+                }
+        }
+        __syncthreads();
+    }
+    if (wave < 8) {
         float *m = smem + ((size_t)wave * 64 + lane) * Sh::MS;
 #pragma unroll
         for (int jj = 0; jj < JL; ++jj)
@@ -478,45 +499,45 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
     __syncthreads();
     DENSE_STAMP(3);
 
-    // finalize: wave w owns tile rows (batch positions) BL*w .. BL*w+BL-1, lane l state position l.
+    // finalize: wave w owns tile rows (batch positions) RW*w .. RW*w+RW-1, lane l state position l.
     // Row r lives in lane group bg = (r & 31) >> 2 at register row bb = (r & 3) + 4*(r >> 5); for
-    // the 4-row group g of this wave (rows BL*w + 4g .. +3) bg and bb & ~3 are constant.
+    // the 4-row group g of this wave (rows RW*w + 4g .. +3) bg and bb & ~3 are constant.
     if (fin_lane) {
         const int p = lane;
         const int src_jg = JL == 2 ? (p >> 1) : (p < 32 ? (p >> 2) : ((p - 32) >> 1));
         const int jj = JL == 2 ? (p & 1) : (p < 32 ? (p & 3) : 4 + (p & 1));
         const int j = j0 + p;
-        float out[BL];
+        float out[RW];
 #pragma unroll
-        for (int g = 0; g < BL / 4; ++g) {
-            const int r0 = BL * wave + 4 * g;
+        for (int g = 0; g < RW / 4; ++g) {
+            const int r0 = RW * wave + 4 * g;
             const int src_bg = (r0 & 31) >> 2;
             const int bb0 = 4 * (r0 >> 5);
             const float *m = smem + (size_t)(src_jg * 8 + src_bg) * Sh::MS + jj * BL + bb0;
             float4 v = *reinterpret_cast<const float4 *>(m);
 #pragma unroll
-            for (int w = 1; w < kNW; ++w) {
+            for (int w = 1; w < 8; ++w) {
                 const float4 x = *reinterpret_cast<const float4 *>(m + (size_t)w * 64 * Sh::MS);
                 v.x = fmaxf(v.x, x.x); v.y = fmaxf(v.y, x.y); v.z = fmaxf(v.z, x.z); v.w = fmaxf(v.w, x.w);
             }
             out[4 * g] = v.x; out[4 * g + 1] = v.y; out[4 * g + 2] = v.z; out[4 * g + 3] = v.w;
         }
 #pragma unroll
-        for (int u = 0; u < BL; ++u) {
-            const int b = b0 + BL * wave + u;
+        for (int u = 0; u < RW; ++u) {
+            const int b = b0 + RW * wave + u;
             const float o = ob[u] + out[u];
             if (b < B && t < frames[b]) hist[((size_t)b * T + t) * S + j] = o;
             out[u] = b < B ? o : 0.0f;
         }
-        float4 *dst = reinterpret_cast<float4 *>(pnext + ((size_t)bt * Kp + j) * BT + BL * wave);
+        float4 *dst = reinterpret_cast<float4 *>(pnext + ((size_t)bt * Kp + j) * BT + RW * wave);
 #pragma unroll
-        for (int h = 0; h < BL / 4; ++h)
+        for (int h = 0; h < RW / 4; ++h)
             dst[h] = make_float4(out[4 * h], out[4 * h + 1], out[4 * h + 2], out[4 * h + 3]);
     }
     DENSE_STAMP(4);
 }
 
-template <int BL, int JL>
-constexpr size_t lds_bytes() { return sizeof(float) * (size_t)StepShape<BL, JL>::LDS_FLOATS; }
+template <int BL, int JL, int NW, int KC>
+constexpr size_t lds_bytes() { return sizeof(float) * (size_t)StepShape<BL, JL, NW, KC>::LDS_FLOATS; }
 
 }  // namespace dense

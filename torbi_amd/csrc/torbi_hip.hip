@@ -406,9 +406,19 @@ inline int bl_override() {
     return v;
 }
 
+// TORBI_HIP_NW=8|16 forces the waves per workgroup of the 8x6 dense tile (experiments)
+inline int nw_override() {
+    static const int v = [] {
+        const char *e = getenv("TORBI_HIP_NW");
+        const int x = e ? atoi(e) : 0;
+        return (x == 8 || x == 16) ? x : 0;
+    }();
+    return v;
+}
+
 inline DenseWorkspace carve_dense(void *base, int B, int T, int S) {
     DenseWorkspace w;
-    w.plan = dense::make_plan(B, S, kNumCUs, bl_override());
+    w.plan = dense::make_plan(B, S, kNumCUs, bl_override(), nw_override());
     char *p = static_cast<char *>(base);
     const size_t panel_bytes = align_up(sizeof(float) * (size_t)w.plan.n_bt * w.plan.Kp * w.plan.BT, 256);
     const size_t trp_bytes = align_up(sizeof(float) * (size_t)w.plan.n_jt * w.plan.Kp * w.plan.W, 256);
@@ -474,19 +484,19 @@ hipError_t launch_finalize(const int32_t *frames, const Workspace &w, int32_t *o
 }
 
 // ---- dense path -----------------------------------------------------------------------
-template <int BL, int JL>
+template <int BL, int JL, int NW, int KC>
 hipError_t launch_dense_steps(const float *obs, const int32_t *frames, const DenseWorkspace &w,
                               int B, int T, int S, hipStream_t stream, int *launches) {
     const dense::Plan &pl = w.plan;
-    const size_t lds = dense::lds_bytes<BL, JL>();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense::step_dense_kernel<BL, JL>),
+    const size_t lds = dense::lds_bytes<BL, JL, NW, KC>();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense::step_dense_kernel<BL, JL, NW, KC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int ntiles = pl.n_bt * pl.n_jt;
     const int grid = 8 * ((ntiles + 7) / 8);
     int n = 0;
     for (int t = 1; t < T; ++t) {
-        hipLaunchKernelGGL((dense::step_dense_kernel<BL, JL>), dim3(grid), dim3(512), lds, stream, obs,
+        hipLaunchKernelGGL((dense::step_dense_kernel<BL, JL, NW, KC>), dim3(grid), dim3(64 * NW), lds, stream, obs,
                            frames, w.trp, w.panel[(t - 1) & 1], w.panel[t & 1], w.hist, w.chunks, B, T, S,
                            t, pl.n_bt, pl.n_jt, pl.JT, pl.Kp, pl.NCH, pl.RB);
         ++n;
@@ -502,7 +512,8 @@ hipError_t launch_dense_forward(const float *obs, const int32_t *frames, const f
     hipLaunchKernelGGL(dense::pack_transition_kernel, dim3((pl.Kp + 63) / 64, pl.n_jt), dim3(256), 0,
                        stream, trans, w.trp, S, pl.JT, pl.W, pl.Kp);
     hipLaunchKernelGGL(dense::build_chunk_lists_kernel, dim3(pl.n_jt), dim3(256),
-                       sizeof(int) * (size_t)pl.NCH, stream, w.trp, w.chunks, S, pl.JT, pl.W, pl.Kp, pl.NCH);
+                       sizeof(int) * (size_t)pl.NCH, stream, w.trp, w.chunks, S, pl.JT, pl.W, pl.Kp, pl.NCH,
+                       pl.KC);
     {
         const size_t n = (size_t)pl.n_bt * pl.BT * pl.Kp;
         const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
@@ -511,14 +522,16 @@ hipError_t launch_dense_forward(const float *obs, const int32_t *frames, const f
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-#define TORBI_DENSE_CASE(BL_, JL_) \
-    if (pl.BL == BL_ && pl.JL == JL_) return launch_dense_steps<BL_, JL_>(obs, frames, w, B, T, S, stream, launches)
-    TORBI_DENSE_CASE(4, 6);
-    TORBI_DENSE_CASE(4, 4);
-    TORBI_DENSE_CASE(4, 2);
-    TORBI_DENSE_CASE(8, 6);
-    TORBI_DENSE_CASE(8, 4);
-    TORBI_DENSE_CASE(8, 2);
+#define TORBI_DENSE_CASE(BL_, JL_, NW_, KC_)                                         \
+    if (pl.BL == BL_ && pl.JL == JL_ && pl.NW == NW_ && pl.KC == KC_)                 \
+        return launch_dense_steps<BL_, JL_, NW_, KC_>(obs, frames, w, B, T, S, stream, launches)
+    TORBI_DENSE_CASE(8, 6, 16, 6);
+    TORBI_DENSE_CASE(8, 6, 8, 12);
+    TORBI_DENSE_CASE(8, 4, 8, 12);
+    TORBI_DENSE_CASE(8, 2, 8, 12);
+    TORBI_DENSE_CASE(4, 6, 8, 12);
+    TORBI_DENSE_CASE(4, 4, 8, 12);
+    TORBI_DENSE_CASE(4, 2, 8, 12);
 #undef TORBI_DENSE_CASE
     return hipErrorInvalidValue;
 }
