@@ -113,6 +113,43 @@ def test_uniform_transition_entry_equals_materialised_matrix(shape, ties):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize('shape', [(64, 1, 64), (33, 2, 100), (32, 3, 8192), (48, 4, 6148)])
+def test_dense_path_edge_shapes(shape):
+    """T = 1 (no recurrence step), T = 2, and panels too long for the chunk-list walk (S > 6144)."""
+    B, T, S = shape
+    obs, trans, init = synth.problem(B, T, S, seed=B + S)
+    frames = np.clip(synth.lengths(B, 1, T, seed=5), 1, T)
+    want = oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())
+    assert np.array_equal(gpu_decode(obs, frames, trans, init), want)
+
+
+@pytest.mark.parametrize('B', [2, 40])
+def test_out_of_range_lengths_are_clamped(B):
+    """batch_frames outside [1, T] is clamped on the device (the reference reads out of bounds
+    for 0, viterbi.cpp:153): 0 and negatives behave as 1, values > T as T."""
+    T, S = 9, 72
+    obs, trans, init = synth.problem(B, T, S, seed=B)
+    frames = np.full((B,), T, np.int32)
+    frames[0], frames[1] = 0, T + 7
+    clamped = np.clip(frames, 1, T)
+    want = oracle.decode(obs, clamped, trans, init)
+    assert np.array_equal(gpu_decode(obs, frames, trans, init), want)
+
+
+def test_non_contiguous_inputs_are_accepted():
+    """the reference calls .contiguous() inside the op (viterbi.cu:325-328)"""
+    dev = torch.device('cuda:0')
+    B, T, S = 34, 6, 80
+    obs, trans, init = synth.problem(B, T, 2 * S, seed=1)
+    o = torch.tensor(obs, device=dev)[:, :, ::2]
+    tr = torch.tensor(synth.scores(2, (2 * S, S), seed=1), device=dev)[::2]
+    i = torch.tensor(init, device=dev)[::2]
+    frames = torch.full((B,), T, dtype=torch.int32, device=dev)
+    got = torbi_amd.decode(o, frames, tr, i).cpu().numpy()
+    want = oracle.decode(o.cpu().numpy(), frames.cpu().numpy(), tr.cpu().numpy(), i.cpu().numpy())
+    assert np.array_equal(got, want)
+
+
 def test_posterior_rows_match_oracle_bitwise():
     B, T, S = 5, 23, 300
     obs, trans, init = synth.problem(B, T, S, seed=77)
