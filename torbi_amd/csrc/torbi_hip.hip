@@ -643,14 +643,14 @@ int torbi_hip_viterbi_decode_uniform(const float *observation, const int32_t *ba
     if (guard.err != hipSuccess) return (int)guard.err;
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define TORBI_UNIFORM_CASE(NQ_, DEPTH_)                                                             \
-    if (S <= 256 * NQ_) {                                                                           \
-        hipLaunchKernelGGL((uniform::uniform_decode_kernel<NQ_, DEPTH_>), dim3(B), dim3(64), 0, s,  \
+    if (S <= 1024 * NQ_) {                                                                          \
+        hipLaunchKernelGGL((uniform::uniform_decode_kernel<NQ_, DEPTH_>), dim3(B), dim3(256), 0, s, \
                            observation, batch_frames, initial, log_transition, indices_out, B, T, S); \
         return (int)hipGetLastError();                                                              \
     }
+    TORBI_UNIFORM_CASE(1, 4)
     TORBI_UNIFORM_CASE(2, 4)
-    TORBI_UNIFORM_CASE(6, 4)
-    TORBI_UNIFORM_CASE(16, 2)
+    TORBI_UNIFORM_CASE(4, 4)
 #undef TORBI_UNIFORM_CASE
     return TORBI_HIP_EUNSUPPORTED;
 }
