@@ -289,5 +289,16 @@ def test_files_round_trip(tmp_path):
         trans = torch.log(torch.load(tf) + torch.finfo(torch.float32).tiny)
         want = torbi_amd.from_probabilities(obs, transition=trans, log_probs=True, gpu=0)
         assert torch.equal(got, want[0].cpu())
+    # length-bucketed batching writes the same files
+    outs2 = [tmp_path / f'sorted{k}.pt' for k in range(len(ins))]
+    saved = torbi_amd.core.BATCH_SIZE
+    torbi_amd.core.BATCH_SIZE = 2
+    try:
+        torbi_amd.from_files_to_files(ins, outs2, transition_file=tf, log_probs=True, gpu=0,
+                                      lengths=[5, 17, 1, 9])
+    finally:
+        torbi_amd.core.BATCH_SIZE = saved
+    for a, b2 in zip(outs, outs2):
+        assert torch.equal(torch.load(a), torch.load(b2))
     torbi_amd.from_file_to_file(ins[1], tmp_path / 'single.pt', log_probs=True, gpu=0)
     assert torch.load(tmp_path / 'single.pt').shape == (1, 17)

@@ -196,13 +196,22 @@ def from_files_to_files(
     initial_file: Optional[Union[str, os.PathLike]] = None,
     log_probs: bool = False,
     gpu: Optional[int] = None,
-    num_threads: Optional[int] = None
+    num_threads: Optional[int] = None,
+    lengths: Optional[List[int]] = None,
+    num_workers: Optional[int] = None
 ) -> None:
     """Decode time-varying categorical distribution files and save (core.py:310-368)
 
     Files are batched `BATCH_SIZE` (512) at a time in the given order, zero-padded to the
     longest item of the batch (reference torbi/data/collate.py:24-33) and each output holds
     the first `frames` indices of its item (core.py:449-457).
+
+    Two additions over the reference signature, both result-neutral (items are independent
+    and every output is written to the file mapped to its input):
+        lengths      frames per input file, when known: batches are then formed from files
+                     of similar length (longest first), which removes most of the padding a
+                     ragged collection costs (every padded frame is a full recurrence step)
+        num_workers  DataLoader workers for torch.load (reference default 0, loader.py:19-25)
     """
     if transition_file:
         transition = torch.load(transition_file)
@@ -216,8 +225,14 @@ def from_files_to_files(
     mapping = {
         input_file: output_file for input_file, output_file in zip(input_files, output_files)}
 
+    if lengths is not None:
+        if len(lengths) != len(input_files):
+            raise ValueError('lengths must have one entry per input file')
+        order = sorted(range(len(input_files)), key=lambda k: (-int(lengths[k]), k))
+        input_files = [input_files[k] for k in order]
+
     from_dataloader(
-        dataloader=_data.loader(input_files),
+        dataloader=_data.loader(input_files, num_workers=num_workers),
         output_files=mapping,
         transition=transition,
         initial=initial,

@@ -13,6 +13,8 @@
 #include <stdint.h>
 #include <math.h>
 
+#include "wave_reduce.hpp"
+
 namespace lazy {
 
 constexpr int kSentinel = 0x7fffffff;
@@ -89,10 +91,46 @@ __global__ __launch_bounds__(64) void backtrace_kernel(const float *__restrict__
     }
 }
 
+// first index (ascending) among this lane's 4*NQ elements whose value equals m, else kSentinel
+template <int NQ>
+__device__ __forceinline__ int lane_first_equal(const float4 (&v)[NQ], float m, int lane, int S) {
+    int k = kSentinel;
+#pragma unroll
+    for (int q = NQ - 1; q >= 0; --q) {
+        const int i = 4 * lane + 256 * q;
+        if (i < S) {
+            int kq = v[q].w == m ? i + 3 : kSentinel;
+            kq = v[q].z == m ? i + 2 : kq;
+            kq = v[q].y == m ? i + 1 : kq;
+            kq = v[q].x == m ? i : kq;
+            k = min(k, kq);
+        }
+    }
+    return k;
+}
+
+template <int NQ>
+__device__ __forceinline__ float lane_max(const float4 (&v)[NQ], int lane, int S) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        if (4 * lane + 256 * q < S)
+            m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fmaxf(v[q].x, v[q].y)), __builtin_fmaxf(v[q].z, v[q].w));
+    return m;
+}
+
+// first argmax over the wave: max value by DPP all-reduce (exact, order independent), then the
+// lowest index whose candidate equals it -- the reference's strict-'>' scan (viterbi.cpp:94-100)
+template <int NQ>
+__device__ __forceinline__ int wave_first_argmax4(const float4 (&v)[NQ], int lane, int S) {
+    const float m = wavered::wave_reduce_f32(lane_max<NQ>(v, lane, S), wavered::MaxOp());
+    return wavered::wave_min_i32(lane_first_equal<NQ>(v, m, lane, S));
+}
+
 // Register-resident form for S % 4 == 0 and S <= 256*NQ: the posterior row of the NEXT path step
 // does not depend on the state being resolved, so it is prefetched into registers while the current
 // step's transition row (which does) is in flight; one wave per batch item, lanes own 4 consecutive
-// prev-states per 256-wide stripe (ascending per lane, as the reference scan).
+// prev-states per 256-wide stripe.
 template <int NQ>
 __global__ __launch_bounds__(64) void backtrace_prefetch_kernel(const float *__restrict__ hist,
                                                                 const float *__restrict__ trans,
@@ -104,7 +142,7 @@ __global__ __launch_bounds__(64) void backtrace_prefetch_kernel(const float *__r
     f = f < 1 ? 1 : (f > T ? T : f);
     const float *h = hist + (size_t)b * T * S;
     int32_t *o = out + (size_t)b * T;
-    const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 
     float4 cur[NQ], nxt[NQ];
     {
@@ -112,28 +150,20 @@ __global__ __launch_bounds__(64) void backtrace_prefetch_kernel(const float *__r
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int i = 4 * lane + 256 * q;
-            cur[q] = i < S ? *reinterpret_cast<const float4 *>(row + i) : ninf;
+            cur[q] = i < S ? *reinterpret_cast<const float4 *>(row + i) : zero;
         }
     }
-    if (f >= 2) {
-        const float *row = h + (size_t)(f - 2) * S;
+    {   // row f-2 (clamped to row 0: valid memory, unused when f == 1)
+        const float *row = h + (size_t)(f >= 2 ? f - 2 : 0) * S;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int i = 4 * lane + 256 * q;
-            nxt[q] = i < S ? *reinterpret_cast<const float4 *>(row + i) : ninf;
+            nxt[q] = i < S ? *reinterpret_cast<const float4 *>(row + i) : zero;
         }
     }
-    float best = -INFINITY;
-    int arg = kSentinel;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int i = 4 * lane + 256 * q;
-        if (i < S) {
-            scan1(cur[q].x, i, best, arg); scan1(cur[q].y, i + 1, best, arg);
-            scan1(cur[q].z, i + 2, best, arg); scan1(cur[q].w, i + 3, best, arg);
-        }
-    }
-    int j = wave_first_argmax(best, arg);
+    // final state = first argmax of the last posterior row (viterbi.cpp:218)
+    int j = wave_first_argmax4<NQ>(cur, lane, S);
+    // every position t >= frames-1 holds the final state (viterbi.cpp:219-221)
     for (int tt = f - 1 + lane; tt < T; tt += 64) o[tt] = j;
 
     for (int tt = f - 1; tt >= 1; --tt) {
@@ -143,30 +173,24 @@ __global__ __launch_bounds__(64) void backtrace_prefetch_kernel(const float *__r
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int i = 4 * lane + 256 * q;
-            q4[q] = i < S ? *reinterpret_cast<const float4 *>(tr + i) : ninf;
+            q4[q] = i < S ? *reinterpret_cast<const float4 *>(tr + i) : zero;
         }
         // ... posterior row tt-1 is already in registers; fetch row tt-2 for the next step
 #pragma unroll
         for (int q = 0; q < NQ; ++q) cur[q] = nxt[q];
-        if (tt >= 2) {
-            const float *row = h + (size_t)(tt - 2) * S;
+        {
+            const float *row = h + (size_t)(tt >= 2 ? tt - 2 : 0) * S;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int i = 4 * lane + 256 * q;
-                nxt[q] = i < S ? *reinterpret_cast<const float4 *>(row + i) : ninf;
+                nxt[q] = i < S ? *reinterpret_cast<const float4 *>(row + i) : zero;
             }
         }
-        best = -INFINITY;
-        arg = kSentinel;
+        float4 cand[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int i = 4 * lane + 256 * q;
-            if (i < S) {
-                scan1(cur[q].x + q4[q].x, i, best, arg); scan1(cur[q].y + q4[q].y, i + 1, best, arg);
-                scan1(cur[q].z + q4[q].z, i + 2, best, arg); scan1(cur[q].w + q4[q].w, i + 3, best, arg);
-            }
-        }
-        j = wave_first_argmax(best, arg);
+        for (int q = 0; q < NQ; ++q)
+            cand[q] = make_float4(cur[q].x + q4[q].x, cur[q].y + q4[q].y, cur[q].z + q4[q].z, cur[q].w + q4[q].w);
+        j = wave_first_argmax4<NQ>(cand, lane, S);
         if (lane == 0) o[tt - 1] = j;
     }
 }
