@@ -99,6 +99,8 @@ def main():
     ap.add_argument('--frames', type=int, default=500)
     ap.add_argument('--states', type=int, default=1440)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--pipeline', type=int, default=2,
+                    help='decodes in flight (torbi_amd.DecodePipeline streams); 1 = strictly serial')
     ap.add_argument('--transition', choices=['dense', 'banded', 'uniform'], default='dense',
                     help="dense = headline workload; banded = the reference's pitch transition "
                          '(torbi/evaluate/core.py:24-33), secondary structured-transition line')
@@ -124,16 +126,22 @@ def main():
     import math
     uniform_c = float(torch.tensor(math.log(1.0 / S), dtype=torch.float32))
 
+    pipe = torbi_amd.DecodePipeline(dev, depth=args.pipeline) if args.pipeline > 1 else None
+
+    def gather(idx):
+        return distributed.gather_indices(idx, B * size, force=True) if collective else idx
+
     def step():
         if args.transition == 'uniform':
-            idx = torbi_amd.decode_uniform(obs, frames, uniform_c, init)
-        else:
-            idx = torbi_amd.decode(obs, frames, trans, init, workspace=ws)
-        if collective:
-            idx = distributed.gather_indices(idx, B * size, force=True)
-        return idx
+            return gather(torbi_amd.decode_uniform(obs, frames, uniform_c, init))
+        if pipe is not None:     # consecutive batches alternate between HIP streams
+            return pipe.decode(obs, frames, trans, init, after=gather)
+        return gather(torbi_amd.decode(obs, frames, trans, init, workspace=ws))
 
     def fence():
+        if pipe is not None:
+            pipe.synchronize()
+        torch.cuda.synchronize()
         if collective:
             dist.barrier()
         torch.cuda.synchronize()
@@ -201,7 +209,8 @@ def main():
                                if args.transition == 'dense' else
                                f'{S} states, {T} frames, batch={B} per GPU, fp32, BANDED transition '
                                f'(half width {args.half_width}, -inf outside; secondary workload)',
-                   'parallelism': f'batch-sharded x{size}' if size > 1 else 'single GPU'},
+                   'parallelism': f'batch-sharded x{size}' if size > 1 else 'single GPU',
+                   'decodes_in_flight': args.pipeline},
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS, 'traffic': None,

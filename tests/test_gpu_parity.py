@@ -150,6 +150,26 @@ def test_non_contiguous_inputs_are_accepted():
     assert np.array_equal(got, want)
 
 
+def test_decode_pipeline_equals_serial_decodes():
+    """torbi_amd.DecodePipeline: consecutive batches on alternating streams, private scratch."""
+    dev = torch.device('cuda:0')
+    pipe = torbi_amd.DecodePipeline(dev, depth=2)
+    S = 360
+    trans = torch.tensor(synth.scores(2, (S, S), seed=3), device=dev)
+    init = torch.tensor(synth.scores(3, (S,), seed=3), device=dev)
+    batches, outs = [], []
+    for k, (B, T) in enumerate([(64, 30), (40, 17), (96, 45), (33, 8), (64, 30), (128, 12)]):
+        obs = torch.tensor(synth.scores(1, (B, T, S), seed=k), device=dev)
+        frames = torch.tensor(np.clip(synth.lengths(B, 1, T, seed=k), 1, T), device=dev)
+        batches.append((obs, frames))
+        outs.append(pipe.decode(obs, frames, trans, init))
+    pipe.synchronize()
+    for (obs, frames), got in zip(batches, outs):
+        want = oracle.decode(obs.cpu().numpy(), frames.cpu().numpy(), trans.cpu().numpy(),
+                             init.cpu().numpy(), num_threads=oracle.max_threads())
+        assert np.array_equal(got.cpu().numpy(), want)
+
+
 def test_posterior_rows_match_oracle_bitwise():
     B, T, S = 5, 23, 300
     obs, trans, init = synth.problem(B, T, S, seed=77)

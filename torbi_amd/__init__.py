@@ -11,7 +11,8 @@ from .core import (BATCH_SIZE, NUM_WORKERS, from_probabilities, from_file, from_
 from . import data
 from . import synth
 from . import distributed
+from .pipeline import DecodePipeline
 
 __all__ = ['decode', 'decode_uniform', 'workspace_bytes', 'from_probabilities', 'from_file', 'from_file_to_file',
            'from_files_to_files', 'from_dataloader', 'save', 'save_masked', 'data', 'synth',
-           'distributed', 'BATCH_SIZE', 'NUM_WORKERS']
+           'distributed', 'DecodePipeline', 'BATCH_SIZE', 'NUM_WORKERS']

@@ -39,7 +39,8 @@ def from_probabilities(
     initial: Optional[torch.Tensor] = None,
     log_probs: bool = False,
     gpu: Optional[int] = None,
-    num_threads: Optional[int] = 1
+    num_threads: Optional[int] = 1,
+    _pipeline=None
 ) -> torch.Tensor:
     """Decode a time-varying categorical distribution
 
@@ -117,6 +118,9 @@ def from_probabilities(
 
     if uniform is not None:
         indices = decode_uniform(observation, batch_frames, uniform, initial)
+    elif _pipeline is not None:
+        # asynchronous: valid after _pipeline.wait(indices); the caller owns the host copy
+        return _pipeline.decode(observation, batch_frames, transition, initial)
     else:
         indices = decode(observation, batch_frames, transition, initial, num_threads=num_threads)
     return indices.cpu() if to_host else indices
@@ -252,7 +256,28 @@ def from_dataloader(
     gpu: Optional[int] = None,
     num_threads: Optional[int] = 1
 ) -> None:
-    """Decode time-varying categorical distributions from dataloader (core.py:376-463)"""
+    """Decode time-varying categorical distributions from dataloader (core.py:376-463)
+
+    The reference loop is serial (decode, copy back, save, next batch).  Here batch k+1 is
+    enqueued (torbi_amd.DecodePipeline: alternating HIP streams) before batch k's indices are
+    copied back and saved, so loading/saving and the backtrace of one batch overlap the forward
+    pass of the next.  Outputs are identical.
+    """
+    from .pipeline import DecodePipeline
+    pipe = None
+    if torch.cuda.is_available():
+        device = torch.device('cuda', torch.cuda.current_device() if gpu is None else gpu)
+        pipe = DecodePipeline(device)
+
+    def finish(item):
+        indices, input_filenames, batch_frames = item
+        if pipe is not None:
+            pipe.wait(indices)
+        filenames = [output_files[file] for file in input_filenames]
+        for row, filename, frames in zip(indices.cpu().detach(), filenames, batch_frames.cpu()):
+            save_masked(row, filename, frames)
+
+    previous = None
     for observation, batch_frames, batch_chunks, input_filenames in dataloader:
         indices = from_probabilities(
             observation=observation,
@@ -261,12 +286,13 @@ def from_dataloader(
             initial=initial,
             log_probs=log_probs,
             gpu=gpu,
-            num_threads=num_threads)
-
-        filenames = [output_files[file] for file in input_filenames]
-
-        for item, filename, frames in zip(indices.cpu().detach(), filenames, batch_frames.cpu()):
-            save_masked(item, filename, frames)
+            num_threads=num_threads,
+            _pipeline=pipe)
+        if previous is not None:
+            finish(previous)
+        previous = (indices, input_filenames, batch_frames)
+    if previous is not None:
+        finish(previous)
 
 
 def save(tensor, file):

@@ -1,0 +1,85 @@
+"""Stream-level pipelining of consecutive decodes.
+
+One decode is a chain of ~500 dependent step launches followed by a latency-bound backtrace
+(one wave per item, ~1 ms at B=512, T=500).  Batches are independent, so the next batch's
+forward pass can run while the previous batch's backtrace drains and its launch gaps are
+filled: alternating decodes between two HIP streams (each with its own scratch) measured
+18.6 ms per 512x500x1440 decode against 20.3 ms on one stream, with identical results.
+
+The reference's driver is fully serial (load -> decode -> save, torbi/core.py:417-457).
+`DecodePipeline` keeps `decode`'s contract per call; only completion is deferred: the returned
+indices are valid once `wait(indices)` / `synchronize()` returns (or on the stream the pipeline
+used, for callers that chain more GPU work).
+"""
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import viterbi
+
+
+class DecodePipeline:
+    """Round-robin decodes over `depth` side streams, each with a private scratch buffer."""
+
+    def __init__(self, device=None, depth: int = 2):
+        if not torch.cuda.is_available():
+            raise RuntimeError('DecodePipeline needs a HIP device; torbi_amd has no CPU path')
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None \
+            else torch.device(device)
+        self.depth = max(1, int(depth))
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
+        self.scratch: List[Optional[torch.Tensor]] = [None] * self.depth
+        self.pending: List[Tuple[torch.Tensor, torch.cuda.Event]] = []
+        self.turn = 0
+
+    def _scratch(self, slot, nbytes):
+        buf = self.scratch[slot]
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+            self.scratch[slot] = buf
+        return buf
+
+    def decode(self, observation, batch_frames, transition, initial, after=None) -> torch.Tensor:
+        """Enqueue one decode; arguments as `torbi_amd.decode` (tensors on `self.device`).
+
+        `after(indices)` (optional) runs on the same side stream right after the decode, e.g. the
+        RCCL gather of a sharded batch or an asynchronous copy to pinned host memory.
+        """
+        slot = self.turn % self.depth
+        self.turn += 1
+        stream = self.streams[slot]
+        B, T, S = observation.shape
+        need = viterbi.workspace_bytes(B, T, S)
+        # the inputs may have been produced on the caller's stream
+        stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(stream):
+            scratch = self._scratch(slot, need)
+            indices = viterbi.decode(observation, batch_frames, transition, initial, workspace=scratch)
+            if after is not None:
+                indices = after(indices)
+            done = torch.cuda.Event()
+            done.record(stream)
+        # keep the inputs alive for the allocator until the side stream is done with them
+        for tensor in (observation, batch_frames, transition, initial):
+            if tensor.is_cuda:
+                tensor.record_stream(stream)
+        self.pending.append((indices, done))
+        if len(self.pending) > 4 * self.depth:
+            self.pending = [(i, e) for i, e in self.pending if not e.query()]
+        return indices
+
+    def wait(self, indices: torch.Tensor) -> torch.Tensor:
+        """Block the host until the decode that produced `indices` has finished."""
+        for tensor, event in self.pending:
+            if tensor is indices:
+                event.synchronize()
+                break
+        return indices
+
+    def synchronize(self) -> None:
+        """Block the host until every enqueued decode has finished."""
+        for _, event in self.pending:
+            event.synchronize()
+        self.pending = []
+        for stream in self.streams:
+            stream.synchronize()
