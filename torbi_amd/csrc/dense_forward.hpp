@@ -256,32 +256,18 @@ __device__ __forceinline__ void load_frag(Frag<BL, JL> &f, const float *lp, cons
     }
 }
 
-#ifndef DENSE_SKEW
-#define DENSE_SKEW 1   // 1: issue the two adds of cell k+1 before the max3 of cell k
-#endif
-
+// 2*BL*JL cells of one fragment: add, add, max3 per prev-state pair.  Orderings that separate a
+// v_max3_f32 from the v_add_f32 pair it consumes (skewing by one cell, or issuing the adds of one
+// to four batch rows before their max3s with sched_barriers) were measured and are not faster in
+// this kernel (contraction loop 66.2K vs 66.5K / 68.2K-70.4K ticks), although a register-only
+// probe prefers them (tools/ubench8); the plain order is kept.
 template <int BL, int JL>
 __device__ __forceinline__ void cells(float (&acc)[BL][JL], const Frag<BL, JL> &f) {
-#if DENSE_SKEW
-    // software-pipelined by one cell so that a v_max3_f32 never directly follows the v_add_f32
-    // pair it consumes
-    float c0 = f.p0[0] + f.t0[0], c1 = f.p1[0] + f.t1[0];
-#pragma unroll
-    for (int k = 1; k < BL * JL; ++k) {
-        const int bb = k / JL, jj = k % JL, pb = (k - 1) / JL, pj = (k - 1) % JL;
-        const float n0 = f.p0[bb] + f.t0[jj], n1 = f.p1[bb] + f.t1[jj];
-        acc[pb][pj] = max3(acc[pb][pj], c0, c1);
-        c0 = n0;
-        c1 = n1;
-    }
-    acc[BL - 1][JL - 1] = max3(acc[BL - 1][JL - 1], c0, c1);
-#else
 #pragma unroll
     for (int bb = 0; bb < BL; ++bb)
 #pragma unroll
         for (int jj = 0; jj < JL; ++jj)
             acc[bb][jj] = max3(acc[bb][jj], f.p0[bb] + f.t0[jj], f.p1[bb] + f.t1[jj]);
-#endif
 }
 
 // One chunk (KC prev-state rows of the posterior panel + of the transition panel) global -> this
