@@ -31,6 +31,22 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz lane-instructions/s
 
 
+def profiled_traffic(kernel_prefix):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (profiles/r01_pmc.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).
+    FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950;
+    both counters are in KiB and include Infinity-Cache hits.  None when no summary matches."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')))
+        for name, counters in pmc.items():
+            if kernel_prefix in name and 'FETCH_SIZE' in counters and 'WRITE_SIZE' in counters:
+                return (2.0 * counters['FETCH_SIZE']['mean_per_dispatch']
+                        + counters['WRITE_SIZE']['mean_per_dispatch']) * 1024.0
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def algorithmic_bytes_per_timestep(S):
     """4S observation read + 4S int32 backpointer write + 8 (backtrace)."""
     return 8 * S + 8
@@ -213,7 +229,12 @@ def main():
                    'decodes_in_flight': args.pipeline},
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+            'frac': achieved / HBM_PEAK_GBS,
+            'traffic': profiled_traffic('step_dense_kernel<8, 6, 8, 12>')
+            if (B, T, S, args.transition) == (512, 500, 1440, 'dense') else None,
+            'traffic_note': 'bytes per launch from profiles/r01_pmc.json (2*FETCH_SIZE + WRITE_SIZE, '
+                            'Infinity-Cache hits included); the excess over the algorithmic bytes is '
+                            'transition/posterior panels re-read from the Infinity Cache each launch',
             'kernel': 'forward step (one timestep of the whole batch per launch)',
             'launch_us': per_launch_s * 1e6, 'launches_per_decode': launches,
             'algorithmic_bytes_per_launch': bytes_per_launch,
