@@ -10,7 +10,7 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-template <int BL, int JL, int NW, int KC>
+template <int BL, int JL, int NW, int KC, int MSL = 8>
 void run(int B, int T, int S, int reps) {
     dense::Plan pl = dense::make_plan(B, S, 256, BL, NW);
     if (pl.NW != NW || pl.KC != KC) { printf("plan NW/KC %d/%d != %d/%d, skip\n", pl.NW, pl.KC, NW, KC); return; }
@@ -39,21 +39,49 @@ void run(int B, int T, int S, int reps) {
                        pl.JT, pl.W, pl.Kp, pl.NCH, pl.KC);
     std::vector<int> hf(B, T);
     CHECK(hipMemcpy(frames, hf.data(), B * 4, hipMemcpyHostToDevice));
-    const size_t lds = dense::lds_bytes<BL, JL, NW, KC>();
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense::step_dense_kernel<BL, JL, NW, KC>),
+    const size_t lds = dense::lds_bytes<BL, JL, NW, KC, MSL>();
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense::step_dense_kernel<BL, JL, NW, KC, MSL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int ntiles = pl.n_bt * pl.n_jt, grid = 8 * ((ntiles + 7) / 8);
     {
         int nb = 0;
-        CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dense::step_dense_kernel<BL, JL, NW, KC>, 64 * NW, lds));
+        CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dense::step_dense_kernel<BL, JL, NW, KC, MSL>, 64 * NW, lds));
         hipFuncAttributes fa;
-        CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&dense::step_dense_kernel<BL, JL, NW, KC>)));
+        CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&dense::step_dense_kernel<BL, JL, NW, KC, MSL>)));
         printf("   occupancy API: %d blocks/CU, numRegs %d, static LDS %zu, dyn LDS %zu\n", nb, fa.numRegs, fa.sharedSizeBytes, lds);
     }
+    float *q0, *q1; CHECK(hipMalloc(&q0, panel * 4)); CHECK(hipMalloc(&q1, panel * 4));
+    CHECK(hipMemcpy(q0, h.data(), panel * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(q1, h.data(), panel * 4, hipMemcpyHostToDevice));
+    hipStream_t s0, s1; CHECK(hipStreamCreate(&s0)); CHECK(hipStreamCreate(&s1));
+    const bool two = getenv("TWO") != nullptr;
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    auto go2 = [&](int n) {      // two independent step chains on two streams (two decodes in flight)
+        for (int t = 1; t <= n; ++t) {
+            hipLaunchKernelGGL((dense::step_dense_kernel<BL, JL, NW, KC, MSL>), dim3(grid), dim3(64 * NW), lds, s0, obs, frames, tr,
+                               (t & 1) ? p0 : p1, (t & 1) ? p1 : p0, hist, chunks, B, T, S, 1 + (t % (T - 1)), pl.n_bt,
+                               pl.n_jt, pl.JT, pl.Kp, pl.NCH, pl.RB);
+            hipLaunchKernelGGL((dense::step_dense_kernel<BL, JL, NW, KC, MSL>), dim3(grid), dim3(64 * NW), lds, s1, obs, frames, tr,
+                               (t & 1) ? q0 : q1, (t & 1) ? q1 : q0, hist, chunks, B, T, S, 1 + (t % (T - 1)), pl.n_bt,
+                               pl.n_jt, pl.JT, pl.Kp, pl.NCH, pl.RB);
+        }
+    };
+    if (two) {
+        go2(20); CHECK(hipDeviceSynchronize());
+        float best2 = 1e30f;
+        for (int r = 0; r < 3; ++r) {
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipEventRecord(a, s0)); CHECK(hipStreamWaitEvent(s1, a, 0)); go2(reps);
+            CHECK(hipEventRecord(b, s1)); CHECK(hipStreamWaitEvent(s0, b, 0)); CHECK(hipEventRecord(b, s0));
+            CHECK(hipEventSynchronize(b)); CHECK(hipDeviceSynchronize());
+            float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+            if (ms < best2) best2 = ms;
+        }
+        printf("TWO streams BL=%d JL=%d NW=%d KC=%d MSL=%d lds=%zu: %.2f us per step (each of the 2 chains advances one step per 2x that)\n",
+               BL, JL, NW, KC, MSL, lds, best2 * 1e3 / (2 * reps));
+    }
     auto go = [&](int n) {
         for (int t = 1; t <= n; ++t)
-            hipLaunchKernelGGL((dense::step_dense_kernel<BL, JL, NW, KC>), dim3(grid), dim3(64 * NW), lds, 0, obs, frames, tr,
+            hipLaunchKernelGGL((dense::step_dense_kernel<BL, JL, NW, KC, MSL>), dim3(grid), dim3(64 * NW), lds, 0, obs, frames, tr,
                                (t & 1) ? p0 : p1, (t & 1) ? p1 : p0, hist, chunks, B, T, S, 1 + (t % (T - 1)), pl.n_bt,
                                pl.n_jt, pl.JT, pl.Kp, pl.NCH, pl.RB);
     };

@@ -52,6 +52,7 @@ struct Plan {
     int n_jt;   // state tiles
     int JT;     // next-states per tile (<= W)
     int NW;     // waves per workgroup = contraction slices (8 or 16)
+    int MSL;    // partial tiles merged through LDS at once (8; 4 = small-footprint variant)
     int KC;     // prev-state rows staged per chunk (12 with 8 waves, 6 with 16)
     int Kp;     // padded contraction length (multiple of KC) >= S
     int NCH;    // chunks of KC prev-state rows per panel = Kp / KC
@@ -99,6 +100,10 @@ inline Plan make_plan(int B, int S, int num_cus, int bl_override = 0, int nw_ove
     // instruction mix does not improve with occupancy.  `nw_override` = 16 still selects it.
     best.NW = (nw_override == 16 && BL == 8 && best.JL == 6) ? 16 : 8;
     best.KC = best.NW == 16 ? 6 : 12;
+    // (a small-footprint variant -- 8-row chunks, 4 merge slices, 57 KB LDS, 128 VGPRs, two
+    // workgroups of two in-flight decodes per CU -- was measured at 44.1 vs 37.3 us per step: the
+    // SIMDs are VALU-bound, extra resident waves only add staging overhead)
+    best.MSL = 8;
     best.NCH = (S + best.KC - 1) / best.KC;
     best.Kp = best.NCH * best.KC;
     best.RB = n_bt >= 2 ? (n_bt + 1) / 2 : 1;
@@ -208,7 +213,7 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
     return __builtin_fmaxf(__builtin_fmaxf(a, b), c);
 }
 
-template <int BL, int JL, int NW, int KC>
+template <int BL, int JL, int NW, int KC, int MSL = 8>
 struct StepShape {
     static_assert(KC % 2 == 0 && KC >= 4, "fragments are prev-state pairs, two in flight");
     static constexpr int BT = 8 * BL;
@@ -218,7 +223,7 @@ struct StepShape {
     static constexpr int STAGE = CHP + CHT;               // floats per wave per stage
     static constexpr int MS = BL * JL + 4;                // merge row stride per lane (bank-spread)
     static constexpr int STAGE_FLOATS = NW * 2 * STAGE;   // two stages per wave (ping-pong)
-    static constexpr int MERGE_FLOATS = 8 * 64 * MS;      // at most 8 partial tiles are in LDS at once
+    static constexpr int MERGE_FLOATS = MSL * 64 * MS;    // MSL partial tiles are in LDS at once
     static constexpr int LDS_FLOATS = STAGE_FLOATS > MERGE_FLOATS ? STAGE_FLOATS : MERGE_FLOATS;
 };
 
@@ -311,14 +316,14 @@ __device__ __forceinline__ void dma_chunk(const float *gp, const float *gt, floa
 // the wave's private LDS stage by LDS-DMA (two stages, ping-pong) -> ds_read fragments, with two
 // fragments (prev-state pairs) in flight while 2*BL*JL cells of a third are computed.
 // ---------------------------------------------------------------------------------------
-template <int BL, int JL, int NW, int KC>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4 * (BL == 4 ? 2 : 1), NW / 4 * (BL == 4 ? 2 : 1))))
+template <int BL, int JL, int NW, int KC, int MSL = 8>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4 * ((BL == 4 || MSL == 4) ? 2 : 1), NW / 4 * ((BL == 4 || MSL == 4) ? 2 : 1))))
 void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict__ frames,
                        const float *__restrict__ trp, const float *__restrict__ pcur,
                        float *__restrict__ pnext, float *__restrict__ hist,
                        const int32_t *__restrict__ chunks, int B, int T, int S, int t, int n_bt, int n_jt,
                        int JT, int Kp, int NCH, int RB) {
-    using Sh = StepShape<BL, JL, NW, KC>;
+    using Sh = StepShape<BL, JL, NW, KC, MSL>;
     constexpr int W = Sh::W, BT = Sh::BT;
     constexpr int RW = BT / NW;                     // tile rows (batch positions) finalised per wave
     static_assert(RW % 4 == 0 && RW >= 4, "each wave finalises whole groups of 4 batch rows");
@@ -448,9 +453,12 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
     // both the writes and the reads are ds_*_b128.  With 16 waves the upper 8 first fold into the
     // lower 8 (at most 8 partial tiles fit in LDS).
     __syncthreads();
-    if (NW == 16) {
-        float *m = smem + ((size_t)(wave & 7) * 64 + lane) * Sh::MS;
-        if (wave >= 8) {
+    // fold the upper half of the active waves into the lower half until MSL partial tiles remain
+#pragma unroll
+    for (int active = NW; active > MSL; active /= 2) {
+        const int half = active / 2;
+        float *m = smem + ((size_t)(wave % half) * 64 + lane) * Sh::MS;
+        if (wave >= half && wave < active) {
 #pragma unroll
             for (int jj = 0; jj < JL; ++jj)
 #pragma unroll
@@ -459,7 +467,7 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
                         make_float4(acc[4 * h][jj], acc[4 * h + 1][jj], acc[4 * h + 2][jj], acc[4 * h + 3][jj]);
         }
         __syncthreads();
-        if (wave < 8) {
+        if (wave < half) {
 #pragma unroll
             for (int jj = 0; jj < JL; ++jj)
 #pragma unroll
@@ -473,7 +481,8 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
         }
         __syncthreads();
     }
-    if (wave < 8) {
+    constexpr int NSL = NW < MSL ? NW : MSL;                  // partial tiles left
+    if (wave < NSL) {
         float *m = smem + ((size_t)wave * 64 + lane) * Sh::MS;
 #pragma unroll
         for (int jj = 0; jj < JL; ++jj)
@@ -502,7 +511,7 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
             const float *m = smem + (size_t)(src_jg * 8 + src_bg) * Sh::MS + jj * BL + bb0;
             float4 v = *reinterpret_cast<const float4 *>(m);
 #pragma unroll
-            for (int w = 1; w < 8; ++w) {
+            for (int w = 1; w < NSL; ++w) {
                 const float4 x = *reinterpret_cast<const float4 *>(m + (size_t)w * 64 * Sh::MS);
                 v.x = fmaxf(v.x, x.x); v.y = fmaxf(v.y, x.y); v.z = fmaxf(v.z, x.z); v.w = fmaxf(v.w, x.w);
             }
@@ -523,7 +532,7 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
     DENSE_STAMP(4);
 }
 
-template <int BL, int JL, int NW, int KC>
-constexpr size_t lds_bytes() { return sizeof(float) * (size_t)StepShape<BL, JL, NW, KC>::LDS_FLOATS; }
+template <int BL, int JL, int NW, int KC, int MSL = 8>
+constexpr size_t lds_bytes() { return sizeof(float) * (size_t)StepShape<BL, JL, NW, KC, MSL>::LDS_FLOATS; }
 
 }  // namespace dense

@@ -484,19 +484,19 @@ hipError_t launch_finalize(const int32_t *frames, const Workspace &w, int32_t *o
 }
 
 // ---- dense path -----------------------------------------------------------------------
-template <int BL, int JL, int NW, int KC>
+template <int BL, int JL, int NW, int KC, int MSL>
 hipError_t launch_dense_steps(const float *obs, const int32_t *frames, const DenseWorkspace &w,
                               int B, int T, int S, hipStream_t stream, int *launches) {
     const dense::Plan &pl = w.plan;
-    const size_t lds = dense::lds_bytes<BL, JL, NW, KC>();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense::step_dense_kernel<BL, JL, NW, KC>),
+    const size_t lds = dense::lds_bytes<BL, JL, NW, KC, MSL>();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense::step_dense_kernel<BL, JL, NW, KC, MSL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int ntiles = pl.n_bt * pl.n_jt;
     const int grid = 8 * ((ntiles + 7) / 8);
     int n = 0;
     for (int t = 1; t < T; ++t) {
-        hipLaunchKernelGGL((dense::step_dense_kernel<BL, JL, NW, KC>), dim3(grid), dim3(64 * NW), lds, stream, obs,
+        hipLaunchKernelGGL((dense::step_dense_kernel<BL, JL, NW, KC, MSL>), dim3(grid), dim3(64 * NW), lds, stream, obs,
                            frames, w.trp, w.panel[(t - 1) & 1], w.panel[t & 1], w.hist, w.chunks, B, T, S,
                            t, pl.n_bt, pl.n_jt, pl.JT, pl.Kp, pl.NCH, pl.RB);
         ++n;
@@ -522,16 +522,16 @@ hipError_t launch_dense_forward(const float *obs, const int32_t *frames, const f
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-#define TORBI_DENSE_CASE(BL_, JL_, NW_, KC_)                                         \
-    if (pl.BL == BL_ && pl.JL == JL_ && pl.NW == NW_ && pl.KC == KC_)                 \
-        return launch_dense_steps<BL_, JL_, NW_, KC_>(obs, frames, w, B, T, S, stream, launches)
-    TORBI_DENSE_CASE(8, 6, 16, 6);
-    TORBI_DENSE_CASE(8, 6, 8, 12);
-    TORBI_DENSE_CASE(8, 4, 8, 12);
-    TORBI_DENSE_CASE(8, 2, 8, 12);
-    TORBI_DENSE_CASE(4, 6, 8, 12);
-    TORBI_DENSE_CASE(4, 4, 8, 12);
-    TORBI_DENSE_CASE(4, 2, 8, 12);
+#define TORBI_DENSE_CASE(BL_, JL_, NW_, KC_, MSL_)                                             \
+    if (pl.BL == BL_ && pl.JL == JL_ && pl.NW == NW_ && pl.KC == KC_ && pl.MSL == MSL_)         \
+        return launch_dense_steps<BL_, JL_, NW_, KC_, MSL_>(obs, frames, w, B, T, S, stream, launches)
+    TORBI_DENSE_CASE(8, 6, 8, 12, 8);
+    TORBI_DENSE_CASE(8, 6, 16, 6, 8);
+    TORBI_DENSE_CASE(8, 4, 8, 12, 8);
+    TORBI_DENSE_CASE(8, 2, 8, 12, 8);
+    TORBI_DENSE_CASE(4, 6, 8, 12, 8);
+    TORBI_DENSE_CASE(4, 4, 8, 12, 8);
+    TORBI_DENSE_CASE(4, 2, 8, 12, 8);
 #undef TORBI_DENSE_CASE
     return hipErrorInvalidValue;
 }
