@@ -265,7 +265,9 @@ __device__ __forceinline__ void load_frag(Frag<BL, JL> &f, const float *lp, cons
 // v_max3_f32 from the v_add_f32 pair it consumes (skewing by one cell, or issuing the adds of one
 // to four batch rows before their max3s with sched_barriers) were measured and are not faster in
 // this kernel (contraction loop 66.2K vs 66.5K / 68.2K-70.4K ticks), although a register-only
-// probe prefers them (tools/ubench8); the plain order is kept.
+// probe prefers them (tools/ubench8); the plain order is kept.  Likewise v_min3_u32 on the bit
+// patterns (valid when every candidate is <= 0; tools/ubench9 measures add,add,min3_u32 13 % above
+// add,add,max3_f32) runs the loop in 68.8K ticks.
 template <int BL, int JL>
 __device__ __forceinline__ void cells(float (&acc)[BL][JL], const Frag<BL, JL> &f) {
 #pragma unroll
