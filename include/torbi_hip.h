@@ -122,6 +122,15 @@ int torbi_hip_read_posterior(const void *workspace, size_t workspace_bytes,
                              int B, int T, int S, int device, void *stream);
 
 /*
+ * In-place epsilon clamp of from_probabilities (reference torbi/core.py:193-197):
+ *     x <- log(exp(x) + FLT_MIN)        three torch ops upstream (exp_, += tiny, log_)
+ * fused into one pass over the (B,T,S) observation tensor.  Uses the same device math
+ * functions as PyTorch-ROCm's elementwise kernels; tests/test_gpu_parity.py checks bit
+ * equality with the three torch ops on the same device.
+ */
+int torbi_hip_epsilon_clamp(float *x, uint64_t count, int device, void *stream);
+
+/*
  * Measurement helper (not part of the reference interface): fills dst[0..count) with the
  * deterministic synthetic scores of torbi_amd/synth.py -- value(k) = 0 - u24(hash(stream_id,
  * seed, start + k)) * 2^-20 -- so bench.py can build the 1.5 GB headline input in HBM

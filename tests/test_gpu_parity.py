@@ -170,6 +170,23 @@ def test_decode_pipeline_equals_serial_decodes():
         assert np.array_equal(got.cpu().numpy(), want)
 
 
+def test_fused_epsilon_clamp_is_bit_identical_to_the_torch_ops():
+    """reference torbi/core.py:193-197: exp_, += tiny, log_ -- fused into one pass here."""
+    dev = torch.device('cuda:0')
+    gen = torch.Generator(device=dev).manual_seed(0)
+    x = torch.empty(8_000_003, device=dev).uniform_(-100.0, 2.0, generator=gen)
+    x[:12] = torch.tensor([0.0, -0.0, -float('inf'), -87.3, -87.4, -103.0, -104.0, -1e-7, -1e-38, 1.0,
+                           -88.0, -16.0], device=dev)
+    probs = torch.rand(1_000_000, device=dev, generator=gen)
+    x[100:100 + probs.numel()] = torch.log(probs)
+    want = x.clone()
+    torch.exp_(want)
+    want += torch.finfo(torch.float32).tiny
+    torch.log_(want)
+    got = viterbi.epsilon_clamp_(x.clone())
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+
+
 def test_posterior_rows_match_oracle_bitwise():
     B, T, S = 5, 23, 300
     obs, trans, init = synth.problem(B, T, S, seed=77)

@@ -36,6 +36,7 @@ SYMBOLS = {
     'torbi_hip_read_posterior': (_c.c_int, [
         _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p,
         _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+    'torbi_hip_epsilon_clamp': (_c.c_int, [_c.c_void_p, _c.c_uint64, _c.c_int, _c.c_void_p]),
     'torbi_hip_fill_synthetic': (_c.c_int, [
         _c.c_void_p, _c.c_uint64, _c.c_uint64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
 }

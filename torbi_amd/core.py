@@ -11,7 +11,7 @@ from typing import Dict, List, Optional, Union
 import torch
 
 from . import data as _data
-from .viterbi import decode, decode_uniform
+from .viterbi import decode, decode_uniform, epsilon_clamp_
 
 # reference torbi/config/defaults.py:80,83
 BATCH_SIZE = 512
@@ -111,10 +111,9 @@ def from_probabilities(
         observation = torch.log(observation)
     observation = observation.to(device=device, dtype=torch.float32)
 
-    # Add epsilon for stability (core.py:193-197; in place, like the reference)
-    torch.exp_(observation)
-    observation += tiny
-    torch.log_(observation)
+    # Add epsilon for stability (core.py:193-197; in place, like the reference): exp_, += tiny,
+    # log_ as ONE elementwise pass on the device
+    epsilon_clamp_(observation)
 
     if uniform is not None:
         indices = decode_uniform(observation, batch_frames, uniform, initial)

@@ -349,6 +349,25 @@ __global__ __launch_bounds__(256) void gather_history_kernel(const float *__rest
     }
 }
 
+// x <- log(exp(x) + tiny), the epsilon clamp of from_probabilities (torbi/core.py:193-197)
+__global__ __launch_bounds__(256) void epsilon_clamp_kernel(float *__restrict__ x, uint64_t count) {
+    const float tiny = 1.17549435e-38f;   // torch.finfo(torch.float32).tiny
+    const uint64_t n4 = count / 4;
+    float4 *x4 = reinterpret_cast<float4 *>(x);
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4;
+         e += (uint64_t)gridDim.x * blockDim.x) {
+        float4 v = x4[e];
+        v.x = logf(expf(v.x) + tiny);
+        v.y = logf(expf(v.y) + tiny);
+        v.z = logf(expf(v.z) + tiny);
+        v.w = logf(expf(v.w) + tiny);
+        x4[e] = v;
+    }
+    for (uint64_t e = n4 * 4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count;
+         e += (uint64_t)gridDim.x * blockDim.x)
+        x[e] = logf(expf(x[e]) + tiny);
+}
+
 // deterministic synthetic scores, same function as torbi_amd/synth.py::scores
 __global__ __launch_bounds__(256) void fill_synthetic_kernel(float *__restrict__ dst,
                                                              uint64_t count, uint64_t start,
@@ -710,6 +729,18 @@ int torbi_hip_read_posterior(const void *workspace, size_t workspace_bytes,
                            static_cast<hipStream_t>(stream), w.post[0], w.post[1], batch_frames,
                            posterior_out, B, T, S);
     }
+    return (int)hipGetLastError();
+}
+
+int torbi_hip_epsilon_clamp(float *x, uint64_t count, int device, void *stream) {
+    if (count == 0) return TORBI_HIP_OK;
+    if (!x || (reinterpret_cast<uintptr_t>(x) & 15)) return TORBI_HIP_EINVAL;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return (int)guard.err;
+    const uint64_t blocks = (count / 4 + 255) / 256 + 1;
+    const int grid = (int)(blocks < 16384 ? blocks : 16384);
+    hipLaunchKernelGGL(epsilon_clamp_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       count);
     return (int)hipGetLastError();
 }
 

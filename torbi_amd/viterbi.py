@@ -175,6 +175,23 @@ def read_posterior(workspace, batch_frames, batch, frames, states):
     return out
 
 
+def epsilon_clamp_(x: torch.Tensor) -> torch.Tensor:
+    """In place `x <- log(exp(x) + tiny)`: the three elementwise passes of reference
+    torbi/core.py:193-197 (`exp_`, `+= tiny`, `log_`) fused into one (bit-identical to the torch
+    ops on the same device; tested).  Falls back to the torch ops for tensors the fused kernel
+    does not take (non-CUDA, non-fp32, non-contiguous)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.data_ptr() % 16 == 0):
+        torch.exp_(x)
+        x += torch.finfo(torch.float32).tiny
+        torch.log_(x)
+        return x
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    _lib.check(lib.torbi_hip_epsilon_clamp(x.data_ptr(), x.numel(), x.device.index or 0,
+                                           ctypes.c_void_p(stream)), 'torbi_hip_epsilon_clamp')
+    return x
+
+
 def fill_synthetic(shape, stream_id, seed=0, device=None, start=0):
     """Device-side torbi_amd.synth.scores(): deterministic fp32 scores in (-16, 0]."""
     _require_gpu()
