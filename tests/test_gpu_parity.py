@@ -250,6 +250,48 @@ def test_headline_shape_properties():
     assert torch.equal(idx2, idx[sub])
 
 
+def test_large_state_shape_properties():
+    """B=128, T=2000, S=4096 (BASELINE config 5, the large-S stress): the first 2 items equal the
+    committed reference output; every decoded path re-scores to its item's final posterior
+    maximum bit for bit; ragged lengths keep their tail fill."""
+    dev = torch.device('cuda:0')
+    B, T, S = 128, 2000, 4096
+    obs = viterbi.fill_synthetic((B, T, S), synth.STREAM_OBSERVATION, device=dev)
+    trans = viterbi.fill_synthetic((S, S), synth.STREAM_TRANSITION, device=dev)
+    init = viterbi.fill_synthetic((S,), synth.STREAM_INITIAL, device=dev)
+    frames = torch.full((B,), T, dtype=torch.int32, device=dev)
+    frames[5], frames[77] = 1234, 1
+    ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+    idx = torbi_amd.decode(obs, frames, trans, init, workspace=ws)
+    post = viterbi.read_posterior(ws, frames, B, T, S)
+    g = np.load(__import__('conftest').GOLDEN + '/golden_large.npz')
+    assert np.array_equal(idx[:2].cpu().numpy(), g['g5_c5_first2_2x2000x4096/indices'])
+    assert int(idx.min()) >= 0 and int(idx.max()) < S
+    score = path_score(obs, trans, init, idx, frames)
+    assert torch.equal(score, post.max(dim=1).values)
+    last = idx[torch.arange(B, device=dev), (frames - 1).long()].long()
+    assert torch.equal(last, post.argmax(dim=1))
+    assert bool((idx[5, 1233:] == idx[5, 1233]).all()) and bool((idx[77] == idx[77, 0]).all())
+
+
+def test_dispatcher_registration_matches_reference_call_site():
+    """reference torbi/viterbi.py:53: torch.ops.torbi.viterbi_decode(observation, batch_frames,
+    transition, initial) -- the same call reaches the HIP decode after torch_op.register()."""
+    from torbi_amd import torch_op
+    op = torch_op.register()
+    assert torch_op.register() is not None            # idempotent
+    dev = torch.device('cuda:0')
+    obs, trans, init = synth.problem(40, 12, 96, seed=21)
+    frames = np.clip(synth.lengths(40, 1, 12, seed=2), 1, 12)
+    got = op(torch.tensor(obs, device=dev), torch.tensor(frames, device=dev),
+             torch.tensor(trans, device=dev), torch.tensor(init, device=dev))
+    assert got.dtype == torch.int32 and got.is_cuda
+    assert np.array_equal(got.cpu().numpy(), oracle.decode(obs, frames, trans, init))
+    with pytest.raises(RuntimeError):                 # int64 lengths are rejected, as upstream
+        op(torch.tensor(obs, device=dev), torch.tensor(frames, device=dev).long(),
+           torch.tensor(trans, device=dev), torch.tensor(init, device=dev))
+
+
 def test_ragged_batch_equals_single_item_decodes():
     """collate-style padded batch == per-file decodes (reference collate.py:24-33,
     core.py:449-457)."""
