@@ -25,6 +25,7 @@
 #include "dense_forward.hpp"
 #include "lazy_backtrace.hpp"
 #include "uniform_decode.hpp"
+#include "pruned_forward.hpp"
 
 namespace {
 
@@ -406,6 +407,48 @@ constexpr int kNumCUs = 256;   // MI355X; the tiling plan is a pure function of 
 // kernels above, which materialise the int32 trellis like the reference does.
 inline bool use_dense(int B, int S) { return B >= 32 && S >= 64; }
 
+// TORBI_HIP_FORWARD=pruned selects the exact pruned forward pass (pruned_forward.hpp) where it is
+// supported; anything else keeps the dense (max,+) GEMM.
+inline bool want_pruned() {
+    static const bool v = [] {
+        const char *e = getenv("TORBI_HIP_FORWARD");
+        return e && e[0] == 'p';
+    }();
+    return v;
+}
+inline bool use_pruned(int B, int S) { return want_pruned() && pruned::supported(B, S); }
+
+struct PrunedWorkspace {
+    pruned::Plan plan;
+    float2 *sorted;    // [S][SpP] transition rows in descending order: {t, prev-state byte offset}
+    float *tt;         // [S][S]   transposed transition matrix
+    float *topv;       // [2][n_jt][B][6] partial top lists (values), ping-pong by timestep parity
+    int32_t *topi;     // [2][n_jt][B][6] their prev-states
+    size_t top_stride; // elements per parity
+    float *hist;       // [B][T][S] posterior history
+    size_t top_bytes;
+    size_t bytes;
+};
+
+inline PrunedWorkspace carve_pruned(void *base, int B, int T, int S) {
+    PrunedWorkspace w;
+    w.plan = pruned::make_plan(B, S, kNumCUs);
+    char *p = static_cast<char *>(base);
+    const size_t sorted_bytes = align_up(sizeof(float2) * (size_t)S * w.plan.SpP, 256);
+    const size_t tt_bytes = align_up(sizeof(float) * (size_t)S * S, 256);
+    w.top_stride = (size_t)w.plan.n_jt * B * pruned::kTop;
+    const size_t topv_bytes = align_up(sizeof(float) * 2 * w.top_stride, 256);
+    const size_t topi_bytes = align_up(sizeof(int32_t) * 2 * w.top_stride, 256);
+    w.sorted = reinterpret_cast<float2 *>(p);
+    w.tt = reinterpret_cast<float *>(p + sorted_bytes);
+    w.topv = reinterpret_cast<float *>(p + sorted_bytes + tt_bytes);
+    w.topi = reinterpret_cast<int32_t *>(p + sorted_bytes + tt_bytes + topv_bytes);
+    w.hist = reinterpret_cast<float *>(p + sorted_bytes + tt_bytes + topv_bytes + topi_bytes);
+    w.top_bytes = topv_bytes + topi_bytes;
+    w.bytes = sorted_bytes + tt_bytes + topv_bytes + topi_bytes + align_up(sizeof(float) * (size_t)B * T * S, 256);
+    return w;
+}
+
 struct DenseWorkspace {
     dense::Plan plan;
     float *panel[2];   // [n_bt][Kp][BT] posterior panels (ping-pong)
@@ -555,13 +598,55 @@ hipError_t launch_dense_forward(const float *obs, const int32_t *frames, const f
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_dense_backtrace(const float *trans, const int32_t *frames, const DenseWorkspace &w,
-                                  int32_t *out, int B, int T, int S, hipStream_t stream) {
+hipError_t launch_pruned_forward(const float *obs, const int32_t *frames, const float *trans,
+                                 const float *init, const PrunedWorkspace &w, int B, int T, int S,
+                                 hipStream_t stream, int *launches) {
+    const pruned::Plan &pl = w.plan;
+    hipLaunchKernelGGL(pruned::sort_rows_kernel, dim3(S), dim3(256), sizeof(float) * 2 * (size_t)pl.NPOW, stream,
+                       trans, w.sorted, S, pl.SpP, pl.NPOW);
+    hipLaunchKernelGGL(pruned::transpose_kernel, dim3((S + 31) / 32, (S + 31) / 32), dim3(256), 0, stream, trans,
+                       w.tt, S);
+    {
+        const size_t n = (size_t)B * S;
+        const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipLaunchKernelGGL(pruned::init_history_kernel, dim3(grid), dim3(256), 0, stream, obs, init, w.hist, B, T, S);
+        // partial top lists of "timestep 0": state tile 0 carries the full list, the others are empty
+        const size_t m = 2 * w.top_stride;
+        const int grid2 = (int)((m + 255) / 256 < 4096 ? (m + 255) / 256 : 4096);
+        hipLaunchKernelGGL(pruned::clear_top_kernel, dim3(grid2), dim3(256), 0, stream, w.topv, w.topi, m);
+        if (S <= 512)
+            hipLaunchKernelGGL(pruned::top_kernel<2>, dim3(B), dim3(64), 0, stream, w.hist, w.topv, w.topi, B, T, S);
+        else if (S <= 1536)
+            hipLaunchKernelGGL(pruned::top_kernel<6>, dim3(B), dim3(64), 0, stream, w.hist, w.topv, w.topi, B, T, S);
+        else
+            hipLaunchKernelGGL(pruned::top_kernel<8>, dim3(B), dim3(64), 0, stream, w.hist, w.topv, w.topi, B, T, S);
+    }
+    const size_t lds = pruned::lds_bytes(S, pl.JT);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pruned::step_pruned_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    int n = 0;
+    for (int t = 1; t < T; ++t) {
+        const size_t in = ((t - 1) & 1) * w.top_stride, out = (t & 1) * w.top_stride;
+        hipLaunchKernelGGL(pruned::step_pruned_kernel, dim3(pl.n_bt * pl.n_jt), dim3(64 * pruned::kWaves), lds, stream,
+                           obs, frames, w.tt, w.sorted, w.topv + in, w.topi + in, w.topv + out, w.topi + out, w.hist,
+                           B, T, S, t, pl.SpP, pl.n_bt, pl.n_jt, pl.JT);
+        ++n;
+    }
+    if (launches) *launches = n;
+    return hipGetLastError();
+}
+
+hipError_t launch_backtrace_on(const float *hist, const float *trans, const int32_t *frames, int32_t *out,
+                               int B, int T, int S, hipStream_t stream);
+
+hipError_t launch_backtrace_on(const float *hist, const float *trans, const int32_t *frames, int32_t *out,
+                               int B, int T, int S, hipStream_t stream) {
     const bool vec = (S % 4 == 0) && ((reinterpret_cast<uintptr_t>(trans) & 15) == 0);
     if (vec && S <= 256 * 16) {
 #define TORBI_BT_CASE(NQ_)                                                                          \
     if (S <= 256 * NQ_) {                                                                           \
-        hipLaunchKernelGGL(lazy::backtrace_prefetch_kernel<NQ_>, dim3(B), dim3(64), 0, stream, w.hist, \
+        hipLaunchKernelGGL(lazy::backtrace_prefetch_kernel<NQ_>, dim3(B), dim3(64), 0, stream, hist, \
                            trans, frames, out, B, T, S);                                            \
         return hipGetLastError();                                                                   \
     }
@@ -571,12 +656,17 @@ hipError_t launch_dense_backtrace(const float *trans, const int32_t *frames, con
 #undef TORBI_BT_CASE
     }
     if (vec)
-        hipLaunchKernelGGL(lazy::backtrace_kernel<4>, dim3(B), dim3(64), 0, stream, w.hist, trans,
+        hipLaunchKernelGGL(lazy::backtrace_kernel<4>, dim3(B), dim3(64), 0, stream, hist, trans,
                            frames, out, B, T, S);
     else
-        hipLaunchKernelGGL(lazy::backtrace_kernel<1>, dim3(B), dim3(64), 0, stream, w.hist, trans,
+        hipLaunchKernelGGL(lazy::backtrace_kernel<1>, dim3(B), dim3(64), 0, stream, hist, trans,
                            frames, out, B, T, S);
     return hipGetLastError();
+}
+
+hipError_t launch_dense_backtrace(const float *trans, const int32_t *frames, const DenseWorkspace &w,
+                                  int32_t *out, int B, int T, int S, hipStream_t stream) {
+    return launch_backtrace_on(w.hist, trans, frames, out, B, T, S, stream);
 }
 
 // one decode on `s`; optional events bracket the forward and backtrace phases
@@ -585,7 +675,12 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
                       hipEvent_t *ev, int *launches) {
     hipError_t e;
     if (ev) (void)hipEventRecord(ev[0], s);
-    if (use_dense(B, S)) {
+    if (use_pruned(B, S)) {
+        const PrunedWorkspace w = carve_pruned(workspace, B, T, S);
+        e = launch_pruned_forward(obs, frames, trans, init, w, B, T, S, s, launches);
+        if (ev) (void)hipEventRecord(ev[1], s);
+        if (e == hipSuccess) e = launch_backtrace_on(w.hist, trans, frames, out, B, T, S, s);
+    } else if (use_dense(B, S)) {
         const DenseWorkspace w = carve_dense(workspace, B, T, S);
         e = launch_dense_forward(obs, frames, trans, init, w, B, T, S, s, launches);
         if (ev) (void)hipEventRecord(ev[1], s);
@@ -631,8 +726,12 @@ int torbi_hip_device_count(void) {
 
 size_t torbi_hip_workspace_bytes(int B, int T, int S) {
     if (B <= 0 || T <= 0 || S <= 0) return 256;
-    if (use_dense(B, S)) return carve_dense(nullptr, B, T, S).bytes;
-    return carve(nullptr, B, T, S).bytes;
+    size_t need = use_dense(B, S) ? carve_dense(nullptr, B, T, S).bytes : carve(nullptr, B, T, S).bytes;
+    if (use_pruned(B, S)) {
+        const size_t p = carve_pruned(nullptr, B, T, S).bytes;
+        if (p > need) need = p;
+    }
+    return need;
 }
 
 int torbi_hip_viterbi_decode(const float *observation, const int32_t *batch_frames,
@@ -718,7 +817,12 @@ int torbi_hip_read_posterior(const void *workspace, size_t workspace_bytes,
     if (guard.err != hipSuccess) return (int)guard.err;
     const size_t n = (size_t)B * S;
     const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    if (use_dense(B, S)) {
+    if (use_pruned(B, S)) {
+        const PrunedWorkspace w = carve_pruned(const_cast<void *>(workspace), B, T, S);
+        hipLaunchKernelGGL(gather_history_kernel, dim3(grid), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), w.hist, batch_frames, posterior_out, B,
+                           T, S);
+    } else if (use_dense(B, S)) {
         const DenseWorkspace w = carve_dense(const_cast<void *>(workspace), B, T, S);
         hipLaunchKernelGGL(gather_history_kernel, dim3(grid), dim3(256), 0,
                            static_cast<hipStream_t>(stream), w.hist, batch_frames, posterior_out, B,
