@@ -13,10 +13,11 @@
 // banded matrices far fewer.  Worst case (flat rows) every cell is examined at a higher cost per
 // cell than the dense kernel -- the host selects the path (torbi_hip.hip).
 //
-// Lanes: 16 batch items x 4 next-states per wave.  The 16 lanes of a next-state load 16 consecutive
-// list entries with one coalesced 8-byte load each and consume them by DPP row rotation (max is
-// order independent): per candidate one DPP address add, one LDS gather from the [prev][16 items]
-// posterior tile, one DPP add and half a v_max3.
+// Lanes: one next-state x 4 batch items per lane, 16 next-states x 4 item groups per wave.  Every lane
+// walks its own sorted row (16-entry blocks, ping-pong in registers); a list entry costs one
+// ds_read_b128 of the [prev-state][16 items] posterior tile, 4 v_add_f32 and, entries taken in pairs,
+// 2 v_max3_f32 per 4 candidates: no cross-lane traffic.  (tools/prune_proto*.hip hold the measured
+// alternatives: DPP row rotation, LDS-DMA / ds_write staged lists, entry-major lists.)
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -29,8 +30,10 @@ namespace pruned {
 
 constexpr int kR = 5;        // explicit top candidates per item; thr = (kR+1)-th largest posterior
 constexpr int kNB = 16;      // batch items per tile (= lanes per next-state)
-constexpr int kLook = 4;     // 16-entry list blocks in flight per next-state
-constexpr int kWaves = 16;   // waves per workgroup
+constexpr int kBlk = 16;     // list entries per termination test
+constexpr int kPad = 4 * kBlk;  // (-inf) entries after every list row: prefetches never leave the row
+constexpr int kWaves = 12;   // waves per workgroup (3 per SIMD: 168 VGPRs each)
+constexpr int kMaxTileStates = 16 * kWaves;   // next-states per tile: one per lane group of 4
 constexpr int kTop = kR + 1;
 constexpr int kMaxJT = 16;   // state tiles per batch tile (kMaxJT * kTop candidates <= 2 per lane)
 
@@ -39,7 +42,7 @@ struct Plan {
     int n_jt;    // next-state tiles
     int JT;      // next-states per tile (multiple of 4)
     int Sp;      // list length rounded up to 16
-    int SpP;     // list row stride in entries: Sp + 16*kLook all-(-inf) entries so prefetch never leaves the row
+    int SpP;     // list row stride in entries: Sp + kPad all-(-inf) entries so prefetch never leaves the row
     int NPOW;    // sort width (power of two >= S)
 };
 
@@ -53,14 +56,15 @@ inline Plan make_plan(int B, int S, int num_cus) {
     p.n_bt = (B + kNB - 1) / kNB;
     int n_jt = num_cus / p.n_bt;
     if (n_jt < 1) n_jt = 1;
-    if (n_jt < (S + 255) / 256) n_jt = (S + 255) / 256;   // the per-tile top selection holds 4 outputs per lane
+    const int min_jt = (S + kMaxTileStates - 1) / kMaxTileStates;   // one pass of the workgroup covers a tile
+    if (n_jt < min_jt) n_jt = min_jt;
     if (n_jt > kMaxJT) n_jt = kMaxJT;     // the per-item top lists of all state tiles are merged by one wave
     int JT = (S + n_jt - 1) / n_jt;
-    JT = (JT + 3) / 4 * 4;                // S <= 2048 and n_jt >= S/256 keep JT <= 256
+    JT = (JT + 3) / 4 * 4;                // S <= 2048: JT <= 192 whenever n_jt >= min_jt (<= 11)
     p.JT = JT;
     p.n_jt = (S + JT - 1) / JT;
     p.Sp = (S + 15) / 16 * 16;
-    p.SpP = p.Sp + 16 * kLook;
+    p.SpP = p.Sp + kPad;
     p.NPOW = 64;
     while (p.NPOW < S) p.NPOW *= 2;
     return p;
@@ -187,40 +191,24 @@ __global__ __launch_bounds__(64) void top_kernel(const float *__restrict__ hist,
     });
 }
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
-}
+struct ListBlock { float4 e[kBlk / 2]; };   // 16 entries: e[u] = {t(2u), off(2u), t(2u+1), off(2u+1)}
 
-// one rotation step: every lane consumes the list entry held by lane (c + N) % 16 of its next-state
-template <int N>
-__device__ __forceinline__ void rot_step(float &best, float pt, int poff, int cbytes, const char *tile) {
-    float tt;
-    int addr;
-    if (N == 0) {
-        tt = pt;
-        addr = poff + cbytes;
-    } else {
-        asm("v_add_u32_dpp %0, %1, %2 row_ror:%3 row_mask:0xf bank_mask:0xf" : "=v"(addr) : "v"(poff), "v"(cbytes), "i"(N));
-        tt = dpp_f<0x120 + (N == 0 ? 1 : N)>(pt);
-    }
-    best = fmaxf(best, *reinterpret_cast<const float *>(tile + addr) + tt);
+__device__ __forceinline__ void load_list_block(ListBlock &blk, const float2 *row, int k) {
+#pragma unroll
+    for (int u = 0; u < kBlk / 2; ++u) blk.e[u] = *reinterpret_cast<const float4 *>(row + k + 2 * u);
 }
-
-struct QuadPrefetch {        // everything a group of 4 next-states needs from memory, issued one group ahead
-    float seed[kR];
-    float2 pf[kLook];
-    float first[kLook];      // largest t of each 16-entry block (broadcast load)
-    float ob;                // observation of this lane's (item, next-state)
-};
 
 // ---------------------------------------------------------------------------------------
-// one timestep.  grid = n_bt * n_jt, block = 1024, dynamic LDS = lds_bytes(S, JT).
+// one timestep.  grid = n_bt * n_jt, block = 64 * kWaves, dynamic LDS = lds_bytes(S, JT).
 //
 // Per-item top lists travel between timesteps as PARTIAL lists: each state tile leaves the kTop
 // largest of the outputs it produced for each of its 16 items (ptop[t & 1][jt][b][r]); the next
 // timestep's tiles merge the n_jt partial lists of their items (every member of the global top
 // kTop is in the top kTop of its own tile).  No separate selection kernel, no extra launch.
+//
+// Order inside the workgroup: merge top lists -> barrier -> issue the seed gathers, observation
+// loads and first list block (their latency hides behind the tile staging) -> stage the posterior
+// tile -> barrier -> scan -> outputs -> barrier -> this tile's partial top lists.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     const float *__restrict__ obs, const int32_t *__restrict__ frames, const float *__restrict__ tt,
@@ -238,17 +226,12 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     // skip tiles whose batch items have all ended (t >= batch_frames[b])
     if (!__syncthreads_or(tid < kNB && b0 + tid < B && t < frames[b0 + tid])) return;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 15, js = lane >> 4;
-    const int b = b0 + c;
-    const int bq = b < B ? b : B - 1;
-    const bool live = b < B && t < frames[bq];
     const int JTv = S - j0 < JT ? S - j0 : JT;                   // next-states of this tile
-    const int nquads = (JTv + 3) / 4;
-    const int nb = (S + 15) / 16;
+    const int Sp = (S + 15) / 16 * 16;
 
     // wave w merges the partial top lists of item b0 + w: n_jt * kTop candidates, <= 2 per lane
-    if (wave < kNB) {
-        const int bw = b0 + wave < B ? b0 + wave : B - 1;
+    for (int item = wave; item < kNB; item += kWaves) {
+        const int bw = b0 + item < B ? b0 + item : B - 1;
         float v[2];
         int tag[2];
 #pragma unroll
@@ -262,8 +245,33 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
             tag[e] = ok ? idx : 0x7fffffff;
         }
         wave_top<2>(v, tag, [&](int r, float m, int k) {
-            if (lane == 0) { mtopv[wave * kTop + r] = m; mtopi[wave * kTop + r] = k; }
+            if (lane == 0) { mtopv[item * kTop + r] = m; mtopi[item * kTop + r] = k; }
         });
+    }
+    __syncthreads();
+
+    // lane = next-state jl of the wave's 16 x item group g (items 4g .. 4g+3 of the tile)
+    const int jl = lane >> 2, g = lane & 3;
+    const int jj = 16 * wave + jl;
+    const bool jv = jj < JTv;
+    const int jr = jv ? j0 + jj : j0;
+    const float2 *row = sorted + (size_t)jr * SpP;
+    ListBlock cur, nxt;
+    load_list_block(cur, row, 0);
+    float seedv[4][kR], seedt[4][kR], thr[4], ob[4];
+    bool live[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int item = 4 * g + it;
+        const int b = b0 + item < B ? b0 + item : B - 1;
+        live[it] = b0 + item < B && t < frames[b];
+        thr[it] = mtopv[item * kTop + kR];
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            seedv[it][r] = mtopv[item * kTop + r];
+            seedt[it][r] = tt[(size_t)mtopi[item * kTop + r] * S + jr];        // trans[jr][i_r]
+        }
+        ob[it] = obs[((size_t)b * T + t) * S + jr];
     }
 
     // stage the 16 posterior rows as [prev-state][16 items]: lanes = 16 rows x 4 float4 columns
@@ -292,82 +300,63 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     }
     __syncthreads();
 
-    float tv[kR];
-    int ti[kR];
+    float best[4];
 #pragma unroll
-    for (int r = 0; r < kR; ++r) { tv[r] = mtopv[c * kTop + r]; ti[r] = mtopi[c * kTop + r]; }
-    const float thr = mtopv[c * kTop + kR];
-
-    auto issue = [&](QuadPrefetch &pre, int q) {
-        const int jj = 4 * q + js;
-        const int jr = jj < JTv ? j0 + jj : j0;
+    for (int it = 0; it < 4; ++it) {
+        float m = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < kR; ++r) pre.seed[r] = tt[(size_t)ti[r] * S + jr];   // trans[jr][i_r]
-        const float2 *row = sorted + (size_t)jr * SpP + c;
-#pragma unroll
-        for (int u = 0; u < kLook; ++u) { pre.pf[u] = row[16 * u]; pre.first[u] = row[16 * u - c].x; }
-        pre.ob = obs[((size_t)bq * T + t) * S + jr];
+        for (int r = 0; r < kR; ++r) m = fmaxf(m, seedv[it][r] + seedt[it][r]);
+        best[it] = m;
+    }
+    const char *ptile = reinterpret_cast<const char *>(lds) + 16 * g;
+    // stop once no lane's bound fl(t_first + thr) exceeds its best (t_first = largest unexamined entry)
+    auto more = [&](const ListBlock &blk) {
+        const float tn = blk.e[0].x;
+        return __any(jv && ((tn + thr[0] > best[0]) | (tn + thr[1] > best[1]) | (tn + thr[2] > best[2]) |
+                            (tn + thr[3] > best[3])));
     };
-    QuadPrefetch cur, nxt;
-    if (wave < nquads) issue(cur, wave);
-
-    const char *ptile = reinterpret_cast<const char *>(lds);
-    const int cbytes = 4 * c;
-    for (int q = wave; q < nquads; q += kWaves) {
-        if (q + kWaves < nquads) issue(nxt, q + kWaves);
-        const int jj = 4 * q + js;
-        const bool jv = jj < JTv;
-        const int jr = jv ? j0 + jj : j0;
-        float best = -INFINITY;
+    auto consume = [&](const ListBlock &blk) {
 #pragma unroll
-        for (int r = 0; r < kR; ++r) best = fmaxf(best, tv[r] + cur.seed[r]);
-        const float2 *row = sorted + (size_t)jr * SpP + c;
-        for (int kb = 0; kb < nb; kb += kLook) {
-#pragma unroll
-            for (int u = 0; u < kLook; u += 2) {
-                // two 16-entry blocks per test: stop once no lane's bound t_first + thr exceeds its best
-                if (kb + u >= nb || !__any(jv && cur.first[u] + thr > best)) goto done;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float pt = cur.pf[u + h].x;
-                    const int pi = __builtin_bit_cast(int, cur.pf[u + h].y);
-                    // rows are padded with 16*kLook (-inf) entries: the prefetch never leaves the row
-                    cur.pf[u + h] = row[16 * (kb + u + h + kLook)];
-                    cur.first[u + h] = row[16 * (kb + u + h + kLook) - c].x;
-                    rot_step<0>(best, pt, pi, cbytes, ptile); rot_step<1>(best, pt, pi, cbytes, ptile);
-                    rot_step<2>(best, pt, pi, cbytes, ptile); rot_step<3>(best, pt, pi, cbytes, ptile);
-                    rot_step<4>(best, pt, pi, cbytes, ptile); rot_step<5>(best, pt, pi, cbytes, ptile);
-                    rot_step<6>(best, pt, pi, cbytes, ptile); rot_step<7>(best, pt, pi, cbytes, ptile);
-                    rot_step<8>(best, pt, pi, cbytes, ptile); rot_step<9>(best, pt, pi, cbytes, ptile);
-                    rot_step<10>(best, pt, pi, cbytes, ptile); rot_step<11>(best, pt, pi, cbytes, ptile);
-                    rot_step<12>(best, pt, pi, cbytes, ptile); rot_step<13>(best, pt, pi, cbytes, ptile);
-                    rot_step<14>(best, pt, pi, cbytes, ptile); rot_step<15>(best, pt, pi, cbytes, ptile);
-                }
-            }
+        for (int u = 0; u < kBlk / 2; ++u) {
+            const float4 p0 = *reinterpret_cast<const float4 *>(ptile + __float_as_int(blk.e[u].y));
+            const float4 p1 = *reinterpret_cast<const float4 *>(ptile + __float_as_int(blk.e[u].w));
+            const float t0 = blk.e[u].x, t1 = blk.e[u].z;
+            best[0] = fmaxf(fmaxf(best[0], t0 + p0.x), t1 + p1.x);
+            best[1] = fmaxf(fmaxf(best[1], t0 + p0.y), t1 + p1.y);
+            best[2] = fmaxf(fmaxf(best[2], t0 + p0.z), t1 + p1.z);
+            best[3] = fmaxf(fmaxf(best[3], t0 + p0.w), t1 + p1.w);
         }
-    done:
-        {
-            const float o = cur.ob + best;                                    // post'[j] = obs[t,j] + max
-            if (jv && live) hist[((size_t)b * T + t) * S + jr] = o;
-            if (jv) outs[c * JT + jj] = o;
-        }
-        cur = nxt;
+    };
+    // two blocks ping-pong by name (no register copies); rows carry kPad (-inf) entries past Sp
+    for (int k = 0; k < Sp; k += 2 * kBlk) {
+        if (!more(cur)) break;
+        load_list_block(nxt, row, k + kBlk);
+        consume(cur);
+        if (!more(nxt)) break;
+        load_list_block(cur, row, k + 2 * kBlk);
+        consume(nxt);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const float o = ob[it] + best[it];                                   // post'[j] = obs[t,j] + max
+        if (jv && live[it]) hist[((size_t)(b0 + 4 * g + it) * T + t) * S + jr] = o;
+        if (jv) outs[(4 * g + it) * JT + jj] = o;
     }
     __syncthreads();
 
     // partial top list of this tile for each of its items: wave w scans item w's JTv outputs
-    if (wave < kNB) {
-        constexpr int NE = 4;                 // JT <= 256 outputs per item -> 4 per lane
+    for (int item = wave; item < kNB; item += kWaves) {
+        constexpr int NE = (kMaxTileStates + 63) / 64;
         float v[NE];
         int tag[NE];
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            const int jj = lane + 64 * e;
-            const bool ok = jj < JTv;
-            v[e] = ok ? outs[wave * JT + jj] : -INFINITY;
-            tag[e] = ok ? j0 + jj : 0x7fffffff;
+            const int oj = lane + 64 * e;
+            const bool ok = oj < JTv;
+            v[e] = ok ? outs[item * JT + oj] : -INFINITY;
+            tag[e] = ok ? j0 + oj : 0x7fffffff;
         }
-        const int bw = b0 + wave;
+        const int bw = b0 + item;
         wave_top<NE>(v, tag, [&](int r, float m, int k) {
             if (lane == 0 && bw < B) {
                 ptopv_out[((size_t)jt * B + bw) * kTop + r] = m;
