@@ -115,6 +115,8 @@ def main():
     ap.add_argument('--frames', type=int, default=500)
     ap.add_argument('--states', type=int, default=1440)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--forward', choices=['auto', 'dense', 'pruned'], default='auto',
+                    help='forward-recurrence path (include/torbi_hip.h); every path gives identical indices')
     ap.add_argument('--pipeline', type=int, default=2,
                     help='decodes in flight (torbi_amd.DecodePipeline streams); 1 = strictly serial')
     ap.add_argument('--transition', choices=['dense', 'banded', 'uniform'], default='dense',
@@ -129,6 +131,7 @@ def main():
     dev = torch.device('cuda', torch.cuda.current_device())
     collective = dist.is_available() and dist.is_initialized()
     B, T, S = args.batch, args.frames, args.states
+    viterbi.set_forward_path(args.forward)
 
     # synthetic inputs generated in HBM (rank-specific observation stream; shared transition)
     obs = viterbi.fill_synthetic((B, T, S), synth.STREAM_OBSERVATION, seed=rank, device=dev)
@@ -209,6 +212,9 @@ def main():
         fwd_ms += prof[0] / 3
         bt_ms += prof[1] / 3
         launches = max(int(prof[2]), 1)
+    path = {2: 'pruned', 1: 'dense', 0: 'generic'}[int(prof[3])]
+    step_kernel = {'pruned': 'pruned::step_pruned_kernel', 'dense': 'step_dense_kernel<8, 6, 8, 12>',
+                   'generic': 'step_rows_kernel'}[path]
     per_launch_s = fwd_ms * 1e-3 / launches
     bytes_per_launch = B * algorithmic_bytes_per_timestep(S)
     achieved = bytes_per_launch / per_launch_s / 1e9
@@ -226,22 +232,25 @@ def main():
                                f'{S} states, {T} frames, batch={B} per GPU, fp32, BANDED transition '
                                f'(half width {args.half_width}, -inf outside; secondary workload)',
                    'parallelism': f'batch-sharded x{size}' if size > 1 else 'single GPU',
-                   'decodes_in_flight': args.pipeline},
+                   'decodes_in_flight': args.pipeline, 'forward_path': path},
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS,
-            'traffic': profiled_traffic('step_dense_kernel<8, 6, 8, 12>')
+            'traffic': profiled_traffic(step_kernel)
             if (B, T, S, args.transition) == (512, 500, 1440, 'dense') else None,
             'traffic_note': 'bytes per launch from profiles/r01_pmc.json (2*FETCH_SIZE + WRITE_SIZE, '
                             'Infinity-Cache hits included); the excess over the algorithmic bytes is '
-                            'transition/posterior panels re-read from the Infinity Cache each launch',
-            'kernel': 'forward step (one timestep of the whole batch per launch)',
+                            'posterior rows / transition lists re-read by the tiles of one launch',
+            'kernel': f'{step_kernel} (forward step: one timestep of the whole batch per launch)',
             'launch_us': per_launch_s * 1e6, 'launches_per_decode': launches,
             'algorithmic_bytes_per_launch': bytes_per_launch,
-            'note': 'dense (max,+) recurrence is VALU-bound (S/4 = 360 op/B); see valu',
+            'note': 'the (max,+) recurrence holds S/4 = 360 cells per algorithmic byte: the dense kernel is '
+                    'VALU-bound, the pruned kernel is bound by the CU load path (list entries through the '
+                    'texture path, posterior gathers through the LDS); see valu and DESIGN.md',
         },
         'valu': {
-            'cells_per_s': cells_per_launch / per_launch_s,
+            # cells of the full S x S recurrence per second: for the pruned path most are never evaluated
+            'dense_equivalent_cells_per_s': cells_per_launch / per_launch_s,
             'lane_instr_peak_per_s': VALU_LANE_OPS,
             'frac_at_1_instr_per_cell': cells_per_launch / per_launch_s / VALU_LANE_OPS,
         },

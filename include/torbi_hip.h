@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TORBI_HIP_ABI_VERSION 2
+#define TORBI_HIP_ABI_VERSION 3
 
 #define TORBI_HIP_OK 0
 #define TORBI_HIP_EINVAL (-1)      /* null pointer / non-positive dimension            */
@@ -68,6 +68,23 @@ int torbi_hip_device_count(void);
  * tensor from the caching allocator).  Contents need no initialisation.
  */
 size_t torbi_hip_workspace_bytes(int B, int T, int S);
+
+/*
+ * Forward-recurrence path used by torbi_hip_viterbi_decode (all paths give identical indices):
+ *   GENERIC  B < 32 or S < 64: trellis kernels shaped like the reference's
+ *   DENSE    value-only (max,+) GEMM, every (prev, next) cell evaluated
+ *   PRUNED   value-only, exact: sorted transition rows + per-item top posteriors bound the cells
+ *            that can still win, the rest are never touched (B >= 32, S % 4 == 0, 64 <= S <= 2048)
+ * AUTO (the default; also the environment variable TORBI_HIP_FORWARD=dense|pruned read once) takes
+ * PRUNED where supported, else DENSE, else GENERIC.  The setting is process-wide; a workspace of
+ * torbi_hip_workspace_bytes() fits every path.  torbi_hip_forward_path reports what a (B, S)
+ * problem would run: TORBI_HIP_FORWARD_PRUNED, _DENSE, or 0 for the generic kernels.
+ */
+#define TORBI_HIP_FORWARD_AUTO 0
+#define TORBI_HIP_FORWARD_DENSE 1
+#define TORBI_HIP_FORWARD_PRUNED 2
+int torbi_hip_set_forward_path(int path);
+int torbi_hip_forward_path(int B, int S);
 
 /*
  * The operator.  Replaces viterbi_decode_cuda (viterbi.cu:309-362) = forward trellis
@@ -103,7 +120,7 @@ int torbi_hip_viterbi_decode_uniform(const float *observation, const int32_t *ba
  * final-argmax + backtrace with hipEvents on `stream`, SYNCHRONISES the stream, and
  * returns the phases in milliseconds:
  *   phase_ms[0] = forward recurrence (all timesteps)   phase_ms[1] = argmax + backtrace
- *   phase_ms[2] = number of forward kernel launches     phase_ms[3] = reserved (0)
+ *   phase_ms[2] = number of forward kernel launches     phase_ms[3] = torbi_hip_forward_path(B, S)
  * `phase_ms` is a HOST pointer to 4 floats.
  */
 int torbi_hip_viterbi_decode_profiled(const float *observation, const int32_t *batch_frames,

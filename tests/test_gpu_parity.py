@@ -15,6 +15,15 @@ from conftest import SMALL_NAMES, LARGE_NAMES
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=['auto', 'dense'])
+def forward(request):
+    """Every test runs twice: with the automatic path choice (the exact pruned forward pass wherever it is
+    supported) and with the dense (max,+) GEMM forced.  Small batches take the generic kernels either way."""
+    viterbi.set_forward_path(request.param)
+    yield request.param
+    viterbi.set_forward_path('auto')
+
+
 def gpu_decode(obs, frames, trans, init):
     dev = torch.device('cuda:0')
     out = torbi_amd.decode(torch.as_tensor(obs, dtype=torch.float32).to(dev),
@@ -121,6 +130,43 @@ def test_dense_path_edge_shapes(shape):
     frames = np.clip(synth.lengths(B, 1, T, seed=5), 1, T)
     want = oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())
     assert np.array_equal(gpu_decode(obs, frames, trans, init), want)
+
+
+def test_forward_path_selection(forward):
+    assert viterbi.forward_path(4, 1440) == 'generic'
+    assert viterbi.forward_path(128, 4096) == 'dense'              # posterior tile does not fit the LDS
+    assert viterbi.forward_path(512, 1440) == ('pruned' if forward == 'auto' else 'dense')
+    assert viterbi.forward_path(64, 130) == 'dense'                # S % 4 != 0
+    assert viterbi.workspace_bytes(512, 500, 1440) >= 512 * 500 * 1440 * 4
+
+
+@pytest.mark.parametrize('kind', ['flat', 'nearly_flat', 'peaked', 'anti', 'two_level'])
+@pytest.mark.parametrize('shape', [(32, 12, 64), (33, 9, 132), (48, 6, 1444), (40, 5, 2048), (64, 10, 360)])
+def test_pruned_path_adversarial_inputs(kind, shape):
+    """Inputs chosen against the pruning bound: rows without spread (nothing can be pruned: the scan runs to
+    the end of every list), posteriors with a few dominant peaks (the explicit seeds carry the maximum),
+    transitions anti-correlated with the observations, and heavy ties."""
+    B, T, S = shape
+    obs, trans, init = synth.problem(B, T, S, seed=41)
+    rng = np.random.default_rng(S + T)
+    if kind == 'flat':
+        trans = np.full((S, S), np.float32(-1.25))
+    elif kind == 'nearly_flat':
+        trans = (trans * np.float32(2 ** -12)).astype(np.float32)
+    elif kind == 'peaked':
+        peaks = rng.integers(0, S, size=(B, T, 2))
+        obs = (obs - np.float32(40.0)).astype(np.float32)
+        for k in range(2):
+            np.put_along_axis(obs, peaks[:, :, k:k + 1], np.float32(-0.5 * k), axis=2)
+    elif kind == 'anti':
+        # large transitions exactly where the first observations are small
+        trans = (-obs[0, 0][None, :] - np.float32(16.0) + trans * np.float32(2 ** -6)).astype(np.float32)
+    elif kind == 'two_level':
+        trans = np.where(rng.random((S, S)) < 0.1, np.float32(-1.0), np.float32(-3.0)).astype(np.float32)
+        obs = np.round(obs).astype(np.float32)
+    frames = synth.lengths(B, 1, T, seed=S)
+    want = oracle.decode(obs, frames, trans, init, mode=1)
+    np.testing.assert_array_equal(gpu_decode(obs, frames, trans, init), want)
 
 
 @pytest.mark.parametrize('B', [2, 40])

@@ -1,0 +1,16 @@
+"""Fold the rocprofv3 CSVs written by tools/collect_profiles.sh into r01_pmc.json / r01_bench_kernel_stats.csv."""
+import collections, csv, glob, json, os, shutil, sys
+
+out = sys.argv[1]
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(out, 'pmc_*', '**', '*counter_collection.csv'), recursive=True):
+    for r in csv.DictReader(open(f)):
+        name = r['Kernel_Name'].split('(')[0].replace('void ', '').strip()
+        pmc[name][r['Counter_Name']].append(float(r['Counter_Value']))
+summary = {k: {c: {'mean_per_dispatch': sum(v) / len(v), 'dispatches': len(v)} for c, v in cs.items()}
+           for k, cs in pmc.items()}
+json.dump(summary, open(os.path.join(out, 'pmc.json'), 'w'), indent=1)
+for f in glob.glob(os.path.join(out, 'trace', '**', '*kernel_stats.csv'), recursive=True):
+    shutil.copy(f, os.path.join(out, 'kernel_stats.csv'))
+print(json.dumps({k: {c: v['mean_per_dispatch'] for c, v in cs.items()} for k, cs in summary.items()
+                  if 'step' in k}, indent=1))

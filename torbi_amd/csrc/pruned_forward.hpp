@@ -23,18 +23,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <type_traits>
 
 #include "wave_reduce.hpp"
 
 namespace pruned {
 
-constexpr int kR = 5;        // explicit top candidates per item; thr = (kR+1)-th largest posterior
+constexpr int kR = 3;        // explicit top candidates per item; thr = (kR+1)-th largest posterior
 constexpr int kNB = 16;      // batch items per tile (= lanes per next-state)
 constexpr int kBlk = 16;     // list entries per termination test
 constexpr int kPad = 4 * kBlk;  // (-inf) entries after every list row: prefetches never leave the row
 constexpr int kWaves = 12;   // waves per workgroup (3 per SIMD: 168 VGPRs each)
 constexpr int kMaxTileStates = 16 * kWaves;   // next-states per tile: one per lane group of 4
 constexpr int kTop = kR + 1;
+constexpr int kMaxS = 2048;  // the posterior tile [S][16] fp32 must leave room in the 160 KB LDS
 constexpr int kMaxJT = 16;   // state tiles per batch tile (kMaxJT * kTop candidates <= 2 per lane)
 
 struct Plan {
@@ -46,10 +48,11 @@ struct Plan {
     int NPOW;    // sort width (power of two >= S)
 };
 
-inline bool supported(int B, int S) { return B >= 32 && S % 4 == 0 && S >= 64 && S <= 2048; }
+inline bool supported(int B, int S) { return B >= 32 && S % 4 == 0 && S >= 64 && S <= kMaxS; }
 
 // dynamic LDS of step_pruned_kernel: posterior tile [S][16] + this tile's outputs [16][JT] + merged top lists
-inline size_t lds_bytes(int S, int JT) { return sizeof(float) * ((size_t)kNB * S + (size_t)kNB * JT + 2 * kNB * kTop); }
+// + the 16 items' frame counts
+inline size_t lds_bytes(int S, int JT) { return sizeof(float) * ((size_t)kNB * S + (size_t)kNB * JT + 2 * kNB * kTop + kNB); }
 
 inline Plan make_plan(int B, int S, int num_cus) {
     Plan p{};
@@ -167,6 +170,28 @@ __device__ __forceinline__ void wave_top(float (&v)[NE], const int (&tag)[NE], E
     }
 }
 
+// The same selection inside one 16-lane row (four independent selections per wave, DPP row reductions only):
+// kTop largest of the 16 * NE values a row holds.  `emit(r, value, tag)` runs on every lane with its row's result.
+template <int NE, typename Emit>
+__device__ __forceinline__ void row_top(float (&v)[NE], const int (&tag)[NE], Emit emit) {
+    unsigned picked = 0;
+#pragma unroll
+    for (int r = 0; r < kTop; ++r) {
+        float lm = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            if (!((picked >> e) & 1u)) lm = fmaxf(lm, v[e]);
+        const float m = wavered::row_reduce_f32(lm, wavered::MaxOp());
+        int lk = 0x7fffffff, le = 0;
+#pragma unroll
+        for (int e = NE - 1; e >= 0; --e)
+            if (!((picked >> e) & 1u) && tag[e] != 0x7fffffff && v[e] == m) { lk = tag[e]; le = e; }
+        const int k = wavered::row_min_i32(lk);
+        if (lk == k && k != 0x7fffffff) picked |= 1u << le;
+        emit(r, k == 0x7fffffff ? -INFINITY : m, k == 0x7fffffff ? 0 : k);
+    }
+}
+
 // once per decode: the kTop largest entries of history row 0 of every item, stored as the partial list of
 // state tile 0 (parity 0).  One wave per item; NQ float4 per lane (S <= 256*NQ).  grid = B, block = 64.
 template <int NQ>
@@ -190,6 +215,15 @@ __global__ __launch_bounds__(64) void top_kernel(const float *__restrict__ hist,
         if (lane == 0) { topv[(size_t)b * kTop + r] = m; topi[(size_t)b * kTop + r] = k; }
     });
 }
+
+#ifdef PRUNED_STAMP
+// build-time instrumentation (tools/pruned_stamps.py): per-wave cycle stamps of the last launch
+constexpr int kStamps = 10;
+__device__ unsigned long long g_stamps[1024 * kWaves * kStamps];
+#define PSTAMP(i) st[i] = __builtin_readcyclecounter()
+#else
+#define PSTAMP(i)
+#endif
 
 struct ListBlock { float4 e[kBlk / 2]; };   // 16 entries: e[u] = {t(2u), off(2u), t(2u+1), off(2u+1)}
 
@@ -219,38 +253,26 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     float *outs = lds + (size_t)kNB * S;                   // [16 items][JT] outputs of this tile
     float *mtopv = outs + (size_t)kNB * JT;                // [16][kTop] merged top values
     int *mtopi = reinterpret_cast<int *>(mtopv + kNB * kTop);
+    int *sframes = mtopi + kNB * kTop;                     // [16] frames of the tile's items (0 past the batch)
     const int tile_id = blockIdx.x;
     const int bt = tile_id % n_bt, jt = tile_id / n_bt;
     const int b0 = bt * kNB, j0 = jt * JT;
     const int tid = threadIdx.x, lane = tid & 63;
-    // skip tiles whose batch items have all ended (t >= batch_frames[b])
-    if (!__syncthreads_or(tid < kNB && b0 + tid < B && t < frames[b0 + tid])) return;
+#ifdef PRUNED_STAMP
+    unsigned long long st[kStamps] = {};
+#endif
+    PSTAMP(0);
+    int fr = 0;
+    if (tid < kNB) {
+        fr = b0 + tid < B ? frames[b0 + tid] : 0;
+        sframes[tid] = fr;
+    }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int JTv = S - j0 < JT ? S - j0 : JT;                   // next-states of this tile
     const int Sp = (S + 15) / 16 * 16;
 
-    // wave w merges the partial top lists of item b0 + w: n_jt * kTop candidates, <= 2 per lane
-    for (int item = wave; item < kNB; item += kWaves) {
-        const int bw = b0 + item < B ? b0 + item : B - 1;
-        float v[2];
-        int tag[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int cand = lane + 64 * e;
-            const bool ok = cand < n_jt * kTop;
-            const size_t src = ((size_t)(ok ? cand / kTop : 0) * B + bw) * kTop + (ok ? cand % kTop : 0);
-            v[e] = ok ? ptopv_in[src] : -INFINITY;
-            const int idx = ok ? ptopi_in[src] : 0;
-            // tag = prev-state; equal values from different tiles cannot share a prev-state
-            tag[e] = ok ? idx : 0x7fffffff;
-        }
-        wave_top<2>(v, tag, [&](int r, float m, int k) {
-            if (lane == 0) { mtopv[item * kTop + r] = m; mtopi[item * kTop + r] = k; }
-        });
-    }
-    __syncthreads();
-
-    // lane = next-state jl of the wave's 16 x item group g (items 4g .. 4g+3 of the tile)
+    // lane = next-state jl of the wave's 16 x item group g (items 4g .. 4g+3 of the tile); the first list
+    // blocks and the observations do not depend on anything staged below: issue them first
     const int jl = lane >> 2, g = lane & 3;
     const int jj = 16 * wave + jl;
     const bool jv = jj < JTv;
@@ -258,63 +280,85 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     const float2 *row = sorted + (size_t)jr * SpP;
     ListBlock cur, nxt;
     load_list_block(cur, row, 0);
-    float seedv[4][kR], seedt[4][kR], thr[4], ob[4];
+    load_list_block(nxt, row, kBlk);
+    float ob[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int b = b0 + 4 * g + it < B ? b0 + 4 * g + it : B - 1;
+        ob[it] = obs[((size_t)b * T + t) * S + jr];
+    }
+
+    // every thread fetches its share of the 16 posterior rows in ONE round trip (all loads in flight before the
+    // first LDS write); waves 0..3 merge the top lists while theirs are on the way
+    constexpr int NCH = (kNB * (kMaxS / 4) + 64 * kWaves - 1) / (64 * kWaves);
+    const int n4 = kNB * (S / 4);
+    float4 pv[NCH];
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        const int e = tid + u * 64 * kWaves;
+        const int bb = e & (kNB - 1), i4 = e / kNB;
+        const int brow = b0 + bb < B ? b0 + bb : B - 1;
+        if (e < n4) pv[u] = *reinterpret_cast<const float4 *>(hist + ((size_t)brow * T + (t - 1)) * S + 4 * i4);
+    }
+    PSTAMP(1);
+    if (wave < kNB / 4) {
+        // every 16-lane row merges the partial top lists of one item (n_jt * kTop <= 16 * NE candidates)
+        const int item = 4 * wave + (lane >> 4), l16 = lane & 15;
+        const int bw = b0 + item < B ? b0 + item : B - 1;
+        auto merge = [&](auto NEc) {
+            constexpr int NE = decltype(NEc)::value;
+            float v[NE];
+            int tag[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int cand = l16 + 16 * e;
+                const bool ok = cand < n_jt * kTop;
+                const size_t src = ((size_t)(ok ? cand / kTop : 0) * B + bw) * kTop + (ok ? cand % kTop : 0);
+                v[e] = ok ? ptopv_in[src] : -INFINITY;
+                // tag = prev-state; equal values from different tiles cannot share a prev-state
+                tag[e] = ok ? ptopi_in[src] : 0x7fffffff;
+            }
+            row_top<NE>(v, tag, [&](int r, float m, int k) {
+                if (l16 == 0) { mtopv[item * kTop + r] = m; mtopi[item * kTop + r] = k; }
+            });
+        };
+        if (n_jt * kTop <= 32) merge(std::integral_constant<int, 2>());
+        else merge(std::integral_constant<int, (kMaxJT * kTop + 15) / 16>());
+    }
+    // tile layout [prev-state][16 items]: lanes = 16 rows x 4 float4 columns
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        const int e = tid + u * 64 * kWaves;
+        if (e < n4) {
+            const int bb = e & (kNB - 1), i4 = e / kNB;
+            float *d = lds + (4 * i4) * kNB + bb;
+            d[0] = pv[u].x; d[kNB] = pv[u].y; d[2 * kNB] = pv[u].z; d[3 * kNB] = pv[u].w;
+        }
+    }
+    PSTAMP(2);
+    // one barrier publishes the tile, the merged lists and the frame counts; tiles whose items have all
+    // ended (t >= batch_frames[b]) stop here
+    if (!__syncthreads_or(t < fr)) return;
+    PSTAMP(3);
+
+    // seeds: the kR largest posteriors of each item are explicit candidates; their gathers fly while the
+    // first list block is consumed (examining more candidates never changes the maximum)
+    float seedv[4][kR], seedt[4][kR], thr[4];
     bool live[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int item = 4 * g + it;
-        const int b = b0 + item < B ? b0 + item : B - 1;
-        live[it] = b0 + item < B && t < frames[b];
+        live[it] = t < sframes[item];
         thr[it] = mtopv[item * kTop + kR];
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
             seedv[it][r] = mtopv[item * kTop + r];
-            seedt[it][r] = tt[(size_t)mtopi[item * kTop + r] * S + jr];        // trans[jr][i_r]
-        }
-        ob[it] = obs[((size_t)b * T + t) * S + jr];
-    }
-
-    // stage the 16 posterior rows as [prev-state][16 items]: lanes = 16 rows x 4 float4 columns
-    {
-        const int n4 = kNB * (S / 4);
-        for (int e0 = tid; e0 < n4; e0 += 4 * 64 * kWaves) {
-            float4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * 64 * kWaves;
-                const int bb = e & (kNB - 1), i4 = e / kNB;
-                const int brow = b0 + bb < B ? b0 + bb : B - 1;
-                v[u] = e < n4 ? *reinterpret_cast<const float4 *>(hist + ((size_t)brow * T + (t - 1)) * S + 4 * i4)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * 64 * kWaves;
-                if (e < n4) {
-                    const int bb = e & (kNB - 1), i4 = e / kNB;
-                    float *d = lds + (4 * i4) * kNB + bb;
-                    d[0] = v[u].x; d[kNB] = v[u].y; d[2 * kNB] = v[u].z; d[3 * kNB] = v[u].w;
-                }
-            }
+            seedt[it][r] = tt[(unsigned)(mtopi[item * kTop + r] * S + jr)];        // trans[jr][i_r]
         }
     }
-    __syncthreads();
-
-    float best[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        float m = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < kR; ++r) m = fmaxf(m, seedv[it][r] + seedt[it][r]);
-        best[it] = m;
-    }
+    PSTAMP(4);
     const char *ptile = reinterpret_cast<const char *>(lds) + 16 * g;
-    // stop once no lane's bound fl(t_first + thr) exceeds its best (t_first = largest unexamined entry)
-    auto more = [&](const ListBlock &blk) {
-        const float tn = blk.e[0].x;
-        return __any(jv && ((tn + thr[0] > best[0]) | (tn + thr[1] > best[1]) | (tn + thr[2] > best[2]) |
-                            (tn + thr[3] > best[3])));
-    };
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     auto consume = [&](const ListBlock &blk) {
 #pragma unroll
         for (int u = 0; u < kBlk / 2; ++u) {
@@ -327,15 +371,31 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
             best[3] = fmaxf(fmaxf(best[3], t0 + p0.w), t1 + p1.w);
         }
     };
-    // two blocks ping-pong by name (no register copies); rows carry kPad (-inf) entries past Sp
-    for (int k = 0; k < Sp; k += 2 * kBlk) {
-        if (!more(cur)) break;
-        load_list_block(nxt, row, k + kBlk);
-        consume(cur);
+    consume(cur);
+    load_list_block(cur, row, 2 * kBlk);
+    PSTAMP(5);
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int r = 0; r < kR; ++r) best[it] = fmaxf(best[it], seedv[it][r] + seedt[it][r]);
+    PSTAMP(6);
+    // stop once no lane's bound fl(t_first + thr) exceeds its best (t_first = largest unexamined entry)
+    auto more = [&](const ListBlock &blk) {
+        const float tn = blk.e[0].x;
+        return __any(jv && ((tn + thr[0] > best[0]) | (tn + thr[1] > best[1]) | (tn + thr[2] > best[2]) |
+                            (tn + thr[3] > best[3])));
+    };
+    // two blocks ping-pong by name (no register copies); rows carry kPad (-inf) entries past Sp.
+    // Block 0 is done; `nxt` holds block 1, `cur` is being refilled with block 2.
+    for (int k = kBlk; k < Sp; k += 2 * kBlk) {
         if (!more(nxt)) break;
-        load_list_block(cur, row, k + 2 * kBlk);
         consume(nxt);
+        load_list_block(nxt, row, k + 2 * kBlk);
+        if (!more(cur)) break;
+        consume(cur);
+        load_list_block(cur, row, k + 3 * kBlk);
     }
+    PSTAMP(7);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const float o = ob[it] + best[it];                                   // post'[j] = obs[t,j] + max
@@ -343,27 +403,34 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
         if (jv) outs[(4 * g + it) * JT + jj] = o;
     }
     __syncthreads();
+    PSTAMP(8);
 
-    // partial top list of this tile for each of its items: wave w scans item w's JTv outputs
-    for (int item = wave; item < kNB; item += kWaves) {
-        constexpr int NE = (kMaxTileStates + 63) / 64;
+    // partial top lists of this tile: waves 0..3, one item per 16-lane row, JTv <= 192 outputs = 12 per lane
+    if (wave < kNB / 4) {
+        constexpr int NE = (kMaxTileStates + 15) / 16;
+        const int item = 4 * wave + (lane >> 4), l16 = lane & 15;
         float v[NE];
         int tag[NE];
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            const int oj = lane + 64 * e;
+            const int oj = l16 + 16 * e;
             const bool ok = oj < JTv;
             v[e] = ok ? outs[item * JT + oj] : -INFINITY;
             tag[e] = ok ? j0 + oj : 0x7fffffff;
         }
         const int bw = b0 + item;
-        wave_top<NE>(v, tag, [&](int r, float m, int k) {
-            if (lane == 0 && bw < B) {
+        row_top<NE>(v, tag, [&](int r, float m, int k) {
+            if (l16 == 0 && bw < B) {
                 ptopv_out[((size_t)jt * B + bw) * kTop + r] = m;
                 ptopi_out[((size_t)jt * B + bw) * kTop + r] = k;
             }
         });
     }
+#ifdef PRUNED_STAMP
+    PSTAMP(9);
+    if (lane == 0 && blockIdx.x < 1024)
+        for (int i = 0; i < kStamps; ++i) g_stamps[((size_t)blockIdx.x * kWaves + wave) * kStamps + i] = st[i];
+#endif
 }
 
 }  // namespace pruned

@@ -16,6 +16,7 @@
 // See DESIGN.md for the roofline analysis and kernel inventory.
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stddef.h>
 #include <math.h>
@@ -407,16 +408,23 @@ constexpr int kNumCUs = 256;   // MI355X; the tiling plan is a pure function of 
 // kernels above, which materialise the int32 trellis like the reference does.
 inline bool use_dense(int B, int S) { return B >= 32 && S >= 64; }
 
-// TORBI_HIP_FORWARD=pruned selects the exact pruned forward pass (pruned_forward.hpp) where it is
-// supported; anything else keeps the dense (max,+) GEMM.
-inline bool want_pruned() {
-    static const bool v = [] {
+// Forward-pass selection among the value-only paths: TORBI_HIP_FORWARD_AUTO picks the exact pruned
+// recurrence (pruned_forward.hpp) wherever it is supported and the dense (max,+) GEMM elsewhere;
+// torbi_hip_set_forward_path / the TORBI_HIP_FORWARD environment variable ("dense", "pruned") force one.
+std::atomic<int> g_forward_path{-1};
+inline int forward_path() {
+    int v = g_forward_path.load(std::memory_order_relaxed);
+    if (v < 0) {
         const char *e = getenv("TORBI_HIP_FORWARD");
-        return e && e[0] == 'p';
-    }();
+        v = !e ? TORBI_HIP_FORWARD_AUTO
+               : e[0] == 'd' ? TORBI_HIP_FORWARD_DENSE : e[0] == 'p' ? TORBI_HIP_FORWARD_PRUNED : TORBI_HIP_FORWARD_AUTO;
+        g_forward_path.store(v, std::memory_order_relaxed);
+    }
     return v;
 }
-inline bool use_pruned(int B, int S) { return want_pruned() && pruned::supported(B, S); }
+inline bool use_pruned(int B, int S) {
+    return forward_path() != TORBI_HIP_FORWARD_DENSE && pruned::supported(B, S);
+}
 
 struct PrunedWorkspace {
     pruned::Plan plan;
@@ -726,12 +734,26 @@ int torbi_hip_device_count(void) {
 
 size_t torbi_hip_workspace_bytes(int B, int T, int S) {
     if (B <= 0 || T <= 0 || S <= 0) return 256;
+    // the larger of the candidate paths, so a workspace stays valid across torbi_hip_set_forward_path
     size_t need = use_dense(B, S) ? carve_dense(nullptr, B, T, S).bytes : carve(nullptr, B, T, S).bytes;
-    if (use_pruned(B, S)) {
+    if (pruned::supported(B, S)) {
         const size_t p = carve_pruned(nullptr, B, T, S).bytes;
         if (p > need) need = p;
     }
     return need;
+}
+
+int torbi_hip_set_forward_path(int path) {
+    if (path != TORBI_HIP_FORWARD_AUTO && path != TORBI_HIP_FORWARD_DENSE && path != TORBI_HIP_FORWARD_PRUNED)
+        return TORBI_HIP_EINVAL;
+    g_forward_path.store(path, std::memory_order_relaxed);
+    return TORBI_HIP_OK;
+}
+
+int torbi_hip_forward_path(int B, int S) {
+    if (B <= 0 || S <= 0) return TORBI_HIP_EINVAL;
+    if (use_pruned(B, S)) return TORBI_HIP_FORWARD_PRUNED;
+    return use_dense(B, S) ? TORBI_HIP_FORWARD_DENSE : TORBI_HIP_FORWARD_AUTO;
 }
 
 int torbi_hip_viterbi_decode(const float *observation, const int32_t *batch_frames,
@@ -800,7 +822,7 @@ int torbi_hip_viterbi_decode_profiled(const float *observation, const int32_t *b
         (void)hipEventElapsedTime(&phase_ms[0], ev[0], ev[1]);
         (void)hipEventElapsedTime(&phase_ms[1], ev[1], ev[2]);
         phase_ms[2] = (float)launches;
-        phase_ms[3] = use_dense(B, S) ? 1.0f : 0.0f;
+        phase_ms[3] = (float)torbi_hip_forward_path(B, S);
     }
     for (auto &x : ev) (void)hipEventDestroy(x);
     return (int)e;
@@ -864,3 +886,10 @@ int torbi_hip_fill_synthetic(float *dst, uint64_t count, uint64_t start, int str
 }
 
 }  // extern "C"
+
+#ifdef PRUNED_STAMP
+// instrumentation build only (tools/pruned_stamps.py); not part of include/torbi_hip.h
+extern "C" int torbi_hip_debug_stamps(unsigned long long *host, size_t count) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pruned::g_stamps), count * sizeof(unsigned long long));
+}
+#endif

@@ -31,6 +31,24 @@ __device__ __forceinline__ int wave_min_i32(int x) {
                min(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)));
 }
 
+// the same four DPP steps alone: every lane ends with the reduction of its own 16-lane row
+template <typename Op>
+__device__ __forceinline__ float row_reduce_f32(float x, Op op) {
+    x = op(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true)));
+    x = op(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true)));
+    x = op(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true)));
+    x = op(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, true)));
+    return x;
+}
+
+__device__ __forceinline__ int row_min_i32(int x) {
+    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true));
+    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true));
+    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true));
+    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, true));
+    return x;
+}
+
 struct MaxOp {
     __device__ __forceinline__ float operator()(float a, float b) const { return __builtin_fmaxf(a, b); }
 };

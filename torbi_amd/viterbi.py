@@ -114,6 +114,23 @@ def decode(
     return indices if home == device else indices.to(home)
 
 
+FORWARD_PATHS = {'auto': 0, 'dense': 1, 'pruned': 2}
+
+
+def set_forward_path(path: str = 'auto') -> None:
+    """Process-wide choice of the forward recurrence (include/torbi_hip.h): 'auto' (default:
+    the exact pruned pass where supported, else the dense (max,+) GEMM), 'dense' or 'pruned'.
+    Every path returns identical indices; this is a performance knob and a test hook."""
+    _lib.check(_lib.load().torbi_hip_set_forward_path(FORWARD_PATHS[path]),
+               'torbi_hip_set_forward_path')
+
+
+def forward_path(batch: int, states: int) -> str:
+    """Which forward path a (batch, states) problem runs: 'pruned', 'dense' or 'generic'."""
+    code = _lib.load().torbi_hip_forward_path(int(batch), int(states))
+    return {2: 'pruned', 1: 'dense', 0: 'generic'}[code]
+
+
 def uniform_supported(states: int) -> bool:
     """Shapes the uniform-transition entry point covers (include/torbi_hip.h)."""
     return states % 4 == 0 and states <= 4096
