@@ -114,6 +114,55 @@ __global__ __launch_bounds__(256) void sort_rows_kernel(const float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// once per decode, after the sort: reorder the entries INSIDE every 16-entry block so that the four rows of an
+// aligned row quad (4q .. 4q+3) name prev-states of different residue mod 4 at the same block position wherever
+// possible.  The step kernel puts a row quad on one ds_read_b128 lane group, all four rows read the same
+// position at the same time, and a posterior row [prev-state][16 items] is 64 B = a quarter of the 256-byte
+// bank row: equal residues are a bank conflict (2.1 LDS cycles per read for random lists, ~1.4 after this
+// pass).  The maximum is order independent and position 0 (the block's largest t, used by the termination
+// test) stays put, so results do not change.  One thread per (row quad, block); grid covers S/4 * SpP/16 threads.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void arrange_blocks_kernel(float2 *__restrict__ sorted, int S, int SpP) {
+    const int nblk = SpP / kBlk;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (S / 4) * nblk) return;
+    const int q = id / nblk, kb = id % nblk;
+    unsigned present[kBlk];                 // per position: 4 x 8-bit counts of the residues placed so far
+    {
+        const float2 *r0 = sorted + (size_t)(4 * q) * SpP + kb * kBlk;
+        for (int p = 0; p < kBlk; ++p) present[p] = 1u << (8 * ((__float_as_int(r0[p].y) >> 6) & 3));
+    }
+    for (int r = 1; r < 4; ++r) {
+        float2 *row = sorted + (size_t)(4 * q + r) * SpP + kb * kBlk;
+        float2 ent[kBlk], out[kBlk];
+        unsigned remaining = 0;             // 4 x 8-bit counts of the residues still to place
+        for (int e = 0; e < kBlk; ++e) {
+            ent[e] = row[e];
+            if (e) remaining += 1u << (8 * ((__float_as_int(ent[e].y) >> 6) & 3));
+        }
+        out[0] = ent[0];
+        present[0] += 1u << (8 * ((__float_as_int(ent[0].y) >> 6) & 3));
+        unsigned used = 1u;
+        for (int p = 1; p < kBlk; ++p) {
+            int pick = -1, key = 1 << 30;
+            for (int e = 1; e < kBlk; ++e) {
+                if ((used >> e) & 1u) continue;
+                const int res = (__float_as_int(ent[e].y) >> 6) & 3;
+                // fewest equal residues already at this position; then the residue with most entries left
+                const int k = (int)((present[p] >> (8 * res)) & 0xffu) * 64 - (int)((remaining >> (8 * res)) & 0xffu);
+                if (k < key) { key = k; pick = e; }
+            }
+            const int res = (__float_as_int(ent[pick].y) >> 6) & 3;
+            used |= 1u << pick;
+            remaining -= 1u << (8 * res);
+            present[p] += 1u << (8 * res);
+            out[p] = ent[pick];
+        }
+        for (int p = 1; p < kBlk; ++p) row[p] = out[p];
+    }
+}
+
 // once per decode: tt[i][j] = trans[j][i] (seed candidates are read along next-states)
 __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ trans, float *__restrict__ tt,
                                                         int S) {
@@ -225,12 +274,22 @@ __device__ unsigned long long g_stamps[1024 * kWaves * kStamps];
 #define PSTAMP(i)
 #endif
 
-struct ListBlock { float4 e[kBlk / 2]; };   // 16 entries: e[u] = {t(2u), off(2u), t(2u+1), off(2u+1)}
+// A 16-entry list block of one row is held by the row's FOUR lanes (item groups g = 0..3), four entries each:
+// the wave loads every list byte once (duplicate lanes would quadruple the texture-path bytes, the busiest unit of
+// this kernel) and the entries are handed round the quad by DPP quad_perm broadcasts when they are consumed.
+struct ListBlock { float4 e[2]; };   // entries 4g .. 4g+3 of the block: e[h] = {t, off, t, off}
 
-__device__ __forceinline__ void load_list_block(ListBlock &blk, const float2 *row, int k) {
-#pragma unroll
-    for (int u = 0; u < kBlk / 2; ++u) blk.e[u] = *reinterpret_cast<const float4 *>(row + k + 2 * u);
+__device__ __forceinline__ void load_list_block(ListBlock &blk, const float2 *row_g, int k) {   // row_g = row + 4g
+    blk.e[0] = *reinterpret_cast<const float4 *>(row_g + k);
+    blk.e[1] = *reinterpret_cast<const float4 *>(row_g + k + 2);
 }
+
+template <int G>
+__device__ __forceinline__ float quad_bcast(float x) {     // value held by lane G of this lane's quad
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), G * 0x55, 0xf, 0xf, true));
+}
+template <int G>
+__device__ __forceinline__ int quad_bcast(int x) { return __builtin_amdgcn_update_dpp(0, x, G * 0x55, 0xf, 0xf, true); }
 
 // ---------------------------------------------------------------------------------------
 // one timestep.  grid = n_bt * n_jt, block = 64 * kWaves, dynamic LDS = lds_bytes(S, JT).
@@ -273,11 +332,13 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
 
     // lane = next-state jl of the wave's 16 x item group g (items 4g .. 4g+3 of the tile); the first list
     // blocks and the observations do not depend on anything staged below: issue them first
-    const int jl = lane >> 2, g = lane & 3;
+    // quads of lanes -> next-states so that every ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31},
+    // +32) holds an aligned row quad (arrange_blocks_kernel keeps those conflict-poor)
+    const int jl = (int)((0xFBAE9DC873261540ull >> (4 * (lane >> 2))) & 15), g = lane & 3;
     const int jj = 16 * wave + jl;
     const bool jv = jj < JTv;
     const int jr = jv ? j0 + jj : j0;
-    const float2 *row = sorted + (size_t)jr * SpP;
+    const float2 *row = sorted + (size_t)jr * SpP + 4 * g;      // this lane's quarter of every 16-entry block
     ListBlock cur, nxt;
     load_list_block(cur, row, 0);
     load_list_block(nxt, row, kBlk);
@@ -359,17 +420,26 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     PSTAMP(4);
     const char *ptile = reinterpret_cast<const char *>(lds) + 16 * g;
     float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    auto consume = [&](const ListBlock &blk) {
+    auto pair = [&](float t0, int o0, float t1, int o1) {
+        const float4 p0 = *reinterpret_cast<const float4 *>(ptile + o0);
+        const float4 p1 = *reinterpret_cast<const float4 *>(ptile + o1);
+        best[0] = fmaxf(fmaxf(best[0], t0 + p0.x), t1 + p1.x);
+        best[1] = fmaxf(fmaxf(best[1], t0 + p0.y), t1 + p1.y);
+        best[2] = fmaxf(fmaxf(best[2], t0 + p0.z), t1 + p1.z);
+        best[3] = fmaxf(fmaxf(best[3], t0 + p0.w), t1 + p1.w);
+    };
+    auto owner = [&](auto Gc, const ListBlock &blk) {      // the four entries held by lane G of the quad
+        constexpr int G = decltype(Gc)::value;
 #pragma unroll
-        for (int u = 0; u < kBlk / 2; ++u) {
-            const float4 p0 = *reinterpret_cast<const float4 *>(ptile + __float_as_int(blk.e[u].y));
-            const float4 p1 = *reinterpret_cast<const float4 *>(ptile + __float_as_int(blk.e[u].w));
-            const float t0 = blk.e[u].x, t1 = blk.e[u].z;
-            best[0] = fmaxf(fmaxf(best[0], t0 + p0.x), t1 + p1.x);
-            best[1] = fmaxf(fmaxf(best[1], t0 + p0.y), t1 + p1.y);
-            best[2] = fmaxf(fmaxf(best[2], t0 + p0.z), t1 + p1.z);
-            best[3] = fmaxf(fmaxf(best[3], t0 + p0.w), t1 + p1.w);
-        }
+        for (int h = 0; h < 2; ++h)
+            pair(quad_bcast<G>(blk.e[h].x), quad_bcast<G>(__float_as_int(blk.e[h].y)),
+                 quad_bcast<G>(blk.e[h].z), quad_bcast<G>(__float_as_int(blk.e[h].w)));
+    };
+    auto consume = [&](const ListBlock &blk) {
+        owner(std::integral_constant<int, 0>(), blk);
+        owner(std::integral_constant<int, 1>(), blk);
+        owner(std::integral_constant<int, 2>(), blk);
+        owner(std::integral_constant<int, 3>(), blk);
     };
     consume(cur);
     load_list_block(cur, row, 2 * kBlk);
@@ -381,7 +451,7 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     PSTAMP(6);
     // stop once no lane's bound fl(t_first + thr) exceeds its best (t_first = largest unexamined entry)
     auto more = [&](const ListBlock &blk) {
-        const float tn = blk.e[0].x;
+        const float tn = quad_bcast<0>(blk.e[0].x);
         return __any(jv && ((tn + thr[0] > best[0]) | (tn + thr[1] > best[1]) | (tn + thr[2] > best[2]) |
                             (tn + thr[3] > best[3])));
     };

@@ -612,6 +612,10 @@ hipError_t launch_pruned_forward(const float *obs, const int32_t *frames, const 
     const pruned::Plan &pl = w.plan;
     hipLaunchKernelGGL(pruned::sort_rows_kernel, dim3(S), dim3(256), sizeof(float) * 2 * (size_t)pl.NPOW, stream,
                        trans, w.sorted, S, pl.SpP, pl.NPOW);
+    {
+        const int n = (S / 4) * (pl.SpP / pruned::kBlk);
+        hipLaunchKernelGGL(pruned::arrange_blocks_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, w.sorted, S, pl.SpP);
+    }
     hipLaunchKernelGGL(pruned::transpose_kernel, dim3((S + 31) / 32, (S + 31) / 32), dim3(256), 0, stream, trans,
                        w.tt, S);
     {
