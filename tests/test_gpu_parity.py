@@ -15,10 +15,11 @@ from conftest import SMALL_NAMES, LARGE_NAMES
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=['auto', 'dense'])
+@pytest.fixture(autouse=True, params=['auto', 'dense', 'pruned'])
 def forward(request):
-    """Every test runs twice: with the automatic path choice (the exact pruned forward pass wherever it is
-    supported) and with the dense (max,+) GEMM forced.  Small batches take the generic kernels either way."""
+    """Every test runs three times: with the automatic path choice (pruned, or dense for narrow-band
+    matrices), with the dense (max,+) GEMM forced and with the exact pruned pass forced wherever it is
+    supported.  Small batches take the generic kernels every time."""
     viterbi.set_forward_path(request.param)
     yield request.param
     viterbi.set_forward_path('auto')
@@ -135,9 +136,29 @@ def test_dense_path_edge_shapes(shape):
 def test_forward_path_selection(forward):
     assert viterbi.forward_path(4, 1440) == 'generic'
     assert viterbi.forward_path(128, 4096) == 'dense'              # posterior tile does not fit the LDS
-    assert viterbi.forward_path(512, 1440) == ('pruned' if forward == 'auto' else 'dense')
+    assert viterbi.forward_path(512, 1440) == ('dense' if forward == 'dense' else 'pruned')
     assert viterbi.forward_path(64, 130) == 'dense'                # S % 4 != 0
     assert viterbi.workspace_bytes(512, 500, 1440) >= 512 * 500 * 1440 * 4
+
+
+def test_auto_takes_the_dense_kernel_for_narrow_bands_only(forward):
+    """The Python layer looks at the transition once per tensor version (torbi_amd/viterbi.py)."""
+    if forward != 'auto':
+        pytest.skip('path forced')
+    B, T, S = 64, 6, 360
+    obs, trans, init = synth.problem(B, T, S, seed=3)
+    frames = np.full(B, T, dtype=np.int32)
+    dev = torch.device('cuda:0')
+    args = [torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)]
+    prof = []
+    torbi_amd.decode(*args, _profile=prof)
+    assert int(prof[3]) == 2                                         # dense random matrix: pruned
+    band = torch.as_tensor(synth.banded_transition(S, 20.0)).to(dev)
+    torbi_amd.decode(args[0], args[1], band, args[3], _profile=prof)
+    assert int(prof[3]) == 1                                         # narrow band: dense + -inf skipping
+    band.fill_(-1.0)                                                 # same storage, new version
+    torbi_amd.decode(args[0], args[1], band, args[3], _profile=prof)
+    assert int(prof[3]) == 2
 
 
 @pytest.mark.parametrize('kind', ['flat', 'nearly_flat', 'peaked', 'anti', 'two_level'])

@@ -79,16 +79,28 @@ inline Plan make_plan(int B, int S, int num_cus) {
 // dynamic LDS = NPOW * 8 bytes.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sort_rows_kernel(const float *__restrict__ trans,
-                                                        float2 *__restrict__ sorted, int S, int SpP, int NPOW) {
+                                                        float2 *__restrict__ sorted, int32_t *__restrict__ row_range,
+                                                        int S, int SpP, int NPOW) {
     extern __shared__ float skey[];
     int *sval = reinterpret_cast<int *>(skey + NPOW);
+    __shared__ int s_lo, s_hi;
     const int j = blockIdx.x;
     const float *row = trans + (size_t)j * S;
-    for (int k = threadIdx.x; k < NPOW; k += 256) {
-        skey[k] = k < S ? row[k] : -INFINITY;
-        sval[k] = k < S ? k * (kNB * 4) : 0;
-    }
+    if (threadIdx.x == 0) { s_lo = S; s_hi = -1; }
     __syncthreads();
+    int lo = S, hi = -1;
+    for (int k = threadIdx.x; k < NPOW; k += 256) {
+        const float v = k < S ? row[k] : -INFINITY;
+        skey[k] = v;
+        sval[k] = k < S ? k * (kNB * 4) : 0;
+        if (v != -INFINITY) { lo = min(lo, k); hi = max(hi, k); }
+    }
+    if (hi >= 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+    __syncthreads();
+    // prev-states this row can reach: [lo, hi]; a row of (-inf) only claims everything (never pruned anyway)
+    const bool dead = s_hi < 0;
+    const int row_lo = dead ? 0 : s_lo, row_hi = dead ? S - 1 : s_hi;
+    if (threadIdx.x == 0) { row_range[2 * j] = row_lo; row_range[2 * j + 1] = row_hi; }
     for (int size = 2; size <= NPOW; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int k = threadIdx.x; k < NPOW; k += 256) {
@@ -109,7 +121,9 @@ __global__ __launch_bounds__(256) void sort_rows_kernel(const float *__restrict_
     for (int k = threadIdx.x; k < SpP; k += 256) {
         float2 v;
         v.x = k < S ? skey[k] : -INFINITY;
-        v.y = __builtin_bit_cast(float, k < S ? sval[k] : 0);
+        // (-inf) entries and the padding name a prev-state inside the row's range: a tile stages only the
+        // posterior rows its next-states can reach, and the scan may still touch such an entry (block granularity)
+        v.y = __builtin_bit_cast(float, (k < S && v.x != -INFINITY) ? sval[k] : row_lo * (kNB * 4));
         out[k] = v;
     }
 }
@@ -161,6 +175,18 @@ __global__ __launch_bounds__(64) void arrange_blocks_kernel(float2 *__restrict__
         }
         for (int p = 1; p < kBlk; ++p) row[p] = out[p];
     }
+}
+
+// once per decode: prev-state range [lo, hi] (in units of 4 prev-states) each state tile has to stage
+__global__ __launch_bounds__(64) void tile_range_kernel(const int32_t *__restrict__ row_range,
+                                                        int32_t *__restrict__ tile_range, int S, int JT) {
+    const int jt = blockIdx.x, j0 = jt * JT;
+    const int jend = j0 + JT < S ? j0 + JT : S;
+    int lo = S, hi = 0;
+    for (int j = j0 + (int)threadIdx.x; j < jend; j += 64) { lo = min(lo, row_range[2 * j]); hi = max(hi, row_range[2 * j + 1]); }
+    lo = wavered::wave_min_i32(lo);
+    hi = -wavered::wave_min_i32(-hi);
+    if (threadIdx.x == 0) { tile_range[2 * jt] = lo / 4; tile_range[2 * jt + 1] = hi / 4; }
 }
 
 // once per decode: tt[i][j] = trans[j][i] (seed candidates are read along next-states)
@@ -305,9 +331,9 @@ __device__ __forceinline__ int quad_bcast(int x) { return __builtin_amdgcn_updat
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     const float *__restrict__ obs, const int32_t *__restrict__ frames, const float *__restrict__ tt,
-    const float2 *__restrict__ sorted, const float *__restrict__ ptopv_in, const int32_t *__restrict__ ptopi_in,
-    float *__restrict__ ptopv_out, int32_t *__restrict__ ptopi_out, float *__restrict__ hist, int B, int T, int S,
-    int t, int SpP, int n_bt, int n_jt, int JT) {
+    const float2 *__restrict__ sorted, const int32_t *__restrict__ tile_range, const float *__restrict__ ptopv_in,
+    const int32_t *__restrict__ ptopi_in, float *__restrict__ ptopv_out, int32_t *__restrict__ ptopi_out,
+    float *__restrict__ hist, int B, int T, int S, int t, int SpP, int n_bt, int n_jt, int JT) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *outs = lds + (size_t)kNB * S;                   // [16 items][JT] outputs of this tile
     float *mtopv = outs + (size_t)kNB * JT;                // [16][kTop] merged top values
@@ -351,13 +377,16 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
 
     // every thread fetches its share of the 16 posterior rows in ONE round trip (all loads in flight before the
     // first LDS write); waves 0..3 merge the top lists while theirs are on the way
+    // Only the prev-states this tile's next-states can reach are staged (tile_range: the whole range for a
+    // dense matrix, the band for a banded one).
     constexpr int NCH = (kNB * (kMaxS / 4) + 64 * kWaves - 1) / (64 * kWaves);
-    const int n4 = kNB * (S / 4);
+    const int lo4 = tile_range[2 * jt], hi4 = tile_range[2 * jt + 1];
+    const int n4 = kNB * (hi4 - lo4 + 1);
     float4 pv[NCH];
 #pragma unroll
     for (int u = 0; u < NCH; ++u) {
         const int e = tid + u * 64 * kWaves;
-        const int bb = e & (kNB - 1), i4 = e / kNB;
+        const int bb = e & (kNB - 1), i4 = lo4 + e / kNB;
         const int brow = b0 + bb < B ? b0 + bb : B - 1;
         if (e < n4) pv[u] = *reinterpret_cast<const float4 *>(hist + ((size_t)brow * T + (t - 1)) * S + 4 * i4);
     }
@@ -391,7 +420,7 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     for (int u = 0; u < NCH; ++u) {
         const int e = tid + u * 64 * kWaves;
         if (e < n4) {
-            const int bb = e & (kNB - 1), i4 = e / kNB;
+            const int bb = e & (kNB - 1), i4 = lo4 + e / kNB;
             float *d = lds + (4 * i4) * kNB + bb;
             d[0] = pv[u].x; d[kNB] = pv[u].y; d[2 * kNB] = pv[u].z; d[3 * kNB] = pv[u].w;
         }

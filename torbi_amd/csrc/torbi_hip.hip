@@ -430,6 +430,8 @@ struct PrunedWorkspace {
     pruned::Plan plan;
     float2 *sorted;    // [S][SpP] transition rows in descending order: {t, prev-state byte offset}
     float *tt;         // [S][S]   transposed transition matrix
+    int32_t *row_range;  // [S][2]    finite prev-state range of every transition row
+    int32_t *tile_range; // [n_jt][2] prev-state range (units of 4) each state tile stages
     float *topv;       // [2][n_jt][B][6] partial top lists (values), ping-pong by timestep parity
     int32_t *topi;     // [2][n_jt][B][6] their prev-states
     size_t top_stride; // elements per parity
@@ -447,13 +449,17 @@ inline PrunedWorkspace carve_pruned(void *base, int B, int T, int S) {
     w.top_stride = (size_t)w.plan.n_jt * B * pruned::kTop;
     const size_t topv_bytes = align_up(sizeof(float) * 2 * w.top_stride, 256);
     const size_t topi_bytes = align_up(sizeof(int32_t) * 2 * w.top_stride, 256);
+    const size_t range_bytes = align_up(sizeof(int32_t) * 2 * ((size_t)S + pruned::kMaxJT), 256);
     w.sorted = reinterpret_cast<float2 *>(p);
     w.tt = reinterpret_cast<float *>(p + sorted_bytes);
     w.topv = reinterpret_cast<float *>(p + sorted_bytes + tt_bytes);
     w.topi = reinterpret_cast<int32_t *>(p + sorted_bytes + tt_bytes + topv_bytes);
-    w.hist = reinterpret_cast<float *>(p + sorted_bytes + tt_bytes + topv_bytes + topi_bytes);
+    w.row_range = reinterpret_cast<int32_t *>(p + sorted_bytes + tt_bytes + topv_bytes + topi_bytes);
+    w.tile_range = w.row_range + 2 * (size_t)S;
+    w.hist = reinterpret_cast<float *>(p + sorted_bytes + tt_bytes + topv_bytes + topi_bytes + range_bytes);
     w.top_bytes = topv_bytes + topi_bytes;
-    w.bytes = sorted_bytes + tt_bytes + topv_bytes + topi_bytes + align_up(sizeof(float) * (size_t)B * T * S, 256);
+    w.bytes = sorted_bytes + tt_bytes + topv_bytes + topi_bytes + range_bytes +
+              align_up(sizeof(float) * (size_t)B * T * S, 256);
     return w;
 }
 
@@ -611,7 +617,8 @@ hipError_t launch_pruned_forward(const float *obs, const int32_t *frames, const 
                                  hipStream_t stream, int *launches) {
     const pruned::Plan &pl = w.plan;
     hipLaunchKernelGGL(pruned::sort_rows_kernel, dim3(S), dim3(256), sizeof(float) * 2 * (size_t)pl.NPOW, stream,
-                       trans, w.sorted, S, pl.SpP, pl.NPOW);
+                       trans, w.sorted, w.row_range, S, pl.SpP, pl.NPOW);
+    hipLaunchKernelGGL(pruned::tile_range_kernel, dim3(pl.n_jt), dim3(64), 0, stream, w.row_range, w.tile_range, S, pl.JT);
     {
         const int n = (S / 4) * (pl.SpP / pruned::kBlk);
         hipLaunchKernelGGL(pruned::arrange_blocks_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, w.sorted, S, pl.SpP);
@@ -641,7 +648,7 @@ hipError_t launch_pruned_forward(const float *obs, const int32_t *frames, const 
     for (int t = 1; t < T; ++t) {
         const size_t in = ((t - 1) & 1) * w.top_stride, out = (t & 1) * w.top_stride;
         hipLaunchKernelGGL(pruned::step_pruned_kernel, dim3(pl.n_bt * pl.n_jt), dim3(64 * pruned::kWaves), lds, stream,
-                           obs, frames, w.tt, w.sorted, w.topv + in, w.topi + in, w.topv + out, w.topi + out, w.hist,
+                           obs, frames, w.tt, w.sorted, w.tile_range, w.topv + in, w.topi + in, w.topv + out, w.topi + out, w.hist,
                            B, T, S, t, pl.SpP, pl.n_bt, pl.n_jt, pl.JT);
         ++n;
     }
