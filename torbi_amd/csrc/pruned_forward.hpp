@@ -33,7 +33,10 @@ constexpr int kR = 3;        // explicit top candidates per item; thr = (kR+1)-t
 constexpr int kNB = 16;      // batch items per tile (= lanes per next-state)
 constexpr int kBlk = 16;     // list entries per termination test
 constexpr int kPad = 4 * kBlk;  // (-inf) entries after every list row: prefetches never leave the row
-constexpr int kWaves = 12;   // waves per workgroup (3 per SIMD: 168 VGPRs each)
+#ifndef PRUNED_WAVES
+#define PRUNED_WAVES 12
+#endif
+constexpr int kWaves = PRUNED_WAVES;   // waves per workgroup (12 = 3 per SIMD: 168 VGPRs each)
 constexpr int kMaxTileStates = 16 * kWaves;   // next-states per tile: one per lane group of 4
 constexpr int kTop = kR + 1;
 constexpr int kMaxS = 2048;  // the posterior tile [S][16] fp32 must leave room in the 160 KB LDS
@@ -50,9 +53,12 @@ struct Plan {
 
 inline bool supported(int B, int S) { return B >= 32 && S % 4 == 0 && S >= 64 && S <= kMaxS; }
 
-// dynamic LDS of step_pruned_kernel: posterior tile [S][16] + this tile's outputs [16][JT] + merged top lists
-// + the 16 items' frame counts
-inline size_t lds_bytes(int S, int JT) { return sizeof(float) * ((size_t)kNB * S + (size_t)kNB * JT + 2 * kNB * kTop + kNB); }
+// dynamic LDS of step_pruned_kernel: posterior tile [S][16] + merged top lists + the 16 items' frame counts
+// + this tile's running top lists (64-bit keys)
+inline size_t lds_bytes(int S, int JT) {
+    (void)JT;
+    return sizeof(float) * ((size_t)kNB * S + 2 * kNB * kTop + kNB) + sizeof(unsigned long long) * kNB * kTop;
+}
 
 inline Plan make_plan(int B, int S, int num_cus) {
     Plan p{};
@@ -335,8 +341,10 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     const int32_t *__restrict__ ptopi_in, float *__restrict__ ptopv_out, int32_t *__restrict__ ptopi_out,
     float *__restrict__ hist, int B, int T, int S, int t, int SpP, int n_bt, int n_jt, int JT) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *outs = lds + (size_t)kNB * S;                   // [16 items][JT] outputs of this tile
-    float *mtopv = outs + (size_t)kNB * JT;                // [16][kTop] merged top values
+    // [16][kTop] running top list of this tile's outputs per item, as 64-bit keys (order-preserving value bits,
+    // ~next-state); 8-byte aligned because kNB * S is even
+    unsigned long long *ttop = reinterpret_cast<unsigned long long *>(lds + (size_t)kNB * S);
+    float *mtopv = reinterpret_cast<float *>(ttop + kNB * kTop);   // [16][kTop] merged top values of t-1
     int *mtopi = reinterpret_cast<int *>(mtopv + kNB * kTop);
     int *sframes = mtopi + kNB * kTop;                     // [16] frames of the tile's items (0 past the batch)
     const int tile_id = blockIdx.x;
@@ -352,9 +360,28 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
         fr = b0 + tid < B ? frames[b0 + tid] : 0;
         sframes[tid] = fr;
     }
+    if (tid < kNB * kTop) ttop[tid] = 0ull;                // 0 = empty (every real key is > 0)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int JTv = S - j0 < JT ? S - j0 : JT;                   // next-states of this tile
     const int Sp = (S + 15) / 16 * 16;
+
+    // waves 0..3 merge top lists later; their candidates (n_jt * kTop <= 16 * kMergeNE per item, tag = prev-state:
+    // equal values from different tiles cannot share a prev-state) are the first loads of the kernel
+    constexpr int kMergeNE = (kMaxJT * kTop + 15) / 16;
+    const int mitem = 4 * wave + (lane >> 4), ml16 = lane & 15;
+    float mv[kMergeNE];
+    int mtag[kMergeNE];
+    if (wave < kNB / 4) {
+        const int bw = b0 + mitem < B ? b0 + mitem : B - 1;
+#pragma unroll
+        for (int e = 0; e < kMergeNE; ++e) {
+            const int cand = ml16 + 16 * e;
+            const bool ok = cand < n_jt * kTop;
+            const size_t src = ((size_t)(ok ? cand / kTop : 0) * B + bw) * kTop + (ok ? cand % kTop : 0);
+            mv[e] = ok ? ptopv_in[src] : -INFINITY;
+            mtag[e] = ok ? ptopi_in[src] : 0x7fffffff;
+        }
+    }
 
     // lane = next-state jl of the wave's 16 x item group g (items 4g .. 4g+3 of the tile); the first list
     // blocks and the observations do not depend on anything staged below: issue them first
@@ -392,28 +419,17 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     }
     PSTAMP(1);
     if (wave < kNB / 4) {
-        // every 16-lane row merges the partial top lists of one item (n_jt * kTop <= 16 * NE candidates)
-        const int item = 4 * wave + (lane >> 4), l16 = lane & 15;
-        const int bw = b0 + item < B ? b0 + item : B - 1;
-        auto merge = [&](auto NEc) {
-            constexpr int NE = decltype(NEc)::value;
-            float v[NE];
-            int tag[NE];
-#pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                const int cand = l16 + 16 * e;
-                const bool ok = cand < n_jt * kTop;
-                const size_t src = ((size_t)(ok ? cand / kTop : 0) * B + bw) * kTop + (ok ? cand % kTop : 0);
-                v[e] = ok ? ptopv_in[src] : -INFINITY;
-                // tag = prev-state; equal values from different tiles cannot share a prev-state
-                tag[e] = ok ? ptopi_in[src] : 0x7fffffff;
-            }
-            row_top<NE>(v, tag, [&](int r, float m, int k) {
-                if (l16 == 0) { mtopv[item * kTop + r] = m; mtopi[item * kTop + r] = k; }
-            });
+        // every 16-lane row merges the partial top lists of one item (candidates fetched at kernel entry)
+        auto emit = [&](int r, float m, int k) {
+            if (ml16 == 0) { mtopv[mitem * kTop + r] = m; mtopi[mitem * kTop + r] = k; }
         };
-        if (n_jt * kTop <= 32) merge(std::integral_constant<int, 2>());
-        else merge(std::integral_constant<int, (kMaxJT * kTop + 15) / 16>());
+        if (n_jt * kTop <= 32) {
+            float v2[2] = {mv[0], mv[1]};
+            const int t2[2] = {mtag[0], mtag[1]};
+            row_top<2>(v2, t2, emit);
+        } else {
+            row_top<kMergeNE>(mv, mtag, emit);
+        }
     }
     // tile layout [prev-state][16 items]: lanes = 16 rows x 4 float4 columns
 #pragma unroll
@@ -450,6 +466,9 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     const char *ptile = reinterpret_cast<const char *>(lds) + 16 * g;
     float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     auto pair = [&](float t0, int o0, float t1, int o1) {
+        // keep the broadcast t values in registers: folded into the adds they become four half-rate
+        // v_add_f32_dpp per entry instead of one v_mov_b32_dpp + four full-rate v_add_f32
+        asm volatile("" : "+v"(t0), "+v"(t1));
         const float4 p0 = *reinterpret_cast<const float4 *>(ptile + o0);
         const float4 p1 = *reinterpret_cast<const float4 *>(ptile + o1);
         best[0] = fmaxf(fmaxf(best[0], t0 + p0.x), t1 + p1.x);
@@ -495,35 +514,37 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
         load_list_block(cur, row, k + 3 * kBlk);
     }
     PSTAMP(7);
+    // outputs, and this tile's top lists: an output enters the item's list only if it beats the list's current
+    // last entry (rare once a few outputs have arrived); insertion is a cascade of 64-bit LDS atomic maxima, the
+    // displaced key moving one rank down -- every rank ends with the maximum of what passed through it.
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
+        const int item = 4 * g + it;
         const float o = ob[it] + best[it];                                   // post'[j] = obs[t,j] + max
-        if (jv && live[it]) hist[((size_t)(b0 + 4 * g + it) * T + t) * S + jr] = o;
-        if (jv) outs[(4 * g + it) * JT + jj] = o;
+        if (jv && live[it]) hist[((size_t)(b0 + item) * T + t) * S + jr] = o;
+        unsigned u = __float_as_uint(o);
+        u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;                           // unsigned order == float order
+        unsigned long long x = ((unsigned long long)u << 32) | (unsigned)(0x7fffffff - jr);
+        if (!jv || x <= ttop[item * kTop + kTop - 1]) x = 0ull;
+#pragma unroll
+        for (int r = 0; r < kTop; ++r) {
+            if (x != 0ull) {
+                const unsigned long long old = atomicMax(&ttop[item * kTop + r], x);
+                x = old < x ? old : x;
+            }
+        }
     }
     __syncthreads();
     PSTAMP(8);
-
-    // partial top lists of this tile: waves 0..3, one item per 16-lane row, JTv <= 192 outputs = 12 per lane
-    if (wave < kNB / 4) {
-        constexpr int NE = (kMaxTileStates + 15) / 16;
-        const int item = 4 * wave + (lane >> 4), l16 = lane & 15;
-        float v[NE];
-        int tag[NE];
-#pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            const int oj = l16 + 16 * e;
-            const bool ok = oj < JTv;
-            v[e] = ok ? outs[item * JT + oj] : -INFINITY;
-            tag[e] = ok ? j0 + oj : 0x7fffffff;
+    if (tid < kNB * kTop) {
+        const int item = tid / kTop, r = tid % kTop;
+        const unsigned long long k = ttop[tid];
+        unsigned u = (unsigned)(k >> 32);
+        u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;
+        if (b0 + item < B) {
+            ptopv_out[((size_t)jt * B + b0 + item) * kTop + r] = k ? __uint_as_float(u) : -INFINITY;
+            ptopi_out[((size_t)jt * B + b0 + item) * kTop + r] = k ? 0x7fffffff - (int)(unsigned)k : 0;
         }
-        const int bw = b0 + item;
-        row_top<NE>(v, tag, [&](int r, float m, int k) {
-            if (l16 == 0 && bw < B) {
-                ptopv_out[((size_t)jt * B + bw) * kTop + r] = m;
-                ptopi_out[((size_t)jt * B + bw) * kTop + r] = k;
-            }
-        });
     }
 #ifdef PRUNED_STAMP
     PSTAMP(9);
