@@ -347,20 +347,20 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     float *mtopv = reinterpret_cast<float *>(ttop + kNB * kTop);   // [16][kTop] merged top values of t-1
     int *mtopi = reinterpret_cast<int *>(mtopv + kNB * kTop);
     int *sframes = mtopi + kNB * kTop;                     // [16] frames of the tile's items (0 past the batch)
-    const int tile_id = blockIdx.x;
-    const int bt = tile_id % n_bt, jt = tile_id / n_bt;
+    // grid = (n_bt, n_jt): linear workgroup id = bt + n_bt * jt (the 8 state tiles of a batch tile share an XCD
+    // whenever n_bt % 8 == 0)
+    const int bt = blockIdx.x, jt = blockIdx.y;
     const int b0 = bt * kNB, j0 = jt * JT;
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef PRUNED_STAMP
     unsigned long long st[kStamps] = {};
 #endif
     PSTAMP(0);
+    // the staged prev-state range is needed for the tile addresses: request it before anything else
+    const int lo4 = tile_range[2 * jt], hi4 = tile_range[2 * jt + 1];
+    __builtin_amdgcn_sched_barrier(0);
     int fr = 0;
-    if (tid < kNB) {
-        fr = b0 + tid < B ? frames[b0 + tid] : 0;
-        sframes[tid] = fr;
-    }
-    if (tid < kNB * kTop) ttop[tid] = 0ull;                // 0 = empty (every real key is > 0)
+    if (tid < kNB) fr = b0 + tid < B ? frames[b0 + tid] : 0;     // stored to LDS after the loads are out
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int JTv = S - j0 < JT ? S - j0 : JT;                   // next-states of this tile
     const int Sp = (S + 15) / 16 * 16;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
         for (int e = 0; e < kMergeNE; ++e) {
             const int cand = ml16 + 16 * e;
             const bool ok = cand < n_jt * kTop;
-            const size_t src = ((size_t)(ok ? cand / kTop : 0) * B + bw) * kTop + (ok ? cand % kTop : 0);
+            const unsigned src = ((unsigned)(ok ? cand / kTop : 0) * B + bw) * kTop + (ok ? cand % kTop : 0);
             mv[e] = ok ? ptopv_in[src] : -INFINITY;
             mtag[e] = ok ? ptopi_in[src] : 0x7fffffff;
         }
@@ -396,10 +396,13 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     load_list_block(cur, row, 0);
     load_list_block(nxt, row, kBlk);
     float ob[4];
+    {
+        // one 64-bit address, then a uniform stride per item (items past the batch re-read the last one)
+        const int bfirst = b0 + 4 * g < B ? b0 + 4 * g : B - 1;
+        const float *osrc = obs + ((size_t)bfirst * T + t) * S + jr;
+        const size_t ostride = (size_t)T * S;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int b = b0 + 4 * g + it < B ? b0 + 4 * g + it : B - 1;
-        ob[it] = obs[((size_t)b * T + t) * S + jr];
+        for (int it = 0; it < 4; ++it) ob[it] = osrc[(bfirst + it < B ? it : B - 1 - bfirst) * ostride];
     }
 
     // every thread fetches its share of the 16 posterior rows in ONE round trip (all loads in flight before the
@@ -407,17 +410,21 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     // Only the prev-states this tile's next-states can reach are staged (tile_range: the whole range for a
     // dense matrix, the band for a banded one).
     constexpr int NCH = (kNB * (kMaxS / 4) + 64 * kWaves - 1) / (64 * kWaves);
-    const int lo4 = tile_range[2 * jt], hi4 = tile_range[2 * jt + 1];
     const int n4 = kNB * (hi4 - lo4 + 1);
     float4 pv[NCH];
-#pragma unroll
-    for (int u = 0; u < NCH; ++u) {
-        const int e = tid + u * 64 * kWaves;
-        const int bb = e & (kNB - 1), i4 = lo4 + e / kNB;
+    {
+        // 64 * kWaves is a multiple of 16: a thread keeps its item and walks prev-states in steps of 4 * 48
+        static_assert((64 * kWaves) % kNB == 0, "tile staging assumes a fixed item per thread");
+        const int bb = tid & (kNB - 1);
         const int brow = b0 + bb < B ? b0 + bb : B - 1;
-        if (e < n4) pv[u] = *reinterpret_cast<const float4 *>(hist + ((size_t)brow * T + (t - 1)) * S + 4 * i4);
+        const float *psrc = hist + ((size_t)brow * T + (t - 1)) * S + 4 * (lo4 + tid / kNB);
+#pragma unroll
+        for (int u = 0; u < NCH; ++u)
+            if (tid + u * 64 * kWaves < n4) pv[u] = *reinterpret_cast<const float4 *>(psrc + u * (4 * 64 * kWaves / kNB));
     }
     PSTAMP(1);
+    if (tid < kNB) sframes[tid] = fr;
+    if (tid < kNB * kTop) ttop[tid] = 0ull;                // 0 = empty (every real key is > 0)
     if (wave < kNB / 4) {
         // every 16-lane row merges the partial top lists of one item (candidates fetched at kernel entry)
         auto emit = [&](int r, float m, int k) {
@@ -548,8 +555,9 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     }
 #ifdef PRUNED_STAMP
     PSTAMP(9);
-    if (lane == 0 && blockIdx.x < 1024)
-        for (int i = 0; i < kStamps; ++i) g_stamps[((size_t)blockIdx.x * kWaves + wave) * kStamps + i] = st[i];
+    const int linear = blockIdx.x + gridDim.x * blockIdx.y;
+    if (lane == 0 && linear < 1024)
+        for (int i = 0; i < kStamps; ++i) g_stamps[((size_t)linear * kWaves + wave) * kStamps + i] = st[i];
 #endif
 }
 

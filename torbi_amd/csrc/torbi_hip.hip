@@ -647,7 +647,7 @@ hipError_t launch_pruned_forward(const float *obs, const int32_t *frames, const 
     int n = 0;
     for (int t = 1; t < T; ++t) {
         const size_t in = ((t - 1) & 1) * w.top_stride, out = (t & 1) * w.top_stride;
-        hipLaunchKernelGGL(pruned::step_pruned_kernel, dim3(pl.n_bt * pl.n_jt), dim3(64 * pruned::kWaves), lds, stream,
+        hipLaunchKernelGGL(pruned::step_pruned_kernel, dim3(pl.n_bt, pl.n_jt), dim3(64 * pruned::kWaves), lds, stream,
                            obs, frames, w.tt, w.sorted, w.tile_range, w.topv + in, w.topi + in, w.topv + out, w.topi + out, w.hist,
                            B, T, S, t, pl.SpP, pl.n_bt, pl.n_jt, pl.JT);
         ++n;
