@@ -149,3 +149,29 @@ def test_assign_batches_is_a_partition():
     for rank in plan:
         for batch in rank:
             assert batch == list(range(batch[0], batch[0] + len(batch))) and len(batch) <= 512
+
+
+def test_auto_path_choice_reads_the_transition_structure_once_per_version():
+    """torbi_amd/viterbi.py::_choose_path: narrow bands -> dense kernel (-inf block skipping), everything else ->
+    pruned; forced paths and unsupported shapes pass through; the look is cached per tensor version."""
+    import torch
+    from torbi_amd import synth, viterbi
+    S = 256
+    dense = torch.as_tensor(synth.problem(1, 1, S, seed=1)[1])
+    band = torch.as_tensor(synth.banded_transition(S, 12.0))
+    assert viterbi._choose_path(dense, dense, 64, S) == 'pruned'
+    assert viterbi._choose_path(band, band, 64, S) == 'dense'
+    key = (band.data_ptr(), band._version, S, str(band.device))
+    assert 0.0 < viterbi._structure_cache[key] < viterbi.BANDED_RANGE
+    band.fill_(-1.0)                                  # new version of the same storage: looked at again
+    assert viterbi._choose_path(band, band, 64, S) == 'pruned'
+    dead = torch.full((S, S), float('-inf'))
+    assert viterbi._choose_path(dead, dead, 64, S) == 'pruned'          # reach 0: nothing to skip *to*
+    assert viterbi._choose_path(dense, dense, 8, S) == 'auto'           # small batch: generic kernels either way
+    assert viterbi._choose_path(dense, dense, 64, 4096) == 'auto'       # outside the pruned path's range
+    old = viterbi._forced_path
+    try:
+        viterbi._forced_path = 'dense'
+        assert viterbi._choose_path(dense, dense, 64, S) == 'dense'
+    finally:
+        viterbi._forced_path = old

@@ -9,15 +9,16 @@
 // fl(post + trans) <= fl(thr + t_k) by monotonicity of rounding; once that bound is <= best the
 // maximum is final.  Only VALUES are needed here (the backpointer is recomputed along the decoded
 // path by lazy_backtrace.hpp), so ties need no care and the result is bit-identical to the dense
-// scan.  On the uniform-random benchmark ~8 % of the cells are examined; on peaked posteriors or
-// banded matrices far fewer.  Worst case (flat rows) every cell is examined at a higher cost per
-// cell than the dense kernel -- the host selects the path (torbi_hip.hip).
+// scan.  On the uniform-random benchmark ~9 % of the cells are examined; on peaked posteriors or
+// banded matrices far fewer.  Worst case (nothing prunable) every cell is examined at a higher cost
+// per cell than the dense kernel -- torbi_hip.hip / torbi_amd/viterbi.py select the path.
 //
-// Lanes: one next-state x 4 batch items per lane, 16 next-states x 4 item groups per wave.  Every lane
-// walks its own sorted row (16-entry blocks, ping-pong in registers); a list entry costs one
-// ds_read_b128 of the [prev-state][16 items] posterior tile, 4 v_add_f32 and, entries taken in pairs,
-// 2 v_max3_f32 per 4 candidates: no cross-lane traffic.  (tools/prune_proto*.hip hold the measured
-// alternatives: DPP row rotation, LDS-DMA / ds_write staged lists, entry-major lists.)
+// Lanes: one next-state x 4 batch items per lane, 16 next-states x 4 item groups per wave.  Every
+// next-state walks its own sorted row in 16-entry blocks (two blocks ping-pong in registers, four
+// entries per lane of the quad, handed round by DPP quad_perm); a list entry costs one
+// ds_read_b128 of the [prev-state][16 items] posterior tile, 4 v_add_f32 and, entries taken in
+// pairs, 2 v_max3_f32 per 4 candidates.  DESIGN.md 4.3 has the measurements; tools/prune_proto*.hip
+// the alternatives that lost (DPP row rotation, LDS-DMA / ds_write staged lists, entry-major lists).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -40,7 +41,7 @@ constexpr int kWaves = PRUNED_WAVES;   // waves per workgroup (12 = 3 per SIMD: 
 constexpr int kMaxTileStates = 16 * kWaves;   // next-states per tile: one per lane group of 4
 constexpr int kTop = kR + 1;
 constexpr int kMaxS = 2048;  // the posterior tile [S][16] fp32 must leave room in the 160 KB LDS
-constexpr int kMaxJT = 16;   // state tiles per batch tile (kMaxJT * kTop candidates <= 2 per lane)
+constexpr int kMaxJT = 16;   // state tiles per batch tile (kMaxJT * kTop candidates = 4 per lane of a 16-lane row)
 
 struct Plan {
     int n_bt;    // batch tiles of 16 items
@@ -67,7 +68,7 @@ inline Plan make_plan(int B, int S, int num_cus) {
     if (n_jt < 1) n_jt = 1;
     const int min_jt = (S + kMaxTileStates - 1) / kMaxTileStates;   // one pass of the workgroup covers a tile
     if (n_jt < min_jt) n_jt = min_jt;
-    if (n_jt > kMaxJT) n_jt = kMaxJT;     // the per-item top lists of all state tiles are merged by one wave
+    if (n_jt > kMaxJT) n_jt = kMaxJT;     // the per-item top lists of all state tiles are merged by one 16-lane row
     int JT = (S + n_jt - 1) / n_jt;
     JT = (JT + 3) / 4 * 4;                // S <= 2048: JT <= 192 whenever n_jt >= min_jt (<= 11)
     p.JT = JT;
