@@ -226,8 +226,8 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
         'data': 'synthetic',
         'config': {'workload': f'{S} states, {T} frames, batch={B} per GPU, fp32, dense '
-                               f'transition (BASELINE configs[2]); decode = forward + argmax + '
-                               f'backtrace, inputs resident in HBM'
+                               f'transition{" (BASELINE configs[2])" if (B, T, S) == (512, 500, 1440) else ""}; '
+                               f'decode = forward + argmax + backtrace, inputs resident in HBM'
                                if args.transition == 'dense' else
                                f'{S} states, {T} frames, batch={B} per GPU, fp32, BANDED transition '
                                f'(half width {args.half_width}, -inf outside; secondary workload)',

@@ -135,7 +135,8 @@ def test_dense_path_edge_shapes(shape):
 
 def test_forward_path_selection(forward):
     assert viterbi.forward_path(4, 1440) == 'generic'
-    assert viterbi.forward_path(128, 4096) == 'dense'              # posterior tile does not fit the LDS
+    assert viterbi.forward_path(128, 4096) == ('dense' if forward == 'dense' else 'pruned')   # 8-item tiles
+    assert viterbi.forward_path(128, 4100) == 'dense'              # posterior tile does not fit the LDS
     assert viterbi.forward_path(512, 1440) == ('dense' if forward == 'dense' else 'pruned')
     assert viterbi.forward_path(64, 130) == 'dense'                # S % 4 != 0
     assert viterbi.workspace_bytes(512, 500, 1440) >= 512 * 500 * 1440 * 4
@@ -162,7 +163,8 @@ def test_auto_takes_the_dense_kernel_for_narrow_bands_only(forward):
 
 
 @pytest.mark.parametrize('kind', ['flat', 'nearly_flat', 'peaked', 'anti', 'two_level'])
-@pytest.mark.parametrize('shape', [(32, 12, 64), (33, 9, 132), (48, 6, 1444), (40, 5, 2048), (64, 10, 360)])
+@pytest.mark.parametrize('shape', [(32, 12, 64), (33, 9, 132), (48, 6, 1444), (40, 5, 2048), (64, 10, 360),
+                                   (36, 4, 2052), (32, 3, 4096)])
 def test_pruned_path_adversarial_inputs(kind, shape):
     """Inputs chosen against the pruning bound: rows without spread (nothing can be pruned: the scan runs to
     the end of every list), posteriors with a few dominant peaks (the explicit seeds carry the maximum),

@@ -168,7 +168,7 @@ def test_auto_path_choice_reads_the_transition_structure_once_per_version():
     dead = torch.full((S, S), float('-inf'))
     assert viterbi._choose_path(dead, dead, 64, S) == 'pruned'          # reach 0: nothing to skip *to*
     assert viterbi._choose_path(dense, dense, 8, S) == 'auto'           # small batch: generic kernels either way
-    assert viterbi._choose_path(dense, dense, 64, 4096) == 'auto'       # outside the pruned path's range
+    assert viterbi._choose_path(dense, dense, 64, 8192) == 'auto'       # outside the pruned path's range
     old = viterbi._forced_path
     try:
         viterbi._forced_path = 'dense'

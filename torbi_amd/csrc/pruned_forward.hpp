@@ -31,20 +31,21 @@
 namespace pruned {
 
 constexpr int kR = 3;        // explicit top candidates per item; thr = (kR+1)-th largest posterior
-constexpr int kNB = 16;      // batch items per tile (= lanes per next-state)
+constexpr int kNB = 16;      // batch items per tile for S <= 2048 (4 item groups per next-state); 8 above (2 groups)
 constexpr int kBlk = 16;     // list entries per termination test
 constexpr int kPad = 4 * kBlk;  // (-inf) entries after every list row: prefetches never leave the row
 #ifndef PRUNED_WAVES
 #define PRUNED_WAVES 12
 #endif
 constexpr int kWaves = PRUNED_WAVES;   // waves per workgroup (12 = 3 per SIMD: 168 VGPRs each)
-constexpr int kMaxTileStates = 16 * kWaves;   // next-states per tile: one per lane group of 4
 constexpr int kTop = kR + 1;
-constexpr int kMaxS = 2048;  // the posterior tile [S][16] fp32 must leave room in the 160 KB LDS
+constexpr int kMaxS16 = 2048; // the posterior tile [S][16 items] fp32 must leave room in the 160 KB LDS
+constexpr int kMaxS = 4096;   // [S][8 items] tiles above kMaxS16
 constexpr int kMaxJT = 16;   // state tiles per batch tile (kMaxJT * kTop candidates = 4 per lane of a 16-lane row)
 
 struct Plan {
-    int n_bt;    // batch tiles of 16 items
+    int NI;      // batch items per tile: 16 (S <= kMaxS16) or 8
+    int n_bt;    // batch tiles of NI items
     int n_jt;    // next-state tiles
     int JT;      // next-states per tile (multiple of 4)
     int Sp;      // list length rounded up to 16
@@ -54,23 +55,24 @@ struct Plan {
 
 inline bool supported(int B, int S) { return B >= 32 && S % 4 == 0 && S >= 64 && S <= kMaxS; }
 
-// dynamic LDS of step_pruned_kernel: posterior tile [S][16] + merged top lists + the 16 items' frame counts
+// dynamic LDS of step_pruned_kernel: posterior tile [S][NI] + merged top lists + the NI items' frame counts
 // + this tile's running top lists (64-bit keys)
-inline size_t lds_bytes(int S, int JT) {
-    (void)JT;
-    return sizeof(float) * ((size_t)kNB * S + 2 * kNB * kTop + kNB) + sizeof(unsigned long long) * kNB * kTop;
+inline size_t lds_bytes(int S, int NI) {
+    return sizeof(float) * ((size_t)NI * S + 2 * NI * kTop + NI) + sizeof(unsigned long long) * NI * kTop;
 }
 
 inline Plan make_plan(int B, int S, int num_cus) {
     Plan p{};
-    p.n_bt = (B + kNB - 1) / kNB;
+    p.NI = S <= kMaxS16 ? kNB : kNB / 2;
+    p.n_bt = (B + p.NI - 1) / p.NI;
     int n_jt = num_cus / p.n_bt;
     if (n_jt < 1) n_jt = 1;
-    const int min_jt = (S + kMaxTileStates - 1) / kMaxTileStates;   // one pass of the workgroup covers a tile
+    const int tile_states = (64 / (p.NI / 4)) * kWaves;             // one next-state per lane group of NI/4 lanes
+    const int min_jt = (S + tile_states - 1) / tile_states;          // one pass of the workgroup covers a tile
     if (n_jt < min_jt) n_jt = min_jt;
     if (n_jt > kMaxJT) n_jt = kMaxJT;     // the per-item top lists of all state tiles are merged by one 16-lane row
     int JT = (S + n_jt - 1) / n_jt;
-    JT = (JT + 3) / 4 * 4;                // S <= 2048: JT <= 192 whenever n_jt >= min_jt (<= 11)
+    JT = (JT + 3) / 4 * 4;                // stays <= tile_states whenever n_jt >= min_jt (<= 11)
     p.JT = JT;
     p.n_jt = (S + JT - 1) / JT;
     p.Sp = (S + 15) / 16 * 16;
@@ -82,12 +84,12 @@ inline Plan make_plan(int B, int S, int num_cus) {
 
 // ---------------------------------------------------------------------------------------
 // once per decode: sort every transition row in descending order (bitonic, one workgroup per row).
-// Entry = {t, byte offset of prev-state i in the posterior tile = i * 64}.  grid = S, block = 256,
+// Entry = {t, byte offset of prev-state i in the posterior tile = i * row_bytes (4 bytes x items per tile)}.  grid = S, block = 256,
 // dynamic LDS = NPOW * 8 bytes.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sort_rows_kernel(const float *__restrict__ trans,
                                                         float2 *__restrict__ sorted, int32_t *__restrict__ row_range,
-                                                        int S, int SpP, int NPOW) {
+                                                        int S, int SpP, int NPOW, int row_bytes) {
     extern __shared__ float skey[];
     int *sval = reinterpret_cast<int *>(skey + NPOW);
     __shared__ int s_lo, s_hi;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void sort_rows_kernel(const float *__restrict_
     for (int k = threadIdx.x; k < NPOW; k += 256) {
         const float v = k < S ? row[k] : -INFINITY;
         skey[k] = v;
-        sval[k] = k < S ? k * (kNB * 4) : 0;
+        sval[k] = k < S ? k * row_bytes : 0;
         if (v != -INFINITY) { lo = min(lo, k); hi = max(hi, k); }
     }
     if (hi >= 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void sort_rows_kernel(const float *__restrict_
         v.x = k < S ? skey[k] : -INFINITY;
         // (-inf) entries and the padding name a prev-state inside the row's range: a tile stages only the
         // posterior rows its next-states can reach, and the scan may still touch such an entry (block granularity)
-        v.y = __builtin_bit_cast(float, (k < S && v.x != -INFINITY) ? sval[k] : row_lo * (kNB * 4));
+        v.y = __builtin_bit_cast(float, (k < S && v.x != -INFINITY) ? sval[k] : row_lo * row_bytes);
         out[k] = v;
     }
 }
@@ -234,20 +236,20 @@ __global__ __launch_bounds__(256) void clear_top_kernel(float *__restrict__ topv
 // take the lowest tag.  Results are wave-uniform; `emit(r, value, tag)` is called once per rank.
 template <int NE, typename Emit>
 __device__ __forceinline__ void wave_top(float (&v)[NE], const int (&tag)[NE], Emit emit) {
-    unsigned picked = 0;
+    unsigned long long picked = 0;
 #pragma unroll
     for (int r = 0; r < kTop; ++r) {
         float lm = -INFINITY;
 #pragma unroll
         for (int e = 0; e < NE; ++e)
-            if (!((picked >> e) & 1u)) lm = fmaxf(lm, v[e]);
+            if (!((picked >> e) & 1ull)) lm = fmaxf(lm, v[e]);
         const float m = wavered::wave_reduce_f32(lm, wavered::MaxOp());
         int lk = 0x7fffffff, le = 0;
 #pragma unroll
         for (int e = NE - 1; e >= 0; --e)
-            if (!((picked >> e) & 1u) && tag[e] != 0x7fffffff && v[e] == m) { lk = tag[e]; le = e; }
+            if (!((picked >> e) & 1ull) && tag[e] != 0x7fffffff && v[e] == m) { lk = tag[e]; le = e; }
         const int k = wavered::wave_min_i32(lk);
-        if (lk == k && k != 0x7fffffff) picked |= 1u << le;
+        if (lk == k && k != 0x7fffffff) picked |= 1ull << le;
         emit(r, k == 0x7fffffff ? -INFINITY : m, k == 0x7fffffff ? 0 : k);
     }
 }
@@ -310,19 +312,25 @@ __device__ unsigned long long g_stamps[1024 * kWaves * kStamps];
 // A 16-entry list block of one row is held by the row's FOUR lanes (item groups g = 0..3), four entries each:
 // the wave loads every list byte once (duplicate lanes would quadruple the texture-path bytes, the busiest unit of
 // this kernel) and the entries are handed round the quad by DPP quad_perm broadcasts when they are consumed.
-struct ListBlock { float4 e[2]; };   // entries 4g .. 4g+3 of the block: e[h] = {t, off, t, off}
+template <int EPL>
+struct ListBlock { float4 e[EPL / 2]; };   // EPL entries of the block held by this lane: e[h] = {t, off, t, off}
 
-__device__ __forceinline__ void load_list_block(ListBlock &blk, const float2 *row_g, int k) {   // row_g = row + 4g
-    blk.e[0] = *reinterpret_cast<const float4 *>(row_g + k);
-    blk.e[1] = *reinterpret_cast<const float4 *>(row_g + k + 2);
+template <int EPL>
+__device__ __forceinline__ void load_list_block(ListBlock<EPL> &blk, const float2 *row_g, int k) {   // row_g = row + EPL*g
+#pragma unroll
+    for (int h = 0; h < EPL / 2; ++h) blk.e[h] = *reinterpret_cast<const float4 *>(row_g + k + 2 * h);
 }
 
-template <int G>
-__device__ __forceinline__ float quad_bcast(float x) {     // value held by lane G of this lane's quad
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), G * 0x55, 0xf, 0xf, true));
+// value held by lane O of this lane's group of G lanes (G = 4: the quad; G = 2: the lane pair)
+template <int G, int O>
+__device__ __forceinline__ int group_bcast(int x) {
+    constexpr int ctrl = G == 4 ? O * 0x55 : (O | (O << 2) | ((2 + O) << 4) | ((2 + O) << 6));
+    return __builtin_amdgcn_update_dpp(0, x, ctrl, 0xf, 0xf, true);
 }
-template <int G>
-__device__ __forceinline__ int quad_bcast(int x) { return __builtin_amdgcn_update_dpp(0, x, G * 0x55, 0xf, 0xf, true); }
+template <int G, int O>
+__device__ __forceinline__ float group_bcast(float x) {
+    return __builtin_bit_cast(float, group_bcast<G, O>(__builtin_bit_cast(int, x)));
+}
 
 // ---------------------------------------------------------------------------------------
 // one timestep.  grid = n_bt * n_jt, block = 64 * kWaves, dynamic LDS = lds_bytes(S, JT).
@@ -336,22 +344,26 @@ __device__ __forceinline__ int quad_bcast(int x) { return __builtin_amdgcn_updat
 // loads and first list block (their latency hides behind the tile staging) -> stage the posterior
 // tile -> barrier -> scan -> outputs -> barrier -> this tile's partial top lists.
 // ---------------------------------------------------------------------------------------
+template <int NI>
 __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     const float *__restrict__ obs, const int32_t *__restrict__ frames, const float *__restrict__ tt,
     const float2 *__restrict__ sorted, const int32_t *__restrict__ tile_range, const float *__restrict__ ptopv_in,
     const int32_t *__restrict__ ptopi_in, float *__restrict__ ptopv_out, int32_t *__restrict__ ptopi_out,
     float *__restrict__ hist, int B, int T, int S, int t, int SpP, int n_bt, int n_jt, int JT) {
+    constexpr int G = NI / 4;            // lanes per next-state (item groups of 4)
+    constexpr int RW = 64 / G;           // next-states per wave
+    constexpr int EPL = kBlk / G;        // list entries per lane per block
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // [16][kTop] running top list of this tile's outputs per item, as 64-bit keys (order-preserving value bits,
-    // ~next-state); 8-byte aligned because kNB * S is even
-    unsigned long long *ttop = reinterpret_cast<unsigned long long *>(lds + (size_t)kNB * S);
-    float *mtopv = reinterpret_cast<float *>(ttop + kNB * kTop);   // [16][kTop] merged top values of t-1
-    int *mtopi = reinterpret_cast<int *>(mtopv + kNB * kTop);
-    int *sframes = mtopi + kNB * kTop;                     // [16] frames of the tile's items (0 past the batch)
+    // [NI][kTop] running top list of this tile's outputs per item, as 64-bit keys (order-preserving value bits,
+    // ~next-state); 8-byte aligned because NI * S is even
+    unsigned long long *ttop = reinterpret_cast<unsigned long long *>(lds + (size_t)NI * S);
+    float *mtopv = reinterpret_cast<float *>(ttop + NI * kTop);   // [16][kTop] merged top values of t-1
+    int *mtopi = reinterpret_cast<int *>(mtopv + NI * kTop);
+    int *sframes = mtopi + NI * kTop;                     // [16] frames of the tile's items (0 past the batch)
     // grid = (n_bt, n_jt): linear workgroup id = bt + n_bt * jt (the 8 state tiles of a batch tile share an XCD
     // whenever n_bt % 8 == 0)
     const int bt = blockIdx.x, jt = blockIdx.y;
-    const int b0 = bt * kNB, j0 = jt * JT;
+    const int b0 = bt * NI, j0 = jt * JT;
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef PRUNED_STAMP
     unsigned long long st[kStamps] = {};
@@ -361,7 +373,7 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     const int lo4 = tile_range[2 * jt], hi4 = tile_range[2 * jt + 1];
     __builtin_amdgcn_sched_barrier(0);
     int fr = 0;
-    if (tid < kNB) fr = b0 + tid < B ? frames[b0 + tid] : 0;     // stored to LDS after the loads are out
+    if (tid < NI) fr = b0 + tid < B ? frames[b0 + tid] : 0;     // stored to LDS after the loads are out
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int JTv = S - j0 < JT ? S - j0 : JT;                   // next-states of this tile
     const int Sp = (S + 15) / 16 * 16;
@@ -372,7 +384,7 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     const int mitem = 4 * wave + (lane >> 4), ml16 = lane & 15;
     float mv[kMergeNE];
     int mtag[kMergeNE];
-    if (wave < kNB / 4) {
+    if (wave < NI / 4) {
         const int bw = b0 + mitem < B ? b0 + mitem : B - 1;
 #pragma unroll
         for (int e = 0; e < kMergeNE; ++e) {
@@ -388,12 +400,14 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     // blocks and the observations do not depend on anything staged below: issue them first
     // quads of lanes -> next-states so that every ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31},
     // +32) holds an aligned row quad (arrange_blocks_kernel keeps those conflict-poor)
-    const int jl = (int)((0xFBAE9DC873261540ull >> (4 * (lane >> 2))) & 15), g = lane & 3;
-    const int jj = 16 * wave + jl;
+    // (8-item tiles: plain order, no arrangement pass)
+    const int g = lane & (G - 1);
+    const int jl = G == 4 ? (int)((0xFBAE9DC873261540ull >> (4 * (lane >> 2))) & 15) : lane >> 1;
+    const int jj = RW * wave + jl;
     const bool jv = jj < JTv;
     const int jr = jv ? j0 + jj : j0;
-    const float2 *row = sorted + (size_t)jr * SpP + 4 * g;      // this lane's quarter of every 16-entry block
-    ListBlock cur, nxt;
+    const float2 *row = sorted + (size_t)jr * SpP + EPL * g;    // this lane's share of every 16-entry block
+    ListBlock<EPL> cur, nxt;
     load_list_block(cur, row, 0);
     load_list_block(nxt, row, kBlk);
     float ob[4];
@@ -410,23 +424,23 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     // first LDS write); waves 0..3 merge the top lists while theirs are on the way
     // Only the prev-states this tile's next-states can reach are staged (tile_range: the whole range for a
     // dense matrix, the band for a banded one).
-    constexpr int NCH = (kNB * (kMaxS / 4) + 64 * kWaves - 1) / (64 * kWaves);
-    const int n4 = kNB * (hi4 - lo4 + 1);
+    constexpr int NCH = (NI * ((NI == 16 ? kMaxS16 : kMaxS) / 4) + 64 * kWaves - 1) / (64 * kWaves);
+    const int n4 = NI * (hi4 - lo4 + 1);
     float4 pv[NCH];
     {
         // 64 * kWaves is a multiple of 16: a thread keeps its item and walks prev-states in steps of 4 * 48
-        static_assert((64 * kWaves) % kNB == 0, "tile staging assumes a fixed item per thread");
-        const int bb = tid & (kNB - 1);
+        static_assert((64 * kWaves) % NI == 0, "tile staging assumes a fixed item per thread");
+        const int bb = tid & (NI - 1);
         const int brow = b0 + bb < B ? b0 + bb : B - 1;
-        const float *psrc = hist + ((size_t)brow * T + (t - 1)) * S + 4 * (lo4 + tid / kNB);
+        const float *psrc = hist + ((size_t)brow * T + (t - 1)) * S + 4 * (lo4 + tid / NI);
 #pragma unroll
         for (int u = 0; u < NCH; ++u)
-            if (tid + u * 64 * kWaves < n4) pv[u] = *reinterpret_cast<const float4 *>(psrc + u * (4 * 64 * kWaves / kNB));
+            if (tid + u * 64 * kWaves < n4) pv[u] = *reinterpret_cast<const float4 *>(psrc + u * (4 * 64 * kWaves / NI));
     }
     PSTAMP(1);
-    if (tid < kNB) sframes[tid] = fr;
-    if (tid < kNB * kTop) ttop[tid] = 0ull;                // 0 = empty (every real key is > 0)
-    if (wave < kNB / 4) {
+    if (tid < NI) sframes[tid] = fr;
+    if (tid < NI * kTop) ttop[tid] = 0ull;                // 0 = empty (every real key is > 0)
+    if (wave < NI / 4) {
         // every 16-lane row merges the partial top lists of one item (candidates fetched at kernel entry)
         auto emit = [&](int r, float m, int k) {
             if (ml16 == 0) { mtopv[mitem * kTop + r] = m; mtopi[mitem * kTop + r] = k; }
@@ -444,9 +458,9 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     for (int u = 0; u < NCH; ++u) {
         const int e = tid + u * 64 * kWaves;
         if (e < n4) {
-            const int bb = e & (kNB - 1), i4 = lo4 + e / kNB;
-            float *d = lds + (4 * i4) * kNB + bb;
-            d[0] = pv[u].x; d[kNB] = pv[u].y; d[2 * kNB] = pv[u].z; d[3 * kNB] = pv[u].w;
+            const int bb = e & (NI - 1), i4 = lo4 + e / NI;
+            float *d = lds + (4 * i4) * NI + bb;
+            d[0] = pv[u].x; d[NI] = pv[u].y; d[2 * NI] = pv[u].z; d[3 * NI] = pv[u].w;
         }
     }
     PSTAMP(2);
@@ -484,18 +498,20 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
         best[2] = fmaxf(fmaxf(best[2], t0 + p0.z), t1 + p1.z);
         best[3] = fmaxf(fmaxf(best[3], t0 + p0.w), t1 + p1.w);
     };
-    auto owner = [&](auto Gc, const ListBlock &blk) {      // the four entries held by lane G of the quad
-        constexpr int G = decltype(Gc)::value;
+    auto owner = [&](auto Oc, const ListBlock<EPL> &blk) {      // the entries held by lane O of the group
+        constexpr int O = decltype(Oc)::value;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-            pair(quad_bcast<G>(blk.e[h].x), quad_bcast<G>(__float_as_int(blk.e[h].y)),
-                 quad_bcast<G>(blk.e[h].z), quad_bcast<G>(__float_as_int(blk.e[h].w)));
+        for (int h = 0; h < EPL / 2; ++h)
+            pair(group_bcast<G, O>(blk.e[h].x), group_bcast<G, O>(__float_as_int(blk.e[h].y)),
+                 group_bcast<G, O>(blk.e[h].z), group_bcast<G, O>(__float_as_int(blk.e[h].w)));
     };
-    auto consume = [&](const ListBlock &blk) {
+    auto consume = [&](const ListBlock<EPL> &blk) {
         owner(std::integral_constant<int, 0>(), blk);
         owner(std::integral_constant<int, 1>(), blk);
-        owner(std::integral_constant<int, 2>(), blk);
-        owner(std::integral_constant<int, 3>(), blk);
+        if (G == 4) {
+            owner(std::integral_constant<int, 2 % G>(), blk);
+            owner(std::integral_constant<int, 3 % G>(), blk);
+        }
     };
     consume(cur);
     load_list_block(cur, row, 2 * kBlk);
@@ -506,8 +522,8 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
         for (int r = 0; r < kR; ++r) best[it] = fmaxf(best[it], seedv[it][r] + seedt[it][r]);
     PSTAMP(6);
     // stop once no lane's bound fl(t_first + thr) exceeds its best (t_first = largest unexamined entry)
-    auto more = [&](const ListBlock &blk) {
-        const float tn = quad_bcast<0>(blk.e[0].x);
+    auto more = [&](const ListBlock<EPL> &blk) {
+        const float tn = group_bcast<G, 0>(blk.e[0].x);
         return __any(jv && ((tn + thr[0] > best[0]) | (tn + thr[1] > best[1]) | (tn + thr[2] > best[2]) |
                             (tn + thr[3] > best[3])));
     };
@@ -544,7 +560,7 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     }
     __syncthreads();
     PSTAMP(8);
-    if (tid < kNB * kTop) {
+    if (tid < NI * kTop) {
         const int item = tid / kTop, r = tid % kTop;
         const unsigned long long k = ttop[tid];
         unsigned u = (unsigned)(k >> 32);

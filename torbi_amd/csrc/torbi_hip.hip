@@ -617,9 +617,9 @@ hipError_t launch_pruned_forward(const float *obs, const int32_t *frames, const 
                                  hipStream_t stream, int *launches) {
     const pruned::Plan &pl = w.plan;
     hipLaunchKernelGGL(pruned::sort_rows_kernel, dim3(S), dim3(256), sizeof(float) * 2 * (size_t)pl.NPOW, stream,
-                       trans, w.sorted, w.row_range, S, pl.SpP, pl.NPOW);
+                       trans, w.sorted, w.row_range, S, pl.SpP, pl.NPOW, pl.NI * 4);
     hipLaunchKernelGGL(pruned::tile_range_kernel, dim3(pl.n_jt), dim3(64), 0, stream, w.row_range, w.tile_range, S, pl.JT);
-    {
+    if (pl.NI == pruned::kNB) {      // the bank-quarter arrangement is specific to 64-byte posterior rows
         const int n = (S / 4) * (pl.SpP / pruned::kBlk);
         hipLaunchKernelGGL(pruned::arrange_blocks_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, w.sorted, S, pl.SpP);
     }
@@ -637,19 +637,28 @@ hipError_t launch_pruned_forward(const float *obs, const int32_t *frames, const 
             hipLaunchKernelGGL(pruned::top_kernel<2>, dim3(B), dim3(64), 0, stream, w.hist, w.topv, w.topi, B, T, S);
         else if (S <= 1536)
             hipLaunchKernelGGL(pruned::top_kernel<6>, dim3(B), dim3(64), 0, stream, w.hist, w.topv, w.topi, B, T, S);
-        else
+        else if (S <= 2048)
             hipLaunchKernelGGL(pruned::top_kernel<8>, dim3(B), dim3(64), 0, stream, w.hist, w.topv, w.topi, B, T, S);
+        else
+            hipLaunchKernelGGL(pruned::top_kernel<16>, dim3(B), dim3(64), 0, stream, w.hist, w.topv, w.topi, B, T, S);
     }
-    const size_t lds = pruned::lds_bytes(S, pl.JT);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pruned::step_pruned_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = pruned::lds_bytes(S, pl.NI);
+    const void *fn = pl.NI == pruned::kNB ? reinterpret_cast<const void *>(&pruned::step_pruned_kernel<pruned::kNB>)
+                                          : reinterpret_cast<const void *>(&pruned::step_pruned_kernel<pruned::kNB / 2>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     int n = 0;
     for (int t = 1; t < T; ++t) {
         const size_t in = ((t - 1) & 1) * w.top_stride, out = (t & 1) * w.top_stride;
-        hipLaunchKernelGGL(pruned::step_pruned_kernel, dim3(pl.n_bt, pl.n_jt), dim3(64 * pruned::kWaves), lds, stream,
-                           obs, frames, w.tt, w.sorted, w.tile_range, w.topv + in, w.topi + in, w.topv + out, w.topi + out, w.hist,
-                           B, T, S, t, pl.SpP, pl.n_bt, pl.n_jt, pl.JT);
+        if (pl.NI == pruned::kNB)
+            hipLaunchKernelGGL(pruned::step_pruned_kernel<pruned::kNB>, dim3(pl.n_bt, pl.n_jt), dim3(64 * pruned::kWaves),
+                               lds, stream, obs, frames, w.tt, w.sorted, w.tile_range, w.topv + in, w.topi + in,
+                               w.topv + out, w.topi + out, w.hist, B, T, S, t, pl.SpP, pl.n_bt, pl.n_jt, pl.JT);
+        else
+            hipLaunchKernelGGL(pruned::step_pruned_kernel<pruned::kNB / 2>, dim3(pl.n_bt, pl.n_jt),
+                               dim3(64 * pruned::kWaves), lds, stream, obs, frames, w.tt, w.sorted, w.tile_range,
+                               w.topv + in, w.topi + in, w.topv + out, w.topi + out, w.hist, B, T, S, t, pl.SpP,
+                               pl.n_bt, pl.n_jt, pl.JT);
         ++n;
     }
     if (launches) *launches = n;
