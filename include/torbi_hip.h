@@ -71,10 +71,11 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
 
 /*
  * Forward-recurrence path used by torbi_hip_viterbi_decode (all paths give identical indices):
- *   GENERIC  B < 32 or S < 64: trellis kernels shaped like the reference's
+ *   GENERIC  B <= 16 or S < 64 (and 17 <= B < 32 with shapes PRUNED does not take): trellis kernels
+ *            shaped like the reference's
  *   DENSE    value-only (max,+) GEMM, every (prev, next) cell evaluated
  *   PRUNED   value-only, exact: sorted transition rows + per-item top posteriors bound the cells
- *            that can still win, the rest are never touched (B >= 32, S % 4 == 0, 64 <= S <= 4096)
+ *            that can still win, the rest are never touched (B >= 17, S % 4 == 0, 64 <= S <= 4096)
  * AUTO (the default; also the environment variable TORBI_HIP_FORWARD=dense|pruned read once) takes
  * PRUNED where supported, else DENSE, else GENERIC.  The setting is process-wide; a workspace of
  * torbi_hip_workspace_bytes() fits every path.  torbi_hip_forward_path reports what a (B, S)

@@ -58,7 +58,8 @@ def test_golden_large(golden, name):
 @pytest.mark.parametrize('shape', [(1, 50, 1440), (3, 40, 1440), (24, 30, 360), (33, 20, 257),
                                    (64, 17, 64), (65, 9, 63), (100, 12, 130), (257, 5, 33),
                                    (2, 30, 4096), (40, 6, 2049), (32, 7, 64), (96, 11, 1441),
-                                   (512, 3, 100), (128, 5, 4096), (70, 40, 360), (600, 4, 97)])
+                                   (512, 3, 100), (128, 5, 4096), (70, 40, 360), (600, 4, 97),
+                                   (17, 7, 256), (31, 5, 1440), (24, 6, 1442), (16, 9, 1440), (200, 3, 40)])
 @pytest.mark.parametrize('ties', [False, True])
 def test_random_shapes_against_oracle(shape, ties):
     B, T, S = shape

@@ -53,7 +53,8 @@ struct Plan {
     int NPOW;    // sort width (power of two >= S)
 };
 
-inline bool supported(int B, int S) { return B >= 32 && S % 4 == 0 && S >= 64 && S <= kMaxS; }
+// B > 16: below that the generic row kernels (one workgroup per 4 next-states and item) are at least as fast
+inline bool supported(int B, int S) { return B > 16 && S % 4 == 0 && S >= 64 && S <= kMaxS; }
 
 // dynamic LDS of step_pruned_kernel: posterior tile [S][NI] + merged top lists + the NI items' frame counts
 // + this tile's running top lists (64-bit keys)

@@ -528,7 +528,9 @@ hipError_t launch_forward(const float *obs, const int32_t *frames, const float *
         hipLaunchKernelGGL(init_posterior_kernel, dim3(grid), dim3(256), 0, stream, obs, init,
                            w.post[0], B, T, S);
     }
-    const bool tiled = B >= 24;
+    // the 64 x 64 tile kernel only pays for many items over a tiny state space; everything else that lands here
+    // (B < 32, or shapes the value-only paths do not take) runs one workgroup per (rows, item)
+    const bool tiled = B >= 64 && S < 64;
     int n = 0;
     for (int t = 1; t < T; ++t) {
         const float *pc = w.post[(t - 1) & 1];
