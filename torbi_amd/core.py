@@ -109,7 +109,9 @@ def from_probabilities(
     # Ensure observation probabilities are in log space (core.py:189-191)
     if not log_probs:
         observation = torch.log(observation)
-    observation = observation.to(device=device, dtype=torch.float32)
+    # non_blocking: a pinned host batch (data.loader) is copied asynchronously, so the copy of batch k+1
+    # runs under the decode of batch k; pageable sources fall back to the synchronous path by themselves
+    observation = observation.to(device=device, dtype=torch.float32, non_blocking=True)
 
     # Add epsilon for stability (core.py:193-197; in place, like the reference): exp_, += tiny,
     # log_ as ONE elementwise pass on the device

@@ -63,12 +63,19 @@ def separate(indices, batch_chunks, batch_frames):
     return separated
 
 
-def loader(input_files, num_workers=None, collate_fn=collate, batch_size=None):
-    """DataLoader over observation files in the given order (loader.py:10-25)."""
+def loader(input_files, num_workers=None, collate_fn=collate, batch_size=None, pin_memory=None):
+    """DataLoader over observation files in the given order (loader.py:10-25).
+
+    Batches are collated into pinned host memory when a HIP device is present (the reference has
+    `pin_memory` commented out, loader.py:22): from_probabilities then copies them with a
+    non-blocking H2D that overlaps the previous batch's decode (PCIe)."""
     from . import core
+    if pin_memory is None:
+        pin_memory = torch.cuda.is_available()
     return torch.utils.data.DataLoader(
         Dataset(input_files),
         num_workers=core.NUM_WORKERS if num_workers is None else num_workers,
         batch_size=core.BATCH_SIZE if batch_size is None else batch_size,
         shuffle=False,
-        collate_fn=collate_fn)
+        collate_fn=collate_fn,
+        pin_memory=pin_memory)
