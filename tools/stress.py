@@ -1,0 +1,45 @@
+"""Randomised parity stress (GPU box): random shapes, lengths, -inf densities and tie levels under the three forward
+paths against the C oracle.   python tools/stress.py [cases] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import oracle, torbi_amd
+from torbi_amd import synth, viterbi
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = torch.device('cuda:0')
+bad = 0
+t0 = time.time()
+for c in range(cases):
+    S = int(rng.choice([rng.integers(16, 80), rng.integers(16, 560) * 4, rng.integers(64, 2200), rng.integers(513, 1025) * 4]))
+    B = int(rng.choice([rng.integers(1, 20), rng.integers(17, 70), rng.integers(60, 160)]))
+    T = int(rng.integers(1, 10))
+    if B * T * S * S > 6e9:
+        B = max(1, int(6e9 / (T * S * S)))
+    obs, trans, init = synth.problem(B, T, S, seed=int(rng.integers(1 << 30)))
+    kind = rng.integers(6)
+    if kind == 1:      # heavy ties
+        obs = np.round(obs / 4) * 4; trans = np.round(trans / 8) * 8
+    elif kind == 2:    # random -inf entries
+        trans = np.where(rng.random((S, S)) < rng.choice([0.3, 0.9, 0.99]), -np.inf, trans).astype(np.float32)
+    elif kind == 3:    # band
+        trans = np.where(np.abs(np.arange(S)[:, None] - np.arange(S)[None, :]) > rng.integers(1, max(2, S // 4)), -np.inf, trans).astype(np.float32)
+    elif kind == 4:    # -inf observations / initial
+        obs = np.where(rng.random(obs.shape) < 0.2, -np.inf, obs).astype(np.float32)
+        init = np.where(rng.random(S) < 0.5, -np.inf, init).astype(np.float32)
+    elif kind == 5:    # tiny spread: nothing prunable
+        trans = (trans * np.float32(2.0 ** -int(rng.integers(8, 20)))).astype(np.float32)
+    frames = rng.integers(1, T + 1, size=B).astype(np.int32)
+    want = oracle.decode(obs.astype(np.float32), frames, trans.astype(np.float32), init.astype(np.float32), num_threads=oracle.max_threads())
+    args = [torch.as_tensor(np.ascontiguousarray(x)).to(dev) for x in (obs.astype(np.float32), frames, trans.astype(np.float32), init.astype(np.float32))]
+    for path in ('auto', 'dense', 'pruned'):
+        viterbi.set_forward_path(path)
+        got = torbi_amd.decode(*args).cpu().numpy()
+        if not np.array_equal(got, want):
+            bad += 1
+            print('MISMATCH', dict(B=B, T=T, S=S, kind=int(kind), path=path, used=viterbi.forward_path(B, S)), int((got != want).sum()))
+viterbi.set_forward_path('auto')
+print(f'{cases} cases x 3 paths, {bad} mismatches, {time.time() - t0:.0f} s')
+sys.exit(1 if bad else 0)
