@@ -193,6 +193,36 @@ def test_pruned_path_adversarial_inputs(kind, shape):
     np.testing.assert_array_equal(gpu_decode(obs, frames, trans, init), want)
 
 
+@pytest.mark.parametrize('seed', [11, 12, 13])
+def test_randomised_shapes_lengths_and_structures(seed):
+    """A slice of tools/stress.py (1200 cases x 3 paths clean on the box): random batch/state counts around the
+    path thresholds, ragged lengths, -inf densities, bands, heavy ties and unprunable matrices."""
+    rng = np.random.default_rng(seed)
+    for _ in range(12):
+        S = int(rng.choice([rng.integers(16, 80), rng.integers(16, 560) * 4, rng.integers(64, 2200)]))
+        B = int(rng.choice([rng.integers(1, 20), rng.integers(17, 70), rng.integers(60, 160)]))
+        T = int(rng.integers(1, 9))
+        if B * T * S * S > 3e9:
+            B = max(1, int(3e9 / (T * S * S)))
+        obs, trans, init = synth.problem(B, T, S, seed=int(rng.integers(1 << 30)))
+        kind = int(rng.integers(5))
+        if kind == 1:
+            obs = np.round(obs / 4) * 4
+            trans = np.round(trans / 8) * 8
+        elif kind == 2:
+            trans = np.where(rng.random((S, S)) < rng.choice([0.3, 0.9, 0.99]), -np.inf, trans)
+        elif kind == 3:
+            reach = rng.integers(1, max(2, S // 4))
+            trans = np.where(np.abs(np.arange(S)[:, None] - np.arange(S)[None, :]) > reach, -np.inf, trans)
+        elif kind == 4:
+            trans = trans * np.float32(2.0 ** -int(rng.integers(8, 20)))
+        obs, trans, init = (np.ascontiguousarray(x, dtype=np.float32) for x in (obs, trans, init))
+        frames = rng.integers(1, T + 1, size=B).astype(np.int32)
+        want = oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())
+        np.testing.assert_array_equal(gpu_decode(obs, frames, trans, init), want,
+                                      err_msg=f'B={B} T={T} S={S} kind={kind}')
+
+
 @pytest.mark.parametrize('B', [2, 40])
 def test_out_of_range_lengths_are_clamped(B):
     """batch_frames outside [1, T] is clamped on the device (the reference reads out of bounds
