@@ -40,7 +40,8 @@ def from_probabilities(
     log_probs: bool = False,
     gpu: Optional[int] = None,
     num_threads: Optional[int] = 1,
-    _pipeline=None
+    _pipeline=None,
+    _model: Optional[dict] = None
 ) -> torch.Tensor:
     """Decode a time-varying categorical distribution
 
@@ -86,25 +87,32 @@ def from_probabilities(
         batch_frames = torch.full((batch,), frames, dtype=torch.int32, device=device)
     batch_frames = batch_frames.to(dtype=torch.int32, device=device)
 
-    # Default to uniform initial probabilities (core.py:161-166)
-    if initial is None:
-        initial = torch.full(
-            (states,), math.log((1. / states) + tiny), dtype=torch.float32, device=device)
+    # `_model` (from_dataloader): initial/transition are the same objects for every batch, so their
+    # log(), device move and (in torbi_amd.decode) structure look are done once, not per batch
+    if _model is not None and 'initial' in _model:
+        initial, transition, uniform = _model['initial'], _model['transition'], _model['uniform']
     else:
-        if not log_probs:
-            initial = torch.log(initial)
-        initial = initial.to(device)
+        # Default to uniform initial probabilities (core.py:161-166)
+        if initial is None:
+            initial = torch.full(
+                (states,), math.log((1. / states) + tiny), dtype=torch.float32, device=device)
+        else:
+            if not log_probs:
+                initial = torch.log(initial)
+            initial = initial.to(device)
 
-    # Default to uniform transition probabilities (core.py:175-180).  The reference
-    # materialises torch.full((S, S), log(1/S)); a matrix of identical entries is decoded by the
-    # O(S)-per-timestep entry point instead, with identical results (decode_uniform).
-    uniform = None
-    if transition is None:
-        uniform = float(torch.tensor(math.log(1. / states), dtype=torch.float32))
-    else:
-        if not log_probs:
-            transition = torch.log(transition)
-        transition = transition.to(device)
+        # Default to uniform transition probabilities (core.py:175-180).  The reference
+        # materialises torch.full((S, S), log(1/S)); a matrix of identical entries is decoded by the
+        # O(S)-per-timestep entry point instead, with identical results (decode_uniform).
+        uniform = None
+        if transition is None:
+            uniform = float(torch.tensor(math.log(1. / states), dtype=torch.float32))
+        else:
+            if not log_probs:
+                transition = torch.log(transition)
+            transition = transition.to(device)
+        if _model is not None:
+            _model.update(initial=initial, transition=transition, uniform=uniform)
 
     # Ensure observation probabilities are in log space (core.py:189-191)
     if not log_probs:
@@ -279,6 +287,7 @@ def from_dataloader(
             save_masked(row, filename, frames)
 
     previous = None
+    model = {}
     for observation, batch_frames, batch_chunks, input_filenames in dataloader:
         indices = from_probabilities(
             observation=observation,
@@ -288,7 +297,8 @@ def from_dataloader(
             log_probs=log_probs,
             gpu=gpu,
             num_threads=num_threads,
-            _pipeline=pipe)
+            _pipeline=pipe,
+            _model=model)
         if previous is not None:
             finish(previous)
         previous = (indices, input_filenames, batch_frames)
