@@ -75,7 +75,7 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
  *            shaped like the reference's
  *   DENSE    value-only (max,+) GEMM, every (prev, next) cell evaluated
  *   PRUNED   value-only, exact: sorted transition rows + per-item top posteriors bound the cells
- *            that can still win, the rest are never touched (B >= 17, S % 4 == 0, 64 <= S <= 4096)
+ *            that can still win, the rest are never touched (B >= 17, 64 <= S <= 4096)
  * AUTO (the default; also the environment variable TORBI_HIP_FORWARD=dense|pruned read once) takes
  * PRUNED where supported, else DENSE, else GENERIC.  The setting is process-wide; a workspace of
  * torbi_hip_workspace_bytes() fits every path.  torbi_hip_forward_path reports what a (B, S)

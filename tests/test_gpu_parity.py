@@ -139,7 +139,7 @@ def test_forward_path_selection(forward):
     assert viterbi.forward_path(128, 4096) == ('dense' if forward == 'dense' else 'pruned')   # 8-item tiles
     assert viterbi.forward_path(128, 4100) == 'dense'              # posterior tile does not fit the LDS
     assert viterbi.forward_path(512, 1440) == ('dense' if forward == 'dense' else 'pruned')
-    assert viterbi.forward_path(64, 130) == 'dense'                # S % 4 != 0
+    assert viterbi.forward_path(64, 130) == ('dense' if forward == 'dense' else 'pruned')      # any S in range
     assert viterbi.workspace_bytes(512, 500, 1440) >= 512 * 500 * 1440 * 4
 
 

@@ -54,12 +54,13 @@ struct Plan {
 };
 
 // B > 16: below that the generic row kernels (one workgroup per 4 next-states and item) are at least as fast
-inline bool supported(int B, int S) { return B > 16 && S % 4 == 0 && S >= 64 && S <= kMaxS; }
+inline bool supported(int B, int S) { return B > 16 && S >= 64 && S <= kMaxS; }
 
 // dynamic LDS of step_pruned_kernel: posterior tile [S][NI] + merged top lists + the NI items' frame counts
 // + this tile's running top lists (64-bit keys)
 inline size_t lds_bytes(int S, int NI) {
-    return sizeof(float) * ((size_t)NI * S + 2 * NI * kTop + NI) + sizeof(unsigned long long) * NI * kTop;
+    const size_t S4 = ((size_t)S + 3) / 4 * 4;      // the tile is staged four prev-states at a time
+    return sizeof(float) * (NI * S4 + 2 * NI * kTop + NI) + sizeof(unsigned long long) * NI * kTop;
 }
 
 inline Plan make_plan(int B, int S, int num_cus) {
@@ -290,11 +291,12 @@ __global__ __launch_bounds__(64) void top_kernel(const float *__restrict__ hist,
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int i = 4 * lane + 256 * q;
-        float4 x = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        if (i < S) x = *reinterpret_cast<const float4 *>(row + i);
-        v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+        // history rows are 16-byte aligned only when S % 4 == 0: plain loads (this kernel runs once per decode)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) tag[4 * q + u] = i < S ? i + u : 0x7fffffff;
+        for (int u = 0; u < 4; ++u) {
+            v[4 * q + u] = i + u < S ? row[i + u] : -INFINITY;
+            tag[4 * q + u] = i + u < S ? i + u : 0x7fffffff;
+        }
     }
     wave_top<NQ * 4>(v, tag, [&](int r, float m, int k) {
         if (lane == 0) { topv[(size_t)b * kTop + r] = m; topi[(size_t)b * kTop + r] = k; }
@@ -356,8 +358,8 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     constexpr int EPL = kBlk / G;        // list entries per lane per block
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // [NI][kTop] running top list of this tile's outputs per item, as 64-bit keys (order-preserving value bits,
-    // ~next-state); 8-byte aligned because NI * S is even
-    unsigned long long *ttop = reinterpret_cast<unsigned long long *>(lds + (size_t)NI * S);
+    // ~next-state); 8-byte aligned because NI is even
+    unsigned long long *ttop = reinterpret_cast<unsigned long long *>(lds + (size_t)NI * ((S + 3) / 4 * 4));
     float *mtopv = reinterpret_cast<float *>(ttop + NI * kTop);   // [16][kTop] merged top values of t-1
     int *mtopi = reinterpret_cast<int *>(mtopv + NI * kTop);
     int *sframes = mtopi + NI * kTop;                     // [16] frames of the tile's items (0 past the batch)
@@ -433,10 +435,23 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
         static_assert((64 * kWaves) % NI == 0, "tile staging assumes a fixed item per thread");
         const int bb = tid & (NI - 1);
         const int brow = b0 + bb < B ? b0 + bb : B - 1;
-        const float *psrc = hist + ((size_t)brow * T + (t - 1)) * S + 4 * (lo4 + tid / NI);
+        const int ifirst = 4 * (lo4 + tid / NI);
+        const float *psrc = hist + ((size_t)brow * T + (t - 1)) * S + ifirst;
+        if ((S & 3) == 0) {
 #pragma unroll
-        for (int u = 0; u < NCH; ++u)
-            if (tid + u * 64 * kWaves < n4) pv[u] = *reinterpret_cast<const float4 *>(psrc + u * (4 * 64 * kWaves / NI));
+            for (int u = 0; u < NCH; ++u)
+                if (tid + u * 64 * kWaves < n4) pv[u] = *reinterpret_cast<const float4 *>(psrc + u * (4 * 64 * kWaves / NI));
+        } else {
+            // S % 4 != 0: history rows are not 16-byte aligned; four plain loads, prev-states past S read as 0
+#pragma unroll
+            for (int u = 0; u < NCH; ++u) {
+                if (tid + u * 64 * kWaves < n4) {
+                    const int i = ifirst + u * (4 * 64 * kWaves / NI);
+                    const float *q = psrc + u * (4 * 64 * kWaves / NI);
+                    pv[u] = make_float4(i < S ? q[0] : 0.f, i + 1 < S ? q[1] : 0.f, i + 2 < S ? q[2] : 0.f, i + 3 < S ? q[3] : 0.f);
+                }
+            }
+        }
     }
     PSTAMP(1);
     if (tid < NI) sframes[tid] = fr;

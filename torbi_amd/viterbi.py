@@ -142,7 +142,7 @@ def set_forward_path(path: str = 'auto') -> None:
 
 
 def _choose_path(trans: torch.Tensor, original: torch.Tensor, batch: int, states: int) -> str:
-    if _forced_path != 'auto' or batch < 32 or states < 64 or states > 4096 or states % 4:   # dense needs B >= 32
+    if _forced_path != 'auto' or batch < 32 or states < 64 or states > 4096:   # dense needs B >= 32
         return _forced_path
     key = (original.data_ptr(), original._version, states, str(original.device))
     reach = _structure_cache.get(key)
