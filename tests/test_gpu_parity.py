@@ -59,7 +59,8 @@ def test_golden_large(golden, name):
                                    (64, 17, 64), (65, 9, 63), (100, 12, 130), (257, 5, 33),
                                    (2, 30, 4096), (40, 6, 2049), (32, 7, 64), (96, 11, 1441),
                                    (512, 3, 100), (128, 5, 4096), (70, 40, 360), (600, 4, 97),
-                                   (17, 7, 256), (31, 5, 1440), (24, 6, 1442), (16, 9, 1440), (200, 3, 40)])
+                                   (17, 7, 256), (31, 5, 1440), (24, 6, 1442), (16, 9, 1440), (200, 3, 40),
+                                   (256, 4, 360), (300, 3, 1440), (272, 5, 132), (260, 3, 1443)])
 @pytest.mark.parametrize('ties', [False, True])
 def test_random_shapes_against_oracle(shape, ties):
     B, T, S = shape
@@ -165,7 +166,7 @@ def test_auto_takes_the_dense_kernel_for_narrow_bands_only(forward):
 
 @pytest.mark.parametrize('kind', ['flat', 'nearly_flat', 'peaked', 'anti', 'two_level'])
 @pytest.mark.parametrize('shape', [(32, 12, 64), (33, 9, 132), (48, 6, 1444), (40, 5, 2048), (64, 10, 360),
-                                   (36, 4, 2052), (32, 3, 4096)])
+                                   (36, 4, 2052), (32, 3, 4096), (256, 4, 724), (270, 3, 1440)])
 def test_pruned_path_adversarial_inputs(kind, shape):
     """Inputs chosen against the pruning bound: rows without spread (nothing can be pruned: the scan runs to
     the end of every list), posteriors with a few dominant peaks (the explicit seeds carry the maximum),

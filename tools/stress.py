@@ -14,7 +14,7 @@ bad = 0
 t0 = time.time()
 for c in range(cases):
     S = int(rng.choice([rng.integers(16, 80), rng.integers(16, 560) * 4, rng.integers(64, 2200), rng.integers(513, 1025) * 4]))
-    B = int(rng.choice([rng.integers(1, 20), rng.integers(17, 70), rng.integers(60, 160)]))
+    B = int(rng.choice([rng.integers(1, 20), rng.integers(17, 70), rng.integers(60, 160), rng.integers(250, 300)]))
     T = int(rng.integers(1, 10))
     if B * T * S * S > 6e9:
         B = max(1, int(6e9 / (T * S * S)))

@@ -65,7 +65,8 @@ inline size_t lds_bytes(int S, int NI) {
 
 inline Plan make_plan(int B, int S, int num_cus) {
     Plan p{};
-    p.NI = S <= kMaxS16 ? kNB : kNB / 2;
+    // 8-item tiles also for batches too small to give every CU a 16-item tile (n_jt is capped at kMaxJT)
+    p.NI = (S <= kMaxS16 && ((B + kNB - 1) / kNB) * kMaxJT >= num_cus) ? kNB : kNB / 2;
     p.n_bt = (B + p.NI - 1) / p.NI;
     int n_jt = num_cus / p.n_bt;
     if (n_jt < 1) n_jt = 1;
