@@ -115,6 +115,9 @@ def main():
     ap.add_argument('--frames', type=int, default=500)
     ap.add_argument('--states', type=int, default=1440)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--reuse-preparation', action='store_true',
+                    help='let consecutive decodes share the per-transition preparation (sorted rows / packed '
+                         'panels) as a serving loop would; off by default: every timed decode does all of its work')
     ap.add_argument('--forward', choices=['auto', 'dense', 'pruned'], default='auto',
                     help='forward-recurrence path (include/torbi_hip.h); every path gives identical indices')
     ap.add_argument('--pipeline', type=int, default=2,
@@ -145,7 +148,8 @@ def main():
     import math
     uniform_c = float(torch.tensor(math.log(1.0 / S), dtype=torch.float32))
 
-    pipe = torbi_amd.DecodePipeline(dev, depth=args.pipeline) if args.pipeline > 1 else None
+    pipe = torbi_amd.DecodePipeline(dev, depth=args.pipeline, reuse_preparation=args.reuse_preparation) \
+        if args.pipeline > 1 else None
 
     def gather(idx):
         return distributed.gather_indices(idx, B * size, force=True) if collective else idx
@@ -155,7 +159,8 @@ def main():
             return gather(torbi_amd.decode_uniform(obs, frames, uniform_c, init))
         if pipe is not None:     # consecutive batches alternate between HIP streams
             return pipe.decode(obs, frames, trans, init, after=gather)
-        return gather(torbi_amd.decode(obs, frames, trans, init, workspace=ws))
+        return gather(torbi_amd.decode(obs, frames, trans, init, workspace=ws,
+                                       reuse_preparation=args.reuse_preparation))
 
     def fence():
         if pipe is not None:
@@ -232,7 +237,9 @@ def main():
                                f'{S} states, {T} frames, batch={B} per GPU, fp32, BANDED transition '
                                f'(half width {args.half_width}, -inf outside; secondary workload)',
                    'parallelism': f'batch-sharded x{size}' if size > 1 else 'single GPU',
-                   'decodes_in_flight': args.pipeline, 'forward_path': path},
+                   'decodes_in_flight': args.pipeline, 'forward_path': path,
+                   'transition_preparation': 'reused across decodes' if args.reuse_preparation
+                   else 'rebuilt by every decode'},
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS,

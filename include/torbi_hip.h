@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TORBI_HIP_ABI_VERSION 3
+#define TORBI_HIP_ABI_VERSION 4
 
 #define TORBI_HIP_OK 0
 #define TORBI_HIP_EINVAL (-1)      /* null pointer / non-positive dimension            */
@@ -100,6 +100,20 @@ int torbi_hip_viterbi_decode(const float *observation, const int32_t *batch_fram
                              const float *transition, const float *initial,
                              int32_t *indices_out, void *workspace, size_t workspace_bytes,
                              int B, int T, int S, int device, void *stream);
+
+/*
+ * The operator with flags.  TORBI_HIP_REUSE_TRANSITION: the caller promises that the previous call
+ * that used `workspace` had the same B, T, S, forward path and transition CONTENTS and that nothing
+ * else has written to the workspace since; the per-transition preparation (sorted transition rows /
+ * packed panels, 0.2 ms at S = 1440) is then taken from the workspace instead of being rebuilt.
+ * A serving loop that decodes batch after batch with one matrix sets it from the second batch on
+ * (torbi_amd.DecodePipeline does).  flags = 0 is torbi_hip_viterbi_decode.  Unknown bits: EINVAL.
+ */
+#define TORBI_HIP_REUSE_TRANSITION 1u
+int torbi_hip_viterbi_decode_ex(const float *observation, const int32_t *batch_frames,
+                                const float *transition, const float *initial,
+                                int32_t *indices_out, void *workspace, size_t workspace_bytes,
+                                int B, int T, int S, int device, void *stream, unsigned flags);
 
 /*
  * The operator for a UNIFORM transition matrix (every entry == log_transition), i.e. the

@@ -251,6 +251,38 @@ def test_non_contiguous_inputs_are_accepted():
     assert np.array_equal(got, want)
 
 
+def test_preparation_reuse_follows_the_transition_and_the_shape():
+    """decode(workspace=..., reuse_preparation=True) skips the per-transition preparation only when the
+    workspace's previous decode had the same shape, path and transition version (include/torbi_hip.h,
+    TORBI_HIP_REUSE_TRANSITION); everything else rebuilds it."""
+    dev = torch.device('cuda:0')
+    B, T, S = 48, 7, 360
+    obs, trans, init = synth.problem(B, T, S, seed=5)
+    obs2 = synth.problem(B, T, S, seed=6)[0]
+    frames = synth.lengths(B, 1, T, seed=2)
+    d = [torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)]
+    ws = torch.empty(viterbi.workspace_bytes(64, 9, 512), dtype=torch.uint8, device=dev)
+    want1 = oracle.decode(obs, frames, trans, init)
+    want2 = oracle.decode(obs2, frames, trans, init)
+    for _ in range(2):
+        np.testing.assert_array_equal(torbi_amd.decode(*d, workspace=ws, reuse_preparation=True).cpu().numpy(), want1)
+    got = torbi_amd.decode(torch.as_tensor(obs2).to(dev), d[1], d[2], d[3], workspace=ws, reuse_preparation=True)
+    np.testing.assert_array_equal(got.cpu().numpy(), want2)            # same matrix, new observations: reused
+    d[2].mul_(0.5)                                                     # new version of the matrix: rebuilt
+    want3 = oracle.decode(obs, frames, (trans * np.float32(0.5)).astype(np.float32), init)
+    np.testing.assert_array_equal(torbi_amd.decode(*d, workspace=ws, reuse_preparation=True).cpu().numpy(), want3)
+    # another shape in between invalidates what the workspace holds
+    o4, t4, i4 = synth.problem(40, 5, 512, seed=9)
+    f4 = np.full(40, 5, dtype=np.int32)
+    d4 = [torch.as_tensor(x).to(dev) for x in (o4, f4, t4, i4)]
+    np.testing.assert_array_equal(torbi_amd.decode(*d4, workspace=ws, reuse_preparation=True).cpu().numpy(),
+                                  oracle.decode(o4, f4, t4, i4))
+    np.testing.assert_array_equal(torbi_amd.decode(*d, workspace=ws, reuse_preparation=True).cpu().numpy(), want3)
+    lib = torbi_amd._lib.load()
+    assert lib.torbi_hip_viterbi_decode_ex(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
+                                           got.data_ptr(), ws.data_ptr(), ws.numel(), B, T, S, 0, None, 2) == -1
+
+
 def test_decode_pipeline_equals_serial_decodes():
     """torbi_amd.DecodePipeline: consecutive batches on alternating streams, private scratch."""
     dev = torch.device('cuda:0')

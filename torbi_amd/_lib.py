@@ -14,7 +14,7 @@ ROOT = os.path.dirname(_HERE)
 SOURCE = os.path.join(_HERE, 'csrc', 'torbi_hip.hip')
 INCLUDE = os.path.join(ROOT, 'include')
 LIBRARY = os.path.join(_HERE, 'libtorbi_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/torbi_hip.h declares: name -> (restype, argtypes)
 _c = ctypes
@@ -33,6 +33,9 @@ SYMBOLS = {
         _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
         _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
         _c.POINTER(_c.c_float)]),
+    'torbi_hip_viterbi_decode_ex': (_c.c_int, [
+        _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+        _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint]),
     'torbi_hip_set_forward_path': (_c.c_int, [_c.c_int]),
     'torbi_hip_forward_path': (_c.c_int, [_c.c_int, _c.c_int]),
     'torbi_hip_read_posterior': (_c.c_int, [

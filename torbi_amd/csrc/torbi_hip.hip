@@ -585,13 +585,15 @@ hipError_t launch_dense_steps(const float *obs, const int32_t *frames, const Den
 
 hipError_t launch_dense_forward(const float *obs, const int32_t *frames, const float *trans,
                                 const float *init, const DenseWorkspace &w, int B, int T, int S,
-                                hipStream_t stream, int *launches) {
+                                hipStream_t stream, int *launches, bool reuse) {
     const dense::Plan &pl = w.plan;
-    hipLaunchKernelGGL(dense::pack_transition_kernel, dim3((pl.Kp + 63) / 64, pl.n_jt), dim3(256), 0,
-                       stream, trans, w.trp, S, pl.JT, pl.W, pl.Kp);
-    hipLaunchKernelGGL(dense::build_chunk_lists_kernel, dim3(pl.n_jt), dim3(256),
-                       sizeof(int) * (size_t)pl.NCH, stream, w.trp, w.chunks, S, pl.JT, pl.W, pl.Kp, pl.NCH,
-                       pl.KC);
+    if (!reuse) {      // per-transition preparation: packed panels + per-tile lists of chunks that are not all -inf
+        hipLaunchKernelGGL(dense::pack_transition_kernel, dim3((pl.Kp + 63) / 64, pl.n_jt), dim3(256), 0,
+                           stream, trans, w.trp, S, pl.JT, pl.W, pl.Kp);
+        hipLaunchKernelGGL(dense::build_chunk_lists_kernel, dim3(pl.n_jt), dim3(256),
+                           sizeof(int) * (size_t)pl.NCH, stream, w.trp, w.chunks, S, pl.JT, pl.W, pl.Kp, pl.NCH,
+                           pl.KC);
+    }
     {
         const size_t n = (size_t)pl.n_bt * pl.BT * pl.Kp;
         const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
@@ -616,17 +618,21 @@ hipError_t launch_dense_forward(const float *obs, const int32_t *frames, const f
 
 hipError_t launch_pruned_forward(const float *obs, const int32_t *frames, const float *trans,
                                  const float *init, const PrunedWorkspace &w, int B, int T, int S,
-                                 hipStream_t stream, int *launches) {
+                                 hipStream_t stream, int *launches, bool reuse) {
     const pruned::Plan &pl = w.plan;
-    hipLaunchKernelGGL(pruned::sort_rows_kernel, dim3(S), dim3(256), sizeof(float) * 2 * (size_t)pl.NPOW, stream,
-                       trans, w.sorted, w.row_range, S, pl.SpP, pl.NPOW, pl.NI * 4);
-    hipLaunchKernelGGL(pruned::tile_range_kernel, dim3(pl.n_jt), dim3(64), 0, stream, w.row_range, w.tile_range, S, pl.JT);
-    if (pl.NI == pruned::kNB) {      // the bank-quarter arrangement is specific to 64-byte posterior rows
-        const int n = (S / 4) * (pl.SpP / pruned::kBlk);
-        hipLaunchKernelGGL(pruned::arrange_blocks_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, w.sorted, S, pl.SpP);
+    if (!reuse) {      // per-transition preparation: sorted + arranged lists, row/tile ranges, transposed copy
+        hipLaunchKernelGGL(pruned::sort_rows_kernel, dim3(S), dim3(256), sizeof(float) * 2 * (size_t)pl.NPOW, stream,
+                           trans, w.sorted, w.row_range, S, pl.SpP, pl.NPOW, pl.NI * 4);
+        hipLaunchKernelGGL(pruned::tile_range_kernel, dim3(pl.n_jt), dim3(64), 0, stream, w.row_range, w.tile_range, S,
+                           pl.JT);
+        if (pl.NI == pruned::kNB) {      // the bank-quarter arrangement is specific to 64-byte posterior rows
+            const int n = (S / 4) * (pl.SpP / pruned::kBlk);
+            hipLaunchKernelGGL(pruned::arrange_blocks_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, w.sorted, S,
+                               pl.SpP);
+        }
+        hipLaunchKernelGGL(pruned::transpose_kernel, dim3((S + 31) / 32, (S + 31) / 32), dim3(256), 0, stream, trans,
+                           w.tt, S);
     }
-    hipLaunchKernelGGL(pruned::transpose_kernel, dim3((S + 31) / 32, (S + 31) / 32), dim3(256), 0, stream, trans,
-                       w.tt, S);
     {
         const size_t n = (size_t)B * S;
         const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
@@ -702,17 +708,17 @@ hipError_t launch_dense_backtrace(const float *trans, const int32_t *frames, con
 // one decode on `s`; optional events bracket the forward and backtrace phases
 hipError_t run_decode(const float *obs, const int32_t *frames, const float *trans, const float *init,
                       int32_t *out, void *workspace, int B, int T, int S, hipStream_t s,
-                      hipEvent_t *ev, int *launches) {
+                      hipEvent_t *ev, int *launches, bool reuse) {
     hipError_t e;
     if (ev) (void)hipEventRecord(ev[0], s);
     if (use_pruned(B, S)) {
         const PrunedWorkspace w = carve_pruned(workspace, B, T, S);
-        e = launch_pruned_forward(obs, frames, trans, init, w, B, T, S, s, launches);
+        e = launch_pruned_forward(obs, frames, trans, init, w, B, T, S, s, launches, reuse);
         if (ev) (void)hipEventRecord(ev[1], s);
         if (e == hipSuccess) e = launch_backtrace_on(w.hist, trans, frames, out, B, T, S, s);
     } else if (use_dense(B, S)) {
         const DenseWorkspace w = carve_dense(workspace, B, T, S);
-        e = launch_dense_forward(obs, frames, trans, init, w, B, T, S, s, launches);
+        e = launch_dense_forward(obs, frames, trans, init, w, B, T, S, s, launches, reuse);
         if (ev) (void)hipEventRecord(ev[1], s);
         if (e == hipSuccess) e = launch_dense_backtrace(trans, frames, w, out, B, T, S, s);
     } else {
@@ -788,7 +794,22 @@ int torbi_hip_viterbi_decode(const float *observation, const int32_t *batch_fram
     DeviceGuard guard(device);
     if (guard.err != hipSuccess) return (int)guard.err;
     return (int)run_decode(observation, batch_frames, transition, initial, indices_out, workspace,
-                           B, T, S, static_cast<hipStream_t>(stream), nullptr, nullptr);
+                           B, T, S, static_cast<hipStream_t>(stream), nullptr, nullptr, false);
+}
+
+int torbi_hip_viterbi_decode_ex(const float *observation, const int32_t *batch_frames,
+                                const float *transition, const float *initial,
+                                int32_t *indices_out, void *workspace, size_t workspace_bytes,
+                                int B, int T, int S, int device, void *stream, unsigned flags) {
+    if (flags & ~(unsigned)TORBI_HIP_REUSE_TRANSITION) return TORBI_HIP_EINVAL;
+    const int rc = check_args(observation, batch_frames, transition, initial, indices_out,
+                              workspace, workspace_bytes, B, T, S);
+    if (rc != TORBI_HIP_OK || B == 0) return rc;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return (int)guard.err;
+    return (int)run_decode(observation, batch_frames, transition, initial, indices_out, workspace,
+                           B, T, S, static_cast<hipStream_t>(stream), nullptr, nullptr,
+                           (flags & TORBI_HIP_REUSE_TRANSITION) != 0);
 }
 
 int torbi_hip_viterbi_decode_uniform(const float *observation, const int32_t *batch_frames,
@@ -837,7 +858,7 @@ int torbi_hip_viterbi_decode_profiled(const float *observation, const int32_t *b
     }
     int launches = 0;
     hipError_t e = run_decode(observation, batch_frames, transition, initial, indices_out,
-                              workspace, B, T, S, s, ev, &launches);
+                              workspace, B, T, S, s, ev, &launches, false);
     hipError_t es = hipEventSynchronize(ev[2]);
     if (e == hipSuccess) e = es;
     if (e == hipSuccess) {

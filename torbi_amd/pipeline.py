@@ -21,12 +21,15 @@ from . import viterbi
 class DecodePipeline:
     """Round-robin decodes over `depth` side streams, each with a private scratch buffer."""
 
-    def __init__(self, device=None, depth: int = 2):
+    def __init__(self, device=None, depth: int = 2, reuse_preparation: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError('DecodePipeline needs a HIP device; torbi_amd has no CPU path')
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None \
             else torch.device(device)
         self.depth = max(1, int(depth))
+        # each slot's scratch is private, so the per-transition preparation of one decode can serve the next
+        # decode of the same slot when shape and transition tensor are unchanged (decode(reuse_preparation=))
+        self.reuse_preparation = bool(reuse_preparation)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
         self.scratch: List[Optional[torch.Tensor]] = [None] * self.depth
         self.pending: List[Tuple[torch.Tensor, torch.cuda.Event]] = []
@@ -54,7 +57,8 @@ class DecodePipeline:
         stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(stream):
             scratch = self._scratch(slot, need)
-            indices = viterbi.decode(observation, batch_frames, transition, initial, workspace=scratch)
+            indices = viterbi.decode(observation, batch_frames, transition, initial, workspace=scratch,
+                                     reuse_preparation=self.reuse_preparation)
             if after is not None:
                 indices = after(indices)
             done = torch.cuda.Event()
