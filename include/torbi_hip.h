@@ -110,10 +110,25 @@ int torbi_hip_viterbi_decode(const float *observation, const int32_t *batch_fram
  * (torbi_amd.DecodePipeline does).  flags = 0 is torbi_hip_viterbi_decode.  Unknown bits: EINVAL.
  */
 #define TORBI_HIP_REUSE_TRANSITION 1u
+#define TORBI_HIP_COLLECT_STATS 2u     /* a PRUNED decode also leaves scan statistics: torbi_hip_scan_stats */
 int torbi_hip_viterbi_decode_ex(const float *observation, const int32_t *batch_frames,
                                 const float *transition, const float *initial,
                                 int32_t *indices_out, void *workspace, size_t workspace_bytes,
                                 int B, int T, int S, int device, void *stream, unsigned flags);
+
+/*
+ * Scan statistics of the last PRUNED decode that ran with TORBI_HIP_COLLECT_STATS on `workspace`
+ * (zeros otherwise; for adaptive path selection;
+ * torbi_amd/viterbi.py uses them): copies 128 uint32 to `stats_out` (DEVICE pointer) on `stream`:
+ *   stats_out[0..63]   sum over (sampled timestep, tile) of the deepest scan among the tile's waves, in
+ *                      16-entry list blocks (a launch lasts as long as its deepest wave)
+ *   stats_out[64..127] number of (timestep, tile) pairs counted (every 8th timestep is sampled)
+ * sum(first half) / sum(second half) = blocks on the critical path of a launch: about 11 of the
+ * S/16 = 90 on the 1440-state benchmark; near S/16 nothing is being pruned and the dense path is
+ * faster.  TORBI_HIP_EUNSUPPORTED when (B, S) does not take the pruned path.
+ */
+int torbi_hip_scan_stats(const void *workspace, size_t workspace_bytes, int B, int T, int S,
+                         unsigned *stats_out, int device, void *stream);
 
 /*
  * The operator for a UNIFORM transition matrix (every entry == log_transition), i.e. the

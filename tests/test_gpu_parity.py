@@ -280,7 +280,32 @@ def test_preparation_reuse_follows_the_transition_and_the_shape():
     np.testing.assert_array_equal(torbi_amd.decode(*d, workspace=ws, reuse_preparation=True).cpu().numpy(), want3)
     lib = torbi_amd._lib.load()
     assert lib.torbi_hip_viterbi_decode_ex(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
-                                           got.data_ptr(), ws.data_ptr(), ws.numel(), B, T, S, 0, None, 2) == -1
+                                           got.data_ptr(), ws.data_ptr(), ws.numel(), B, T, S, 0, None, 4) == -1
+
+
+def test_auto_tuner_switches_paths_without_changing_results(forward):
+    """Repeated decodes with one transition tensor: the Python layer may move between the pruned and the dense
+    path by measurement (viterbi._Tuner); indices stay those of the oracle, and on data where a few states
+    dominate every posterior row the dense path has been tried by the end."""
+    if forward != 'auto':
+        pytest.skip('path forced')
+    dev = torch.device('cuda:0')
+    B, T, S = 64, 30, 720
+    obs, trans, init = synth.problem(B, T, S, seed=21)
+    obs = (obs + np.float32(40.0) * (obs > np.float32(-0.03))).astype(np.float32)
+    frames = np.full(B, T, dtype=np.int32)
+    want = oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())
+    d = [torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)]
+    ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+    for _ in range(6):
+        got = torbi_amd.decode(*d, workspace=ws, reuse_preparation=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+    tuner = viterbi._tuner_for(d[2], S, dev)
+    tuner._collect()
+    assert tuner.blocks is not None
+    if not tuner.settled():
+        assert tuner.time['pruned'] is not None and tuner.time['dense'] is not None
 
 
 def test_decode_pipeline_equals_serial_decodes():

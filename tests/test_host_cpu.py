@@ -161,8 +161,7 @@ def test_auto_path_choice_reads_the_transition_structure_once_per_version():
     band = torch.as_tensor(synth.banded_transition(S, 12.0))
     assert viterbi._choose_path(dense, dense, 64, S) == 'pruned'
     assert viterbi._choose_path(band, band, 64, S) == 'dense'
-    key = (band.data_ptr(), band._version, S, str(band.device))
-    assert 0.0 < viterbi._structure_cache[key] < viterbi.BANDED_RANGE
+    assert 0.0 < viterbi._structure_cache[id(band)][2] < viterbi.BANDED_RANGE
     band.fill_(-1.0)                                  # new version of the same storage: looked at again
     assert viterbi._choose_path(band, band, 64, S) == 'pruned'
     dead = torch.full((S, S), float('-inf'))
@@ -175,3 +174,37 @@ def test_auto_path_choice_reads_the_transition_structure_once_per_version():
         assert viterbi._choose_path(dense, dense, 64, S) == 'dense'
     finally:
         viterbi._forced_path = old
+
+
+def test_tuner_probes_the_dense_path_only_when_pruning_is_not_clearly_working():
+    """torbi_amd/viterbi.py::_Tuner with stand-in events: the decision logic, no GPU."""
+    from torbi_amd import viterbi
+
+    class Event:
+        def __init__(self, ms, done=True):
+            self.ms, self.done = ms, done
+
+        def query(self):
+            return self.done
+
+        def elapsed_time(self, other):
+            return other.ms
+
+    def run(tuner, ms, blocks, done=True):
+        path = tuner.choose()
+        tuner.launched(path, Event(0.0), Event(ms[path], done), None, 1)
+        if path == 'pruned' and tuner.blocks is None and done:
+            tuner.blocks = blocks
+        return path
+
+    good = viterbi._Tuner()                           # benchmark-like: 12 blocks on the critical path
+    assert [run(good, {'pruned': 1.0, 'dense': 2.0}, 12.0) for _ in range(200)] == ['pruned'] * 200
+    bad = viterbi._Tuner()                            # a few dominant states: pruned slower than dense
+    paths = [run(bad, {'pruned': 1.4, 'dense': 1.0}, 28.0) for _ in range(130)]
+    assert paths[0] == 'pruned' and paths[1] == 'dense'
+    assert paths.count('pruned') == 1 + 2              # the first decode and the re-probes at 64 and 128
+    mild = viterbi._Tuner()                           # wide but prunable: probed once, pruned kept
+    paths = [run(mild, {'pruned': 0.8, 'dense': 1.0}, 25.0) for _ in range(70)]
+    assert paths[:3] == ['pruned', 'dense', 'pruned'] and paths.count('dense') == 2
+    lag = viterbi._Tuner()                            # nothing has completed yet: keep going on the pruned path
+    assert [run(lag, {'pruned': 1.0, 'dense': 1.0}, 30.0, done=False) for _ in range(5)] == ['pruned'] * 5

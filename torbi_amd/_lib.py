@@ -36,6 +36,8 @@ SYMBOLS = {
     'torbi_hip_viterbi_decode_ex': (_c.c_int, [
         _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
         _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint]),
+    'torbi_hip_scan_stats': (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
+                                        _c.c_int, _c.c_void_p]),
     'torbi_hip_set_forward_path': (_c.c_int, [_c.c_int]),
     'torbi_hip_forward_path': (_c.c_int, [_c.c_int, _c.c_int]),
     'torbi_hip_read_posterior': (_c.c_int, [

@@ -41,6 +41,7 @@ constexpr int kWaves = PRUNED_WAVES;   // waves per workgroup (12 = 3 per SIMD: 
 constexpr int kTop = kR + 1;
 constexpr int kMaxS16 = 2048; // the posterior tile [S][16 items] fp32 must leave room in the 160 KB LDS
 constexpr int kMaxS = 4096;   // [S][8 items] tiles above kMaxS16
+constexpr int kStatSlots = 64;   // scan statistics: [0,64) blocks on the critical path, [64,128) workgroups counted
 constexpr int kMaxJT = 16;   // state tiles per batch tile (kMaxJT * kTop candidates = 4 per lane of a 16-lane row)
 
 struct Plan {
@@ -57,10 +58,10 @@ struct Plan {
 inline bool supported(int B, int S) { return B > 16 && S >= 64 && S <= kMaxS; }
 
 // dynamic LDS of step_pruned_kernel: posterior tile [S][NI] + merged top lists + the NI items' frame counts
-// + this tile's running top lists (64-bit keys)
+// + this tile's running top lists (64-bit keys) + the workgroup's deepest scan (statistics)
 inline size_t lds_bytes(int S, int NI) {
     const size_t S4 = ((size_t)S + 3) / 4 * 4;      // the tile is staged four prev-states at a time
-    return sizeof(float) * (NI * S4 + 2 * NI * kTop + NI) + sizeof(unsigned long long) * NI * kTop;
+    return sizeof(float) * (NI * S4 + 2 * NI * kTop + NI + 1) + sizeof(unsigned long long) * NI * kTop;
 }
 
 inline Plan make_plan(int B, int S, int num_cus) {
@@ -228,7 +229,9 @@ __global__ __launch_bounds__(256) void init_history_kernel(const float *__restri
 }
 
 // once per decode: empty partial top lists (value -inf, prev-state 0) for both parities
-__global__ __launch_bounds__(256) void clear_top_kernel(float *__restrict__ topv, int32_t *__restrict__ topi, size_t n) {
+__global__ __launch_bounds__(256) void clear_top_kernel(float *__restrict__ topv, int32_t *__restrict__ topi, size_t n,
+                                                        unsigned *__restrict__ stats) {
+    if (blockIdx.x == 0 && threadIdx.x < 2 * kStatSlots) stats[threadIdx.x] = 0u;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         topv[e] = -INFINITY;
         topi[e] = 0;
@@ -353,7 +356,8 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     const float *__restrict__ obs, const int32_t *__restrict__ frames, const float *__restrict__ tt,
     const float2 *__restrict__ sorted, const int32_t *__restrict__ tile_range, const float *__restrict__ ptopv_in,
     const int32_t *__restrict__ ptopi_in, float *__restrict__ ptopv_out, int32_t *__restrict__ ptopi_out,
-    float *__restrict__ hist, int B, int T, int S, int t, int SpP, int n_bt, int n_jt, int JT) {
+    float *__restrict__ hist, unsigned *__restrict__ stats, int B, int T, int S, int t, int SpP, int n_bt, int n_jt,
+    int JT) {
     constexpr int G = NI / 4;            // lanes per next-state (item groups of 4)
     constexpr int RW = 64 / G;           // next-states per wave
     constexpr int EPL = kBlk / G;        // list entries per lane per block
@@ -364,6 +368,7 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     float *mtopv = reinterpret_cast<float *>(ttop + NI * kTop);   // [16][kTop] merged top values of t-1
     int *mtopi = reinterpret_cast<int *>(mtopv + NI * kTop);
     int *sframes = mtopi + NI * kTop;                     // [16] frames of the tile's items (0 past the batch)
+    int *sdeep = sframes + NI;                            // deepest scan (16-entry blocks) among this tile's waves
     // grid = (n_bt, n_jt): linear workgroup id = bt + n_bt * jt (the 8 state tiles of a batch tile share an XCD
     // whenever n_bt % 8 == 0)
     const int bt = blockIdx.x, jt = blockIdx.y;
@@ -457,6 +462,7 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     PSTAMP(1);
     if (tid < NI) sframes[tid] = fr;
     if (tid < NI * kTop) ttop[tid] = 0ull;                // 0 = empty (every real key is > 0)
+    if (tid == 0) *sdeep = 0;
     if (wave < NI / 4) {
         // every 16-lane row merges the partial top lists of one item (candidates fetched at kernel entry)
         auto emit = [&](int r, float m, int k) {
@@ -530,6 +536,7 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
             owner(std::integral_constant<int, 3 % G>(), blk);
         }
     };
+    int nblk = 1;                          // wave-uniform: blocks this wave examines
     consume(cur);
     load_list_block(cur, row, 2 * kBlk);
     PSTAMP(5);
@@ -548,9 +555,11 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     // Block 0 is done; `nxt` holds block 1, `cur` is being refilled with block 2.
     for (int k = kBlk; k < Sp; k += 2 * kBlk) {
         if (!more(nxt)) break;
+        ++nblk;
         consume(nxt);
         load_list_block(nxt, row, k + 2 * kBlk);
         if (!more(cur)) break;
+        ++nblk;
         consume(cur);
         load_list_block(cur, row, k + 3 * kBlk);
     }
@@ -575,8 +584,16 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
             }
         }
     }
+    const bool sampled = stats != nullptr && (t & 7) == 1;       // on request, from every 8th timestep
+    if (sampled && lane == 0) atomicMax(sdeep, nblk);
     __syncthreads();
     PSTAMP(8);
+    // statistics for adaptive path selection (torbi_hip_scan_stats): the launch lasts as long as its deepest wave
+    if (sampled && tid == 0) {
+        const int slot = (blockIdx.x + gridDim.x * blockIdx.y) & (kStatSlots - 1);
+        atomicAdd(&stats[slot], (unsigned)*sdeep);
+        atomicAdd(&stats[kStatSlots + slot], 1u);
+    }
     if (tid < NI * kTop) {
         const int item = tid / kTop, r = tid % kTop;
         const unsigned long long k = ttop[tid];

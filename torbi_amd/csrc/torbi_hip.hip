@@ -432,6 +432,7 @@ struct PrunedWorkspace {
     float *tt;         // [S][S]   transposed transition matrix
     int32_t *row_range;  // [S][2]    finite prev-state range of every transition row
     int32_t *tile_range; // [n_jt][2] prev-state range (units of 4) each state tile stages
+    unsigned *stats;     // [128]     scan statistics of the last decode (torbi_hip_scan_stats)
     float *topv;       // [2][n_jt][B][6] partial top lists (values), ping-pong by timestep parity
     int32_t *topi;     // [2][n_jt][B][6] their prev-states
     size_t top_stride; // elements per parity
@@ -449,13 +450,14 @@ inline PrunedWorkspace carve_pruned(void *base, int B, int T, int S) {
     w.top_stride = (size_t)w.plan.n_jt * B * pruned::kTop;
     const size_t topv_bytes = align_up(sizeof(float) * 2 * w.top_stride, 256);
     const size_t topi_bytes = align_up(sizeof(int32_t) * 2 * w.top_stride, 256);
-    const size_t range_bytes = align_up(sizeof(int32_t) * 2 * ((size_t)S + pruned::kMaxJT), 256);
+    const size_t range_bytes = align_up(sizeof(int32_t) * 2 * ((size_t)S + pruned::kMaxJT), 256) + 512;
     w.sorted = reinterpret_cast<float2 *>(p);
     w.tt = reinterpret_cast<float *>(p + sorted_bytes);
     w.topv = reinterpret_cast<float *>(p + sorted_bytes + tt_bytes);
     w.topi = reinterpret_cast<int32_t *>(p + sorted_bytes + tt_bytes + topv_bytes);
     w.row_range = reinterpret_cast<int32_t *>(p + sorted_bytes + tt_bytes + topv_bytes + topi_bytes);
     w.tile_range = w.row_range + 2 * (size_t)S;
+    w.stats = reinterpret_cast<unsigned *>(p + sorted_bytes + tt_bytes + topv_bytes + topi_bytes + range_bytes - 512);
     w.hist = reinterpret_cast<float *>(p + sorted_bytes + tt_bytes + topv_bytes + topi_bytes + range_bytes);
     w.top_bytes = topv_bytes + topi_bytes;
     w.bytes = sorted_bytes + tt_bytes + topv_bytes + topi_bytes + range_bytes +
@@ -618,8 +620,9 @@ hipError_t launch_dense_forward(const float *obs, const int32_t *frames, const f
 
 hipError_t launch_pruned_forward(const float *obs, const int32_t *frames, const float *trans,
                                  const float *init, const PrunedWorkspace &w, int B, int T, int S,
-                                 hipStream_t stream, int *launches, bool reuse) {
+                                 hipStream_t stream, int *launches, bool reuse, bool collect) {
     const pruned::Plan &pl = w.plan;
+    unsigned *const stats = collect ? w.stats : nullptr;
     if (!reuse) {      // per-transition preparation: sorted + arranged lists, row/tile ranges, transposed copy
         hipLaunchKernelGGL(pruned::sort_rows_kernel, dim3(S), dim3(256), sizeof(float) * 2 * (size_t)pl.NPOW, stream,
                            trans, w.sorted, w.row_range, S, pl.SpP, pl.NPOW, pl.NI * 4);
@@ -640,7 +643,7 @@ hipError_t launch_pruned_forward(const float *obs, const int32_t *frames, const 
         // partial top lists of "timestep 0": state tile 0 carries the full list, the others are empty
         const size_t m = 2 * w.top_stride;
         const int grid2 = (int)((m + 255) / 256 < 4096 ? (m + 255) / 256 : 4096);
-        hipLaunchKernelGGL(pruned::clear_top_kernel, dim3(grid2), dim3(256), 0, stream, w.topv, w.topi, m);
+        hipLaunchKernelGGL(pruned::clear_top_kernel, dim3(grid2), dim3(256), 0, stream, w.topv, w.topi, m, w.stats);
         if (S <= 512)
             hipLaunchKernelGGL(pruned::top_kernel<2>, dim3(B), dim3(64), 0, stream, w.hist, w.topv, w.topi, B, T, S);
         else if (S <= 1536)
@@ -661,12 +664,12 @@ hipError_t launch_pruned_forward(const float *obs, const int32_t *frames, const 
         if (pl.NI == pruned::kNB)
             hipLaunchKernelGGL(pruned::step_pruned_kernel<pruned::kNB>, dim3(pl.n_bt, pl.n_jt), dim3(64 * pruned::kWaves),
                                lds, stream, obs, frames, w.tt, w.sorted, w.tile_range, w.topv + in, w.topi + in,
-                               w.topv + out, w.topi + out, w.hist, B, T, S, t, pl.SpP, pl.n_bt, pl.n_jt, pl.JT);
+                               w.topv + out, w.topi + out, w.hist, stats, B, T, S, t, pl.SpP, pl.n_bt, pl.n_jt, pl.JT);
         else
             hipLaunchKernelGGL(pruned::step_pruned_kernel<pruned::kNB / 2>, dim3(pl.n_bt, pl.n_jt),
                                dim3(64 * pruned::kWaves), lds, stream, obs, frames, w.tt, w.sorted, w.tile_range,
-                               w.topv + in, w.topi + in, w.topv + out, w.topi + out, w.hist, B, T, S, t, pl.SpP,
-                               pl.n_bt, pl.n_jt, pl.JT);
+                               w.topv + in, w.topi + in, w.topv + out, w.topi + out, w.hist, stats, B, T, S, t,
+                               pl.SpP, pl.n_bt, pl.n_jt, pl.JT);
         ++n;
     }
     if (launches) *launches = n;
@@ -708,12 +711,12 @@ hipError_t launch_dense_backtrace(const float *trans, const int32_t *frames, con
 // one decode on `s`; optional events bracket the forward and backtrace phases
 hipError_t run_decode(const float *obs, const int32_t *frames, const float *trans, const float *init,
                       int32_t *out, void *workspace, int B, int T, int S, hipStream_t s,
-                      hipEvent_t *ev, int *launches, bool reuse) {
+                      hipEvent_t *ev, int *launches, bool reuse, bool collect = false) {
     hipError_t e;
     if (ev) (void)hipEventRecord(ev[0], s);
     if (use_pruned(B, S)) {
         const PrunedWorkspace w = carve_pruned(workspace, B, T, S);
-        e = launch_pruned_forward(obs, frames, trans, init, w, B, T, S, s, launches, reuse);
+        e = launch_pruned_forward(obs, frames, trans, init, w, B, T, S, s, launches, reuse, collect);
         if (ev) (void)hipEventRecord(ev[1], s);
         if (e == hipSuccess) e = launch_backtrace_on(w.hist, trans, frames, out, B, T, S, s);
     } else if (use_dense(B, S)) {
@@ -801,7 +804,7 @@ int torbi_hip_viterbi_decode_ex(const float *observation, const int32_t *batch_f
                                 const float *transition, const float *initial,
                                 int32_t *indices_out, void *workspace, size_t workspace_bytes,
                                 int B, int T, int S, int device, void *stream, unsigned flags) {
-    if (flags & ~(unsigned)TORBI_HIP_REUSE_TRANSITION) return TORBI_HIP_EINVAL;
+    if (flags & ~(unsigned)(TORBI_HIP_REUSE_TRANSITION | TORBI_HIP_COLLECT_STATS)) return TORBI_HIP_EINVAL;
     const int rc = check_args(observation, batch_frames, transition, initial, indices_out,
                               workspace, workspace_bytes, B, T, S);
     if (rc != TORBI_HIP_OK || B == 0) return rc;
@@ -809,7 +812,19 @@ int torbi_hip_viterbi_decode_ex(const float *observation, const int32_t *batch_f
     if (guard.err != hipSuccess) return (int)guard.err;
     return (int)run_decode(observation, batch_frames, transition, initial, indices_out, workspace,
                            B, T, S, static_cast<hipStream_t>(stream), nullptr, nullptr,
-                           (flags & TORBI_HIP_REUSE_TRANSITION) != 0);
+                           (flags & TORBI_HIP_REUSE_TRANSITION) != 0, (flags & TORBI_HIP_COLLECT_STATS) != 0);
+}
+
+int torbi_hip_scan_stats(const void *workspace, size_t workspace_bytes, int B, int T, int S,
+                         unsigned *stats_out, int device, void *stream) {
+    if (B < 1 || T < 1 || S < 1 || !workspace || !stats_out) return TORBI_HIP_EINVAL;
+    if (workspace_bytes < torbi_hip_workspace_bytes(B, T, S)) return TORBI_HIP_EWORKSPACE;
+    if (!use_pruned(B, S)) return TORBI_HIP_EUNSUPPORTED;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return (int)guard.err;
+    const PrunedWorkspace w = carve_pruned(const_cast<void *>(workspace), B, T, S);
+    return (int)hipMemcpyAsync(stats_out, w.stats, sizeof(unsigned) * 2 * pruned::kStatSlots, hipMemcpyDeviceToDevice,
+                               static_cast<hipStream_t>(stream));
 }
 
 int torbi_hip_viterbi_decode_uniform(const float *observation, const int32_t *batch_frames,

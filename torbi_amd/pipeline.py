@@ -78,6 +78,7 @@ class DecodePipeline:
             if tensor is indices:
                 event.synchronize()
                 break
+        viterbi.collect_measurements()
         return indices
 
     def synchronize(self) -> None:
@@ -87,3 +88,4 @@ class DecodePipeline:
         self.pending = []
         for stream in self.streams:
             stream.synchronize()
+        viterbi.collect_measurements()

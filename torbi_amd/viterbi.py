@@ -111,22 +111,44 @@ def decode(
     index = device.index if device.index is not None else torch.cuda.current_device()
     stream = torch.cuda.current_stream(device).cuda_stream
     path = _choose_path(trans, transition, B, S)
+    tuner = None
+    if path == 'pruned' and _forced_path == 'auto' and B >= 32 and _profile is None:
+        # both value-only paths are available and nothing is forced: pick by measurement (see _Tuner)
+        tuner = _tuner_for(transition, S, device)
+        path = tuner.choose()
+        begin = None
+        if not tuner.settled():
+            begin = torch.cuda.Event(enable_timing=True)
+            begin.record(torch.cuda.current_stream(device))
     lib.torbi_hip_set_forward_path(FORWARD_PATHS[path])
     args = (obs.data_ptr(), frames.data_ptr(), trans.data_ptr(), init.data_ptr(),
             indices.data_ptr(), workspace.data_ptr(), workspace.numel(), B, T, S, index,
             ctypes.c_void_p(stream))
     # what the workspace will hold after this call: the preparation of this transition for this shape/path
-    state = (B, T, S, path, transition.data_ptr(), transition._version, str(transition.device), stream)
+    # (the transition is identified by the tensor OBJECT and its version: a new tensor can reuse a freed address)
+    state = (B, T, S, path, transition._version, stream)
     known = _prepared.get(id(workspace))
     flags = 0
-    if reuse_preparation and known is not None and known[0]() is workspace and known[1] == state:
+    if (reuse_preparation and known is not None and known[0]() is workspace and known[1] == state
+            and known[2]() is transition):
         flags = 1                                  # TORBI_HIP_REUSE_TRANSITION
     if len(_prepared) > 64:
         for key in [k for k, v in _prepared.items() if v[0]() is None]:
             del _prepared[key]
-    _prepared[id(workspace)] = (weakref.ref(workspace), state)
+    _prepared[id(workspace)] = (weakref.ref(workspace), state, weakref.ref(transition))
     if _profile is None:
-        _lib.check(lib.torbi_hip_viterbi_decode_ex(*args, flags), 'torbi_hip_viterbi_decode_ex')
+        collect = tuner is not None and begin is not None and path == 'pruned' and tuner.blocks is None
+        _lib.check(lib.torbi_hip_viterbi_decode_ex(*args, flags | (2 if collect else 0)),      # COLLECT_STATS
+                   'torbi_hip_viterbi_decode_ex')
+        if tuner is not None and begin is not None:
+            stats = None
+            if collect:
+                # device -> pinned host, enqueued now and read (without any synchronising call) once `end` is done
+                stats = torch.empty((128,), dtype=torch.int32, pin_memory=True)
+                stats.copy_(scan_stats(workspace, B, T, S), non_blocking=True)
+            end = torch.cuda.Event(enable_timing=True)
+            end.record(torch.cuda.current_stream(device))
+            tuner.launched(path, begin, end, stats, B * T)
     else:
         phases = (ctypes.c_float * 4)()
         _lib.check(lib.torbi_hip_viterbi_decode_profiled(*args, phases),
@@ -136,9 +158,84 @@ def decode(
 
 
 FORWARD_PATHS = {'auto': 0, 'dense': 1, 'pruned': 2}
+
+
+class _Tuner:
+    """Per transition tensor (and state count): which value-only forward path is faster on the caller's data.
+
+    The pruned pass wins when posteriors and transitions have comparable spread (2x on the benchmark) and loses
+    up to 1.4x to the dense kernel when a handful of states dominate every posterior row or the observations
+    spread far wider than the transitions (tools/peaked_probe.py).  The first decode runs pruned and leaves its
+    scan statistics (torbi_hip_scan_stats); if fewer than `GATE` list blocks sat on the critical path the
+    matter is settled.  Otherwise one decode runs on the dense path and from then on the path with the
+    smaller GPU time per timestep (events around each decode, read without blocking once they have completed)
+    is used; every `REPROBE`-th decode tries the other one again.  All paths return identical indices."""
+    GATE = 18.0
+    REPROBE = 64
+
+    def __init__(self):
+        self.time = {'pruned': None, 'dense': None}      # ms per timestep of the latest completed decode
+        self.blocks = None                               # critical-path blocks of a pruned decode
+        self.pending = []
+        self.count = 0
+
+    def _collect(self):
+        done = [entry for entry in self.pending if entry[2].query()]
+        if self.blocks is None:
+            for entry in done:
+                if entry[3] is not None:
+                    self.blocks = critical_blocks(entry[3])
+                    break
+        if self.settled():
+            self.pending = []            # nothing else to learn; in particular no event timing queries
+            return
+        for path, begin, end, stats, steps in done:
+            self.time[path] = begin.elapsed_time(end) / steps
+        self.pending = [entry for entry in self.pending if entry not in done][-8:]
+
+    def settled(self) -> bool:
+        """Pruning clearly works on this data: nothing more to measure (no events, no statistics copies)."""
+        return self.blocks is not None and self.blocks < self.GATE
+
+    def choose(self) -> str:
+        if self.settled():
+            return 'pruned'
+        self._collect()
+        self.count += 1
+        if self.time['pruned'] is None or (self.blocks is not None and self.blocks < self.GATE):
+            return 'pruned'
+        if self.time['dense'] is None:
+            return 'pruned' if any(p[0] == 'dense' for p in self.pending) else 'dense'
+        fast, slow = ('pruned', 'dense') if self.time['pruned'] <= self.time['dense'] else ('dense', 'pruned')
+        return slow if self.count % self.REPROBE == 0 else fast
+
+    def launched(self, path, begin, end, stats, steps):
+        self.pending.append((path, begin, end, stats, steps))
+
+
+_tuners = {}                     # id(transition) -> (weakref, version, states, _Tuner)
+
+
+def collect_measurements() -> None:
+    """Fold completed decodes into the path tuners now (DecodePipeline calls this whenever it has waited for the
+    device anyway, so the bookkeeping does not land at the start of the next decode)."""
+    for known in list(_tuners.values()):
+        if not known[3].settled():
+            known[3]._collect()
+
+
+def _tuner_for(transition: torch.Tensor, states: int, device) -> _Tuner:
+    known = _tuners.get(id(transition))
+    if known is None or known[0]() is not transition or known[1:3] != (transition._version, states):
+        if len(_tuners) > 64:
+            for key in [k for k, v in _tuners.items() if v[0]() is None]:
+                del _tuners[key]
+        known = (weakref.ref(transition), transition._version, states, _Tuner())
+        _tuners[id(transition)] = known
+    return known[3]
 _forced_path = {'d': 'dense', 'p': 'pruned'}.get(os.environ.get('TORBI_HIP_FORWARD', 'a')[:1], 'auto')
 _prepared = {}                   # id(workspace) -> (weakref, state): see decode(reuse_preparation=True)
-_structure_cache = {}            # (data_ptr, version, shape, device) -> mean finite range of a row / S
+_structure_cache = {}            # id(transition) -> (weakref, (version, states), mean finite range of a row / S)
 BANDED_RANGE = 0.25              # rows reaching less than this fraction of the states: dense + -inf skipping
 
 
@@ -161,11 +258,55 @@ def set_forward_path(path: str = 'auto') -> None:
                'torbi_hip_set_forward_path')
 
 
+def scan_stats(workspace: torch.Tensor, batch: int, frames: int, states: int) -> Optional[torch.Tensor]:
+    """Enqueue a copy of the scan statistics the last pruned decode left in `workspace`
+    (include/torbi_hip.h, torbi_hip_scan_stats): a (128,) int32 device tensor, valid once the
+    current stream reaches it; None when the shape does not take the pruned path."""
+    lib = _lib.load()
+    out = torch.empty((128,), dtype=torch.int32, device=workspace.device)
+    rc = lib.torbi_hip_scan_stats(workspace.data_ptr(), workspace.numel(), batch, frames, states, out.data_ptr(),
+                                  workspace.device.index or 0,
+                                  ctypes.c_void_p(torch.cuda.current_stream(workspace.device).cuda_stream))
+    if rc == -5:
+        return None
+    _lib.check(rc, 'torbi_hip_scan_stats')
+    return out
+
+
+def critical_blocks(stats: torch.Tensor) -> float:
+    """Mean number of 16-entry list blocks on the critical path of a launch (host sync)."""
+    host = (stats if not stats.is_cuda else stats.cpu()).to(torch.int64)
+    return float(host[:64].sum()) / max(1.0, float(host[64:].sum()))
+
+
+def _estimate_scan_depth(obs: torch.Tensor, trans: torch.Tensor, init: torch.Tensor, items: int = 8,
+                         rows: int = 64, rank: int = 4) -> float:
+    """How many entries of a sorted transition row the pruned pass would examine on this data: the
+    95th percentile over a sample of (item, next-state) pairs, computed with torch ops on the exact
+    posterior after one timestep (frames 0 and 1 of the first `items` items, `rows` evenly spaced
+    next-states).  One small reduction and a host sync; used once per transition tensor version."""
+    B, T, S = obs.shape
+    items = max(1, min(items, B, (256 << 20) // (4 * S * S)))
+    p = obs[:items, 0, :] + init[None, :]
+    if T > 1:
+        p = obs[:items, 1, :] + (p[:, None, :] + trans[None, :, :]).amax(dim=-1)
+    pick = torch.linspace(0, S - 1, min(rows, S), device=trans.device).long()
+    tj = trans[pick]                                                   # (rows, S)
+    best = (p[:, None, :] + tj[None, :, :]).amax(dim=-1)               # (items, rows)
+    thr = torch.topk(p, min(rank, S), dim=-1).values[:, -1]            # (items,)
+    limit = best - thr[:, None]                                        # an entry t is examined while t > limit
+    depth = (tj[None, :, :] > limit[:, :, None]).sum(dim=-1).float()   # (items, rows)
+    depth = torch.nan_to_num(depth, nan=float(S))
+    return float(torch.quantile(depth.flatten(), 0.95).item())
+
+
 def _choose_path(trans: torch.Tensor, original: torch.Tensor, batch: int, states: int) -> str:
     if _forced_path != 'auto' or batch < 32 or states < 64 or states > 4096:   # dense needs B >= 32
         return _forced_path
-    key = (original.data_ptr(), original._version, states, str(original.device))
-    reach = _structure_cache.get(key)
+    known = _structure_cache.get(id(original))
+    reach = None
+    if known is not None and known[0]() is original and known[1] == (original._version, states):
+        reach = known[2]
     if reach is None:
         finite = trans != float('-inf')
         index = torch.arange(states, device=trans.device)
@@ -174,7 +315,7 @@ def _choose_path(trans: torch.Tensor, original: torch.Tensor, batch: int, states
         reach = float((hi - lo + 1).clamp(min=0).float().mean().item()) / states
         if len(_structure_cache) >= 64:
             _structure_cache.clear()
-        _structure_cache[key] = reach
+        _structure_cache[id(original)] = (weakref.ref(original), (original._version, states), reach)
     return 'dense' if 0.0 < reach < BANDED_RANGE else 'pruned'
 
 
