@@ -351,7 +351,7 @@ __device__ __forceinline__ float group_bcast(float x) {
 // loads and first list block (their latency hides behind the tile staging) -> stage the posterior
 // tile -> barrier -> scan -> outputs -> barrier -> this tile's partial top lists.
 // ---------------------------------------------------------------------------------------
-template <int NI>
+template <int NI, bool STATS>
 __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     const float *__restrict__ obs, const int32_t *__restrict__ frames, const float *__restrict__ tt,
     const float2 *__restrict__ sorted, const int32_t *__restrict__ tile_range, const float *__restrict__ ptopv_in,
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     PSTAMP(1);
     if (tid < NI) sframes[tid] = fr;
     if (tid < NI * kTop) ttop[tid] = 0ull;                // 0 = empty (every real key is > 0)
-    if (tid == 0) *sdeep = 0;
+    if (STATS && tid == 0) *sdeep = 0;
     if (wave < NI / 4) {
         // every 16-lane row merges the partial top lists of one item (candidates fetched at kernel entry)
         auto emit = [&](int r, float m, int k) {
@@ -555,11 +555,11 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     // Block 0 is done; `nxt` holds block 1, `cur` is being refilled with block 2.
     for (int k = kBlk; k < Sp; k += 2 * kBlk) {
         if (!more(nxt)) break;
-        ++nblk;
+        if (STATS) ++nblk;
         consume(nxt);
         load_list_block(nxt, row, k + 2 * kBlk);
         if (!more(cur)) break;
-        ++nblk;
+        if (STATS) ++nblk;
         consume(cur);
         load_list_block(cur, row, k + 3 * kBlk);
     }
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
             }
         }
     }
-    const bool sampled = stats != nullptr && (t & 7) == 1;       // on request, from every 8th timestep
+    const bool sampled = STATS && (t & 7) == 1;       // the STATS instance only, from every 8th timestep
     if (sampled && lane == 0) atomicMax(sdeep, nblk);
     __syncthreads();
     PSTAMP(8);

@@ -654,22 +654,25 @@ hipError_t launch_pruned_forward(const float *obs, const int32_t *frames, const 
             hipLaunchKernelGGL(pruned::top_kernel<16>, dim3(B), dim3(64), 0, stream, w.hist, w.topv, w.topi, B, T, S);
     }
     const size_t lds = pruned::lds_bytes(S, pl.NI);
-    const void *fn = pl.NI == pruned::kNB ? reinterpret_cast<const void *>(&pruned::step_pruned_kernel<pruned::kNB>)
-                                          : reinterpret_cast<const void *>(&pruned::step_pruned_kernel<pruned::kNB / 2>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // four instances: items per tile x with/without the scan statistics (the statistics cost 1.6 % even when they
+    // are only compiled in, so the plain instance has none)
+    using StepFn = void (*)(const float *, const int32_t *, const float *, const float2 *, const int32_t *, const float *,
+                            const int32_t *, float *, int32_t *, float *, unsigned *, int, int, int, int, int, int, int, int);
+    StepFn fn;
+    if (pl.NI == pruned::kNB)
+        fn = collect ? &pruned::step_pruned_kernel<pruned::kNB, true> : &pruned::step_pruned_kernel<pruned::kNB, false>;
+    else
+        fn = collect ? &pruned::step_pruned_kernel<pruned::kNB / 2, true>
+                     : &pruned::step_pruned_kernel<pruned::kNB / 2, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
     if (e != hipSuccess) return e;
     int n = 0;
     for (int t = 1; t < T; ++t) {
         const size_t in = ((t - 1) & 1) * w.top_stride, out = (t & 1) * w.top_stride;
-        if (pl.NI == pruned::kNB)
-            hipLaunchKernelGGL(pruned::step_pruned_kernel<pruned::kNB>, dim3(pl.n_bt, pl.n_jt), dim3(64 * pruned::kWaves),
-                               lds, stream, obs, frames, w.tt, w.sorted, w.tile_range, w.topv + in, w.topi + in,
-                               w.topv + out, w.topi + out, w.hist, stats, B, T, S, t, pl.SpP, pl.n_bt, pl.n_jt, pl.JT);
-        else
-            hipLaunchKernelGGL(pruned::step_pruned_kernel<pruned::kNB / 2>, dim3(pl.n_bt, pl.n_jt),
-                               dim3(64 * pruned::kWaves), lds, stream, obs, frames, w.tt, w.sorted, w.tile_range,
-                               w.topv + in, w.topi + in, w.topv + out, w.topi + out, w.hist, stats, B, T, S, t,
-                               pl.SpP, pl.n_bt, pl.n_jt, pl.JT);
+        hipLaunchKernelGGL(fn, dim3(pl.n_bt, pl.n_jt), dim3(64 * pruned::kWaves), lds, stream, obs, frames, w.tt,
+                           w.sorted, w.tile_range, w.topv + in, w.topi + in, w.topv + out, w.topi + out, w.hist, stats,
+                           B, T, S, t, pl.SpP, pl.n_bt, pl.n_jt, pl.JT);
         ++n;
     }
     if (launches) *launches = n;
