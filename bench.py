@@ -218,7 +218,7 @@ def main():
         bt_ms += prof[1] / 3
         launches = max(int(prof[2]), 1)
     path = {2: 'pruned', 1: 'dense', 0: 'generic'}[int(prof[3])]
-    step_kernel = {'pruned': 'pruned::step_pruned_kernel', 'dense': 'step_dense_kernel<8, 6, 8, 12>',
+    step_kernel = {'pruned': 'pruned::step_pruned_kernel<16, false>', 'dense': 'step_dense_kernel<8, 6, 8, 12>',
                    'generic': 'step_rows_kernel'}[path]
     per_launch_s = fwd_ms * 1e-3 / launches
     bytes_per_launch = B * algorithmic_bytes_per_timestep(S)

@@ -166,14 +166,15 @@ class _Tuner:
     The pruned pass wins when posteriors and transitions have comparable spread (2x on the benchmark) and loses
     up to 1.4x to the dense kernel when a handful of states dominate every posterior row or the observations
     spread far wider than the transitions (tools/peaked_probe.py).  The first decode runs pruned and leaves its
-    scan statistics (torbi_hip_scan_stats); if fewer than `GATE` list blocks sat on the critical path the
-    matter is settled.  Otherwise one decode runs on the dense path and from then on the path with the
+    scan statistics (torbi_hip_scan_stats); if less than `GATE` of a row's list blocks sat on the critical path
+    the matter is settled.  Otherwise one decode runs on the dense path and from then on the path with the
     smaller GPU time per timestep (events around each decode, read without blocking once they have completed)
     is used; every `REPROBE`-th decode tries the other one again.  All paths return identical indices."""
-    GATE = 18.0
+    GATE = 0.2          # fraction of a row's S/16 list blocks on the critical path below which pruned is kept
     REPROBE = 64
 
-    def __init__(self):
+    def __init__(self, states: int = 1440):
+        self.gate = self.GATE * states / 16.0
         self.time = {'pruned': None, 'dense': None}      # ms per timestep of the latest completed decode
         self.blocks = None                               # critical-path blocks of a pruned decode
         self.pending = []
@@ -195,14 +196,14 @@ class _Tuner:
 
     def settled(self) -> bool:
         """Pruning clearly works on this data: nothing more to measure (no events, no statistics copies)."""
-        return self.blocks is not None and self.blocks < self.GATE
+        return self.blocks is not None and self.blocks < self.gate
 
     def choose(self) -> str:
         if self.settled():
             return 'pruned'
         self._collect()
         self.count += 1
-        if self.time['pruned'] is None or (self.blocks is not None and self.blocks < self.GATE):
+        if self.time['pruned'] is None or (self.blocks is not None and self.blocks < self.gate):
             return 'pruned'
         if self.time['dense'] is None:
             return 'pruned' if any(p[0] == 'dense' for p in self.pending) else 'dense'
@@ -230,7 +231,7 @@ def _tuner_for(transition: torch.Tensor, states: int, device) -> _Tuner:
         if len(_tuners) > 64:
             for key in [k for k, v in _tuners.items() if v[0]() is None]:
                 del _tuners[key]
-        known = (weakref.ref(transition), transition._version, states, _Tuner())
+        known = (weakref.ref(transition), transition._version, states, _Tuner(states))
         _tuners[id(transition)] = known
     return known[3]
 _forced_path = {'d': 'dense', 'p': 'pruned'}.get(os.environ.get('TORBI_HIP_FORWARD', 'a')[:1], 'auto')
