@@ -6,6 +6,7 @@ Differences that follow from "GPU only" are stated in each docstring and in INTE
 """
 import math
 import os
+import weakref
 from typing import Dict, List, Optional, Union
 
 import torch
@@ -30,6 +31,24 @@ def _compute_device(gpu, observation):
     if gpu == 'mps':
         raise RuntimeError('the MPS backend of the reference is out of scope on MI355X')
     return torch.device(f'cuda:{gpu}')
+
+
+_transition_cache = {}        # id(caller's tensor) -> (weakref, version, log_probs, device, prepared tensor)
+
+
+def _prepared_transition(transition: torch.Tensor, log_probs: bool, device) -> torch.Tensor:
+    """log() (unless `log_probs`) and device move of the transition matrix (core.py:181-187), remembered per
+    caller tensor and version: repeated calls with one matrix then hand torbi_amd.decode the SAME device
+    tensor, which is what its per-tensor structure look and path measurements are keyed on."""
+    known = _transition_cache.get(id(transition))
+    state = (transition._version, bool(log_probs), str(device))
+    if known is not None and known[0]() is transition and known[1] == state:
+        return known[2]
+    prepared = (transition if log_probs else torch.log(transition)).to(device)
+    if len(_transition_cache) >= 16:
+        _transition_cache.clear()
+    _transition_cache[id(transition)] = (weakref.ref(transition), state, prepared)
+    return prepared
 
 
 def from_probabilities(
@@ -108,9 +127,7 @@ def from_probabilities(
         if transition is None:
             uniform = float(torch.tensor(math.log(1. / states), dtype=torch.float32))
         else:
-            if not log_probs:
-                transition = torch.log(transition)
-            transition = transition.to(device)
+            transition = _prepared_transition(transition, log_probs, device)
         if _model is not None:
             _model.update(initial=initial, transition=transition, uniform=uniform)
 
