@@ -76,7 +76,8 @@ inline Plan make_plan(int B, int S, int num_cus) {
     if (n_jt < min_jt) n_jt = min_jt;
     if (n_jt > kMaxJT) n_jt = kMaxJT;     // the per-item top lists of all state tiles are merged by one 16-lane row
     int JT = (S + n_jt - 1) / n_jt;
-    JT = (JT + 3) / 4 * 4;                // stays <= tile_states whenever n_jt >= min_jt (<= 11)
+    const int align = p.NI == kNB ? 4 : 8;        // row groups of the arrangement pass start at tile boundaries
+    JT = (JT + align - 1) / align * align;        // stays <= tile_states whenever n_jt >= min_jt (<= 11)
     p.JT = JT;
     p.n_jt = (S + JT - 1) / JT;
     p.Sp = (S + 15) / 16 * 16;
@@ -142,48 +143,52 @@ __global__ __launch_bounds__(256) void sort_rows_kernel(const float *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------
-// once per decode, after the sort: reorder the entries INSIDE every 16-entry block so that the four rows of an
-// aligned row quad (4q .. 4q+3) name prev-states of different residue mod 4 at the same block position wherever
-// possible.  The step kernel puts a row quad on one ds_read_b128 lane group, all four rows read the same
-// position at the same time, and a posterior row [prev-state][16 items] is 64 B = a quarter of the 256-byte
-// bank row: equal residues are a bank conflict (2.1 LDS cycles per read for random lists, ~1.4 after this
-// pass).  The maximum is order independent and position 0 (the block's largest t, used by the termination
-// test) stays put, so results do not change.  One thread per (row quad, block); grid covers S/4 * SpP/16 threads.
+// once per decode, after the sort: reorder the entries INSIDE every 16-entry block so that the RG rows of an
+// aligned row group name prev-states of different residue mod RG at the same block position wherever possible.
+// The step kernel puts a row group on one ds_read_b128 lane group, all its rows read the same position at the
+// same time, and a posterior row [prev-state][NI items] is 256/RG bytes of the 256-byte bank row (RG = 4 for
+// 16-item tiles, 8 for 8-item tiles): equal residues are a bank conflict (2.1 LDS cycles per read for random
+// lists with RG = 4, ~1.4 after this pass).  The maximum is order independent and position 0 (the block's
+// largest t, used by the termination test) stays put, so results do not change.  One thread per (row group,
+// block); grid covers S/RG * SpP/16 threads.
 // ---------------------------------------------------------------------------------------
+template <int RG>
 __global__ __launch_bounds__(64) void arrange_blocks_kernel(float2 *__restrict__ sorted, int S, int SpP) {
+    constexpr int SHIFT = RG == 4 ? 6 : 5;     // log2(bytes of a posterior row)
+    typedef unsigned long long u64;            // RG x 8-bit counters
     const int nblk = SpP / kBlk;
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= (S / 4) * nblk) return;
+    if (id >= (S / RG) * nblk) return;
     const int q = id / nblk, kb = id % nblk;
-    unsigned present[kBlk];                 // per position: 4 x 8-bit counts of the residues placed so far
+    u64 present[kBlk];                      // per position: counts of the residues placed so far
     {
-        const float2 *r0 = sorted + (size_t)(4 * q) * SpP + kb * kBlk;
-        for (int p = 0; p < kBlk; ++p) present[p] = 1u << (8 * ((__float_as_int(r0[p].y) >> 6) & 3));
+        const float2 *r0 = sorted + (size_t)(RG * q) * SpP + kb * kBlk;
+        for (int p = 0; p < kBlk; ++p) present[p] = (u64)1 << (8 * ((__float_as_int(r0[p].y) >> SHIFT) & (RG - 1)));
     }
-    for (int r = 1; r < 4; ++r) {
-        float2 *row = sorted + (size_t)(4 * q + r) * SpP + kb * kBlk;
+    for (int r = 1; r < RG; ++r) {
+        float2 *row = sorted + (size_t)(RG * q + r) * SpP + kb * kBlk;
         float2 ent[kBlk], out[kBlk];
-        unsigned remaining = 0;             // 4 x 8-bit counts of the residues still to place
+        u64 remaining = 0;                  // counts of the residues still to place
         for (int e = 0; e < kBlk; ++e) {
             ent[e] = row[e];
-            if (e) remaining += 1u << (8 * ((__float_as_int(ent[e].y) >> 6) & 3));
+            if (e) remaining += (u64)1 << (8 * ((__float_as_int(ent[e].y) >> SHIFT) & (RG - 1)));
         }
         out[0] = ent[0];
-        present[0] += 1u << (8 * ((__float_as_int(ent[0].y) >> 6) & 3));
+        present[0] += (u64)1 << (8 * ((__float_as_int(ent[0].y) >> SHIFT) & (RG - 1)));
         unsigned used = 1u;
         for (int p = 1; p < kBlk; ++p) {
             int pick = -1, key = 1 << 30;
             for (int e = 1; e < kBlk; ++e) {
                 if ((used >> e) & 1u) continue;
-                const int res = (__float_as_int(ent[e].y) >> 6) & 3;
+                const int res = (__float_as_int(ent[e].y) >> SHIFT) & (RG - 1);
                 // fewest equal residues already at this position; then the residue with most entries left
                 const int k = (int)((present[p] >> (8 * res)) & 0xffu) * 64 - (int)((remaining >> (8 * res)) & 0xffu);
                 if (k < key) { key = k; pick = e; }
             }
-            const int res = (__float_as_int(ent[pick].y) >> 6) & 3;
+            const int res = (__float_as_int(ent[pick].y) >> SHIFT) & (RG - 1);
             used |= 1u << pick;
-            remaining -= 1u << (8 * res);
-            present[p] += 1u << (8 * res);
+            remaining -= (u64)1 << (8 * res);
+            present[p] += (u64)1 << (8 * res);
             out[p] = ent[pick];
         }
         for (int p = 1; p < kBlk; ++p) row[p] = out[p];
@@ -409,9 +414,10 @@ __global__ __launch_bounds__(64 * kWaves) void step_pruned_kernel(
     // blocks and the observations do not depend on anything staged below: issue them first
     // quads of lanes -> next-states so that every ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31},
     // +32) holds an aligned row quad (arrange_blocks_kernel keeps those conflict-poor)
-    // (8-item tiles: plain order, no arrangement pass)
+    // (8-item tiles: lane pairs -> next-states, aligned groups of eight rows per lane group)
     const int g = lane & (G - 1);
-    const int jl = G == 4 ? (int)((0xFBAE9DC873261540ull >> (4 * (lane >> 2))) & 15) : lane >> 1;
+    const int jl = G == 4 ? (int)((0xFBAE9DC873261540ull >> (4 * (lane >> 2))) & 15)
+                          : (int)((0xFE7654DC32BA9810ull >> (4 * ((lane >> 1) & 15))) & 15) + (lane & 32) / 2;
     const int jj = RW * wave + jl;
     const bool jv = jj < JTv;
     const int jr = jv ? j0 + jj : j0;

@@ -628,9 +628,13 @@ hipError_t launch_pruned_forward(const float *obs, const int32_t *frames, const 
                            trans, w.sorted, w.row_range, S, pl.SpP, pl.NPOW, pl.NI * 4);
         hipLaunchKernelGGL(pruned::tile_range_kernel, dim3(pl.n_jt), dim3(64), 0, stream, w.row_range, w.tile_range, S,
                            pl.JT);
-        if (pl.NI == pruned::kNB) {      // the bank-quarter arrangement is specific to 64-byte posterior rows
+        if (pl.NI == pruned::kNB) {
             const int n = (S / 4) * (pl.SpP / pruned::kBlk);
-            hipLaunchKernelGGL(pruned::arrange_blocks_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, w.sorted, S,
+            hipLaunchKernelGGL(pruned::arrange_blocks_kernel<4>, dim3((n + 63) / 64), dim3(64), 0, stream, w.sorted, S,
+                               pl.SpP);
+        } else {
+            const int n = (S / 8) * (pl.SpP / pruned::kBlk);
+            hipLaunchKernelGGL(pruned::arrange_blocks_kernel<8>, dim3((n + 63) / 64), dim3(64), 0, stream, w.sorted, S,
                                pl.SpP);
         }
         hipLaunchKernelGGL(pruned::transpose_kernel, dim3((S + 31) / 32, (S + 31) / 32), dim3(256), 0, stream, trans,
