@@ -280,27 +280,6 @@ def critical_blocks(stats: torch.Tensor) -> float:
     return float(host[:64].sum()) / max(1.0, float(host[64:].sum()))
 
 
-def _estimate_scan_depth(obs: torch.Tensor, trans: torch.Tensor, init: torch.Tensor, items: int = 8,
-                         rows: int = 64, rank: int = 4) -> float:
-    """How many entries of a sorted transition row the pruned pass would examine on this data: the
-    95th percentile over a sample of (item, next-state) pairs, computed with torch ops on the exact
-    posterior after one timestep (frames 0 and 1 of the first `items` items, `rows` evenly spaced
-    next-states).  One small reduction and a host sync; used once per transition tensor version."""
-    B, T, S = obs.shape
-    items = max(1, min(items, B, (256 << 20) // (4 * S * S)))
-    p = obs[:items, 0, :] + init[None, :]
-    if T > 1:
-        p = obs[:items, 1, :] + (p[:, None, :] + trans[None, :, :]).amax(dim=-1)
-    pick = torch.linspace(0, S - 1, min(rows, S), device=trans.device).long()
-    tj = trans[pick]                                                   # (rows, S)
-    best = (p[:, None, :] + tj[None, :, :]).amax(dim=-1)               # (items, rows)
-    thr = torch.topk(p, min(rank, S), dim=-1).values[:, -1]            # (items,)
-    limit = best - thr[:, None]                                        # an entry t is examined while t > limit
-    depth = (tj[None, :, :] > limit[:, :, None]).sum(dim=-1).float()   # (items, rows)
-    depth = torch.nan_to_num(depth, nan=float(S))
-    return float(torch.quantile(depth.flatten(), 0.95).item())
-
-
 def _choose_path(trans: torch.Tensor, original: torch.Tensor, batch: int, states: int) -> str:
     if _forced_path != 'auto' or batch < 32 or states < 64 or states > 4096:   # dense needs B >= 32
         return _forced_path
