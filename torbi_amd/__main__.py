@@ -1,28 +1,39 @@
-"""Command line: same flags as reference torbi/__main__.py:12-53."""
+"""`python -m torbi_amd`: decode observation files to index files on an MI355X.
+
+Flag names and meanings are those of the reference CLI (torbi/__main__.py:16-49) so scripts written
+for it keep working; the decode itself is torbi_amd.from_files_to_files.
+"""
 import argparse
-from pathlib import Path
+import pathlib
+import sys
 
 import torbi_amd
 
+# flag -> argparse keywords.  Paths are pathlib.Path like upstream; unknown flags are ignored like upstream.
+FLAGS = {
+    'input_files': dict(type=pathlib.Path, nargs='+', required=True,
+                        help='torch.save()d (frames, states) observation tensors, one per sequence'),
+    'output_files': dict(type=pathlib.Path, nargs='+', required=True,
+                         help='where the int32 (frames,) index tensors go, same order as --input_files'),
+    'transition_file': dict(type=pathlib.Path, default=None,
+                            help='(states, states) transition matrix indexed [next, prev]; uniform when omitted '
+                                 '(decoded by the O(states)-per-frame kernel)'),
+    'initial_file': dict(type=pathlib.Path, default=None,
+                         help='(states,) initial distribution; uniform when omitted'),
+    'log_probs': dict(action='store_true', help='the files already hold natural-log probabilities'),
+    'gpu': dict(type=int, default=None, help='HIP device index (default: the current device; there is no CPU decoder)'),
+    'num_threads': dict(type=int, default=1, help='accepted for compatibility with the reference CLI; unused'),
+}
 
-def parse_args():
-    parser = argparse.ArgumentParser(
-        description='Viterbi-decode categorical distribution files on an MI355X')
-    parser.add_argument('--input_files', type=Path, nargs='+', required=True,
-                        help='Time-varying categorical distribution files')
-    parser.add_argument('--output_files', type=Path, nargs='+', required=True,
-                        help='Files to save decoded indices')
-    parser.add_argument('--transition_file', type=Path,
-                        help='Categorical transition matrix file; defaults to uniform')
-    parser.add_argument('--initial_file', type=Path,
-                        help='Categorical initial distribution file; defaults to uniform')
-    parser.add_argument('--log_probs', action='store_true',
-                        help='Whether inputs are in (natural) log space')
-    parser.add_argument('--gpu', type=int, help='GPU index to use for decoding')
-    parser.add_argument('--num_threads', type=int, default=1,
-                        help='Ignored (CPU thread count in the reference)')
-    return parser.parse_known_args()[0]
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(prog='python -m torbi_amd', description=__doc__.splitlines()[0])
+    for name, keywords in FLAGS.items():
+        parser.add_argument(f'--{name}', **keywords)
+    options, _ = parser.parse_known_args(argv)
+    torbi_amd.from_files_to_files(**vars(options))
+    return 0
 
 
 if __name__ == '__main__':
-    torbi_amd.from_files_to_files(**vars(parse_args()))
+    sys.exit(main())

@@ -62,40 +62,27 @@ def from_probabilities(
     _pipeline=None,
     _model: Optional[dict] = None
 ) -> torch.Tensor:
-    """Decode a time-varying categorical distribution
+    """Viterbi-decode a batch of per-frame state distributions on the HIP device.
 
-    Mirrors reference torbi/core.py:110-208 step for step: default `batch_frames` (all
-    frames, int32), default uniform `initial` = log(1/S + tiny) and `transition` = log(1/S),
-    `log()` of the inputs unless `log_probs`, fp32 cast + device move, the in-place epsilon
-    round trip `log(exp(x) + tiny)`, then `decode`.
+    Same steps, in the same order, as reference torbi/core.py:110-208: `batch_frames` defaults to
+    every frame (int32); a missing `initial` becomes log(1/S + tiny) and a missing `transition`
+    log(1/S); inputs are taken through `log()` unless `log_probs`; the observation is cast to
+    fp32 on the compute device and goes through the in-place round trip `log(exp(x) + tiny)`;
+    then `decode`.
 
-    Arguments
-        observation
-            Time-varying categorical distribution
-            shape=(batch, frames, states)
-        batch_frames
-            Number of frames in each batch item; defaults to all
-            shape=(batch,)
-        transition
-            Categorical transition matrix; defaults to uniform
-            shape=(states, states)
-        initial
-            Categorical initial distribution; defaults to uniform
-            shape=(states,)
-        log_probs
-            Whether inputs are in (natural) log space
-        gpu
-            GPU index to use for decoding. The reference decodes on the CPU when this is
-            None; here None means "the HIP device the observation lives on, else the
-            current one", and the result is returned on the CPU in that case, as the
-            reference does.
-        num_threads
-            Ignored (CPU thread count in the reference)
+    Args:
+        observation: (batch, frames, states) scores of every state at every frame
+        batch_frames: (batch,) valid frames per item; None = all of them
+        transition: (states, states) matrix indexed [next, prev]; None = uniform (decoded by the
+            O(states)-per-frame kernel, same indices)
+        initial: (states,) distribution over the first frame's states; None = uniform
+        log_probs: the tensors are already natural-log probabilities
+        gpu: HIP device index.  None (CPU decoding upstream) means the device the observation is
+            on, else the current one, and the indices come back on the host as upstream's do
+        num_threads: upstream's CPU thread count; has no meaning here
 
-    Returns
-        indices
-            The decoded bin indices
-            shape=(batch, frames)
+    Returns:
+        (batch, frames) int32 indices of the most likely state sequence of every item
     """
     batch, frames, states = observation.shape
     device = _compute_device(gpu, observation)
@@ -160,48 +147,25 @@ def from_file(
     gpu: Optional[int] = None,
     num_threads: Optional[int] = 1
 ) -> torch.Tensor:
-    """Decode a time-varying categorical distribution file (reference core.py:211-267)
+    """`from_probabilities` for one `torch.save`d (frames, states) observation; returns
+    (1, frames) indices (reference core.py:211-267).  `transition_file` / `initial_file` hold a
+    (states, states) / (states,) tensor and default to uniform."""
+    transition, initial = _load_model(transition_file, initial_file, log_probs, clamp=False)
+    return from_probabilities(torch.load(input_file)[None], None, transition, initial, log_probs, gpu,
+                              num_threads)
 
-    Arguments
-        input_file
-            Time-varying categorical distribution file
-            shape=(frames, states)
-        transition_file
-            Categorical transition matrix file; defaults to uniform
-            shape=(states, states)
-        initial_file
-            Categorical initial distribution file; defaults to uniform
-            shape=(states,)
-        log_probs
-            Whether inputs are in (natural) log space
-        gpu
-            GPU index to use for decoding (None = current HIP device, result on CPU)
-        num_threads
-            Ignored
 
-    Returns
-        indices
-            The decoded bin indices
-            shape=(1, frames)
-    """
-    observation = torch.load(input_file).unsqueeze(dim=0)
-
+def _load_model(transition_file, initial_file, log_probs, clamp):
+    """The optional model files of the file entry points.  Upstream takes log() of a loaded
+    transition exactly when `log_probs` is set, because from_probabilities will not (the files
+    hold probabilities): plainly in from_file (core.py:246-247), with `+ tiny` in
+    from_files_to_files (core.py:341-347).  Kept as is."""
+    transition = None
     if transition_file:
         transition = torch.load(transition_file)
         if log_probs:
-            transition = torch.log(transition)   # core.py:246-247: files hold probabilities
-    else:
-        transition = None
-
-    initial = torch.load(initial_file) if initial_file else None
-
-    return from_probabilities(
-        observation=observation,
-        transition=transition,
-        initial=initial,
-        log_probs=log_probs,
-        gpu=gpu,
-        num_threads=num_threads)
+            transition = torch.log(transition + torch.finfo(transition.dtype).tiny if clamp else transition)
+    return transition, (torch.load(initial_file) if initial_file else None)
 
 
 def from_file_to_file(
@@ -213,10 +177,8 @@ def from_file_to_file(
     gpu: Optional[int] = None,
     num_threads: Optional[int] = None
 ) -> None:
-    """Decode a time-varying categorical distribution file and save (core.py:270-307)"""
-    indices = from_file(
-        input_file, transition_file, initial_file, log_probs, gpu=gpu, num_threads=num_threads)
-    torch.save(indices, output_file)
+    """`from_file`, with the (1, frames) indices written to `output_file` (core.py:270-307)."""
+    torch.save(from_file(input_file, transition_file, initial_file, log_probs, gpu, num_threads), output_file)
 
 
 def from_files_to_files(
@@ -230,7 +192,7 @@ def from_files_to_files(
     lengths: Optional[List[int]] = None,
     num_workers: Optional[int] = None
 ) -> None:
-    """Decode time-varying categorical distribution files and save (core.py:310-368)
+    """Decode many observation files, one index file each (core.py:310-368).
 
     Files are batched `BATCH_SIZE` (512) at a time in the given order, zero-padded to the
     longest item of the batch (reference torbi/data/collate.py:24-33) and each output holds
@@ -243,17 +205,8 @@ def from_files_to_files(
                      ragged collection costs (every padded frame is a full recurrence step)
         num_workers  DataLoader workers for torch.load (reference default 0, loader.py:19-25)
     """
-    if transition_file:
-        transition = torch.load(transition_file)
-        if log_probs:
-            transition = torch.log(transition + torch.finfo(transition.dtype).tiny)  # :341-347
-    else:
-        transition = None
-
-    initial = torch.load(initial_file) if initial_file else None
-
-    mapping = {
-        input_file: output_file for input_file, output_file in zip(input_files, output_files)}
+    transition, initial = _load_model(transition_file, initial_file, log_probs, clamp=True)
+    mapping = dict(zip(input_files, output_files))
 
     if lengths is not None:
         if len(lengths) != len(input_files):
@@ -282,7 +235,8 @@ def from_dataloader(
     gpu: Optional[int] = None,
     num_threads: Optional[int] = 1
 ) -> None:
-    """Decode time-varying categorical distributions from dataloader (core.py:376-463)
+    """Decode every batch a `data.loader` yields and save each item under `output_files[input]`
+    (core.py:376-463).
 
     The reference loop is serial (decode, copy back, save, next batch).  Here batch k+1 is
     enqueued (torbi_amd.DecodePipeline: alternating HIP streams) before batch k's indices are

@@ -25,42 +25,37 @@ class Dataset(torch.utils.data.Dataset):
 
 
 def collate(batch):
-    """Zero-pad to the longest item; returns (observation, batch_frames, batch_chunks,
-    input_files) exactly as collate.py:9-33 (batch_frames is int64 there too)."""
-    observations, input_files = zip(*batch)
+    """(observation, batch_frames, batch_chunks, input_files) for a list of dataset items, with the
+    observation zero-padded to the longest sequence -- the tuple of reference collate.py:9-33
+    (`batch_frames` is int64 there too; `from_probabilities` casts it).
 
-    if isinstance(observations[0], list):
-        batch_chunks = [len(obs) for obs in observations]
-        observations = sum(observations, [])
-    else:
-        batch_chunks = [1] * len(observations)
-    batch_frames = torch.tensor([obs.shape[0] for obs in observations])
-
-    batch = len(observations)
-    if batch == 0:
+    An item whose observation is a list of tensors stands for one file cut into chunks
+    (reference chunk.py, not produced by this package): its pieces become consecutive batch rows
+    and `batch_chunks` remembers how many belong together."""
+    if len(batch) == 0:
         raise ValueError('batch must contain at least 1 item')
-
-    max_frames = max(observation.shape[0] for observation in observations)
-
-    observation = torch.zeros(
-        (batch, max_frames, observations[0].shape[-1]), dtype=observations[0].dtype)
-
-    for i, obs in enumerate(observations):
-        observation[i, :obs.shape[0]] = obs
-
+    input_files = tuple(item[1] for item in batch)
+    pieces, batch_chunks = [], []
+    for observation, _ in batch:
+        group = observation if isinstance(observation, list) else [observation]
+        batch_chunks.append(len(group))
+        pieces.extend(group)
+    batch_frames = torch.tensor([piece.shape[0] for piece in pieces])
+    # pad_sequence zero-fills past each sequence's end, batch-major: (rows, longest, states)
+    observation = torch.nn.utils.rnn.pad_sequence(pieces, batch_first=True, padding_value=0.0)
     return observation, batch_frames, batch_chunks, input_files
 
 
 def separate(indices, batch_chunks, batch_frames):
-    """Re-join chunked items (collate.py:36-45)."""
-    start = 0
-    separated = []
-    for chunks in batch_chunks:
-        frames = batch_frames[start:start + chunks]
-        separated.append(
-            torch.cat([indices[start + i, :frames[i]] for i in range(0, chunks)]))
-        start += chunks
-    return separated
+    """Undo `collate`'s chunk flattening on decoded indices: one 1-D tensor per file, the valid
+    frames of its rows concatenated in order (reference collate.py:36-45)."""
+    lengths = [int(n) for n in batch_frames]
+    rows = [indices[row, :lengths[row]] for row in range(len(lengths))]
+    joined, first = [], 0
+    for count in batch_chunks:
+        joined.append(torch.cat(rows[first:first + count]))
+        first += count
+    return joined
 
 
 def loader(input_files, num_workers=None, collate_fn=collate, batch_size=None, pin_memory=None):
