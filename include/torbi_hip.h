@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TORBI_HIP_ABI_VERSION 4
+#define TORBI_HIP_ABI_VERSION 5
 
 #define TORBI_HIP_OK 0
 #define TORBI_HIP_EINVAL (-1)      /* null pointer / non-positive dimension            */
@@ -61,6 +61,10 @@ const char *torbi_hip_error_string(int code);
 /* Number of visible HIP devices (0 if none or the runtime failed to initialise). */
 int torbi_hip_device_count(void);
 
+/* Compute units of `device` as the tiling plans see them (256 on a whole MI355X, fewer on a
+ * partitioned one); TORBI_HIP_ENODEVICE for an index that does not exist.  Queried once per device. */
+int torbi_hip_compute_units(int device);
+
 /*
  * Bytes of device scratch `torbi_hip_viterbi_decode` needs for a (B,T,S) problem.
  * Replaces the reference's internal at::zeros trellis (B,T,S) int32 + posterior (B,S)
@@ -70,22 +74,35 @@ int torbi_hip_device_count(void);
 size_t torbi_hip_workspace_bytes(int B, int T, int S);
 
 /*
- * Forward-recurrence path used by torbi_hip_viterbi_decode (all paths give identical indices):
- *   GENERIC  B <= 16 or S < 64 (and 17 <= B < 32 with shapes PRUNED does not take): trellis kernels
- *            shaped like the reference's
- *   DENSE    value-only (max,+) GEMM, every (prev, next) cell evaluated
- *   PRUNED   value-only, exact: sorted transition rows + per-item top posteriors bound the cells
- *            that can still win, the rest are never touched (B >= 17, 64 <= S <= 4096)
- * AUTO (the default; also the environment variable TORBI_HIP_FORWARD=dense|pruned read once) takes
- * PRUNED where supported, else DENSE, else GENERIC.  The setting is process-wide; a workspace of
- * torbi_hip_workspace_bytes() fits every path.  torbi_hip_forward_path reports what a (B, S)
- * problem would run: TORBI_HIP_FORWARD_PRUNED, _DENSE, or 0 for the generic kernels.
+ * Forward-recurrence paths (all give identical indices):
+ *   GENERIC   B <= 16 or S < 64 (and 17 <= B < 32 with shapes PRUNED does not take): trellis kernels
+ *             shaped like the reference's
+ *   DENSE     value-only (max,+) GEMM, every (prev, next) cell evaluated, one launch per timestep
+ *   PRUNED    value-only, exact: sorted transition rows + per-item top posteriors bound the cells
+ *             that can still win, the rest are never touched (B >= 17, 64 <= S <= 4096); one launch
+ *             per timestep over (batch tile x state tile) workgroups
+ *   RESIDENT  the PRUNED recurrence with the time loop inside ONE launch: a workgroup owns 16 items x
+ *             all states for every timestep, the posterior rows never leave its LDS (64 <= S <= 2048).
+ *             16 items per compute unit: the path for many items in flight -- several batches through
+ *             torbi_hip_viterbi_decode_batches, or one batch of >= 8 * compute-units items.
+ * AUTO takes RESIDENT when the call's items fill at least half the compute units with workgroups of
+ * 16, else PRUNED where supported, else DENSE, else GENERIC.
+ *
+ * A call selects a path in its `flags` (TORBI_HIP_PATH_FLAG); calls without one use the process-wide
+ * default (torbi_hip_set_forward_path, initially the environment variable
+ * TORBI_HIP_FORWARD=dense|pruned|resident, else AUTO).  A path that does not cover the shape falls
+ * back as AUTO would.  A workspace of torbi_hip_workspace_bytes() fits every path.
+ * torbi_hip_forward_path_on reports what a (B, S) batch would run on `device` with `flags`:
+ * 0 generic, 1 dense, 2 pruned, 3 resident; torbi_hip_forward_path is the same for device 0, flags 0.
  */
 #define TORBI_HIP_FORWARD_AUTO 0
 #define TORBI_HIP_FORWARD_DENSE 1
 #define TORBI_HIP_FORWARD_PRUNED 2
+#define TORBI_HIP_FORWARD_RESIDENT 3
+#define TORBI_HIP_PATH_FLAG(path) (((unsigned)(path) + 1u) << 4)   /* bits 4..6 of `flags`; 0 = process default */
 int torbi_hip_set_forward_path(int path);
 int torbi_hip_forward_path(int B, int S);
+int torbi_hip_forward_path_on(int B, int S, int device, unsigned flags);
 
 /*
  * The operator.  Replaces viterbi_decode_cuda (viterbi.cu:309-362) = forward trellis
@@ -107,7 +124,9 @@ int torbi_hip_viterbi_decode(const float *observation, const int32_t *batch_fram
  * else has written to the workspace since; the per-transition preparation (sorted transition rows /
  * packed panels, 0.2 ms at S = 1440) is then taken from the workspace instead of being rebuilt.
  * A serving loop that decodes batch after batch with one matrix sets it from the second batch on
- * (torbi_amd.DecodePipeline does).  flags = 0 is torbi_hip_viterbi_decode.  Unknown bits: EINVAL.
+ * (torbi_amd.DecodePipeline does).  TORBI_HIP_PATH_FLAG(path) selects the forward path for THIS call
+ * (nothing process-wide is read or written: calls from different host threads on different
+ * streams/devices are independent).  flags = 0 is torbi_hip_viterbi_decode.  Unknown bits: EINVAL.
  */
 #define TORBI_HIP_REUSE_TRANSITION 1u
 #define TORBI_HIP_COLLECT_STATS 2u     /* a PRUNED decode also leaves scan statistics: torbi_hip_scan_stats */
@@ -115,6 +134,36 @@ int torbi_hip_viterbi_decode_ex(const float *observation, const int32_t *batch_f
                                 const float *transition, const float *initial,
                                 int32_t *indices_out, void *workspace, size_t workspace_bytes,
                                 int B, int T, int S, int device, void *stream, unsigned flags);
+
+/*
+ * Several batches that share `transition`/`initial`, decoded together.  Replaces a LOOP over the
+ * operator (reference torbi/core.py:417-457 decodes batch after batch): batch items are independent
+ * (viterbi.cpp:65, viterbi.cu:58), so the batches of a many-file job can share one set of launches.
+ * On the RESIDENT path (the AUTO choice when the group's items fill half the compute units) the whole
+ * group is ONE forward launch and ONE backtrace launch; the per-transition preparation is built once,
+ * in the first non-empty batch's workspace.  Otherwise the batches are decoded one after the other on
+ * `stream`, each on the path it would take alone.  Every batch needs its own workspace of
+ * torbi_hip_workspace_bytes(B, T, S).  Batches may differ in B and T; count <= TORBI_HIP_MAX_BATCHES.
+ *
+ * phase_ms: NULL, or a HOST pointer to 6 floats -- the call then brackets its phases with hipEvents on
+ * `stream` and SYNCHRONISES it (bench.py):
+ *   [0] forward recurrence incl. preparation, ms   [1] argmax + backtrace, ms
+ *   [2] forward kernel launches                    [3] route that ran (0 generic .. 3 resident)
+ *   [4] per-transition preparation alone, ms       [5] batches the forward launch(es) covered
+ * (for batches decoded one after the other [0],[1],[2],[4] describe the LAST batch).
+ */
+#define TORBI_HIP_MAX_BATCHES 16
+typedef struct torbi_hip_batch {
+    const float *observation;     /* (B,T,S) fp32 */
+    const int32_t *batch_frames;  /* (B) int32 */
+    int32_t *indices_out;         /* (B,T) int32, fully overwritten */
+    void *workspace;              /* >= torbi_hip_workspace_bytes(B,T,S) bytes, 256-byte aligned */
+    size_t workspace_bytes;
+    int B, T;
+} torbi_hip_batch;
+int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, const float *transition,
+                                     const float *initial, int S, int device, void *stream, unsigned flags,
+                                     float *phase_ms);
 
 /*
  * Scan statistics of the last PRUNED decode that ran with TORBI_HIP_COLLECT_STATS on `workspace`
@@ -146,27 +195,24 @@ int torbi_hip_viterbi_decode_uniform(const float *observation, const int32_t *ba
                                      void *stream);
 
 /*
- * Same operator, instrumented for bench.py: brackets the forward recurrence and the
- * final-argmax + backtrace with hipEvents on `stream`, SYNCHRONISES the stream, and
- * returns the phases in milliseconds:
- *   phase_ms[0] = forward recurrence (all timesteps)   phase_ms[1] = argmax + backtrace
- *   phase_ms[2] = number of forward kernel launches     phase_ms[3] = torbi_hip_forward_path(B, S)
- * `phase_ms` is a HOST pointer to 4 floats.
+ * Same operator, instrumented for bench.py: torbi_hip_viterbi_decode_batches for one batch with
+ * `phase_ms` (a HOST pointer to 6 floats, see there); SYNCHRONISES the stream.
  */
 int torbi_hip_viterbi_decode_profiled(const float *observation, const int32_t *batch_frames,
                                       const float *transition, const float *initial,
                                       int32_t *indices_out, void *workspace,
                                       size_t workspace_bytes, int B, int T, int S, int device,
-                                      void *stream, float *phase_ms);
+                                      void *stream, unsigned flags, float *phase_ms);
 
 /*
  * Test/diagnostic access to the final posterior rows the forward pass produced by the last
  * decode that used `workspace` (reference: the `posterior` tensor, viterbi.cu:334-336).
- * Copies (B,S) fp32 into `posterior_out` (device pointer) on `stream`.
+ * Copies (B,S) fp32 into `posterior_out` (device pointer) on `stream`.  `flags`: the flags of that
+ * decode (its path decides where the rows live).
  */
 int torbi_hip_read_posterior(const void *workspace, size_t workspace_bytes,
                              const int32_t *batch_frames, float *posterior_out,
-                             int B, int T, int S, int device, void *stream);
+                             int B, int T, int S, int device, void *stream, unsigned flags);
 
 /*
  * In-place epsilon clamp of from_probabilities (reference torbi/core.py:193-197):

@@ -15,11 +15,12 @@ from conftest import SMALL_NAMES, LARGE_NAMES
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=['auto', 'dense', 'pruned'])
+@pytest.fixture(autouse=True, params=['auto', 'dense', 'pruned', 'resident'])
 def forward(request):
-    """Every test runs three times: with the automatic path choice (pruned, or dense for narrow-band
-    matrices), with the dense (max,+) GEMM forced and with the exact pruned pass forced wherever it is
-    supported.  Small batches take the generic kernels every time."""
+    """Every test runs four times: with the automatic path choice (pruned, or dense for narrow-band
+    matrices), with the dense (max,+) GEMM forced, with the exact pruned pass forced wherever it is
+    supported, and with the time-resident kernel forced wherever it is supported (64 <= S <= 2048, ANY
+    batch size).  Small batches take the generic kernels on the first three."""
     viterbi.set_forward_path(request.param)
     yield request.param
     viterbi.set_forward_path('auto')
@@ -136,11 +137,19 @@ def test_dense_path_edge_shapes(shape):
 
 
 def test_forward_path_selection(forward):
-    assert viterbi.forward_path(4, 1440) == 'generic'
+    resident = forward == 'resident'
+    assert viterbi.forward_path(4, 1440) == ('resident' if resident else 'generic')
+    assert viterbi.forward_path(4, 40) == 'generic'                # S < 64: no value-only path
     assert viterbi.forward_path(128, 4096) == ('dense' if forward == 'dense' else 'pruned')   # 8-item tiles
     assert viterbi.forward_path(128, 4100) == 'dense'              # posterior tile does not fit the LDS
-    assert viterbi.forward_path(512, 1440) == ('dense' if forward == 'dense' else 'pruned')
-    assert viterbi.forward_path(64, 130) == ('dense' if forward == 'dense' else 'pruned')      # any S in range
+    assert viterbi.forward_path(512, 1440) == {'dense': 'dense', 'resident': 'resident'}.get(forward, 'pruned')
+    assert viterbi.forward_path(64, 130) == {'dense': 'dense', 'resident': 'resident'}.get(forward, 'pruned')
+    # AUTO: a batch that gives at least half the compute units a 16-item workgroup is decoded time-resident
+    big = 8 * viterbi.compute_units('cuda:0')
+    assert viterbi.forward_path(big, 1440, path='auto') == 'resident'
+    assert viterbi.forward_path(big, 2052, path='auto') == 'pruned'
+    # the path travels with the call: naming one never changes the process default
+    assert viterbi.forward_path(512, 1440, path='dense') == 'dense'
     assert viterbi.workspace_bytes(512, 500, 1440) >= 512 * 500 * 1440 * 4
 
 
@@ -450,9 +459,9 @@ def test_dispatcher_registration_matches_reference_call_site():
            torch.tensor(trans, device=dev), torch.tensor(init, device=dev))
 
 
-def test_ragged_batch_equals_single_item_decodes():
-    """collate-style padded batch == per-file decodes (reference collate.py:24-33,
-    core.py:449-457)."""
+def test_ragged_batch_equals_oracle_decodes_of_every_file():
+    """collate-style padded batch (reference collate.py:24-33) == the ORACLE's decode of each sequence alone
+    (core.py:449-457 keeps the first `frames` indices of every row)."""
     S = 360
     lens = [37, 1, 120, 64, 2, 99]
     obs_full, trans, init = synth.problem(len(lens), max(lens), S, seed=11)
@@ -460,7 +469,7 @@ def test_ragged_batch_equals_single_item_decodes():
         obs_full[b, n:] = 0.0          # zero padding as collate does
     got = gpu_decode(obs_full, lens, trans, init)
     for b, n in enumerate(lens):
-        single = gpu_decode(obs_full[b:b + 1, :n], [n], trans, init)
+        single = oracle.decode(obs_full[b:b + 1, :n], [n], trans, init)
         assert np.array_equal(got[b, :n], single[0])
         assert (got[b, n - 1:] == got[b, n - 1]).all()
 
@@ -502,8 +511,22 @@ def test_from_probabilities_equals_decode_of_same_device_preprocessing():
     assert np.array_equal(want.cpu().numpy(), ref)
 
 
+def _oracle_for_file(observation, transition_probs, states):
+    """What from_files_to_files(log_probs=True) feeds the operator for one file, decoded by the oracle: the
+    observation goes through THIS device's epsilon round trip, the transition through the
+    host's log(p + tiny) (reference core.py:341-347), the initial defaults to log(1/S + tiny) (core.py:161-166)."""
+    import math
+    tiny = torch.finfo(torch.float32).tiny
+    x = observation.to('cuda:0', dtype=torch.float32)
+    x = torch.log(torch.exp(x) + tiny).cpu().numpy()[None]
+    trans = torch.log(transition_probs + tiny).numpy()
+    init = np.full((states,), math.log(1. / states + tiny), dtype=np.float32)
+    return oracle.decode(x, [x.shape[1]], trans, init)[0]
+
+
 def test_files_round_trip(tmp_path):
-    """from_files_to_files == per-file from_file (reference core.py:310-368, 211-267)."""
+    """from_files_to_files / from_file_to_file write, per file, the oracle's decode of that file alone
+    (reference core.py:310-368, 211-307)."""
     S = 40
     ins, outs = [], []
     gen = torch.Generator().manual_seed(3)
@@ -519,13 +542,7 @@ def test_files_round_trip(tmp_path):
         got = torch.load(fout)
         n = torch.load(fin).shape[0]
         assert got.shape == (n,) and got.dtype == torch.int32
-        # from_file logs the transition without the epsilon (core.py:246-247 vs :341-347);
-        # softmax rows have no zeros, so log(p) vs log(p + tiny) agree after rounding or not --
-        # compare against decode of exactly what from_files_to_files fed instead
-        obs = torch.load(fin).unsqueeze(0)
-        trans = torch.log(torch.load(tf) + torch.finfo(torch.float32).tiny)
-        want = torbi_amd.from_probabilities(obs, transition=trans, log_probs=True, gpu=0)
-        assert torch.equal(got, want[0].cpu())
+        assert np.array_equal(got.numpy(), _oracle_for_file(torch.load(fin), torch.load(tf), S))
     # length-bucketed batching writes the same files
     outs2 = [tmp_path / f'sorted{k}.pt' for k in range(len(ins))]
     saved = torbi_amd.core.BATCH_SIZE
@@ -539,3 +556,227 @@ def test_files_round_trip(tmp_path):
         assert torch.equal(torch.load(a), torch.load(b2))
     torbi_amd.from_file_to_file(ins[1], tmp_path / 'single.pt', log_probs=True, gpu=0)
     assert torch.load(tmp_path / 'single.pt').shape == (1, 17)
+
+
+# ---- several batches per call (torbi_hip_viterbi_decode_batches) and the time-resident path -----------------
+
+def _device_problem(B, T, S, seed, dev, ragged=True):
+    obs, trans, init = synth.problem(B, T, S, seed=seed)
+    frames = np.clip(synth.lengths(B, 1, T, seed=seed + 1), 1, T) if ragged else np.full(B, T, np.int32)
+    if ragged:
+        frames[0] = T
+    return obs, frames.astype(np.int32), trans, init
+
+
+@pytest.mark.parametrize('S', [64, 130, 360, 1440, 1442, 2048])
+def test_decode_batches_equals_oracle_per_batch(S):
+    """A group of batches with different sizes and lengths (a many-file job, reference torbi/core.py:417-457)
+    through ONE call: every batch equals the oracle decode of that batch alone, whatever path the group takes
+    (forced 'resident': one forward launch for the whole group; otherwise batch after batch)."""
+    dev = torch.device('cuda:0')
+    shapes = [(40, 9), (17, 23), (1, 5), (96, 4), (33, 1), (16, 12)] if S < 1000 else [(40, 7), (17, 9), (3, 4)]
+    _, trans, init = synth.problem(1, 1, S, seed=S)
+    obs_list, frame_list, want = [], [], []
+    for k, (B, T) in enumerate(shapes):
+        obs, frames, _, _ = _device_problem(B, T, S, seed=100 * k + S, dev=dev)
+        obs_list.append(torch.as_tensor(obs).to(dev))
+        frame_list.append(torch.as_tensor(frames).to(dev))
+        want.append(oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads()))
+    got = viterbi.decode_batches(obs_list, frame_list, torch.as_tensor(trans).to(dev), torch.as_tensor(init).to(dev))
+    for k in range(len(shapes)):
+        np.testing.assert_array_equal(got[k].cpu().numpy(), want[k], err_msg=f'batch {k} {shapes[k]}')
+
+
+def test_decode_batches_auto_goes_resident_when_the_group_fills_the_chip():
+    """AUTO counts the 16-item tiles of the whole group: 8 batches of 272 items are 136 tiles >= half the compute
+    units -> one time-resident launch (phase record: route 3, 8 batches); two of them are decoded one by one."""
+    dev = torch.device('cuda:0')
+    S, T, B = 360, 12, 272
+    _, trans, init = synth.problem(1, 1, S, seed=5)
+    obs_list, frame_list, want = [], [], []
+    for k in range(8):
+        obs, frames, _, _ = _device_problem(B, T, S, seed=40 + k, dev=dev)
+        obs_list.append(torch.as_tensor(obs).to(dev))
+        frame_list.append(torch.as_tensor(frames).to(dev))
+        want.append(oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads()))
+    d_trans, d_init = torch.as_tensor(trans).to(dev), torch.as_tensor(init).to(dev)
+    prof = []
+    got = viterbi.decode_batches(obs_list, frame_list, d_trans, d_init, path='auto', _profile=prof)
+    assert int(prof[3]) == 3 and int(prof[5]) == 8 and int(prof[2]) == 1
+    for k in range(8):
+        np.testing.assert_array_equal(got[k].cpu().numpy(), want[k])
+    got = viterbi.decode_batches(obs_list[:2], frame_list[:2], d_trans, d_init, path='auto', _profile=prof)
+    assert int(prof[3]) == 2 and int(prof[5]) == 1
+    for k in range(2):
+        np.testing.assert_array_equal(got[k].cpu().numpy(), want[k])
+
+
+@pytest.mark.parametrize('B', [40, 270])
+@pytest.mark.parametrize('S', [360, 1440, 4096])
+@pytest.mark.parametrize('kind', ['some', 'rows', 'all'])
+def test_minus_inf_observations_on_the_large_batch_paths(B, S, kind):
+    """-inf observation entries, whole -inf observation rows and all -inf observations at batch sizes that take
+    the value-only paths (the pruned bound sees thr = -inf, keys of -inf outputs, tn + thr > best with -inf)."""
+    T = 6 if S < 4096 else 4
+    obs, trans, init = synth.problem(B, T, S, seed=B + S)
+    rng = np.random.default_rng(B * S)
+    if kind == 'some':
+        obs = np.where(rng.random(obs.shape) < 0.3, -np.inf, obs).astype(np.float32)
+        init = np.where(rng.random(S) < 0.5, -np.inf, init).astype(np.float32)
+    elif kind == 'rows':
+        dead = rng.random((B, T)) < 0.4
+        dead[0, 1] = True
+        obs = np.where(dead[:, :, None], -np.inf, obs).astype(np.float32)
+    else:
+        obs = np.full_like(obs, -np.inf)
+    frames = np.clip(synth.lengths(B, 1, T, seed=S), 1, T)
+    frames[0] = T
+    want = oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())
+    np.testing.assert_array_equal(gpu_decode(obs, frames, trans, init), want)
+
+
+def test_headline_batch_against_the_oracle_on_random_items(forward):
+    """B=512, T=500, S=1440 (BASELINE config 3): 64 randomly chosen items of the full batch against the oracle
+    (lowest-index ties included: the path-score property of test_headline_shape_properties accepts any optimal
+    path).  Host cost: ~1 s per item with all threads on the GPU box."""
+    if forward == 'dense':
+        pytest.skip('the dense kernel sees the same items in test_headline_shape_properties; 40 s per decode')
+    dev = torch.device('cuda:0')
+    B, T, S = 512, 500, 1440
+    obs = viterbi.fill_synthetic((B, T, S), synth.STREAM_OBSERVATION, device=dev)
+    trans = viterbi.fill_synthetic((S, S), synth.STREAM_TRANSITION, device=dev)
+    init = viterbi.fill_synthetic((S,), synth.STREAM_INITIAL, device=dev)
+    frames = torch.full((B,), T, dtype=torch.int32, device=dev)
+    idx = torbi_amd.decode(obs, frames, trans, init)
+    pick = np.sort(np.random.default_rng(20).choice(B, size=64, replace=False))
+    want = oracle.decode(obs[torch.as_tensor(pick).to(dev)].cpu().numpy(), np.full(64, T, np.int32),
+                         trans.cpu().numpy(), init.cpu().numpy(), num_threads=oracle.max_threads(), mode=1)
+    np.testing.assert_array_equal(idx.cpu().numpy()[pick], want)
+
+
+def test_inference_mode_is_supported():
+    """Tensors created under torch.inference_mode() have no version counter; decode / from_probabilities must
+    not depend on one (the reference works there)."""
+    dev = torch.device('cuda:0')
+    B, T, S = 40, 9, 96
+    obs, trans, init = synth.problem(B, T, S, seed=3)
+    frames = np.clip(synth.lengths(B, 1, T, seed=4), 1, T)
+    want = oracle.decode(obs, frames, trans, init)
+    with torch.inference_mode():
+        d = [torch.as_tensor(x).to(dev) * 1 for x in (obs, trans, init)]
+        f = torch.as_tensor(frames).to(dev)
+        ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+        for _ in range(2):
+            got = torbi_amd.decode(d[0], f, d[1], d[2], workspace=ws, reuse_preparation=True)
+            np.testing.assert_array_equal(got.cpu().numpy(), want)
+        probs = torch.rand(2, 7, 30, generator=torch.Generator().manual_seed(0)).softmax(-1)
+        trans_p = torch.rand(30, 30, generator=torch.Generator().manual_seed(1)).softmax(-1)
+        inside = torbi_amd.from_probabilities(probs.clone(), transition=trans_p, gpu=0)
+        assert torch.ops is not None and inside.shape == (2, 7)
+        op = __import__('torbi_amd.torch_op', fromlist=['register']).register()
+        np.testing.assert_array_equal(op(d[0], f, d[1], d[2]).cpu().numpy(), want)
+    outside = torbi_amd.from_probabilities(probs.clone(), transition=trans_p, gpu=0)
+    assert torch.equal(inside.cpu(), outside.cpu())
+
+
+def test_concurrent_host_threads_on_separate_streams():
+    """SURVEY 8(b) threading: two host threads, each with its own stream (and its own device when there are
+    two), decode a banded and a dense matrix at the same time, each naming its forward path in the call.
+    Nothing process-wide is involved, so neither sees the other's choice; both equal the oracle."""
+    import threading
+    n_dev = torch.cuda.device_count()
+    S, T = 360, 16
+    jobs = []
+    for k, (kind, path, B) in enumerate([('banded', 'dense', 64), ('dense', 'pruned', 48)]):
+        obs, frames, trans, init = _device_problem(B, T, S, seed=7 + k, dev=None)
+        if kind == 'banded':
+            trans = synth.banded_transition(S, 12.0)
+        jobs.append(dict(obs=obs, frames=frames, trans=trans, init=init, path=path,
+                         dev=torch.device('cuda', k % n_dev),
+                         want=oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())))
+    errors = []
+
+    def work(job):
+        try:
+            dev = job['dev']
+            torch.cuda.set_device(dev)
+            stream = torch.cuda.Stream(device=dev)
+            d = [torch.as_tensor(job[name]).to(dev) for name in ('obs', 'frames', 'trans', 'init')]
+            ws = torch.empty(viterbi.workspace_bytes(*job['obs'].shape), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize(dev)
+            with torch.cuda.stream(stream):
+                for _ in range(25):
+                    got = torbi_amd.decode(*d, workspace=ws, reuse_preparation=True, path=job['path'])
+                    if not np.array_equal(got.cpu().numpy(), job['want']):
+                        errors.append(f"{job['path']}: indices differ from the oracle")
+                        return
+        except Exception as exc:      # surfaced below: an exception in a thread must fail the test
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=work, args=(job,)) for job in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+
+
+# ---- vectors produced by the reference's own Python on its CPU operator (tests/golden/generate_api.py) -------
+
+API = np.load(__import__('conftest').GOLDEN + '/golden_api.npz')
+
+
+def _write_api_files(tmp_path, tag):
+    count = int(API[f'files_{tag}/count'])
+    ins, outs = [], []
+    for k in range(count):
+        f = tmp_path / f'in{k}.pt'
+        torch.save(torch.as_tensor(API[f'files_{tag}/in{k}']), f)
+        ins.append(f)
+        outs.append(tmp_path / f'out{k}.pt')
+    tf = tmp_path / 'transition.pt'
+    torch.save(torch.as_tensor(API[f'files_{tag}/transition']), tf)
+    return ins, outs, tf
+
+
+def test_from_files_to_files_equals_the_reference_outputs(tmp_path, monkeypatch):
+    """the files the reference's from_files_to_files wrote (real torbi Python, CPU operator, batch
+    size 3: three batches) for seven ragged inputs -- same shapes, dtypes and indices here."""
+    monkeypatch.setattr(torbi_amd.core, 'BATCH_SIZE', int(API['files_plain/batch_size']))
+    ins, outs, tf = _write_api_files(tmp_path, 'plain')
+    torbi_amd.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, gpu=0)
+    for k, f in enumerate(outs):
+        got = torch.load(f)
+        want = API[f'files_plain/out{k}']
+        assert got.dtype == torch.int32 and tuple(got.shape) == want.shape
+        np.testing.assert_array_equal(got.numpy(), want, err_msg=f'file {k}')
+
+
+def test_chunked_from_files_to_files_equals_the_reference_outputs(tmp_path, monkeypatch):
+    """chunked decoding (reference torbi/chunk.py with MIN_CHUNK_SIZE = 8): files are cut at
+    the same frames, decoded as extra batch rows and joined; outputs equal the reference's."""
+    monkeypatch.setattr(torbi_amd.core, 'BATCH_SIZE', int(API['files_chunk/batch_size']))
+    monkeypatch.setattr(torbi_amd.core, 'MIN_CHUNK_SIZE', int(API['chunk/min_chunk_size']))
+    ins, outs, tf = _write_api_files(tmp_path, 'chunk')
+    torbi_amd.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, gpu=0)
+    for k, f in enumerate(outs):
+        got = torch.load(f)
+        want = API[f'files_chunk/out{k}']
+        assert got.dtype == torch.int32 and tuple(got.shape) == want.shape
+        np.testing.assert_array_equal(got.numpy(), want, err_msg=f'file {k}')
+
+
+def test_from_probabilities_equals_the_reference_outputs():
+    """reference from_probabilities (CPU) on probability and log-probability inputs, with given
+    and with default transition / initial (the epsilon round trip runs on different devices: SURVEY 0.5 -- these
+    inputs were checked to decode identically)."""
+    obs = torch.as_tensor(API['probs/observation'])
+    trans = torch.as_tensor(API['probs/transition'])
+    init = torch.as_tensor(API['probs/initial'])
+    frames = torch.as_tensor(API['probs/batch_frames'])
+    got = torbi_amd.from_probabilities(obs.clone(), frames, trans, init, log_probs=False, gpu=0)
+    np.testing.assert_array_equal(got.cpu().numpy(), API['probs/indices'])
+    got = torbi_amd.from_probabilities(obs.clone(), gpu=0)
+    np.testing.assert_array_equal(got.cpu().numpy(), API['probs/indices_defaults'])
+    got = torbi_amd.from_probabilities(torch.log(obs), frames, torch.log(trans), torch.log(init), log_probs=True, gpu=0)
+    np.testing.assert_array_equal(got.cpu().numpy(), API['probs/indices_log'])

@@ -168,12 +168,27 @@ def test_auto_path_choice_reads_the_transition_structure_once_per_version():
     assert viterbi._choose_path(dead, dead, 64, S) == 'pruned'          # reach 0: nothing to skip *to*
     assert viterbi._choose_path(dense, dense, 8, S) == 'auto'           # small batch: generic kernels either way
     assert viterbi._choose_path(dense, dense, 64, 8192) == 'auto'       # outside the pruned path's range
-    old = viterbi._forced_path
+    # a forced path never reaches the look; an explicit per-call 'auto' ignores the process default
+    old, units = viterbi._forced_path, dict(viterbi._compute_units)
     try:
         viterbi._forced_path = 'dense'
-        assert viterbi._choose_path(dense, dense, 64, S) == 'dense'
+        viterbi._compute_units[0] = 256               # what torbi_hip_compute_units(0) reports on an MI355X
+        assert viterbi._resolve_path(dense, dense, 64, S, 'cuda:0', None, 4, False) == ('dense', None)
+        assert viterbi._resolve_path(dense, dense, 64, S, 'cuda:0', 'auto', 4, False) == ('pruned', None)
+        assert viterbi._resolve_path(dense, dense, 64, S, 'cuda:0', 'resident', 4, False) == ('resident', None)
+        # enough 16-item tiles to give half the compute units a workgroup: AUTO decodes time-resident
+        assert viterbi._resolve_path(dense, dense, 2048, S, 'cuda:0', 'auto', 128, False) == ('resident', None)
+        assert viterbi._resolve_path(band, band, 2048, S, 'cuda:0', 'auto', 128, False) == ('resident', None)
     finally:
         viterbi._forced_path = old
+        viterbi._compute_units.clear()
+        viterbi._compute_units.update(units)
+    with torch.inference_mode():                      # no version counter: looked at, never cached
+        inf = torch.as_tensor(synth.banded_transition(S, 12.0)) * 1
+        assert viterbi._version_of(inf) is None
+        assert viterbi._choose_path(inf, inf, 64, S) == 'dense'
+        assert id(inf) not in viterbi._structure_cache
+        assert viterbi._tuner_for(inf, S, 'cpu') is None
 
 
 def test_tuner_probes_the_dense_path_only_when_pruning_is_not_clearly_working():
@@ -208,3 +223,91 @@ def test_tuner_probes_the_dense_path_only_when_pruning_is_not_clearly_working():
     assert paths[:3] == ['pruned', 'dense', 'pruned'] and paths.count('dense') == 2
     lag = viterbi._Tuner()                            # nothing has completed yet: keep going on the pruned path
     assert [run(lag, {'pruned': 1.0, 'dense': 1.0}, 30.0, done=False) for _ in range(5)] == ['pruned'] * 5
+
+
+# ---- vectors produced by the reference's own Python (tests/golden/generate_api.py) ---------------------------
+
+API = np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_api.npz'))
+
+
+def test_collate_equals_the_reference_collate():
+    """reference torbi/data/collate.py:9-33 on ragged items: same padded tensor, lengths, chunk counts, names."""
+    items = [(torch.as_tensor(API[f'collate/item{k}']), str(API['collate/names'][k])) for k in range(4)]
+    observation, batch_frames, batch_chunks, names = torbi_amd.data.collate(items)
+    assert np.array_equal(observation.numpy(), API['collate/observation'])
+    assert observation.dtype == torch.float32
+    assert batch_frames.tolist() == API['collate/batch_frames'].tolist()
+    assert batch_frames.dtype == torch.int64            # upstream builds it with torch.tensor(list of ints)
+    assert list(batch_chunks) == API['collate/batch_chunks'].tolist()
+    assert list(names) == [str(n) for n in API['collate/names']]
+
+
+def test_chunk_cut_points_equal_the_reference(monkeypatch):
+    """reference torbi/chunk.py:12-85 (real Python, MIN_CHUNK_SIZE = 8): entropy, cut points and piece lengths
+    of four files; other sizes / thresholds through the explicit arguments."""
+    chunk_module = __import__('torbi_amd.chunk', fromlist=['split'])
+    size, thr = int(API['chunk/min_chunk_size']), float(API['chunk/entropy_threshold'])
+    assert (size, thr) == (8, torbi_amd.core.ENTROPY_THRESHOLD)
+    monkeypatch.setattr(torbi_amd.core, 'MIN_CHUNK_SIZE', size)
+    for k in range(4):
+        x = torch.as_tensor(API[f'files_chunk/in{k}'])
+        assert np.array_equal(chunk_module.entropy(x).numpy(), API[f'chunk/entropy{k}'])
+        assert chunk_module.split(x, size, thr) == API[f'chunk/split{k}'].tolist()
+        pieces = torbi_amd.chunk(x)                     # defaults read from core at call time
+        assert [p.shape[0] for p in pieces] == API[f'chunk/pieces{k}'].tolist()
+        assert torch.equal(torch.cat(pieces), x)
+    x = torch.as_tensor(API['files_chunk/in2'])
+    for size, thr in [(1, 0.5), (5, 0.9), (40, 0.5), (7, 0.05)]:
+        assert chunk_module.split(x, size, thr) == API[f'chunk/split2_size{size}_thr{thr}'].tolist()
+    with pytest.raises(ValueError):
+        chunk_module.split(x, None, 0.5)
+    assert chunk_module.split(torch.full((30, 4), float('-inf')), 2, 0.5) == []      # NaN entropy never qualifies
+
+
+def test_chunked_dataset_and_collate_equal_the_reference(tmp_path, monkeypatch):
+    """dataset.py:22-23 + collate.py:13-15: files cut into pieces become consecutive batch rows."""
+    monkeypatch.setattr(torbi_amd.core, 'MIN_CHUNK_SIZE', int(API['chunk/min_chunk_size']))
+    files = []
+    for k in range(4):
+        f = tmp_path / f'in{k}.pt'
+        torch.save(torch.as_tensor(API[f'files_chunk/in{k}']), f)
+        files.append(f)
+    dataset = torbi_amd.data.Dataset(files)
+    observation, batch_frames, batch_chunks, names = torbi_amd.data.collate([dataset[k] for k in range(4)])
+    assert batch_frames.tolist() == API['chunk/collate_frames'].tolist()
+    assert list(batch_chunks) == API['chunk/collate_chunks'].tolist()
+    assert list(observation.shape) == API['chunk/collate_shape'].tolist()
+    assert list(names) == files
+
+
+def test_from_dataloader_joins_chunked_files(tmp_path, monkeypatch):
+    """reference torbi/core.py:438-448: with chunked items every FILE gets the concatenation of its rows' valid
+    frames (a stand-in decode labels every position with 1000 * row + frame, no GPU involved)."""
+    monkeypatch.setattr(torbi_amd.core, 'MIN_CHUNK_SIZE', 8)
+    monkeypatch.setattr(torbi_amd.core, 'BATCH_SIZE', 3)
+    files, mapping, lengths = [], {}, {}
+    for k in range(4):
+        f = tmp_path / f'in{k}.pt'
+        x = torch.as_tensor(API[f'files_chunk/in{k}'])
+        torch.save(x, f)
+        files.append(f)
+        mapping[f] = tmp_path / f'out{k}.pt'
+        lengths[f] = API[f'chunk/pieces{k}'].tolist()
+
+    def fake_from_probabilities(observation, batch_frames, **_):
+        rows, frames = observation.shape[:2]
+        return (1000 * torch.arange(rows)[:, None] + torch.arange(frames)[None, :]).to(torch.int32)
+
+    monkeypatch.setattr(torbi_amd.core, 'from_probabilities', fake_from_probabilities)
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: False)
+    torbi_amd.from_dataloader(torbi_amd.data.loader(files, pin_memory=False), mapping)
+    row = 0
+    for k, f in enumerate(files):
+        if k == 3:
+            row = 0                                     # second batch of the loader (batch size 3 files)
+        want = []
+        for n in lengths[f]:
+            want.extend(1000 * row + t for t in range(n))
+            row += 1
+        got = torch.load(mapping[f])
+        assert got.dtype == torch.int32 and got.tolist() == want

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(_HERE)
 SOURCE = os.path.join(_HERE, 'csrc', 'torbi_hip.hip')
 INCLUDE = os.path.join(ROOT, 'include')
 LIBRARY = os.path.join(_HERE, 'libtorbi_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/torbi_hip.h declares: name -> (restype, argtypes)
 _c = ctypes
@@ -22,6 +22,7 @@ SYMBOLS = {
     'torbi_hip_abi_version': (_c.c_int, []),
     'torbi_hip_error_string': (_c.c_char_p, [_c.c_int]),
     'torbi_hip_device_count': (_c.c_int, []),
+    'torbi_hip_compute_units': (_c.c_int, [_c.c_int]),
     'torbi_hip_workspace_bytes': (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int]),
     'torbi_hip_viterbi_decode': (_c.c_int, [
         _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
@@ -31,7 +32,10 @@ SYMBOLS = {
         _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     'torbi_hip_viterbi_decode_profiled': (_c.c_int, [
         _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
-        _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
+        _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint,
+        _c.POINTER(_c.c_float)]),
+    'torbi_hip_viterbi_decode_batches': (_c.c_int, [
+        _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint,
         _c.POINTER(_c.c_float)]),
     'torbi_hip_viterbi_decode_ex': (_c.c_int, [
         _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
@@ -40,13 +44,23 @@ SYMBOLS = {
                                         _c.c_int, _c.c_void_p]),
     'torbi_hip_set_forward_path': (_c.c_int, [_c.c_int]),
     'torbi_hip_forward_path': (_c.c_int, [_c.c_int, _c.c_int]),
+    'torbi_hip_forward_path_on': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_uint]),
     'torbi_hip_read_posterior': (_c.c_int, [
         _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p,
-        _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+        _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint]),
     'torbi_hip_epsilon_clamp': (_c.c_int, [_c.c_void_p, _c.c_uint64, _c.c_int, _c.c_void_p]),
     'torbi_hip_fill_synthetic': (_c.c_int, [
         _c.c_void_p, _c.c_uint64, _c.c_uint64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
 }
+
+MAX_BATCHES = 16        # TORBI_HIP_MAX_BATCHES
+
+
+class Batch(_c.Structure):
+    """torbi_hip_batch (include/torbi_hip.h): one batch of a torbi_hip_viterbi_decode_batches call."""
+    _fields_ = [('observation', _c.c_void_p), ('batch_frames', _c.c_void_p), ('indices_out', _c.c_void_p),
+                ('workspace', _c.c_void_p), ('workspace_bytes', _c.c_size_t), ('B', _c.c_int), ('T', _c.c_int)]
+
 
 _LIB = None
 

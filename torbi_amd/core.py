@@ -12,11 +12,14 @@ from typing import Dict, List, Optional, Union
 import torch
 
 from . import data as _data
-from .viterbi import decode, decode_uniform, epsilon_clamp_
+from .viterbi import decode, decode_uniform, epsilon_clamp_, _version_of
 
 # reference torbi/config/defaults.py:80,83
 BATCH_SIZE = 512
 NUM_WORKERS = 0
+# reference torbi/config/defaults.py:41,44: chunked decoding of long sequences (torbi_amd/chunk.py); off when None
+MIN_CHUNK_SIZE = None
+ENTROPY_THRESHOLD = 0.5
 
 
 def _compute_device(gpu, observation):
@@ -40,14 +43,16 @@ def _prepared_transition(transition: torch.Tensor, log_probs: bool, device) -> t
     """log() (unless `log_probs`) and device move of the transition matrix (core.py:181-187), remembered per
     caller tensor and version: repeated calls with one matrix then hand torbi_amd.decode the SAME device
     tensor, which is what its per-tensor structure look and path measurements are keyed on."""
-    known = _transition_cache.get(id(transition))
-    state = (transition._version, bool(log_probs), str(device))
+    version = _version_of(transition)          # None under torch.inference_mode(): nothing to key a cache on
+    known = _transition_cache.get(id(transition)) if version is not None else None
+    state = (version, bool(log_probs), str(device))
     if known is not None and known[0]() is transition and known[1] == state:
         return known[2]
     prepared = (transition if log_probs else torch.log(transition)).to(device)
-    if len(_transition_cache) >= 16:
-        _transition_cache.clear()
-    _transition_cache[id(transition)] = (weakref.ref(transition), state, prepared)
+    if version is not None:
+        if len(_transition_cache) >= 16:
+            _transition_cache.clear()
+        _transition_cache[id(transition)] = (weakref.ref(transition), state, prepared)
     return prepared
 
 
@@ -250,12 +255,18 @@ def from_dataloader(
         pipe = DecodePipeline(device)
 
     def finish(item):
-        indices, input_filenames, batch_frames = item
+        indices, input_filenames, batch_frames, batch_chunks = item
         if pipe is not None:
             pipe.wait(indices)
         filenames = [output_files[file] for file in input_filenames]
-        for row, filename, frames in zip(indices.cpu().detach(), filenames, batch_frames.cpu()):
-            save_masked(row, filename, frames)
+        rows = indices.cpu().detach()
+        if any(int(count) != 1 for count in batch_chunks):
+            # files that were cut into pieces (torbi_amd/chunk.py): join each file's rows again (core.py:438-448)
+            for joined, filename in zip(_data.separate(rows, batch_chunks, batch_frames.cpu()), filenames):
+                save(joined, filename)
+        else:
+            for row, filename, frames in zip(rows, filenames, batch_frames.cpu()):
+                save_masked(row, filename, frames)
 
     previous = None
     model = {}
@@ -272,7 +283,7 @@ def from_dataloader(
             _model=model)
         if previous is not None:
             finish(previous)
-        previous = (indices, input_filenames, batch_frames)
+        previous = (indices, input_filenames, batch_frames, batch_chunks)
     if previous is not None:
         finish(previous)
 

@@ -40,16 +40,9 @@ __device__ __forceinline__ void scan1(float c, int i, float &best, int &arg) {
 
 // VEC = 4: S % 4 == 0, rows 16-byte aligned -> float4 loads; VEC = 1: any S
 template <int VEC>
-__global__ __launch_bounds__(64) void backtrace_kernel(const float *__restrict__ hist,
-                                                       const float *__restrict__ trans,
-                                                       const int32_t *__restrict__ frames,
-                                                       int32_t *__restrict__ out, int B, int T, int S) {
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x;
-    int f = frames[b];
+__device__ __forceinline__ void backtrace_item(const float *__restrict__ h, const float *__restrict__ trans, int f,
+                                               int32_t *__restrict__ o, int T, int S, int lane) {
     f = f < 1 ? 1 : (f > T ? T : f);
-    const float *h = hist + (size_t)b * T * S;
-    int32_t *o = out + (size_t)b * T;
 
     // final state = first argmax of the last posterior row (viterbi.cpp:218)
     float best = -INFINITY;
@@ -89,6 +82,15 @@ __global__ __launch_bounds__(64) void backtrace_kernel(const float *__restrict__
         j = wave_first_argmax(best, arg);
         if (lane == 0) o[tt - 1] = j;
     }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(64) void backtrace_kernel(const float *__restrict__ hist,
+                                                       const float *__restrict__ trans,
+                                                       const int32_t *__restrict__ frames,
+                                                       int32_t *__restrict__ out, int B, int T, int S) {
+    const int b = blockIdx.x;
+    backtrace_item<VEC>(hist + (size_t)b * T * S, trans, frames[b], out + (size_t)b * T, T, S, threadIdx.x);
 }
 
 // first index (ascending) among this lane's 4*NQ elements whose value equals m, else kSentinel
@@ -132,16 +134,9 @@ __device__ __forceinline__ int wave_first_argmax4(const float4 (&v)[NQ], int lan
 // step's transition row (which does) is in flight; one wave per batch item, lanes own 4 consecutive
 // prev-states per 256-wide stripe.
 template <int NQ>
-__global__ __launch_bounds__(64) void backtrace_prefetch_kernel(const float *__restrict__ hist,
-                                                                const float *__restrict__ trans,
-                                                                const int32_t *__restrict__ frames,
-                                                                int32_t *__restrict__ out, int B, int T, int S) {
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x;
-    int f = frames[b];
+__device__ __forceinline__ void backtrace_prefetch_item(const float *__restrict__ h, const float *__restrict__ trans,
+                                                        int f, int32_t *__restrict__ o, int T, int S, int lane) {
     f = f < 1 ? 1 : (f > T ? T : f);
-    const float *h = hist + (size_t)b * T * S;
-    int32_t *o = out + (size_t)b * T;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 
     float4 cur[NQ], nxt[NQ];
@@ -193,6 +188,15 @@ __global__ __launch_bounds__(64) void backtrace_prefetch_kernel(const float *__r
         j = wave_first_argmax4<NQ>(cand, lane, S);
         if (lane == 0) o[tt - 1] = j;
     }
+}
+
+template <int NQ>
+__global__ __launch_bounds__(64) void backtrace_prefetch_kernel(const float *__restrict__ hist,
+                                                                const float *__restrict__ trans,
+                                                                const int32_t *__restrict__ frames,
+                                                                int32_t *__restrict__ out, int B, int T, int S) {
+    const int b = blockIdx.x;
+    backtrace_prefetch_item<NQ>(hist + (size_t)b * T * S, trans, frames[b], out + (size_t)b * T, T, S, threadIdx.x);
 }
 
 }  // namespace lazy

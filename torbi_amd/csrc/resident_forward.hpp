@@ -1,0 +1,315 @@
+// resident_forward.hpp -- the exact pruned forward recurrence (pruned_forward.hpp) with the TIME LOOP INSIDE the
+// kernel: one workgroup owns 16 batch items x ALL next-states for every timestep of those items.
+//
+// Why: a per-timestep launch of step_pruned_kernel spends 6.9 of its 19.3 us scanning; the rest is what a kernel
+// boundary costs when every state tile needs the whole previous posterior -- re-staging the 92 KB posterior tile
+// from L2 in each of the 8 state tiles (23.6 MB per launch), merging per-tile top lists, waiting for the slowest of
+// 256 workgroups.  Here the 16 items' posterior rows never leave the LDS: a timestep is
+//     barrier -> every wave scans its row groups against the LDS tile (outputs stay in registers, go to hist)
+//     -> barrier -> the outputs overwrite the tile -> next timestep
+// with no inter-workgroup traffic at all (batch items are independent: viterbi.cpp:65, viterbi.cu:58).  The price
+// is parallelism: a 512-item batch is only 32 workgroups, so this path is for MANY items in flight -- several
+// batches decoded by one launch (torbi_hip_viterbi_decode_batches: grid = sum of the batches' tiles), or one
+// batch of >= 2048 items.  Ragged batches cost nothing extra: every workgroup loops to the longest of ITS 16
+// items, not to the batch maximum.
+//
+// Arithmetic, bound and seeds are those of pruned_forward.hpp (same sorted/arranged lists, same transposed
+// matrix), so posterior rows -- and the indices lazy_backtrace.hpp recomputes from them -- are bit-identical.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include <type_traits>
+
+#include "pruned_forward.hpp"
+#include "lazy_backtrace.hpp"
+
+namespace resident {
+
+using pruned::kBlk;
+using pruned::kR;
+using pruned::kTop;
+using pruned::ListBlock;
+using pruned::group_bcast;
+using pruned::load_list_block;
+
+constexpr int kNI = 16;            // batch items per workgroup (4 item groups of 4 per next-state: a lane quad)
+constexpr int kMaxBatches = 16;    // batches one launch can carry
+constexpr int kRowGroup = 16;      // next-states per wave pass (64 lanes / 4 lanes per next-state)
+
+struct Batch {
+    const float *obs;        // (B,T,S)
+    const int32_t *frames;   // (B)
+    float *hist;             // (B,T,S) posterior history of this batch
+    int32_t *out;            // (B,T) decoded indices (backtrace)
+    int B, T;
+    int tile0;               // first workgroup of this batch in the launch
+    int item0;               // first item of this batch in the launch-wide item numbering (backtrace grid)
+};
+
+struct Group {
+    Batch batch[kMaxBatches];
+    int n;
+};
+
+inline bool supported(int S) { return S >= 64 && S <= pruned::kMaxS16; }
+
+typedef unsigned long long u64;
+
+// dynamic LDS: posterior tile [S4][16] + running top lists (64-bit keys) + decoded top lists + frame counts
+inline size_t lds_bytes(int S) {
+    const size_t S4 = ((size_t)S + 3) / 4 * 4;
+    return sizeof(float) * kNI * S4 + sizeof(u64) * kNI * kTop + (sizeof(float) + sizeof(int)) * kNI * kTop +
+           sizeof(int) * kNI;
+}
+
+// order-preserving 64-bit key of (value, state): larger value first, then the lower state
+__device__ __forceinline__ u64 top_key(float v, int state) {
+    unsigned u = __float_as_uint(v);
+    u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
+    return ((u64)u << 32) | (unsigned)(0x7fffffff - state);
+}
+
+// insert into a kTop-entry list kept in descending order by a cascade of LDS atomic maxima: the displaced key
+// moves one rank down, so every rank ends with the maximum of what passed through it
+__device__ __forceinline__ void top_insert(u64 *list, u64 x) {
+    if (x <= list[kTop - 1]) return;
+#pragma unroll
+    for (int r = 0; r < kTop; ++r) {
+        if (x != 0ull) {
+            const u64 old = atomicMax(&list[r], x);
+            x = old < x ? old : x;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The whole forward pass of 16 items.  grid = tiles of every batch of the group, block = 64 * KW,
+// dynamic LDS = lds_bytes(S).  MAXP = ceil(ceil(S/16) / KW) row-group passes per wave and timestep.
+// ---------------------------------------------------------------------------------------
+template <int KW, int MAXP>
+__global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, const float *__restrict__ tt,
+                                                                   const float2 *__restrict__ sorted,
+                                                                   const float *__restrict__ initial, int S, int SpP) {
+    constexpr int G = 4, EPL = kBlk / G;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int S4 = (S + 3) / 4 * 4;
+    u64 *top = reinterpret_cast<u64 *>(lds + (size_t)kNI * S4);       // [16][kTop] this timestep's largest outputs
+    float *mtopv = reinterpret_cast<float *>(top + kNI * kTop);       // [16][kTop] previous timestep's, decoded
+    int *mtopi = reinterpret_cast<int *>(mtopv + kNI * kTop);         // their states, as offsets into tt (state * S)
+    int *sframes = mtopi + kNI * kTop;                                // [16] frames per item (0 past the batch)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // which batch this workgroup belongs to
+    int k = 0;
+#pragma unroll 1
+    for (int q = 1; q < grp.n; ++q)
+        if ((int)blockIdx.x >= grp.batch[q].tile0) k = q;
+    const Batch &bat = grp.batch[k];
+    const float *__restrict__ obs = bat.obs;
+    float *__restrict__ hist = bat.hist;
+    const int B = bat.B, T = bat.T;
+    const int b0 = ((int)blockIdx.x - bat.tile0) * kNI;
+
+    if (tid < kNI) {
+        int f = 0;
+        if (b0 + tid < B) {
+            f = bat.frames[b0 + tid];
+            f = f < 1 ? 1 : (f > T ? T : f);
+        }
+        sframes[tid] = f;
+    }
+    if (tid < kNI * kTop) top[tid] = 0ull;
+    __syncthreads();
+    int fmax = 0;
+#pragma unroll
+    for (int it = 0; it < kNI; ++it) fmax = max(fmax, sframes[it]);
+
+    // t = 0: posterior row 0 = obs[b,0,:] + initial (viterbi.cpp:72-76) into the tile, the history and the top lists
+    for (int item = 0; item < kNI; ++item) {
+        const int b = b0 + item < B ? b0 + item : B - 1;
+        const bool valid = b0 + item < B;
+        const float *src = obs + (size_t)b * T * S;
+        float *dst = hist + (size_t)b * T * S;
+        for (int i = tid; i < S; i += 64 * KW) {
+            const float v = src[i] + initial[i];
+            lds[i * kNI + item] = v;
+            if (valid) dst[i] = v;
+            top_insert(top + item * kTop, top_key(v, i));
+        }
+    }
+
+    // lane = next-state jl of the wave's 16 x item group g; quads of lanes -> next-states so that every
+    // ds_read_b128 lane group holds an aligned row quad (as in pruned::step_pruned_kernel)
+    const int g = lane & 3;
+    const int jl = (int)((0xFBAE9DC873261540ull >> (4 * (lane >> 2))) & 15);
+    const char *ptile = reinterpret_cast<const char *>(lds) + 16 * g;
+    const int nrg = (S + kRowGroup - 1) / kRowGroup;
+    const size_t istride = (size_t)T * S;
+    // items of this lane: 4g .. 4g+3; items past the batch read the last one's observations and store nothing
+    const int bfirst = b0 + 4 * g < B ? b0 + 4 * g : B - 1;
+    int ioff[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) ioff[it] = bfirst + it < B ? it : B - 1 - bfirst;
+
+    float pend[MAXP][4];
+
+    // publish the largest entries of the row the tile holds (decoded; states as offsets into tt) and empty the
+    // running lists for the next row's outputs
+    auto publish_top = [&]() {
+        if (tid < kNI * kTop) {
+            const u64 key = top[tid];
+            unsigned u = (unsigned)(key >> 32);
+            u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;
+            mtopv[tid] = key ? __uint_as_float(u) : -INFINITY;
+            mtopi[tid] = key ? (0x7fffffff - (int)(unsigned)key) * S : 0;
+            top[tid] = 0ull;
+        }
+    };
+    __syncthreads();
+    publish_top();
+
+    for (int t = 1; t < fmax; ++t) {
+        __syncthreads();      // tile = posterior row t-1, mtop = its largest entries, `top` is empty
+
+        // seeds and bound of this lane's four items: the kR largest posteriors are explicit candidates, the
+        // (kR+1)-th bounds every other one.  Items that have ended (t >= frames) get thr = -inf: their bound
+        // never asks for another list block.
+        float seedv[4][kR], thr[4];
+        int seedo[4][kR];
+        bool live[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = 4 * g + it;
+            live[it] = t < sframes[item];
+            const float4 v = *reinterpret_cast<const float4 *>(mtopv + item * kTop);
+            const int4 o = *reinterpret_cast<const int4 *>(mtopi + item * kTop);
+            seedv[it][0] = v.x; seedv[it][1] = v.y; seedv[it][2] = v.z;
+            seedo[it][0] = o.x; seedo[it][1] = o.y; seedo[it][2] = o.z;
+            thr[it] = live[it] ? v.w : -INFINITY;
+        }
+
+        // (an opaque zero keeps the row-group addresses of all MAXP passes from being hoisted out of the time loop,
+        // where they would cost ~10 registers per pass)
+        int opaque = 0;
+        asm volatile("" : "+s"(opaque));
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) {
+            const int rg = wave + KW * p + opaque;          // wave-uniform
+            if (rg < nrg) {
+                const int jj = kRowGroup * rg + jl;
+                const bool jv = jj < S;
+                const int jr = jv ? jj : S - 1;
+                const float2 *row = sorted + (size_t)jr * SpP + EPL * g;
+                ListBlock<EPL> cur, nxt;
+                load_list_block(cur, row, 0);
+                load_list_block(nxt, row, kBlk);
+                float ob[4];
+                {
+                    const float *osrc = obs + ((size_t)bfirst * T + t) * S + jr;
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) ob[it] = osrc[ioff[it] * istride];
+                }
+                float seedt[4][kR];
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+#pragma unroll
+                    for (int r = 0; r < kR; ++r) seedt[it][r] = tt[(unsigned)(seedo[it][r] + jr)];   // trans[jr][i_r]
+
+                float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                auto pair = [&](float t0, int o0, float t1, int o1) {
+                    asm volatile("" : "+v"(t0), "+v"(t1));     // keep the broadcasts out of the adds (half-rate DPP adds)
+                    const float4 p0 = *reinterpret_cast<const float4 *>(ptile + o0);
+                    const float4 p1 = *reinterpret_cast<const float4 *>(ptile + o1);
+                    best[0] = fmaxf(fmaxf(best[0], t0 + p0.x), t1 + p1.x);
+                    best[1] = fmaxf(fmaxf(best[1], t0 + p0.y), t1 + p1.y);
+                    best[2] = fmaxf(fmaxf(best[2], t0 + p0.z), t1 + p1.z);
+                    best[3] = fmaxf(fmaxf(best[3], t0 + p0.w), t1 + p1.w);
+                };
+                auto owner = [&](auto Oc, const ListBlock<EPL> &blk) {
+                    constexpr int O = decltype(Oc)::value;
+#pragma unroll
+                    for (int h = 0; h < EPL / 2; ++h)
+                        pair(group_bcast<G, O>(blk.e[h].x), group_bcast<G, O>(__float_as_int(blk.e[h].y)),
+                             group_bcast<G, O>(blk.e[h].z), group_bcast<G, O>(__float_as_int(blk.e[h].w)));
+                };
+                auto consume = [&](const ListBlock<EPL> &blk) {
+                    owner(std::integral_constant<int, 0>(), blk);
+                    owner(std::integral_constant<int, 1>(), blk);
+                    owner(std::integral_constant<int, 2>(), blk);
+                    owner(std::integral_constant<int, 3>(), blk);
+                };
+                consume(cur);
+                load_list_block(cur, row, 2 * kBlk);
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+#pragma unroll
+                    for (int r = 0; r < kR; ++r) best[it] = fmaxf(best[it], seedv[it][r] + seedt[it][r]);
+                auto more = [&](const ListBlock<EPL> &blk) {
+                    const float tn = group_bcast<G, 0>(blk.e[0].x);
+                    return __any(jv && ((tn + thr[0] > best[0]) | (tn + thr[1] > best[1]) | (tn + thr[2] > best[2]) |
+                                        (tn + thr[3] > best[3])));
+                };
+                const int Sp = (S + 15) / 16 * 16;
+                for (int kk = kBlk; kk < Sp; kk += 2 * kBlk) {
+                    if (!more(nxt)) break;
+                    consume(nxt);
+                    load_list_block(nxt, row, kk + 2 * kBlk);
+                    if (!more(cur)) break;
+                    consume(cur);
+                    load_list_block(cur, row, kk + 3 * kBlk);
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const float o = ob[it] + best[it];                     // post'[j] = obs[t,j] + max
+                    pend[p][it] = o;
+                    if (jv && live[it]) hist[((size_t)(bfirst + ioff[it]) * T + t) * S + jr] = o;
+                    if (jv) top_insert(top + (4 * g + it) * kTop, top_key(o, jr));
+                }
+            }
+        }
+        __syncthreads();      // every wave is done reading the tile and mtop, every output is in `top`
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) {
+            const int rg = wave + KW * p + opaque;
+            const int jj = kRowGroup * rg + jl;
+            if (rg < nrg && jj < S)
+                *reinterpret_cast<float4 *>(lds + (size_t)jj * kNI + 4 * g) =
+                    make_float4(pend[p][0], pend[p][1], pend[p][2], pend[p][3]);
+        }
+        publish_top();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// final state, tail fill and lazy backtrace (lazy_backtrace.hpp) for every item of every batch of the group in
+// ONE launch: grid = items of the whole group, one wave per item.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int batch_of_item(const Group &grp, int item) {
+    int k = 0;
+#pragma unroll 1
+    for (int q = 1; q < grp.n; ++q)
+        if (item >= grp.batch[q].item0) k = q;
+    return k;
+}
+
+template <int NQ>
+__global__ __launch_bounds__(64) void group_backtrace_prefetch_kernel(Group grp, const float *__restrict__ trans, int S) {
+    const Batch &bat = grp.batch[batch_of_item(grp, blockIdx.x)];
+    const int b = (int)blockIdx.x - bat.item0;
+    lazy::backtrace_prefetch_item<NQ>(bat.hist + (size_t)b * bat.T * S, trans, bat.frames[b], bat.out + (size_t)b * bat.T,
+                                      bat.T, S, threadIdx.x);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(64) void group_backtrace_kernel(Group grp, const float *__restrict__ trans, int S) {
+    const Batch &bat = grp.batch[batch_of_item(grp, blockIdx.x)];
+    const int b = (int)blockIdx.x - bat.item0;
+    lazy::backtrace_item<VEC>(bat.hist + (size_t)b * bat.T * S, trans, bat.frames[b], bat.out + (size_t)b * bat.T, bat.T, S,
+                              threadIdx.x);
+}
+
+}  // namespace resident

@@ -16,6 +16,7 @@
 // See DESIGN.md for the roofline analysis and kernel inventory.
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <atomic>
 #include <stdint.h>
 #include <stddef.h>
@@ -27,6 +28,7 @@
 #include "lazy_backtrace.hpp"
 #include "uniform_decode.hpp"
 #include "pruned_forward.hpp"
+#include "resident_forward.hpp"
 
 namespace {
 
@@ -37,23 +39,6 @@ constexpr int kWave = 64;
 // ---------------------------------------------------------------------------------------
 
 __host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-
-struct Workspace {
-    float *post[2];     // (B,S) ping-pong posterior rows
-    int32_t *trellis;   // (B,T,S) backpointers; rows t >= 1 of valid frames are written
-    size_t bytes;
-};
-
-inline Workspace carve(void *base, int B, int T, int S) {
-    Workspace w;
-    char *p = static_cast<char *>(base);
-    const size_t post_bytes = align_up(sizeof(float) * (size_t)B * S, 256);
-    w.post[0] = reinterpret_cast<float *>(p);
-    w.post[1] = reinterpret_cast<float *>(p + post_bytes);
-    w.trellis = reinterpret_cast<int32_t *>(p + 2 * post_bytes);
-    w.bytes = 2 * post_bytes + align_up(sizeof(int32_t) * (size_t)B * T * S, 256);
-    return w;
-}
 
 // (value, index) comparator of the reference CPU scan (viterbi.cpp:94-100): a candidate
 // replaces the incumbent only if strictly greater; among equal values the lower index wins.
@@ -401,76 +386,157 @@ struct DeviceGuard {
     }
 };
 
-constexpr int kNumCUs = 256;   // MI355X; the tiling plan is a pure function of (B, S)
+// Compute units of a device (tiling plans are functions of (B, S, CUs)); queried once per device.
+constexpr int kMaxDevices = 64;
+std::atomic<int> g_cus[kMaxDevices];
+inline int cu_count(int device) {
+    if (device < 0 || device >= kMaxDevices) return 256;
+    int v = g_cus[device].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0) n = 256;
+    g_cus[device].store(n, std::memory_order_relaxed);
+    return n;
+}
 
-// Path selection.  Large batches run the value-only (max,+) GEMM + lazy backtrace
-// (dense_forward.hpp / lazy_backtrace.hpp); small batches and tiny state spaces run the generic
-// kernels above, which materialise the int32 trellis like the reference does.
+// Which forward recurrence runs.  GENERIC materialises the int32 trellis like the reference does; the other three
+// keep the posterior history and recompute backpointers along the decoded path (lazy_backtrace.hpp).
+enum Route { ROUTE_GENERIC = 0, ROUTE_DENSE = 1, ROUTE_PRUNED = 2, ROUTE_RESIDENT = 3 };
+
 inline bool use_dense(int B, int S) { return B >= 32 && S >= 64; }
 
-// Forward-pass selection among the value-only paths: TORBI_HIP_FORWARD_AUTO picks the exact pruned
-// recurrence (pruned_forward.hpp) wherever it is supported and the dense (max,+) GEMM elsewhere;
-// torbi_hip_set_forward_path / the TORBI_HIP_FORWARD environment variable ("dense", "pruned") force one.
+// process-wide default path: torbi_hip_set_forward_path / TORBI_HIP_FORWARD=dense|pruned|resident (read once).
+// A call that carries a path in its flags ignores it.
 std::atomic<int> g_forward_path{-1};
-inline int forward_path() {
+inline int default_path() {
     int v = g_forward_path.load(std::memory_order_relaxed);
     if (v < 0) {
         const char *e = getenv("TORBI_HIP_FORWARD");
         v = !e ? TORBI_HIP_FORWARD_AUTO
-               : e[0] == 'd' ? TORBI_HIP_FORWARD_DENSE : e[0] == 'p' ? TORBI_HIP_FORWARD_PRUNED : TORBI_HIP_FORWARD_AUTO;
+               : e[0] == 'd' ? TORBI_HIP_FORWARD_DENSE
+               : e[0] == 'p' ? TORBI_HIP_FORWARD_PRUNED
+               : e[0] == 'r' ? TORBI_HIP_FORWARD_RESIDENT : TORBI_HIP_FORWARD_AUTO;
         g_forward_path.store(v, std::memory_order_relaxed);
     }
     return v;
 }
-inline bool use_pruned(int B, int S) {
-    return forward_path() != TORBI_HIP_FORWARD_DENSE && pruned::supported(B, S);
+// path carried by the flags of a call ((path + 1) << 4), else the process default
+inline int requested_path(unsigned flags) {
+    const unsigned f = (flags >> 4) & 7u;
+    return f ? (int)f - 1 : default_path();
+}
+constexpr unsigned kKnownFlags = TORBI_HIP_REUSE_TRANSITION | TORBI_HIP_COLLECT_STATS | (7u << 4);
+inline bool flags_ok(unsigned flags) {
+    return !(flags & ~kKnownFlags) && ((flags >> 4) & 7u) <= (unsigned)TORBI_HIP_FORWARD_RESIDENT + 1u;
+}
+
+inline int tiles_of(int B) { return (B + resident::kNI - 1) / resident::kNI; }
+
+// route of ONE batch.  AUTO: the time-resident kernel when the batch alone gives at least half the CUs a
+// workgroup, else the per-timestep pruned pass where supported, else the dense (max,+) GEMM, else generic.
+inline Route route_for(int path, int B, int S, int cus) {
+    if (path == TORBI_HIP_FORWARD_RESIDENT && resident::supported(S)) return ROUTE_RESIDENT;
+    if (path == TORBI_HIP_FORWARD_AUTO && resident::supported(S) && 2 * tiles_of(B) >= cus) return ROUTE_RESIDENT;
+    if (path != TORBI_HIP_FORWARD_DENSE && pruned::supported(B, S)) return ROUTE_PRUNED;
+    return use_dense(B, S) ? ROUTE_DENSE : ROUTE_GENERIC;
+}
+
+// ---- workspace layouts: the (B,T,S) history / trellis first, the per-transition preparation behind it ---------
+inline size_t history_bytes(int B, int T, int S) { return align_up(sizeof(float) * (size_t)B * T * S, 256); }
+
+struct Workspace {
+    float *post[2];     // (B,S) ping-pong posterior rows
+    int32_t *trellis;   // (B,T,S) backpointers; rows t >= 1 of valid frames are written
+    size_t bytes;
+};
+
+inline Workspace carve(void *base, int B, int T, int S) {
+    Workspace w;
+    char *p = static_cast<char *>(base);
+    const size_t post_bytes = align_up(sizeof(float) * (size_t)B * S, 256);
+    w.trellis = reinterpret_cast<int32_t *>(p);
+    w.post[0] = reinterpret_cast<float *>(p + history_bytes(B, T, S));
+    w.post[1] = reinterpret_cast<float *>(p + history_bytes(B, T, S) + post_bytes);
+    w.bytes = history_bytes(B, T, S) + 2 * post_bytes;
+    return w;
 }
 
 struct PrunedWorkspace {
     pruned::Plan plan;
+    float *hist;       // [B][T][S] posterior history
     float2 *sorted;    // [S][SpP] transition rows in descending order: {t, prev-state byte offset}
     float *tt;         // [S][S]   transposed transition matrix
     int32_t *row_range;  // [S][2]    finite prev-state range of every transition row
     int32_t *tile_range; // [n_jt][2] prev-state range (units of 4) each state tile stages
     unsigned *stats;     // [128]     scan statistics of the last decode (torbi_hip_scan_stats)
-    float *topv;       // [2][n_jt][B][6] partial top lists (values), ping-pong by timestep parity
-    int32_t *topi;     // [2][n_jt][B][6] their prev-states
+    float *topv;       // [2][n_jt][B][kTop] partial top lists (values), ping-pong by timestep parity
+    int32_t *topi;     // [2][n_jt][B][kTop] their prev-states
     size_t top_stride; // elements per parity
-    float *hist;       // [B][T][S] posterior history
-    size_t top_bytes;
     size_t bytes;
 };
 
-inline PrunedWorkspace carve_pruned(void *base, int B, int T, int S) {
+inline PrunedWorkspace carve_pruned(void *base, int B, int T, int S, int cus) {
     PrunedWorkspace w;
-    w.plan = pruned::make_plan(B, S, kNumCUs);
+    w.plan = pruned::make_plan(B, S, cus);
     char *p = static_cast<char *>(base);
+    const size_t hist_bytes = history_bytes(B, T, S);
     const size_t sorted_bytes = align_up(sizeof(float2) * (size_t)S * w.plan.SpP, 256);
     const size_t tt_bytes = align_up(sizeof(float) * (size_t)S * S, 256);
-    w.top_stride = (size_t)w.plan.n_jt * B * pruned::kTop;
-    const size_t topv_bytes = align_up(sizeof(float) * 2 * w.top_stride, 256);
-    const size_t topi_bytes = align_up(sizeof(int32_t) * 2 * w.top_stride, 256);
     const size_t range_bytes = align_up(sizeof(int32_t) * 2 * ((size_t)S + pruned::kMaxJT), 256) + 512;
+    w.top_stride = (size_t)w.plan.n_jt * B * pruned::kTop;
+    // sized for the largest plan (kMaxJT state tiles) so the byte count does not depend on the device's CU count
+    const size_t top_cap = (size_t)pruned::kMaxJT * B * pruned::kTop;
+    const size_t topv_bytes = align_up(sizeof(float) * 2 * top_cap, 256);
+    const size_t topi_bytes = align_up(sizeof(int32_t) * 2 * top_cap, 256);
+    w.hist = reinterpret_cast<float *>(p);
+    p += hist_bytes;
     w.sorted = reinterpret_cast<float2 *>(p);
     w.tt = reinterpret_cast<float *>(p + sorted_bytes);
-    w.topv = reinterpret_cast<float *>(p + sorted_bytes + tt_bytes);
-    w.topi = reinterpret_cast<int32_t *>(p + sorted_bytes + tt_bytes + topv_bytes);
-    w.row_range = reinterpret_cast<int32_t *>(p + sorted_bytes + tt_bytes + topv_bytes + topi_bytes);
+    w.row_range = reinterpret_cast<int32_t *>(p + sorted_bytes + tt_bytes);
     w.tile_range = w.row_range + 2 * (size_t)S;
-    w.stats = reinterpret_cast<unsigned *>(p + sorted_bytes + tt_bytes + topv_bytes + topi_bytes + range_bytes - 512);
-    w.hist = reinterpret_cast<float *>(p + sorted_bytes + tt_bytes + topv_bytes + topi_bytes + range_bytes);
-    w.top_bytes = topv_bytes + topi_bytes;
-    w.bytes = sorted_bytes + tt_bytes + topv_bytes + topi_bytes + range_bytes +
-              align_up(sizeof(float) * (size_t)B * T * S, 256);
+    w.stats = reinterpret_cast<unsigned *>(p + sorted_bytes + tt_bytes + range_bytes - 512);
+    w.topv = reinterpret_cast<float *>(p + sorted_bytes + tt_bytes + range_bytes);
+    w.topi = reinterpret_cast<int32_t *>(p + sorted_bytes + tt_bytes + range_bytes + topv_bytes);
+    w.bytes = hist_bytes + sorted_bytes + tt_bytes + range_bytes + topv_bytes + topi_bytes;
+    return w;
+}
+
+// the time-resident path shares the sorted lists / transposed matrix layout of the pruned path (16-item tiles)
+struct ResidentWorkspace {
+    float *hist;
+    float2 *sorted;
+    float *tt;
+    int32_t *row_range;
+    int SpP, NPOW;
+    size_t bytes;
+};
+
+inline ResidentWorkspace carve_resident(void *base, int B, int T, int S) {
+    ResidentWorkspace w;
+    char *p = static_cast<char *>(base);
+    const int Sp = (S + 15) / 16 * 16;
+    w.SpP = Sp + pruned::kPad;
+    w.NPOW = 64;
+    while (w.NPOW < S) w.NPOW *= 2;
+    const size_t hist_bytes = history_bytes(B, T, S);
+    const size_t sorted_bytes = align_up(sizeof(float2) * (size_t)S * w.SpP, 256);
+    const size_t tt_bytes = align_up(sizeof(float) * (size_t)S * S, 256);
+    const size_t range_bytes = align_up(sizeof(int32_t) * 2 * (size_t)S, 256);
+    w.hist = reinterpret_cast<float *>(p);
+    p += hist_bytes;
+    w.sorted = reinterpret_cast<float2 *>(p);
+    w.tt = reinterpret_cast<float *>(p + sorted_bytes);
+    w.row_range = reinterpret_cast<int32_t *>(p + sorted_bytes + tt_bytes);
+    w.bytes = hist_bytes + sorted_bytes + tt_bytes + range_bytes;
     return w;
 }
 
 struct DenseWorkspace {
     dense::Plan plan;
+    float *hist;       // [B][T][S]      posterior history (replaces the int32 trellis)
     float *panel[2];   // [n_bt][Kp][BT] posterior panels (ping-pong)
     float *trp;        // [n_jt][Kp][W]  packed transition panels
     int32_t *chunks;   // [n_jt][NCH+1]  per-tile lists of chunks that are not all -inf
-    float *hist;       // [B][T][S]      posterior history (replaces the int32 trellis)
     size_t bytes;
 };
 
@@ -494,29 +560,53 @@ inline int nw_override() {
     return v;
 }
 
-inline DenseWorkspace carve_dense(void *base, int B, int T, int S) {
+inline DenseWorkspace carve_dense(void *base, int B, int T, int S, int cus) {
     DenseWorkspace w;
-    w.plan = dense::make_plan(B, S, kNumCUs, bl_override(), nw_override());
+    w.plan = dense::make_plan(B, S, cus, bl_override(), nw_override());
     char *p = static_cast<char *>(base);
     const size_t panel_bytes = align_up(sizeof(float) * (size_t)w.plan.n_bt * w.plan.Kp * w.plan.BT, 256);
     const size_t trp_bytes = align_up(sizeof(float) * (size_t)w.plan.n_jt * w.plan.Kp * w.plan.W, 256);
+    const size_t list_bytes = align_up(sizeof(int32_t) * (size_t)w.plan.n_jt * (w.plan.NCH + 1), 256);
+    w.hist = reinterpret_cast<float *>(p);
+    p += history_bytes(B, T, S);
     w.panel[0] = reinterpret_cast<float *>(p);
     w.panel[1] = reinterpret_cast<float *>(p + panel_bytes);
     w.trp = reinterpret_cast<float *>(p + 2 * panel_bytes);
-    const size_t list_bytes = align_up(sizeof(int32_t) * (size_t)w.plan.n_jt * (w.plan.NCH + 1), 256);
     w.chunks = reinterpret_cast<int32_t *>(p + 2 * panel_bytes + trp_bytes);
-    w.hist = reinterpret_cast<float *>(p + 2 * panel_bytes + trp_bytes + list_bytes);
-    w.bytes = 2 * panel_bytes + trp_bytes + list_bytes + align_up(sizeof(float) * (size_t)B * T * S, 256);
+    w.bytes = history_bytes(B, T, S) + 2 * panel_bytes + trp_bytes + list_bytes;
     return w;
 }
 
+// scratch a (B,T,S) problem needs on a device with `cus` compute units, whichever path runs
+inline size_t need_bytes(int B, int T, int S, int cus) {
+    size_t need = carve(nullptr, B, T, S).bytes;
+    if (use_dense(B, S)) need = std::max(need, carve_dense(nullptr, B, T, S, cus).bytes);
+    if (pruned::supported(B, S)) need = std::max(need, carve_pruned(nullptr, B, T, S, cus).bytes);
+    if (resident::supported(S)) need = std::max(need, carve_resident(nullptr, B, T, S).bytes);
+    return need;
+}
+
+// ... on the device with the most demanding plan (devices of one node are normally identical)
+inline size_t need_bytes_any_device(int B, int T, int S) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return need_bytes(B, T, S, 256);
+    size_t need = 0;
+    for (int d = 0; d < n && d < kMaxDevices; ++d) {
+        const int cus = cu_count(d);
+        bool seen = false;
+        for (int e = 0; e < d; ++e) seen = seen || cu_count(e) == cus;
+        if (!seen) need = std::max(need, need_bytes(B, T, S, cus));
+    }
+    return need;
+}
+
 int check_args(const void *a, const void *b, const void *c, const void *d, const void *e,
-               const void *ws, size_t ws_bytes, int B, int T, int S) {
+               const void *ws, size_t ws_bytes, int B, int T, int S, int device) {
     if (B < 0 || T < 1 || S < 1) return TORBI_HIP_EINVAL;
     if (B == 0) return TORBI_HIP_OK;
     if (!a || !b || !c || !d || !e || !ws) return TORBI_HIP_EINVAL;
     if ((size_t)B * T * S > (size_t)1 << 40) return TORBI_HIP_ERANGE;
-    if (ws_bytes < torbi_hip_workspace_bytes(B, T, S)) return TORBI_HIP_EWORKSPACE;
+    if (ws_bytes < need_bytes(B, T, S, cu_count(device))) return TORBI_HIP_EWORKSPACE;
     return TORBI_HIP_OK;
 }
 
@@ -618,27 +708,31 @@ hipError_t launch_dense_forward(const float *obs, const int32_t *frames, const f
     return hipErrorInvalidValue;
 }
 
+// per-transition preparation shared by the pruned and the time-resident paths: descending rows with their
+// prev-states as byte offsets into a [prev-state][items] posterior tile, block arrangement, transposed copy
+void launch_list_preparation(const float *trans, float2 *sorted, int32_t *row_range, float *tt, int S, int SpP, int NPOW,
+                             int items_per_tile, hipStream_t stream) {
+    hipLaunchKernelGGL(pruned::sort_rows_kernel, dim3(S), dim3(256), sizeof(float) * 2 * (size_t)NPOW, stream, trans,
+                       sorted, row_range, S, SpP, NPOW, items_per_tile * 4);
+    if (items_per_tile == pruned::kNB) {
+        const int n = (S / 4) * (SpP / pruned::kBlk);
+        hipLaunchKernelGGL(pruned::arrange_blocks_kernel<4>, dim3((n + 63) / 64), dim3(64), 0, stream, sorted, S, SpP);
+    } else {
+        const int n = (S / 8) * (SpP / pruned::kBlk);
+        hipLaunchKernelGGL(pruned::arrange_blocks_kernel<8>, dim3((n + 63) / 64), dim3(64), 0, stream, sorted, S, SpP);
+    }
+    hipLaunchKernelGGL(pruned::transpose_kernel, dim3((S + 31) / 32, (S + 31) / 32), dim3(256), 0, stream, trans, tt, S);
+}
+
 hipError_t launch_pruned_forward(const float *obs, const int32_t *frames, const float *trans,
                                  const float *init, const PrunedWorkspace &w, int B, int T, int S,
                                  hipStream_t stream, int *launches, bool reuse, bool collect) {
     const pruned::Plan &pl = w.plan;
     unsigned *const stats = collect ? w.stats : nullptr;
-    if (!reuse) {      // per-transition preparation: sorted + arranged lists, row/tile ranges, transposed copy
-        hipLaunchKernelGGL(pruned::sort_rows_kernel, dim3(S), dim3(256), sizeof(float) * 2 * (size_t)pl.NPOW, stream,
-                           trans, w.sorted, w.row_range, S, pl.SpP, pl.NPOW, pl.NI * 4);
+    if (!reuse) {
+        launch_list_preparation(trans, w.sorted, w.row_range, w.tt, S, pl.SpP, pl.NPOW, pl.NI, stream);
         hipLaunchKernelGGL(pruned::tile_range_kernel, dim3(pl.n_jt), dim3(64), 0, stream, w.row_range, w.tile_range, S,
                            pl.JT);
-        if (pl.NI == pruned::kNB) {
-            const int n = (S / 4) * (pl.SpP / pruned::kBlk);
-            hipLaunchKernelGGL(pruned::arrange_blocks_kernel<4>, dim3((n + 63) / 64), dim3(64), 0, stream, w.sorted, S,
-                               pl.SpP);
-        } else {
-            const int n = (S / 8) * (pl.SpP / pruned::kBlk);
-            hipLaunchKernelGGL(pruned::arrange_blocks_kernel<8>, dim3((n + 63) / 64), dim3(64), 0, stream, w.sorted, S,
-                               pl.SpP);
-        }
-        hipLaunchKernelGGL(pruned::transpose_kernel, dim3((S + 31) / 32, (S + 31) / 32), dim3(256), 0, stream, trans,
-                           w.tt, S);
     }
     {
         const size_t n = (size_t)B * S;
@@ -684,9 +778,6 @@ hipError_t launch_pruned_forward(const float *obs, const int32_t *frames, const 
 }
 
 hipError_t launch_backtrace_on(const float *hist, const float *trans, const int32_t *frames, int32_t *out,
-                               int B, int T, int S, hipStream_t stream);
-
-hipError_t launch_backtrace_on(const float *hist, const float *trans, const int32_t *frames, int32_t *out,
                                int B, int T, int S, hipStream_t stream) {
     const bool vec = (S % 4 == 0) && ((reinterpret_cast<uintptr_t>(trans) & 15) == 0);
     if (vec && S <= 256 * 16) {
@@ -710,27 +801,94 @@ hipError_t launch_backtrace_on(const float *hist, const float *trans, const int3
     return hipGetLastError();
 }
 
-hipError_t launch_dense_backtrace(const float *trans, const int32_t *frames, const DenseWorkspace &w,
-                                  int32_t *out, int B, int T, int S, hipStream_t stream) {
-    return launch_backtrace_on(w.hist, trans, frames, out, B, T, S, stream);
+// ---- time-resident path: several batches, one forward launch, one backtrace launch -------------------------
+struct HostBatch {
+    const float *obs;
+    const int32_t *frames;
+    int32_t *out;
+    void *workspace;
+    int B, T;
+};
+
+template <int KW, int MAXP>
+hipError_t launch_resident_kernel(const resident::Group &grp, int tiles, const ResidentWorkspace &w, const float *init,
+                                  int S, hipStream_t stream) {
+    const size_t lds = resident::lds_bytes(S);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resident::resident_forward_kernel<KW, MAXP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((resident::resident_forward_kernel<KW, MAXP>), dim3(tiles), dim3(64 * KW), lds, stream, grp, w.tt,
+                       w.sorted, init, S, w.SpP);
+    return hipGetLastError();
 }
 
-// one decode on `s`; optional events bracket the forward and backtrace phases
-hipError_t run_decode(const float *obs, const int32_t *frames, const float *trans, const float *init,
-                      int32_t *out, void *workspace, int B, int T, int S, hipStream_t s,
-                      hipEvent_t *ev, int *launches, bool reuse, bool collect = false) {
-    hipError_t e;
+// batches with B > 0 only; the preparation lives in the first batch's workspace
+hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const float *init, int S, hipStream_t s,
+                        hipEvent_t *ev, int *launches, bool reuse) {
+    resident::Group grp{};
+    grp.n = n;
+    int tiles = 0, items = 0;
+    for (int k = 0; k < n; ++k) {
+        resident::Batch &b = grp.batch[k];
+        b.obs = hb[k].obs;
+        b.frames = hb[k].frames;
+        b.out = hb[k].out;
+        b.hist = carve_resident(hb[k].workspace, hb[k].B, hb[k].T, S).hist;
+        b.B = hb[k].B;
+        b.T = hb[k].T;
+        b.tile0 = tiles;
+        b.item0 = items;
+        tiles += tiles_of(hb[k].B);
+        items += hb[k].B;
+    }
+    const ResidentWorkspace w = carve_resident(hb[0].workspace, hb[0].B, hb[0].T, S);
     if (ev) (void)hipEventRecord(ev[0], s);
-    if (use_pruned(B, S)) {
-        const PrunedWorkspace w = carve_pruned(workspace, B, T, S);
+    if (!reuse) launch_list_preparation(trans, w.sorted, w.row_range, w.tt, S, w.SpP, w.NPOW, resident::kNI, s);
+    if (ev) (void)hipEventRecord(ev[3], s);
+    hipError_t e;
+    const int nrg = (S + resident::kRowGroup - 1) / resident::kRowGroup;
+    if (nrg <= 72) e = launch_resident_kernel<12, 6>(grp, tiles, w, init, S, s);
+    else if (nrg <= 96) e = launch_resident_kernel<12, 8>(grp, tiles, w, init, S, s);
+    else e = launch_resident_kernel<12, 11>(grp, tiles, w, init, S, s);
+    if (launches) *launches = 1;
+    if (ev) (void)hipEventRecord(ev[1], s);
+    if (e != hipSuccess) return e;
+    const bool vec = (S % 4 == 0) && ((reinterpret_cast<uintptr_t>(trans) & 15) == 0);
+    if (vec && S <= 512)
+        hipLaunchKernelGGL(resident::group_backtrace_prefetch_kernel<2>, dim3(items), dim3(64), 0, s, grp, trans, S);
+    else if (vec && S <= 1536)
+        hipLaunchKernelGGL(resident::group_backtrace_prefetch_kernel<6>, dim3(items), dim3(64), 0, s, grp, trans, S);
+    else if (vec)
+        hipLaunchKernelGGL(resident::group_backtrace_prefetch_kernel<8>, dim3(items), dim3(64), 0, s, grp, trans, S);
+    else
+        hipLaunchKernelGGL(resident::group_backtrace_kernel<1>, dim3(items), dim3(64), 0, s, grp, trans, S);
+    if (ev) (void)hipEventRecord(ev[2], s);
+    return hipGetLastError();
+}
+
+// one decode on `s`; optional events bracket the forward and backtrace phases (ev[3]: end of the preparation)
+hipError_t run_decode(const float *obs, const int32_t *frames, const float *trans, const float *init,
+                      int32_t *out, void *workspace, int B, int T, int S, int device, hipStream_t s,
+                      hipEvent_t *ev, int *launches, bool reuse, bool collect, int path) {
+    hipError_t e;
+    const int cus = cu_count(device);
+    const Route route = route_for(path, B, S, cus);
+    if (route == ROUTE_RESIDENT) {
+        const HostBatch hb{obs, frames, out, workspace, B, T};
+        return run_resident(&hb, 1, trans, init, S, s, ev, launches, reuse);
+    }
+    if (ev) (void)hipEventRecord(ev[0], s);
+    if (ev) (void)hipEventRecord(ev[3], s);
+    if (route == ROUTE_PRUNED) {
+        const PrunedWorkspace w = carve_pruned(workspace, B, T, S, cus);
         e = launch_pruned_forward(obs, frames, trans, init, w, B, T, S, s, launches, reuse, collect);
         if (ev) (void)hipEventRecord(ev[1], s);
         if (e == hipSuccess) e = launch_backtrace_on(w.hist, trans, frames, out, B, T, S, s);
-    } else if (use_dense(B, S)) {
-        const DenseWorkspace w = carve_dense(workspace, B, T, S);
+    } else if (route == ROUTE_DENSE) {
+        const DenseWorkspace w = carve_dense(workspace, B, T, S, cus);
         e = launch_dense_forward(obs, frames, trans, init, w, B, T, S, s, launches, reuse);
         if (ev) (void)hipEventRecord(ev[1], s);
-        if (e == hipSuccess) e = launch_dense_backtrace(trans, frames, w, out, B, T, S, s);
+        if (e == hipSuccess) e = launch_backtrace_on(w.hist, trans, frames, out, B, T, S, s);
     } else {
         const Workspace w = carve(workspace, B, T, S);
         e = launch_forward(obs, frames, trans, init, w, B, T, S, s, launches);
@@ -740,6 +898,28 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
     if (ev) (void)hipEventRecord(ev[2], s);
     return e;
 }
+
+struct PhaseEvents {
+    hipEvent_t ev[4] = {};
+    hipError_t err = hipSuccess;
+    PhaseEvents() {
+        for (auto &x : ev)
+            if (err == hipSuccess) err = hipEventCreate(&x);
+    }
+    ~PhaseEvents() {
+        for (auto &x : ev)
+            if (x) (void)hipEventDestroy(x);
+    }
+    // forward (incl. preparation), argmax + backtrace, preparation alone -- after synchronising on the last event
+    hipError_t read(float *phase_ms) {
+        hipError_t e = hipEventSynchronize(ev[2]);
+        if (e != hipSuccess) return e;
+        (void)hipEventElapsedTime(&phase_ms[0], ev[0], ev[1]);
+        (void)hipEventElapsedTime(&phase_ms[1], ev[1], ev[2]);
+        (void)hipEventElapsedTime(&phase_ms[4], ev[0], ev[3]);
+        return hipSuccess;
+    }
+};
 
 }  // namespace
 
@@ -753,7 +933,7 @@ int torbi_hip_abi_version(void) { return TORBI_HIP_ABI_VERSION; }
 const char *torbi_hip_error_string(int code) {
     switch (code) {
         case TORBI_HIP_OK: return "success";
-        case TORBI_HIP_EINVAL: return "invalid argument (null pointer or non-positive dimension)";
+        case TORBI_HIP_EINVAL: return "invalid argument (null pointer, non-positive dimension or unknown flag)";
         case TORBI_HIP_EWORKSPACE: return "workspace smaller than torbi_hip_workspace_bytes()";
         case TORBI_HIP_ERANGE: return "problem dimensions out of range for this build";
         case TORBI_HIP_ENODEVICE: return "no usable HIP device";
@@ -770,66 +950,121 @@ int torbi_hip_device_count(void) {
     return n;
 }
 
+int torbi_hip_compute_units(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return TORBI_HIP_ENODEVICE;
+    return cu_count(device);
+}
+
 size_t torbi_hip_workspace_bytes(int B, int T, int S) {
     if (B <= 0 || T <= 0 || S <= 0) return 256;
-    // the larger of the candidate paths, so a workspace stays valid across torbi_hip_set_forward_path
-    size_t need = use_dense(B, S) ? carve_dense(nullptr, B, T, S).bytes : carve(nullptr, B, T, S).bytes;
-    if (pruned::supported(B, S)) {
-        const size_t p = carve_pruned(nullptr, B, T, S).bytes;
-        if (p > need) need = p;
-    }
-    return need;
+    return need_bytes_any_device(B, T, S);
 }
 
 int torbi_hip_set_forward_path(int path) {
-    if (path != TORBI_HIP_FORWARD_AUTO && path != TORBI_HIP_FORWARD_DENSE && path != TORBI_HIP_FORWARD_PRUNED)
-        return TORBI_HIP_EINVAL;
+    if (path < TORBI_HIP_FORWARD_AUTO || path > TORBI_HIP_FORWARD_RESIDENT) return TORBI_HIP_EINVAL;
     g_forward_path.store(path, std::memory_order_relaxed);
     return TORBI_HIP_OK;
 }
 
-int torbi_hip_forward_path(int B, int S) {
-    if (B <= 0 || S <= 0) return TORBI_HIP_EINVAL;
-    if (use_pruned(B, S)) return TORBI_HIP_FORWARD_PRUNED;
-    return use_dense(B, S) ? TORBI_HIP_FORWARD_DENSE : TORBI_HIP_FORWARD_AUTO;
+int torbi_hip_forward_path(int B, int S) { return torbi_hip_forward_path_on(B, S, 0, 0u); }
+
+int torbi_hip_forward_path_on(int B, int S, int device, unsigned flags) {
+    if (B <= 0 || S <= 0 || !flags_ok(flags)) return TORBI_HIP_EINVAL;
+    return (int)route_for(requested_path(flags), B, S, cu_count(device));
 }
 
 int torbi_hip_viterbi_decode(const float *observation, const int32_t *batch_frames,
                              const float *transition, const float *initial,
                              int32_t *indices_out, void *workspace, size_t workspace_bytes,
                              int B, int T, int S, int device, void *stream) {
-    const int rc = check_args(observation, batch_frames, transition, initial, indices_out,
-                              workspace, workspace_bytes, B, T, S);
-    if (rc != TORBI_HIP_OK || B == 0) return rc;
-    DeviceGuard guard(device);
-    if (guard.err != hipSuccess) return (int)guard.err;
-    return (int)run_decode(observation, batch_frames, transition, initial, indices_out, workspace,
-                           B, T, S, static_cast<hipStream_t>(stream), nullptr, nullptr, false);
+    return torbi_hip_viterbi_decode_ex(observation, batch_frames, transition, initial, indices_out, workspace,
+                                       workspace_bytes, B, T, S, device, stream, 0u);
 }
 
 int torbi_hip_viterbi_decode_ex(const float *observation, const int32_t *batch_frames,
                                 const float *transition, const float *initial,
                                 int32_t *indices_out, void *workspace, size_t workspace_bytes,
                                 int B, int T, int S, int device, void *stream, unsigned flags) {
-    if (flags & ~(unsigned)(TORBI_HIP_REUSE_TRANSITION | TORBI_HIP_COLLECT_STATS)) return TORBI_HIP_EINVAL;
+    if (!flags_ok(flags)) return TORBI_HIP_EINVAL;
     const int rc = check_args(observation, batch_frames, transition, initial, indices_out,
-                              workspace, workspace_bytes, B, T, S);
+                              workspace, workspace_bytes, B, T, S, device);
     if (rc != TORBI_HIP_OK || B == 0) return rc;
     DeviceGuard guard(device);
     if (guard.err != hipSuccess) return (int)guard.err;
     return (int)run_decode(observation, batch_frames, transition, initial, indices_out, workspace,
-                           B, T, S, static_cast<hipStream_t>(stream), nullptr, nullptr,
-                           (flags & TORBI_HIP_REUSE_TRANSITION) != 0, (flags & TORBI_HIP_COLLECT_STATS) != 0);
+                           B, T, S, device, static_cast<hipStream_t>(stream), nullptr, nullptr,
+                           (flags & TORBI_HIP_REUSE_TRANSITION) != 0, (flags & TORBI_HIP_COLLECT_STATS) != 0,
+                           requested_path(flags));
+}
+
+int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, const float *transition,
+                                     const float *initial, int S, int device, void *stream, unsigned flags,
+                                     float *phase_ms) {
+    if (!flags_ok(flags) || count < 0 || count > TORBI_HIP_MAX_BATCHES || S < 1) return TORBI_HIP_EINVAL;
+    if (count == 0) return TORBI_HIP_OK;
+    if (!batches || !transition || !initial) return TORBI_HIP_EINVAL;
+    if (phase_ms)
+        for (int i = 0; i < 6; ++i) phase_ms[i] = 0.0f;
+    const int cus = cu_count(device);
+    HostBatch hb[TORBI_HIP_MAX_BATCHES];
+    int n = 0, tiles = 0;
+    for (int k = 0; k < count; ++k) {
+        const torbi_hip_batch &b = batches[k];
+        const int rc = check_args(b.observation, b.batch_frames, transition, initial, b.indices_out, b.workspace,
+                                  b.workspace_bytes, b.B, b.T, S, device);
+        if (rc != TORBI_HIP_OK) return rc;
+        if (b.B == 0) continue;
+        hb[n++] = HostBatch{b.observation, b.batch_frames, b.indices_out, b.workspace, b.B, b.T};
+        tiles += tiles_of(b.B);
+    }
+    if (n == 0) return TORBI_HIP_OK;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return (int)guard.err;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int path = requested_path(flags);
+    const bool reuse = (flags & TORBI_HIP_REUSE_TRANSITION) != 0;
+    const bool together = resident::supported(S) &&
+                          (path == TORBI_HIP_FORWARD_RESIDENT || (path == TORBI_HIP_FORWARD_AUTO && 2 * tiles >= cus));
+    if (phase_ms) {
+        PhaseEvents pe;
+        if (pe.err != hipSuccess) return (int)pe.err;
+        int launches = 0;
+        hipError_t e;
+        if (together) {
+            e = run_resident(hb, n, transition, initial, S, s, pe.ev, &launches, reuse);
+            phase_ms[3] = (float)ROUTE_RESIDENT;
+        } else {
+            // one batch after the other, each on the path it would take alone; phases of the LAST batch only
+            e = hipSuccess;
+            for (int k = 0; k < n && e == hipSuccess; ++k)
+                e = run_decode(hb[k].obs, hb[k].frames, transition, initial, hb[k].out, hb[k].workspace, hb[k].B,
+                               hb[k].T, S, device, s, k == n - 1 ? pe.ev : nullptr, &launches, reuse, false, path);
+            phase_ms[3] = (float)route_for(path, hb[n - 1].B, S, cus);
+        }
+        if (e == hipSuccess) e = pe.read(phase_ms);
+        phase_ms[2] = (float)launches;
+        phase_ms[5] = (float)(together ? n : 1);
+        return (int)e;
+    }
+    if (together) return (int)run_resident(hb, n, transition, initial, S, s, nullptr, nullptr, reuse);
+    for (int k = 0; k < n; ++k) {
+        const hipError_t e = run_decode(hb[k].obs, hb[k].frames, transition, initial, hb[k].out, hb[k].workspace,
+                                        hb[k].B, hb[k].T, S, device, s, nullptr, nullptr, reuse,
+                                        (flags & TORBI_HIP_COLLECT_STATS) != 0, path);
+        if (e != hipSuccess) return (int)e;
+    }
+    return TORBI_HIP_OK;
 }
 
 int torbi_hip_scan_stats(const void *workspace, size_t workspace_bytes, int B, int T, int S,
                          unsigned *stats_out, int device, void *stream) {
     if (B < 1 || T < 1 || S < 1 || !workspace || !stats_out) return TORBI_HIP_EINVAL;
-    if (workspace_bytes < torbi_hip_workspace_bytes(B, T, S)) return TORBI_HIP_EWORKSPACE;
-    if (!use_pruned(B, S)) return TORBI_HIP_EUNSUPPORTED;
+    if (!pruned::supported(B, S)) return TORBI_HIP_EUNSUPPORTED;
     DeviceGuard guard(device);
     if (guard.err != hipSuccess) return (int)guard.err;
-    const PrunedWorkspace w = carve_pruned(const_cast<void *>(workspace), B, T, S);
+    if (workspace_bytes < need_bytes(B, T, S, cu_count(device))) return TORBI_HIP_EWORKSPACE;
+    const PrunedWorkspace w = carve_pruned(const_cast<void *>(workspace), B, T, S, cu_count(device));
     return (int)hipMemcpyAsync(stats_out, w.stats, sizeof(unsigned) * 2 * pruned::kStatSlots, hipMemcpyDeviceToDevice,
                                static_cast<hipStream_t>(stream));
 }
@@ -864,56 +1099,39 @@ int torbi_hip_viterbi_decode_profiled(const float *observation, const int32_t *b
                                       const float *transition, const float *initial,
                                       int32_t *indices_out, void *workspace,
                                       size_t workspace_bytes, int B, int T, int S, int device,
-                                      void *stream, float *phase_ms) {
-    if (!phase_ms) return TORBI_HIP_EINVAL;
-    phase_ms[0] = phase_ms[1] = phase_ms[2] = phase_ms[3] = 0.0f;
-    const int rc = check_args(observation, batch_frames, transition, initial, indices_out,
-                              workspace, workspace_bytes, B, T, S);
-    if (rc != TORBI_HIP_OK || B == 0) return rc;
-    DeviceGuard guard(device);
-    if (guard.err != hipSuccess) return (int)guard.err;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    hipEvent_t ev[3];
-    for (auto &x : ev) {
-        hipError_t e = hipEventCreate(&x);
-        if (e != hipSuccess) return (int)e;
+                                      void *stream, unsigned flags, float *phase_ms) {
+    if (!phase_ms || !flags_ok(flags)) return TORBI_HIP_EINVAL;
+    const torbi_hip_batch one{observation, batch_frames, indices_out, workspace, workspace_bytes, B, T};
+    // a single batch through the batches entry: same routing as torbi_hip_viterbi_decode_ex for this shape
+    unsigned f = flags;
+    if (((flags >> 4) & 7u) == 0) f |= TORBI_HIP_PATH_FLAG(default_path());
+    if (requested_path(f) == TORBI_HIP_FORWARD_AUTO) {
+        DeviceGuard guard(device);
+        if (guard.err != hipSuccess) return (int)guard.err;
+        // AUTO in the batches entry counts the tiles of the whole group; for one batch that is route_for()
+        const Route r = route_for(TORBI_HIP_FORWARD_AUTO, B > 0 ? B : 1, S, cu_count(device));
+        f = (f & ~(7u << 4)) | TORBI_HIP_PATH_FLAG(r == ROUTE_RESIDENT ? TORBI_HIP_FORWARD_RESIDENT
+                                                   : r == ROUTE_DENSE ? TORBI_HIP_FORWARD_DENSE
+                                                                      : TORBI_HIP_FORWARD_PRUNED);
     }
-    int launches = 0;
-    hipError_t e = run_decode(observation, batch_frames, transition, initial, indices_out,
-                              workspace, B, T, S, s, ev, &launches, false);
-    hipError_t es = hipEventSynchronize(ev[2]);
-    if (e == hipSuccess) e = es;
-    if (e == hipSuccess) {
-        (void)hipEventElapsedTime(&phase_ms[0], ev[0], ev[1]);
-        (void)hipEventElapsedTime(&phase_ms[1], ev[1], ev[2]);
-        phase_ms[2] = (float)launches;
-        phase_ms[3] = (float)torbi_hip_forward_path(B, S);
-    }
-    for (auto &x : ev) (void)hipEventDestroy(x);
-    return (int)e;
+    return torbi_hip_viterbi_decode_batches(&one, 1, transition, initial, S, device, stream, f, phase_ms);
 }
 
 int torbi_hip_read_posterior(const void *workspace, size_t workspace_bytes,
                              const int32_t *batch_frames, float *posterior_out, int B, int T,
-                             int S, int device, void *stream) {
-    if (B < 0 || T < 1 || S < 1) return TORBI_HIP_EINVAL;
+                             int S, int device, void *stream, unsigned flags) {
+    if (B < 0 || T < 1 || S < 1 || !flags_ok(flags)) return TORBI_HIP_EINVAL;
     if (B == 0) return TORBI_HIP_OK;
     if (!workspace || !batch_frames || !posterior_out) return TORBI_HIP_EINVAL;
-    if (workspace_bytes < torbi_hip_workspace_bytes(B, T, S)) return TORBI_HIP_EWORKSPACE;
     DeviceGuard guard(device);
     if (guard.err != hipSuccess) return (int)guard.err;
+    if (workspace_bytes < need_bytes(B, T, S, cu_count(device))) return TORBI_HIP_EWORKSPACE;
     const size_t n = (size_t)B * S;
     const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    if (use_pruned(B, S)) {
-        const PrunedWorkspace w = carve_pruned(const_cast<void *>(workspace), B, T, S);
-        hipLaunchKernelGGL(gather_history_kernel, dim3(grid), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), w.hist, batch_frames, posterior_out, B,
-                           T, S);
-    } else if (use_dense(B, S)) {
-        const DenseWorkspace w = carve_dense(const_cast<void *>(workspace), B, T, S);
-        hipLaunchKernelGGL(gather_history_kernel, dim3(grid), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), w.hist, batch_frames, posterior_out, B,
-                           T, S);
+    if (route_for(requested_path(flags), B, S, cu_count(device)) != ROUTE_GENERIC) {
+        // every value-only path keeps the posterior history at the start of the workspace
+        hipLaunchKernelGGL(gather_history_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const float *>(workspace), batch_frames, posterior_out, B, T, S);
     } else {
         const Workspace w = carve(const_cast<void *>(workspace), B, T, S);
         hipLaunchKernelGGL(gather_posterior_kernel, dim3(grid), dim3(256), 0,

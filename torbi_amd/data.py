@@ -3,8 +3,9 @@
 
 On-disk format (reference torbi/data/preprocess/core.py:50-53, torbi/core.py:471-473):
 inputs are `torch.save`d float (frames, states) tensors, outputs int32 (frames,) tensors.
-Entropy-based chunking (reference torbi/chunk.py) is an approximation that changes results
-and is out of scope; `batch_chunks` is kept in the collate tuple for signature parity.
+With `core.MIN_CHUNK_SIZE` set, a file is cut at low-entropy frames (torbi_amd/chunk.py, reference
+torbi/chunk.py): its pieces become consecutive batch rows, `batch_chunks` says how many rows each file owns,
+and `separate` joins the decoded rows again.
 """
 import torch
 
@@ -18,6 +19,10 @@ class Dataset(torch.utils.data.Dataset):
     def __getitem__(self, index):
         input_file = self.input_files[index]
         observation = torch.load(input_file, map_location='cpu')
+        from . import core
+        if core.MIN_CHUNK_SIZE is not None:          # dataset.py:22-23
+            from .chunk import chunk
+            observation = chunk(observation)
         return observation, input_file
 
     def __len__(self):
@@ -30,8 +35,8 @@ def collate(batch):
     (`batch_frames` is int64 there too; `from_probabilities` casts it).
 
     An item whose observation is a list of tensors stands for one file cut into chunks
-    (reference chunk.py, not produced by this package): its pieces become consecutive batch rows
-    and `batch_chunks` remembers how many belong together."""
+    (torbi_amd/chunk.py): its pieces become consecutive batch rows and `batch_chunks` remembers how
+    many belong together."""
     if len(batch) == 0:
         raise ValueError('batch must contain at least 1 item')
     input_files = tuple(item[1] for item in batch)

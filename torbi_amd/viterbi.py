@@ -52,6 +52,55 @@ def workspace_bytes(batch: int, frames: int, states: int) -> int:
     return int(_lib.load().torbi_hip_workspace_bytes(batch, frames, states))
 
 
+def _version_of(tensor: torch.Tensor):
+    """A tensor's version counter, or None where it has none (tensors created under
+    torch.inference_mode() raise on `_version`): callers then neither cache nor reuse anything keyed on it."""
+    try:
+        return tensor._version
+    except RuntimeError:
+        return None
+
+
+def _path_flag(path: str) -> int:
+    """TORBI_HIP_PATH_FLAG(path): the forward path travels with the call, nothing process-wide is touched."""
+    return (FORWARD_PATHS[path] + 1) << 4
+
+
+def _resolve_path(trans, transition, B, S, device, path, tiles, measure):
+    """The path name this call passes to the library, and the tuner that wants its timing (or None)."""
+    forced = _forced_path if path is None else path
+    if forced not in FORWARD_PATHS:
+        raise ValueError(f'forward path must be one of {sorted(FORWARD_PATHS)}; got {forced!r}')
+    if forced != 'auto':
+        return forced, None
+    chosen = _choose_path(trans, transition, B, S)
+    tuner = None
+    if chosen == 'pruned' and B >= 32 and measure:
+        # both value-only recurrences are available and nothing is forced: pick by measurement (see _Tuner)
+        tuner = _tuner_for(transition, S, device)
+        if tuner is not None:
+            chosen = tuner.choose()
+    if chosen == 'pruned' and 64 <= S <= 2048 and 2 * tiles >= compute_units(device):
+        chosen = 'resident'          # enough items to give the compute units a workgroup of 16 each
+    return chosen, tuner
+
+
+def compute_units(device) -> int:
+    """Compute units of a HIP device as the library's tiling plans see them."""
+    index = torch.device(device).index
+    index = torch.cuda.current_device() if index is None else index
+    known = _compute_units.get(index)
+    if known is None:
+        known = int(_lib.load().torbi_hip_compute_units(index))
+        if known <= 0:
+            raise RuntimeError(f'torbi_hip_compute_units({index}) failed with code {known}')
+        _compute_units[index] = known
+    return known
+
+
+_compute_units = {}
+
+
 def decode(
     observation: torch.Tensor,
     batch_frames: torch.Tensor,
@@ -60,6 +109,7 @@ def decode(
     num_threads: Optional[int] = 0,
     workspace: Optional[torch.Tensor] = None,
     reuse_preparation: bool = False,
+    path: Optional[str] = None,
     _profile: Optional[list] = None,
 ) -> torch.Tensor:
     """Decode a time-varying categorical distribution (log space) on an MI355X
@@ -80,12 +130,15 @@ def decode(
             TORBI_HIP_REUSE_TRANSITION)
         workspace: optional uint8 scratch tensor on the compute device with at least
             `workspace_bytes(N, T, S)` bytes; allocated from torch's caching allocator if None
+        path: forward recurrence for THIS call ('auto', 'dense', 'pruned', 'resident'; None = the
+            process default of `set_forward_path`).  Every path returns the same indices.
 
     Return:
         indices: :math:`(N, T)` int32 decoded bin indices, on the device of `observation`
 
     Tensors on the CPU are moved to the current HIP device, decoded there, and the indices
-    are returned on the CPU (the reference returns on the input device as well).
+    are returned on the CPU (the reference returns on the input device as well).  Calls from
+    different host threads (one per stream or device) are independent.
     """
     B, T, S = _check_inputs(observation, batch_frames, transition, initial)
     _require_gpu()
@@ -110,37 +163,22 @@ def decode(
 
     index = device.index if device.index is not None else torch.cuda.current_device()
     stream = torch.cuda.current_stream(device).cuda_stream
-    path = _choose_path(trans, transition, B, S)
-    tuner = None
-    if path == 'pruned' and _forced_path == 'auto' and B >= 32 and _profile is None:
-        # both value-only paths are available and nothing is forced: pick by measurement (see _Tuner)
-        tuner = _tuner_for(transition, S, device)
-        path = tuner.choose()
-        begin = None
-        if not tuner.settled():
-            begin = torch.cuda.Event(enable_timing=True)
-            begin.record(torch.cuda.current_stream(device))
-    lib.torbi_hip_set_forward_path(FORWARD_PATHS[path])
+    chosen, tuner = _resolve_path(trans, transition, B, S, device, path, (B + 15) // 16, _profile is None)
+    begin = None
+    if tuner is not None and not tuner.settled():
+        begin = torch.cuda.Event(enable_timing=True)
+        begin.record(torch.cuda.current_stream(device))
     args = (obs.data_ptr(), frames.data_ptr(), trans.data_ptr(), init.data_ptr(),
             indices.data_ptr(), workspace.data_ptr(), workspace.numel(), B, T, S, index,
             ctypes.c_void_p(stream))
-    # what the workspace will hold after this call: the preparation of this transition for this shape/path
-    # (the transition is identified by the tensor OBJECT and its version: a new tensor can reuse a freed address)
-    state = (B, T, S, path, transition._version, stream)
-    known = _prepared.get(id(workspace))
-    flags = 0
-    if (reuse_preparation and known is not None and known[0]() is workspace and known[1] == state
-            and known[2]() is transition):
-        flags = 1                                  # TORBI_HIP_REUSE_TRANSITION
-    if len(_prepared) > 64:
-        for key in [k for k, v in _prepared.items() if v[0]() is None]:
-            del _prepared[key]
-    _prepared[id(workspace)] = (weakref.ref(workspace), state, weakref.ref(transition))
+    flags = _path_flag(chosen)
+    if _reusable(workspace, transition, (B, T, S, chosen, stream), reuse_preparation):
+        flags |= 1                                  # TORBI_HIP_REUSE_TRANSITION
     if _profile is None:
-        collect = tuner is not None and begin is not None and path == 'pruned' and tuner.blocks is None
+        collect = begin is not None and chosen == 'pruned' and tuner.blocks is None
         _lib.check(lib.torbi_hip_viterbi_decode_ex(*args, flags | (2 if collect else 0)),      # COLLECT_STATS
                    'torbi_hip_viterbi_decode_ex')
-        if tuner is not None and begin is not None:
+        if begin is not None:
             stats = None
             if collect:
                 # device -> pinned host, enqueued now and read (without any synchronising call) once `end` is done
@@ -148,16 +186,115 @@ def decode(
                 stats.copy_(scan_stats(workspace, B, T, S), non_blocking=True)
             end = torch.cuda.Event(enable_timing=True)
             end.record(torch.cuda.current_stream(device))
-            tuner.launched(path, begin, end, stats, B * T)
+            tuner.launched('pruned' if chosen == 'resident' else chosen, begin, end, stats, B * T)
     else:
-        phases = (ctypes.c_float * 4)()
-        _lib.check(lib.torbi_hip_viterbi_decode_profiled(*args, phases),
+        phases = (ctypes.c_float * 6)()
+        _lib.check(lib.torbi_hip_viterbi_decode_profiled(*args, flags, phases),
                    'torbi_hip_viterbi_decode_profiled')
         _profile[:] = list(phases)
     return indices if home == device else indices.to(home)
 
 
-FORWARD_PATHS = {'auto': 0, 'dense': 1, 'pruned': 2}
+def _reusable(workspace, transition, shape_state, wanted) -> bool:
+    """Remember what `workspace` will hold after the call being issued (the per-transition preparation for this
+    shape, path and stream) and say whether it already does.  The transition is identified by the tensor OBJECT
+    and its version (a new tensor can reuse a freed address); a tensor without a version counter (inference
+    mode) is never reused."""
+    version = _version_of(transition)
+    state = shape_state + (version,)
+    known = _prepared.get(id(workspace))
+    hit = (wanted and version is not None and known is not None and known[0]() is workspace and known[1] == state
+           and known[2]() is transition)
+    if len(_prepared) > 64:
+        for key in [k for k, v in list(_prepared.items()) if v[0]() is None]:
+            _prepared.pop(key, None)
+    _prepared[id(workspace)] = (weakref.ref(workspace), state, weakref.ref(transition))
+    return bool(hit)
+
+
+def decode_batches(
+    observations,
+    batch_frames,
+    transition: torch.Tensor,
+    initial: torch.Tensor,
+    workspaces=None,
+    reuse_preparation: bool = False,
+    path: Optional[str] = None,
+    _profile: Optional[list] = None,
+):
+    """`decode` for several batches that share `transition` and `initial`, in one call
+
+    The reference decodes a many-file job batch after batch (torbi/core.py:417-457).  Batch items are
+    independent, so the batches of such a job can share launches: with enough items (or path='resident')
+    the whole group is ONE forward launch -- a workgroup keeps 16 items' posterior rows in its LDS for every
+    timestep -- and ONE backtrace launch (include/torbi_hip.h, torbi_hip_viterbi_decode_batches).
+    Otherwise the batches are decoded one after the other exactly as `decode` would.
+
+    Args:
+        observations: list of (N_k, T_k, S) float32 tensors on one HIP device
+        batch_frames: list of (N_k) int32 tensors
+        transition, initial: as `decode`
+        workspaces: optional list of uint8 scratch tensors, one per batch, each >= workspace_bytes(N_k, T_k, S)
+        reuse_preparation: as `decode`, for the first workspace
+        path: as `decode`
+
+    Returns:
+        list of (N_k, T_k) int32 index tensors on the device
+    """
+    count = len(observations)
+    if count != len(batch_frames):
+        raise RuntimeError('decode_batches needs one batch_frames tensor per observation tensor')
+    if count == 0:
+        return []
+    if count > _lib.MAX_BATCHES:
+        raise RuntimeError(f'at most {_lib.MAX_BATCHES} batches per call; got {count}')
+    _require_gpu()
+    lib = _lib.load()
+    device = observations[0].device
+    if device.type != 'cuda':
+        raise RuntimeError('decode_batches takes tensors that are already on a HIP device')
+    S = observations[0].shape[-1]
+    shapes = []
+    for obs, frames in zip(observations, batch_frames):
+        shapes.append(_check_inputs(obs, frames, transition, initial))
+        if obs.device != device or frames.device != device or not obs.is_contiguous() or not frames.is_contiguous():
+            raise RuntimeError('decode_batches needs contiguous tensors on one device')
+    trans = transition.to(device).contiguous()
+    init = initial.to(device).contiguous()
+    if workspaces is None:
+        workspaces = [torch.empty((lib.torbi_hip_workspace_bytes(B, T, S),), dtype=torch.uint8, device=device)
+                      for B, T, _ in shapes]
+    if len(workspaces) != count:
+        raise RuntimeError('decode_batches needs one workspace per batch')
+    indices = [torch.empty((B, T), dtype=torch.int32, device=device) for B, T, _ in shapes]
+    table = (_lib.Batch * count)()
+    for k, (B, T, _) in enumerate(shapes):
+        ws = workspaces[k]
+        need = lib.torbi_hip_workspace_bytes(B, T, S)
+        if ws.device != device or ws.dtype != torch.uint8 or ws.numel() < need or not ws.is_contiguous():
+            raise RuntimeError(f'workspace {k} must be a contiguous uint8 tensor of >= {need} bytes on {device}')
+        table[k] = _lib.Batch(observations[k].data_ptr(), batch_frames[k].data_ptr(), indices[k].data_ptr(),
+                              ws.data_ptr(), ws.numel(), B, T)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    largest = max(B for B, _, _ in shapes)
+    tiles = sum((B + 15) // 16 for B, _, _ in shapes)
+    chosen, _ = _resolve_path(trans, transition, largest, S, device, path, tiles, False)
+    flags = _path_flag(chosen)
+    first = next((k for k, (B, _, _) in enumerate(shapes) if B > 0), 0)
+    if _reusable(workspaces[first], transition, (tuple(shapes), chosen, stream), reuse_preparation) \
+            and (chosen == 'resident' or count == 1):
+        flags |= 1
+    phases = (ctypes.c_float * 6)() if _profile is not None else None
+    _lib.check(lib.torbi_hip_viterbi_decode_batches(table, count, trans.data_ptr(), init.data_ptr(), S, index,
+                                                    ctypes.c_void_p(stream), flags, phases),
+               'torbi_hip_viterbi_decode_batches')
+    if _profile is not None:
+        _profile[:] = list(phases)
+    return indices
+
+
+FORWARD_PATHS = {'auto': 0, 'dense': 1, 'pruned': 2, 'resident': 3}
 
 
 class _Tuner:
@@ -225,24 +362,30 @@ def collect_measurements() -> None:
             known[3]._collect()
 
 
-def _tuner_for(transition: torch.Tensor, states: int, device) -> _Tuner:
+def _tuner_for(transition: torch.Tensor, states: int, device) -> Optional[_Tuner]:
+    version = _version_of(transition)
+    if version is None:
+        return None              # no identity to key measurements on (inference tensor): keep the default path
     known = _tuners.get(id(transition))
-    if known is None or known[0]() is not transition or known[1:3] != (transition._version, states):
+    if known is None or known[0]() is not transition or known[1:3] != (version, states):
         if len(_tuners) > 64:
-            for key in [k for k, v in _tuners.items() if v[0]() is None]:
-                del _tuners[key]
-        known = (weakref.ref(transition), transition._version, states, _Tuner(states))
+            for key in [k for k, v in list(_tuners.items()) if v[0]() is None]:
+                _tuners.pop(key, None)
+        known = (weakref.ref(transition), version, states, _Tuner(states))
         _tuners[id(transition)] = known
     return known[3]
-_forced_path = {'d': 'dense', 'p': 'pruned'}.get(os.environ.get('TORBI_HIP_FORWARD', 'a')[:1], 'auto')
+_forced_path = {'d': 'dense', 'p': 'pruned', 'r': 'resident'}.get(os.environ.get('TORBI_HIP_FORWARD', 'a')[:1], 'auto')
 _prepared = {}                   # id(workspace) -> (weakref, state): see decode(reuse_preparation=True)
 _structure_cache = {}            # id(transition) -> (weakref, (version, states), mean finite range of a row / S)
 BANDED_RANGE = 0.25              # rows reaching less than this fraction of the states: dense + -inf skipping
 
 
 def set_forward_path(path: str = 'auto') -> None:
-    """Process-wide choice of the forward recurrence (include/torbi_hip.h): 'auto' (default),
-    'dense' (every cell, (max,+) GEMM with -inf block skipping) or 'pruned' (exact pruned pass).
+    """Process-wide DEFAULT of the forward recurrence (include/torbi_hip.h) for calls that do not name one
+    (`decode(path=...)`): 'auto' (default), 'dense' (every cell, (max,+) GEMM with -inf block skipping),
+    'pruned' (exact pruned pass, one launch per timestep) or 'resident' (the pruned recurrence with the time
+    loop inside one launch; meant for many items in flight).  The path itself travels with every call
+    (TORBI_HIP_PATH_FLAG), so concurrent decodes from several host threads never see each other's choice.
     Every path returns identical indices; this is a performance knob and a test hook.
 
     'auto' in this Python layer refines the library's AUTO (pruned wherever supported) with one
@@ -281,11 +424,14 @@ def critical_blocks(stats: torch.Tensor) -> float:
 
 
 def _choose_path(trans: torch.Tensor, original: torch.Tensor, batch: int, states: int) -> str:
-    if _forced_path != 'auto' or batch < 32 or states < 64 or states > 4096:   # dense needs B >= 32
-        return _forced_path
-    known = _structure_cache.get(id(original))
+    """AUTO's look at the transition matrix: 'dense' for narrow bands, 'pruned' otherwise; 'auto' (the library's
+    own fallbacks) for shapes where the value-only paths offer no choice."""
+    if batch < 32 or states < 64 or states > 4096:   # dense needs B >= 32
+        return 'auto'
+    version = _version_of(original)
+    known = _structure_cache.get(id(original)) if version is not None else None
     reach = None
-    if known is not None and known[0]() is original and known[1] == (original._version, states):
+    if known is not None and known[0]() is original and known[1] == (version, states):
         reach = known[2]
     if reach is None:
         finite = trans != float('-inf')
@@ -293,16 +439,24 @@ def _choose_path(trans: torch.Tensor, original: torch.Tensor, batch: int, states
         lo = torch.where(finite, index, states).amin(dim=1)
         hi = torch.where(finite, index, -1).amax(dim=1)
         reach = float((hi - lo + 1).clamp(min=0).float().mean().item()) / states
-        if len(_structure_cache) >= 64:
-            _structure_cache.clear()
-        _structure_cache[id(original)] = (weakref.ref(original), (original._version, states), reach)
+        if version is not None:
+            if len(_structure_cache) >= 64:
+                _structure_cache.clear()
+            _structure_cache[id(original)] = (weakref.ref(original), (version, states), reach)
     return 'dense' if 0.0 < reach < BANDED_RANGE else 'pruned'
 
 
-def forward_path(batch: int, states: int) -> str:
-    """Which forward path a (batch, states) problem runs: 'pruned', 'dense' or 'generic'."""
-    code = _lib.load().torbi_hip_forward_path(int(batch), int(states))
-    return {2: 'pruned', 1: 'dense', 0: 'generic'}[code]
+ROUTES = {0: 'generic', 1: 'dense', 2: 'pruned', 3: 'resident'}
+
+
+def forward_path(batch: int, states: int, path: Optional[str] = None, device: int = 0) -> str:
+    """Which forward recurrence the library runs for one (batch, states) problem under `path` (None = the process
+    default): 'generic', 'dense', 'pruned' or 'resident'."""
+    code = _lib.load().torbi_hip_forward_path_on(int(batch), int(states), int(device),
+                                                 _path_flag(_forced_path if path is None else path))
+    if code < 0:
+        _lib.check(code, 'torbi_hip_forward_path_on')
+    return ROUTES[code]
 
 
 def uniform_supported(states: int) -> bool:
@@ -352,8 +506,9 @@ def decode_uniform(
     return indices if home == device else indices.to(home)
 
 
-def read_posterior(workspace, batch_frames, batch, frames, states):
-    """Final posterior rows (N, S) of the last decode that used `workspace` (diagnostic)."""
+def read_posterior(workspace, batch_frames, batch, frames, states, path: Optional[str] = None):
+    """Final posterior rows (N, S) of the last decode that used `workspace` (diagnostic); `path` as given to
+    that decode."""
     lib = _lib.load()
     device = workspace.device
     out = torch.empty((batch, states), dtype=torch.float32, device=device)
@@ -361,7 +516,8 @@ def read_posterior(workspace, batch_frames, batch, frames, states):
     stream = torch.cuda.current_stream(device).cuda_stream
     _lib.check(lib.torbi_hip_read_posterior(
         workspace.data_ptr(), workspace.numel(), bf.data_ptr(), out.data_ptr(),
-        batch, frames, states, device.index or 0, ctypes.c_void_p(stream)),
+        batch, frames, states, device.index or 0, ctypes.c_void_p(stream),
+        _path_flag(_forced_path if path is None else path)),
         'torbi_hip_read_posterior')
     return out
 
