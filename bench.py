@@ -1,18 +1,25 @@
 """Headline benchmark: timesteps decoded / second, 1440 states, batch 512 (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]                  (N > 1: starts its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --workload c4 [--gpus N] [--files 40000]             (BASELINE configs[3], strong scaling)
 
-A "step" is ONE decode (forward recurrence + final argmax + backtrace) of a synthetic batch
-of 512 sequences x 500 frames x 1440 states (BASELINE configs[2]) that is already resident
-in HBM.  With N GPUs every rank decodes its own such batch (weak scaling, batch items are
-independent) and the decoded indices are all-gathered over RCCL inside the timed region.
-Rank 0 prints one JSON line; see DESIGN.md "Measurement" for every field.
+A "step" is ONE decode (forward recurrence + final argmax + backtrace) of one synthetic batch of 512
+sequences x 500 frames x 1440 states (BASELINE configs[2]) that is already resident in HBM.  Consecutive
+steps are decoded in groups (torbi_amd.DecodePipeline(group=8)): the batches of a group share ONE forward
+launch of the time-resident kernel and one backtrace launch; groups alternate between two HIP streams.
+With N GPUs every rank decodes its own batches (weak scaling, batch items are independent) and the decoded
+indices of every batch are all-gathered over RCCL inside the timed region.
+Rank 0 prints one JSON line; see DESIGN.md "Measurement" for every field.  Without a HIP device the same
+launch / rendezvous / planning code runs over gloo and the line carries "dry_run": true and no value.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,31 +27,57 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
-import torbi_amd
-from torbi_amd import distributed, synth, viterbi
-
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz lane-instructions/s
+METRIC = 'timesteps decoded/sec, 1440 states batch=512'
+KERNELS = {'resident': 'resident::resident_forward_kernel', 'pruned': 'pruned::step_pruned_kernel',
+           'dense': 'dense::step_dense_kernel', 'generic': 'step_rows'}
+ROUTES = {0: 'generic', 1: 'dense', 2: 'pruned', 3: 'resident'}
 
 
-def profiled_traffic(kernel_prefix):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
-    (profiles/r01_pmc.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).
-    FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950;
-    both counters are in KiB and include Infinity-Cache hits.  None when no summary matches."""
-    try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')))
-        for name, counters in pmc.items():
-            if kernel_prefix in name and 'FETCH_SIZE' in counters and 'WRITE_SIZE' in counters:
-                return (2.0 * counters['FETCH_SIZE']['mean_per_dispatch']
-                        + counters['WRITE_SIZE']['mean_per_dispatch']) * 1024.0
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=16)
+    ap.add_argument('--warmup', type=int, default=8)
+    ap.add_argument('--workload', choices=['c3', 'c4'], default='c3',
+                    help='c3 = BASELINE configs[2] (headline, weak scaling); c4 = configs[3]: ragged many-file job, '
+                         'lengths 100..900, batches of 512 padded to the batch maximum, sharded over the ranks '
+                         '(strong scaling; --steps limits the number of batches, 0 = all of them)')
+    ap.add_argument('--files', type=int, default=40000, help='sequences of the c4 job')
+    ap.add_argument('--end-to-end', type=int, default=0,
+                    help='c4 only: additionally decode this many sequences from torch.save()d files to files '
+                         '(torch.load + H2D + decode + D2H + torch.save), reported under "end_to_end"')
+    ap.add_argument('--batch', type=int, default=512)
+    ap.add_argument('--frames', type=int, default=500)
+    ap.add_argument('--states', type=int, default=1440)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary records (other configs / inputs)')
+    ap.add_argument('--reuse-preparation', action='store_true',
+                    help='let consecutive decodes share the per-transition preparation (sorted rows / packed panels) '
+                         'as a serving loop would; off by default: every timed launch group does all of its work')
+    ap.add_argument('--forward', choices=['auto', 'dense', 'pruned', 'resident'], default='auto',
+                    help='forward-recurrence path (include/torbi_hip.h); every path gives identical indices')
+    ap.add_argument('--pipeline', type=int, default=2, help='HIP streams the launch groups alternate between')
+    ap.add_argument('--group', type=int, default=8,
+                    help='batches decoded per launch group (1 = every batch on its own: per-timestep launches)')
+    ap.add_argument('--transition', choices=['dense', 'banded', 'uniform'], default='dense',
+                    help="dense = headline workload; banded = the reference's pitch transition "
+                         '(torbi/evaluate/core.py:24-33); uniform = the reference default (transition=None)')
+    ap.add_argument('--half-width', type=float, default=87.2,
+                    help='band half width in states for --transition banded (penn: 87.2)')
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start the N ranks ourselves (one process per GPU, rendezvous on
+    127.0.0.1) as a CHILD process -- nothing in this process has touched a GPU -- and leave with its code."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def algorithmic_bytes_per_timestep(S):
@@ -52,13 +85,35 @@ def algorithmic_bytes_per_timestep(S):
     return 8 * S + 8
 
 
+def profiled_traffic(kernel_prefix):
+    """HBM-side bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
+    (profiles/rNN_pmc.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).  FETCH_SIZE is
+    doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950; both counters are in KiB and
+    include Infinity-Cache hits.  (None, None) when no summary names the kernel."""
+    folder = os.path.join(ROOT, 'profiles')
+    try:
+        names = sorted(f for f in os.listdir(folder) if f.endswith('_pmc.json'))
+    except OSError:
+        return None, None
+    for name in reversed(names):
+        try:
+            pmc = json.load(open(os.path.join(folder, name)))
+        except (OSError, ValueError):
+            continue
+        for kernel, counters in pmc.items():
+            if kernel_prefix in kernel and 'FETCH_SIZE' in counters and 'WRITE_SIZE' in counters:
+                return ((2.0 * counters['FETCH_SIZE']['mean_per_dispatch']
+                         + counters['WRITE_SIZE']['mean_per_dispatch']) * 1024.0, name)
+    return None, None
+
+
 def cpu_baseline(obs_dev, trans_dev, init_dev, gpu_indices, budget_s=15.0):
-    """Time the CPU path on this host's cores on a bounded sample of the SAME workload and
-    check the GPU's indices against it.  Uses the reference's own operator (oracle/_ref,
-    kind "reference") when that build is present, else the reference-shaped C port (oracle
-    mode 0, kind "port").  The thread count is calibrated on a 16-frame prefix (the
-    reference's at::parallel_for over states gets SLOWER with hundreds of threads) and the
-    sample is sized to about `budget_s` seconds."""
+    """Time the CPU path on this host's cores on a bounded sample of the SAME workload and check the GPU's
+    indices against it.  Uses the reference's own operator (oracle/_ref, kind "reference") when that build is
+    present, else the reference-shaped C port (oracle mode 0, kind "port").  The thread count is calibrated on a
+    16-frame prefix (the reference's at::parallel_for over states gets SLOWER with hundreds of threads), the
+    sample is sized to about `budget_s` seconds, and the one-thread rate is measured beside it."""
+    import numpy as np
     import oracle
     host = os.cpu_count() or 1
     T, S = obs_dev.shape[1], obs_dev.shape[2]
@@ -82,15 +137,20 @@ def cpu_baseline(obs_dev, trans_dev, init_dev, gpu_indices, budget_s=15.0):
 
     item0 = obs_dev[:1].cpu().numpy()
     cal = np.ascontiguousarray(item0[:, :16])
-    best_threads, best_dt = 1, None
+    best_threads, best_dt, one_dt = 1, None, None
     for threads in (1, 2, 4, 8, 16, 32, 64, 128):
         if threads > host:
             break
         dt, _ = run(cal, np.array([16], np.int32), threads)
+        if threads == 1:
+            one_dt = dt
         if best_dt is None or dt < best_dt:
             best_threads, best_dt = threads, dt
         elif dt > 2 * best_dt:
             break
+    # one thread: a longer prefix of the same item (15 -> 63 recurrence steps), a few seconds at most
+    n1 = 64 if one_dt * 4 < 8.0 else 16
+    dt1, _ = run(np.ascontiguousarray(item0[:, :n1]), np.array([n1], np.int32), 1)
     per_item = best_dt / 15.0 * (T - 1)            # 15 recurrence steps in the prefix
     items = int(max(1, min(obs_dev.shape[0], budget_s / max(per_item, 1e-3))))
     obs = obs_dev[:items].cpu().numpy()
@@ -103,174 +163,413 @@ def cpu_baseline(obs_dev, trans_dev, init_dev, gpu_indices, budget_s=15.0):
                   f'{best_threads} threads (best of a 16-frame calibration; host has {host} '
                   f'logical CPUs), {dt:.1f} s',
         'gpu_matches_cpu': match,
+        'one_thread': {'value': n1 / dt1, 'unit': 'timesteps/s', 'cores': 1,
+                       'sample': f'first {n1} frames of item 0, {dt1:.1f} s'},
     }
+
+
+class Bench:
+    """Everything that needs torch; constructed after the launch decisions."""
+
+    def __init__(self, args):
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        import torbi_amd
+        from torbi_amd import distributed, synth, viterbi
+        self.np, self.torch, self.dist = np, torch, dist
+        self.torbi_amd, self.distributed, self.synth, self.viterbi = torbi_amd, distributed, synth, viterbi
+        self.args = args
+        self.dry = torch.cuda.device_count() == 0
+        backend = 'gloo' if self.dry else None
+        self.rank, self.size, self.local = distributed.init_from_env(backend)
+        assert self.size == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={self.size}'
+        self.collective = dist.is_available() and dist.is_initialized()
+        self.dev = None if self.dry else torch.device('cuda', torch.cuda.current_device())
+
+    # ---- helpers --------------------------------------------------------------------------------------
+    def fence(self, pipe=None):
+        torch = self.torch
+        if pipe is not None:
+            pipe.synchronize()
+        if not self.dry:
+            torch.cuda.synchronize()
+        if self.collective:
+            self.dist.barrier()
+        if not self.dry:
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if not self.collective:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.dev or 'cpu')
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, value):
+        if not self.collective:
+            return value
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.dev or 'cpu')
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def model(self, S, transition='dense', half_width=87.2):
+        v, synth = self.viterbi, self.synth
+        trans = v.fill_synthetic((S, S), synth.STREAM_TRANSITION, seed=0, device=self.dev)
+        if transition == 'banded':
+            trans = self.torch.from_numpy(synth.banded_transition(S, half_width)).to(self.dev)
+        init = v.fill_synthetic((S,), synth.STREAM_INITIAL, seed=0, device=self.dev)
+        return trans, init
+
+    def balanced_groups(self, steps, group):
+        """Group sizes for `steps` consecutive batches: as few launch groups as `group` allows, equally full
+        (20 steps, group 8 -> 7 + 7 + 6 rather than 8 + 8 + 4: a half-empty last group costs a full one's time)."""
+        if group <= 1:
+            return [1] * steps
+        n = max(1, math.ceil(steps / group))
+        base, extra = divmod(steps, n)
+        return [base + (1 if k < extra else 0) for k in range(n)]
+
+    def timed_decodes(self, decode_one, count, warmup=1):
+        """Median-free plain timing of `count` serial decodes (secondary records): seconds per decode."""
+        torch = self.torch
+        for _ in range(warmup):
+            decode_one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(count):
+            out = decode_one()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / count, out
+
+    # ---- headline: BASELINE configs[2] ----------------------------------------------------------------
+    def run_c3(self):
+        args, torch, v, synth = self.args, self.torch, self.viterbi, self.synth
+        B, T, S = args.batch, args.frames, args.states
+        rank, size = self.rank, self.size
+        if self.dry:
+            self.fence()
+            return {'metric': METRIC, 'value': None, 'unit': 'timesteps/s', 'n_gpus': size, 'steps': args.steps,
+                    'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak',
+                    'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'dry_run': True,
+                    'config': {'workload': f'{S} states, {T} frames, batch={B} per GPU (no HIP device: launch, '
+                                           f'rendezvous and planning only)',
+                               'launch_groups': self.balanced_groups(args.steps, args.group)}}
+        dev = self.dev
+        trans, init = self.model(S, args.transition, args.half_width)
+        frames = torch.full((B,), T, dtype=torch.int32, device=dev)
+        uniform_c = float(torch.tensor(math.log(1.0 / S), dtype=torch.float32))
+        group = 1 if args.transition == 'uniform' else max(1, args.group)
+        # distinct observations for the batches of a launch group (rank-specific streams; shared model)
+        obs = [v.fill_synthetic((B, T, S), synth.STREAM_OBSERVATION, seed=rank * 64 + k, device=dev)
+               for k in range(group)]
+        path = None if args.forward == 'auto' else args.forward
+        pipe = self.torbi_amd.DecodePipeline(dev, depth=max(1, args.pipeline), reuse_preparation=args.reuse_preparation,
+                                             group=group, path=path)
+
+        def gather(idx):
+            return self.distributed.gather_indices(idx, B * size, force=True) if self.collective else idx
+
+        def run_steps(count):
+            last, k = None, 0
+            for n in self.balanced_groups(count, group):
+                for j in range(n):
+                    if args.transition == 'uniform':
+                        last = gather(self.torbi_amd.decode_uniform(obs[0], frames, uniform_c, init))
+                    else:
+                        last = pipe.decode(obs[j % group], frames, trans, init, after=gather)
+                    k += 1
+                pipe.flush()
+            return last
+
+        run_steps(args.warmup)
+        self.fence(pipe)
+        t0 = time.perf_counter()
+        indices = run_steps(args.steps)
+        self.fence(pipe)
+        elapsed = self.max_over_ranks(time.perf_counter() - t0)
+        value = float(B) * T * args.steps * size / elapsed
+        last_obs = obs[(self.balanced_groups(args.steps, group)[-1] - 1) % group]
+
+        result = {
+            'metric': METRIC, 'value': value, 'unit': 'timesteps/s', 'n_gpus': size, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        }
+        if args.transition == 'uniform':
+            per = elapsed / args.steps
+            nbytes = float(B) * T * (4 * S + 4)
+            result['config'] = {'workload': f'{S} states, {T} frames, batch={B} per GPU, fp32, UNIFORM transition '
+                                            f'(the reference default, transition=None; secondary workload)'}
+            result['roofline'] = {'bound': 'hbm', 'achieved': nbytes / per / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                  'frac': nbytes / per / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                                  'kernel': 'uniform_decode_kernel (whole decode, host-timed incl. launch)',
+                                  'algorithmic_bytes_per_launch': nbytes}
+            return result
+
+        # dominant kernel, measured live with hipEvents on the launch stream (include/torbi_hip.h: phase_ms) on a
+        # full launch group, averaged over three profiled groups
+        sizes = self.balanced_groups(args.steps, group)
+        g = max(sizes)
+        spaces = [torch.empty(v.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev) for _ in range(g)]
+        prof, fwd_ms, bt_ms, prep_ms = [], 0.0, 0.0, 0.0
+        for _ in range(3):
+            v.decode_batches([obs[k % group] for k in range(g)], [frames] * g, trans, init, workspaces=spaces,
+                             path=path, _profile=prof)
+            fwd_ms += prof[0] / 3
+            bt_ms += prof[1] / 3
+            prep_ms += prof[4] / 3
+        route = ROUTES[int(prof[3])]
+        launches = max(int(prof[2]), 1)
+        covered = max(int(prof[5]), 1)                     # batches one forward launch (chain) covers
+        kernel_s = (fwd_ms - prep_ms) * 1e-3 / launches
+        timesteps_per_launch = float(covered) * B * (T if route == 'resident' else 1)
+        bytes_per_launch = timesteps_per_launch * algorithmic_bytes_per_timestep(S)
+        achieved = bytes_per_launch / kernel_s / 1e9
+        cells_per_launch = timesteps_per_launch * S * S
+        traffic, traffic_file = profiled_traffic(KERNELS[route])
+        del spaces
+        result['config'] = {
+            'workload': (f'{S} states, {T} frames, batch={B} per GPU, fp32, dense transition'
+                         f'{" (BASELINE configs[2])" if (B, T, S) == (512, 500, 1440) else ""}; decode = forward + '
+                         f'argmax + backtrace, inputs resident in HBM') if args.transition == 'dense' else
+                        (f'{S} states, {T} frames, batch={B} per GPU, fp32, BANDED transition (half width '
+                         f'{args.half_width}, -inf outside; secondary workload)'),
+            'parallelism': f'batch-sharded x{size}' if size > 1 else 'single GPU',
+            'launch_groups': sizes, 'streams': args.pipeline, 'forward_path': route,
+            'throughput_mode': f'{sum(sizes)} batches decoded as {len(sizes)} launch groups over {args.pipeline} '
+                               f'streams; "serial" under "secondary" is one batch at a time',
+            'transition_preparation': 'reused across launch groups' if args.reuse_preparation
+            else 'rebuilt by every launch group'}
+        result['roofline'] = {
+            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic if (B, T, S) == (512, 500, 1440) else None,
+            'traffic_note': f'bytes per launch from profiles/{traffic_file} (2*FETCH_SIZE + WRITE_SIZE, Infinity-Cache '
+                            f'hits included)' if traffic_file else 'no PMC summary for this kernel committed',
+            'kernel': KERNELS[route] + (f' (ONE launch = the whole forward pass of {covered} batches)'
+                                        if route == 'resident' else ' (one launch = one timestep of one batch)'),
+            'launch_us': kernel_s * 1e6, 'launches_per_group': launches, 'batches_per_launch': covered,
+            'algorithmic_bytes_per_launch': bytes_per_launch,
+            'note': 'the (max,+) recurrence holds S/4 = 360 cells per algorithmic byte: kernels that evaluate every cell '
+                    'are VALU-bound; the pruned recurrence is bound by LDS gathers + VALU issue (DESIGN.md 4)'}
+        result['valu'] = {
+            'dense_equivalent_cells_per_s': cells_per_launch / kernel_s, 'lane_instr_peak_per_s': VALU_LANE_OPS,
+            'frac_at_1_instr_per_cell': cells_per_launch / kernel_s / VALU_LANE_OPS}
+        result['phases_ms'] = {'group_of': g, 'forward_incl_preparation': fwd_ms, 'preparation': prep_ms,
+                               'argmax_backtrace': bt_ms}
+        result['hbm_roofline_frac_whole_job'] = value / size * algorithmic_bytes_per_timestep(S) / (HBM_PEAK_GBS * 1e9)
+        if rank == 0 and size == 1 and not args.no_secondary and args.transition == 'dense':
+            result['secondary'] = self.secondary(obs[0], frames, trans, init)
+        if rank == 0 and size == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(last_obs, trans, init, indices)
+        return result
+
+    # ---- secondary records: the same run substantiates DESIGN.md's table -------------------------------
+    def secondary(self, obs, frames, trans, init):
+        torch, v, synth, np = self.torch, self.viterbi, self.synth, self.np
+        args, dev = self.args, self.dev
+        B, T, S = obs.shape
+        out = {}
+
+        def record(name, seconds, timesteps, S_, note, extra=None):
+            rate = timesteps / seconds
+            out[name] = {'value': rate, 'unit': 'timesteps/s', 'ms_per_decode': seconds * 1e3,
+                         'roofline_frac': rate * algorithmic_bytes_per_timestep(S_) / (HBM_PEAK_GBS * 1e9),
+                         'note': note}
+            if extra:
+                out[name].update(extra)
+
+        ws = torch.empty(v.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+        sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(obs, frames, trans, init, workspace=ws, path='pruned'), 3)
+        record('serial', sec, B * T, S, 'headline batch, ONE batch at a time on one stream: per-timestep launches of '
+                                       'the pruned recurrence (latency of a single decode)')
+        sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(obs, frames, trans, init, workspace=ws, path='dense'), 2)
+        record('every_cell', sec, B * T, S, 'headline batch, dense (max,+) GEMM forced: every (prev, next) cell evaluated',
+               {'valu_frac_at_1p5_instr_per_cell': 1.5 * B * T * S * S / sec / VALU_LANE_OPS})
+        # posteriorgram-like input: per-frame log_softmax of peaked logits clamped at log(tiny), the reference's
+        # banded pitch transition (torbi/evaluate/core.py:23-34); AUTO's choice after it has settled
+        gen = torch.Generator(device=dev).manual_seed(7)
+        logits = torch.randn((B, T, S), device=dev, generator=gen) * 2.0
+        centre = torch.randint(0, S, (B, T, 1), device=dev, generator=gen)
+        logits -= ((torch.arange(S, device=dev)[None, None, :] - centre).abs().float() / 12.0) ** 2
+        peaked = torch.log_softmax(logits, dim=-1).clamp_(min=math.log(torch.finfo(torch.float32).tiny))
+        del logits
+        band = torch.from_numpy(synth.banded_transition(S, args.half_width)).to(dev)
+        for _ in range(4):
+            self.torbi_amd.decode(peaked, frames, band, init, workspace=ws)
+        prof = []
+        self.torbi_amd.decode(peaked, frames, band, init, workspace=ws, _profile=prof)
+        sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(peaked, frames, band, init, workspace=ws), 3, warmup=0)
+        record('peaked_banded', sec, B * T, S,
+               'posteriorgram-like rows (log_softmax of peaked logits, clamped at log tiny) with the reference\'s banded '
+               'pitch transition; path = what AUTO settled on', {'forward_path': ROUTES[int(prof[3])]})
+        sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(peaked, frames, trans, init, workspace=ws), 3, warmup=4)
+        record('peaked_dense_transition', sec, B * T, S, 'the same peaked rows with the dense random transition (AUTO)')
+        del peaked, band
+        c = float(torch.tensor(math.log(1.0 / S), dtype=torch.float32))
+        sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode_uniform(obs, frames, c, init), 3)
+        out['uniform'] = {'value': B * T / sec, 'unit': 'timesteps/s', 'ms_per_decode': sec * 1e3,
+                          'roofline_frac': B * T * (4 * S + 4) / sec / (HBM_PEAK_GBS * 1e9),
+                          'note': 'uniform transition (reference default, transition=None): O(S) per timestep, '
+                                  'HBM-bound on the 4S observation bytes'}
+        del ws
+        # BASELINE configs[1]: B = 1
+        o1 = obs[:1].contiguous()
+        f1 = frames[:1].contiguous()
+        sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(o1, f1, trans, init), 3)
+        record('c2', sec, T, S, f'BASELINE configs[1]: {S} states, {T} frames, batch=1 (latency bound)',
+               {'us_per_timestep': sec / max(T - 1, 1) * 1e6})
+        # BASELINE configs[4]: 4096 states, 2000 frames, batch 128
+        try:
+            B5, T5, S5 = 128, 2000, 4096
+            o5 = v.fill_synthetic((B5, T5, S5), synth.STREAM_OBSERVATION, seed=5, device=dev)
+            t5 = v.fill_synthetic((S5, S5), synth.STREAM_TRANSITION, seed=0, device=dev)
+            i5 = v.fill_synthetic((S5,), synth.STREAM_INITIAL, seed=0, device=dev)
+            f5 = torch.full((B5,), T5, dtype=torch.int32, device=dev)
+            w5 = torch.empty(v.workspace_bytes(B5, T5, S5), dtype=torch.uint8, device=dev)
+            sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(o5, f5, t5, i5, workspace=w5), 2)
+            record('c5', sec, B5 * T5, S5, 'BASELINE configs[4]: 4096 states, 2000 frames, batch=128')
+            del o5, t5, i5, f5, w5
+        except RuntimeError as exc:     # out of memory next to the headline buffers: say so instead of dying
+            out['c5'] = {'value': None, 'note': f'not measured: {exc}'}
+        # BASELINE configs[3] in miniature: 4096 ragged sequences, one GPU, decode only
+        out['c4_4096_files'] = self.c4_decode_only(4096, steps=0, quiet=True)
+        return out
+
+    # ---- BASELINE configs[3]: ragged many-file job ----------------------------------------------------
+    def c4_plan(self, files):
+        """Batches of the job in file order (reference loader: BATCH_SIZE files per batch, collate pads to the batch
+        maximum) and their assignment to ranks by padded cost."""
+        lengths = self.synth.lengths(files, 100, 900).tolist()
+        plan = self.distributed.assign_batches(lengths, self.args.batch, self.size)
+        return lengths, plan
+
+    def c4_decode_only(self, files, steps, quiet=False):
+        args, torch, v, synth = self.args, self.torch, self.viterbi, self.synth
+        S = args.states
+        lengths, plan = self.c4_plan(files)
+        mine = plan[self.rank] if self.size > 1 else [b for r in plan for b in r]
+        mine = sorted(mine, key=lambda b: b[0])
+        if steps:
+            mine = mine[:steps]
+        valid = sum(lengths[i] for b in mine for i in b)
+        padded = sum(max(lengths[i] for i in b) * len(b) for b in mine)
+        if self.dry:
+            self.fence()
+            total = self.sum_over_ranks(valid)
+            return {'value': None, 'dry_run': True, 'batches_per_rank': [len(r) for r in plan],
+                    'valid_timesteps': total}
+        dev = self.dev
+        trans, init = self.model(S)
+        group = max(1, args.group)
+        slots = group * max(1, args.pipeline)
+        tmax = max((max(lengths[i] for i in b) for b in mine), default=1)
+        # a pool of resident observation buffers: batch k decodes buffer k % slots with ITS lengths
+        pool = [v.fill_synthetic((args.batch, tmax, S), synth.STREAM_OBSERVATION, seed=self.rank * 64 + k, device=dev)
+                for k in range(min(slots, max(len(mine), 1)))]
+        batches = []
+        for k, b in enumerate(mine):
+            t = max(lengths[i] for i in b)
+            frames = torch.tensor([lengths[i] for i in b], dtype=torch.int32, device=dev)
+            # a contiguous (items, longest, S) batch laid over the head of the pool buffer (synthetic values: any
+            # reinterpretation of the buffer is as good a batch as any other)
+            flat = pool[k % len(pool)].view(-1)
+            batches.append((flat[:len(b) * t * S].view(len(b), t, S), frames))
+        pipe = self.torbi_amd.DecodePipeline(dev, depth=max(1, args.pipeline), group=group,
+                                             path=None if args.forward == 'auto' else args.forward)
+
+        def run():
+            for observation, frames in batches:
+                pipe.decode(observation, frames, trans, init)
+            pipe.synchronize()
+
+        run()                                   # warm-up pass over the same batches
+        self.fence(pipe)
+        t0 = time.perf_counter()
+        run()
+        self.fence(pipe)
+        elapsed = self.max_over_ranks(time.perf_counter() - t0)
+        total_valid = self.sum_over_ranks(valid)
+        total_padded = self.sum_over_ranks(padded)
+        record = {'value': total_valid / elapsed, 'unit': 'timesteps/s', 'seconds': elapsed,
+                  'sequences': files if not steps else sum(len(b) for b in mine), 'batches': len(mine),
+                  'valid_timesteps': total_valid, 'padded_timesteps': total_padded,
+                  'padding_overhead': total_padded / max(total_valid, 1.0) - 1.0,
+                  'roofline_frac': total_valid / elapsed * algorithmic_bytes_per_timestep(S) / (HBM_PEAK_GBS * 1e9),
+                  'note': 'lengths 100..900 in file order, batches of 512 padded to the batch maximum like '
+                          'collate.py:24-31; value counts VALID timesteps only; the time-resident kernel runs every '
+                          '16-item tile to the longest of ITS items, so padding costs memory, not recurrence steps'}
+        del pool, batches
+        return record
+
+    def c4_end_to_end(self, files):
+        """torch.save()d inputs -> from_files_to_files -> torch.save()d outputs on this rank's share."""
+        import shutil
+        import tempfile
+        torch, synth = self.torch, self.synth
+        S = self.args.states
+        lengths = synth.lengths(files, 100, 900).tolist()
+        base = '/dev/shm' if os.path.isdir('/dev/shm') else None
+        folder = tempfile.mkdtemp(prefix='torbi_c4_', dir=base)
+        try:
+            ins, outs = [], []
+            gen = torch.Generator().manual_seed(1)
+            block = torch.rand(900, S, generator=gen).log_softmax(-1)
+            for k, n in enumerate(lengths):
+                f = os.path.join(folder, f'in{k}.pt')
+                if self.rank == 0:
+                    torch.save(torch.roll(block, k, dims=0)[:n].clone(), f)
+                ins.append(f)
+                outs.append(os.path.join(folder, f'out{k}.pt'))
+            tf = os.path.join(folder, 'transition.pt')
+            if self.rank == 0:
+                torch.save(torch.rand(S, S, generator=gen).softmax(-1), tf)
+            self.fence()
+            t0 = time.perf_counter()
+            self.distributed.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, lengths=lengths)
+            self.fence()
+            elapsed = self.max_over_ranks(time.perf_counter() - t0)
+            ok = all(os.path.exists(f) for f in outs)
+            return {'value': sum(lengths) / elapsed, 'unit': 'timesteps/s', 'seconds': elapsed, 'sequences': files,
+                    'outputs_written': ok,
+                    'note': 'torch.load + collate + H2D + epsilon clamp + decode + D2H + torch.save, length-bucketed '
+                            f'batches, files in {folder.rsplit("/", 1)[0]}'}
+        finally:
+            if self.rank == 0:
+                shutil.rmtree(folder, ignore_errors=True)
+
+    def run_c4(self):
+        args = self.args
+        record = self.c4_decode_only(args.files, args.steps if args.steps != 16 else 0)
+        result = {'metric': 'timesteps decoded/sec, 1440 states, ragged many-file job (BASELINE configs[3])',
+                  'value': record.get('value'), 'unit': 'timesteps/s', 'n_gpus': self.size,
+                  'steps': record.get('batches'), 'warmup': record.get('batches'),
+                  'ms_per_step': (record['seconds'] / max(record['batches'], 1) * 1e3) if record.get('seconds') else None,
+                  'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
+                  'data': 'synthetic',
+                  'config': {'workload': f'{args.states} states, {args.files} sequences of 100..900 frames, batches of '
+                                         f'{args.batch} padded to the batch maximum, decode only, inputs resident in HBM; '
+                                         f'batches assigned to ranks by padded cost',
+                             'parallelism': f'batches sharded x{self.size}' if self.size > 1 else 'single GPU',
+                             'launch_group': args.group, 'streams': args.pipeline},
+                  'decode_only': record}
+        if record.get('dry_run'):
+            result['dry_run'] = True
+        if args.end_to_end and not self.dry:
+            result['end_to_end'] = self.c4_end_to_end(args.end_to_end)
+        return result
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=512)
-    ap.add_argument('--frames', type=int, default=500)
-    ap.add_argument('--states', type=int, default=1440)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--reuse-preparation', action='store_true',
-                    help='let consecutive decodes share the per-transition preparation (sorted rows / packed '
-                         'panels) as a serving loop would; off by default: every timed decode does all of its work')
-    ap.add_argument('--forward', choices=['auto', 'dense', 'pruned'], default='auto',
-                    help='forward-recurrence path (include/torbi_hip.h); every path gives identical indices')
-    ap.add_argument('--pipeline', type=int, default=2,
-                    help='decodes in flight (torbi_amd.DecodePipeline streams); 1 = strictly serial')
-    ap.add_argument('--transition', choices=['dense', 'banded', 'uniform'], default='dense',
-                    help="dense = headline workload; banded = the reference's pitch transition "
-                         '(torbi/evaluate/core.py:24-33), secondary structured-transition line')
-    ap.add_argument('--half-width', type=float, default=87.2,
-                    help='band half width in states for --transition banded (penn: 87.2)')
-    args = ap.parse_args()
-
-    rank, size, local = distributed.init_from_env()
-    assert size == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={size}'
-    dev = torch.device('cuda', torch.cuda.current_device())
-    collective = dist.is_available() and dist.is_initialized()
-    B, T, S = args.batch, args.frames, args.states
-    viterbi.set_forward_path(args.forward)
-
-    # synthetic inputs generated in HBM (rank-specific observation stream; shared transition)
-    obs = viterbi.fill_synthetic((B, T, S), synth.STREAM_OBSERVATION, seed=rank, device=dev)
-    trans = viterbi.fill_synthetic((S, S), synth.STREAM_TRANSITION, seed=0, device=dev)
-    if args.transition == 'banded':
-        trans = torch.from_numpy(synth.banded_transition(S, args.half_width)).to(dev)
-    init = viterbi.fill_synthetic((S,), synth.STREAM_INITIAL, seed=0, device=dev)
-    frames = torch.full((B,), T, dtype=torch.int32, device=dev)
-    ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
-
-    import math
-    uniform_c = float(torch.tensor(math.log(1.0 / S), dtype=torch.float32))
-
-    pipe = torbi_amd.DecodePipeline(dev, depth=args.pipeline, reuse_preparation=args.reuse_preparation) \
-        if args.pipeline > 1 else None
-
-    def gather(idx):
-        return distributed.gather_indices(idx, B * size, force=True) if collective else idx
-
-    def step():
-        if args.transition == 'uniform':
-            return gather(torbi_amd.decode_uniform(obs, frames, uniform_c, init))
-        if pipe is not None:     # consecutive batches alternate between HIP streams
-            return pipe.decode(obs, frames, trans, init, after=gather)
-        return gather(torbi_amd.decode(obs, frames, trans, init, workspace=ws,
-                                       reuse_preparation=args.reuse_preparation))
-
-    def fence():
-        if pipe is not None:
-            pipe.synchronize()
-        torch.cuda.synchronize()
-        if collective:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        indices = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if collective:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    timesteps = float(B) * T * args.steps * size
-    value = timesteps / elapsed
-
-    # dominant kernel: the forward-recurrence step kernel; average launch duration measured with
-    # hipEvents on the launch stream around the whole chain of launches (one launch = one
-    # timestep of the whole batch), averaged over a few profiled decodes
-    prof, fwd_ms, bt_ms, launches = [], 0.0, 0.0, 1
-    if args.transition == 'uniform':
-        # one kernel per decode, HBM-bound: 4S observation bytes + 4 index bytes per timestep
-        per = elapsed / args.steps
-        nbytes = float(B) * T * (4 * S + 4)
-        result = {
-            'metric': 'timesteps decoded/sec, 1440 states batch=512', 'value': value,
-            'unit': 'timesteps/s', 'n_gpus': size, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': per * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{S} states, {T} frames, batch={B} per GPU, fp32, UNIFORM '
-                                   f'transition (the reference default, transition=None; secondary '
-                                   f'workload)'},
-            'roofline': {'bound': 'hbm', 'achieved': nbytes / per / 1e9, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': nbytes / per / 1e9 / HBM_PEAK_GBS, 'traffic': None,
-                         'kernel': 'uniform_decode_kernel (whole decode, host-timed incl. launch)',
-                         'algorithmic_bytes_per_launch': nbytes},
-        }
-        if rank == 0:
-            print(json.dumps(result), flush=True)
-        if collective:
-            dist.destroy_process_group()
-        return
-    for _ in range(3):
-        torbi_amd.decode(obs, frames, trans, init, workspace=ws, _profile=prof)
-        fwd_ms += prof[0] / 3
-        bt_ms += prof[1] / 3
-        launches = max(int(prof[2]), 1)
-    path = {2: 'pruned', 1: 'dense', 0: 'generic'}[int(prof[3])]
-    step_kernel = {'pruned': 'pruned::step_pruned_kernel<16, false>', 'dense': 'step_dense_kernel<8, 6, 8, 12>',
-                   'generic': 'step_rows_kernel'}[path]
-    per_launch_s = fwd_ms * 1e-3 / launches
-    bytes_per_launch = B * algorithmic_bytes_per_timestep(S)
-    achieved = bytes_per_launch / per_launch_s / 1e9
-    cells_per_launch = float(B) * S * S
-    result = {
-        'metric': 'timesteps decoded/sec, 1440 states batch=512',
-        'value': value, 'unit': 'timesteps/s', 'n_gpus': size, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
-        'data': 'synthetic',
-        'config': {'workload': f'{S} states, {T} frames, batch={B} per GPU, fp32, dense '
-                               f'transition{" (BASELINE configs[2])" if (B, T, S) == (512, 500, 1440) else ""}; '
-                               f'decode = forward + argmax + backtrace, inputs resident in HBM'
-                               if args.transition == 'dense' else
-                               f'{S} states, {T} frames, batch={B} per GPU, fp32, BANDED transition '
-                               f'(half width {args.half_width}, -inf outside; secondary workload)',
-                   'parallelism': f'batch-sharded x{size}' if size > 1 else 'single GPU',
-                   'decodes_in_flight': args.pipeline, 'forward_path': path,
-                   'transition_preparation': 'reused across decodes' if args.reuse_preparation
-                   else 'rebuilt by every decode'},
-        'roofline': {
-            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBS,
-            'traffic': profiled_traffic(step_kernel)
-            if (B, T, S, args.transition) == (512, 500, 1440, 'dense') else None,
-            'traffic_note': 'bytes per launch from profiles/r01_pmc.json (2*FETCH_SIZE + WRITE_SIZE, '
-                            'Infinity-Cache hits included); the excess over the algorithmic bytes is '
-                            'posterior rows / transition lists re-read by the tiles of one launch',
-            'kernel': f'{step_kernel} (forward step: one timestep of the whole batch per launch)',
-            'launch_us': per_launch_s * 1e6, 'launches_per_decode': launches,
-            'algorithmic_bytes_per_launch': bytes_per_launch,
-            'note': 'the (max,+) recurrence holds S/4 = 360 cells per algorithmic byte: the dense kernel is '
-                    'VALU-bound, the pruned kernel is bound by the CU load path (list entries through the '
-                    'texture path, posterior gathers through the LDS); see valu and DESIGN.md',
-        },
-        'valu': {
-            # cells of the full S x S recurrence per second: for the pruned path most are never evaluated
-            'dense_equivalent_cells_per_s': cells_per_launch / per_launch_s,
-            'lane_instr_peak_per_s': VALU_LANE_OPS,
-            'frac_at_1_instr_per_cell': cells_per_launch / per_launch_s / VALU_LANE_OPS,
-        },
-        'phases_ms': {'forward': fwd_ms, 'argmax_backtrace': bt_ms},
-        'hbm_roofline_frac_whole_decode':
-            value / size * algorithmic_bytes_per_timestep(S) / (HBM_PEAK_GBS * 1e9),
-    }
-    if rank == 0 and size == 1 and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline(obs, trans, init, indices)
-    if rank == 0:
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
+    bench = Bench(args)
+    result = bench.run_c4() if args.workload == 'c4' else bench.run_c3()
+    if bench.rank == 0:
         print(json.dumps(result), flush=True)
-    if collective:
-        dist.destroy_process_group()
+    if bench.collective:
+        bench.dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -521,7 +521,7 @@ def _oracle_for_file(observation, transition_probs, states):
     x = torch.log(torch.exp(x) + tiny).cpu().numpy()[None]
     trans = torch.log(transition_probs + tiny).numpy()
     init = np.full((states,), math.log(1. / states + tiny), dtype=np.float32)
-    return oracle.decode(x, [x.shape[1]], trans, init)[0]
+    return oracle.decode(x, [x.shape[1]], trans, init, num_threads=oracle.max_threads())[0]
 
 
 def test_files_round_trip(tmp_path):
@@ -780,3 +780,62 @@ def test_from_probabilities_equals_the_reference_outputs():
     np.testing.assert_array_equal(got.cpu().numpy(), API['probs/indices_defaults'])
     got = torbi_amd.from_probabilities(torch.log(obs), frames, torch.log(trans), torch.log(init), log_probs=True, gpu=0)
     np.testing.assert_array_equal(got.cpu().numpy(), API['probs/indices_log'])
+
+
+# ---- BASELINE configs[3] scaled down: a ragged many-file job through from_files_to_files ---------------------
+
+def _ragged_job(tmp_path, count, S, seed):
+    lengths = synth.lengths(count, 100, 900, seed=seed).tolist()
+    gen = torch.Generator().manual_seed(seed)
+    block = torch.rand(1000, S, generator=gen).mul_(6.0).log_softmax(-1)
+    ins, outs = [], []
+    for k, n in enumerate(lengths):
+        f = tmp_path / f'in{k}.pt'
+        start = (37 * k) % 100
+        torch.save((block[start:start + n] + 0.01 * (k % 7)).log_softmax(-1).clone(), f)
+        ins.append(f)
+        outs.append(tmp_path / f'out{k}.pt')
+    tf = tmp_path / 'transition.pt'
+    torch.save(torch.rand(S, S, generator=gen).mul_(4.0).softmax(-1), tf)
+    return lengths, ins, outs, tf
+
+
+def test_many_file_job_every_file_equals_the_oracle(tmp_path, forward):
+    """2100 sequences of 100..900 frames over 256 states, batches of 512 in file order (five batches -> one launch
+    group) and again length-bucketed: EVERY output file equals the oracle's decode of that file alone."""
+    if forward in ('dense', 'pruned'):
+        pytest.skip('auto (grouped, time-resident) and resident cover the job; the per-timestep paths see ragged '
+                    'batches in the other tests')
+    S, count = 256, 2100
+    lengths, ins, outs, tf = _ragged_job(tmp_path, count, S, seed=4)
+    torbi_amd.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, gpu=0)
+    trans = torch.load(tf)
+    for k in range(count):
+        got = torch.load(outs[k])
+        assert got.dtype == torch.int32 and got.shape == (lengths[k],)
+        want = _oracle_for_file(torch.load(ins[k]), trans, S)
+        assert np.array_equal(got.numpy(), want), f'file {k} ({lengths[k]} frames)'
+    outs2 = [tmp_path / f'bucketed{k}.pt' for k in range(count)]
+    torbi_amd.from_files_to_files(ins, outs2, transition_file=tf, log_probs=True, gpu=0, lengths=lengths)
+    for a, b in zip(outs, outs2):
+        assert torch.equal(torch.load(a), torch.load(b))
+
+
+def test_many_file_job_at_1440_states(tmp_path, forward):
+    """BASELINE configs[3] at its own state count, 560 sequences (two batches: 512 + 48): in-order and
+    length-bucketed batching write identical files, and 40 randomly chosen files equal the oracle's decode of
+    that file alone (about 1 s of host time each)."""
+    if forward == 'dense':
+        pytest.skip('40 s per batch on the dense kernel; covered at 256 states')
+    S, count = 1440, 560
+    lengths, ins, outs, tf = _ragged_job(tmp_path, count, S, seed=9)
+    torbi_amd.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, gpu=0)
+    outs2 = [tmp_path / f'bucketed{k}.pt' for k in range(count)]
+    torbi_amd.from_files_to_files(ins, outs2, transition_file=tf, log_probs=True, gpu=0, lengths=lengths)
+    trans = torch.load(tf)
+    for k in range(count):
+        a, b = torch.load(outs[k]), torch.load(outs2[k])
+        assert a.dtype == torch.int32 and a.shape == (lengths[k],) and torch.equal(a, b)
+    for k in np.random.default_rng(3).choice(count, size=40, replace=False):
+        want = _oracle_for_file(torch.load(ins[k]), trans, S)
+        assert np.array_equal(torch.load(outs[k]).numpy(), want), f'file {k} ({lengths[k]} frames)'

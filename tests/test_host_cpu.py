@@ -311,3 +311,27 @@ def test_from_dataloader_joins_chunked_files(tmp_path, monkeypatch):
             row += 1
         got = torch.load(mapping[f])
         assert got.dtype == torch.int32 and got.tolist() == want
+
+
+def test_bench_starts_its_own_ranks_and_dry_runs_without_a_gpu():
+    """`python bench.py --gpus 2` without a launcher: bench.py starts the two ranks itself (child process, gloo
+    rendezvous on 127.0.0.1) and, with no HIP device, prints a dry-run line carrying the launch plan."""
+    if torch.cuda.device_count() > 0:
+        pytest.skip('a HIP device is present: the real benchmark would run')
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5'],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['dry_run'] is True and line['value'] is None
+    assert line['steps'] == 20 and line['warmup'] == 5 and line['config']['launch_groups'] == [7, 7, 6]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', 'c4', '--files', '3000'],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong'
+    assert line['decode_only']['batches_per_rank'] == [3, 3]
+    assert line['decode_only']['valid_timesteps'] == float(synth.lengths(3000, 100, 900).sum())

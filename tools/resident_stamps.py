@@ -1,0 +1,53 @@
+"""Per-phase cycle sums of resident::resident_forward_kernel (instrumented build, -DRESIDENT_STAMP).
+
+    python tools/resident_stamps.py build        # here (hipcc cross-compiles): tools/libtorbi_hip_rstamp.so
+    python tools/resident_stamps.py [batches] [frames]   # on the GPU box
+"""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+LIB = os.path.join(ROOT, 'tools', 'libtorbi_hip_rstamp.so')
+
+if len(sys.argv) > 1 and sys.argv[1] == 'build':
+    subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
+                           '-fno-slp-vectorize', '-DRESIDENT_STAMP', f'-I{ROOT}/include', '-o', LIB,
+                           f'{ROOT}/torbi_amd/csrc/torbi_hip.hip'] + sys.argv[2:])
+    sys.exit(0)
+
+import numpy as np, torch
+import torbi_amd._lib as _lib
+_lib.LIBRARY = LIB
+import torbi_amd
+from torbi_amd import viterbi
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+B, S = 512, 1440
+dev = torch.device('cuda:0')
+trans = viterbi.fill_synthetic((S, S), 2, device=dev)
+init = viterbi.fill_synthetic((S,), 3, device=dev)
+obs = [viterbi.fill_synthetic((B, T, S), 1, seed=k, device=dev) for k in range(n)]
+frames = [torch.full((B,), T, dtype=torch.int32, device=dev) for _ in range(n)]
+prof = []
+for _ in range(2):
+    viterbi.decode_batches(obs, frames, trans, init, path='resident', _profile=prof)
+torch.cuda.synchronize()
+lib = _lib.load()
+KW, KP = 12, 8
+nwg = n * B // 16
+buf = (ctypes.c_ulonglong * (nwg * 16 * KP))()
+lib.torbi_hip_debug_phases.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+rc = lib.torbi_hip_debug_phases(buf, nwg * 16 * KP)
+acc = np.frombuffer(buf, dtype=np.uint64).reshape(nwg, 16, KP)[:, :KW].astype(np.float64)
+steps = T - 1
+names = ['barrier A (wait for tile)', 'seed reads', 'pass head: loads -> block 0 + seeds', 'scan loop', 'outputs + top insert',
+         'barrier B (wait for waves)', 'tile write + publish']
+tot = acc[:, :, :7].sum(axis=2).mean()
+print(f'rc {rc}; forward {prof[0]:.3f} ms for {n} batches x {T} frames; {tot / steps:.0f} ticks per timestep per wave '
+      f'({prof[0] * 1e3 / steps:.1f} us)')
+for i, name in enumerate(names):
+    v = acc[:, :, i].mean() / steps
+    print(f'{name:38s} {v:9.0f} ticks/step  {100 * v * steps / tot:5.1f} %')
+blocks = acc[:, :, 7].mean() / steps
+print(f'extra list blocks per wave and timestep: {blocks:.1f} over {np.ceil(90 / KW):.0f} passes -> '
+      f'{16 * (1 + blocks / (90 / KW)):.0f} entries per row group on average')
+print('scan ticks per wave: min/mean/max over waves', acc[:, :, 3].min() / steps, acc[:, :, 3].mean() / steps, acc[:, :, 3].max() / steps)

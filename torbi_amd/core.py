@@ -20,6 +20,9 @@ NUM_WORKERS = 0
 # reference torbi/config/defaults.py:41,44: chunked decoding of long sequences (torbi_amd/chunk.py); off when None
 MIN_CHUNK_SIZE = None
 ENTROPY_THRESHOLD = 0.5
+# batches of a many-file job decoded per launch group (torbi_amd.DecodePipeline / decode_batches): 8 x 512 items
+# give every compute unit of an MI355X one 16-item workgroup of the time-resident kernel
+GROUP_SIZE = 8
 
 
 def _compute_device(gpu, observation):
@@ -243,16 +246,18 @@ def from_dataloader(
     """Decode every batch a `data.loader` yields and save each item under `output_files[input]`
     (core.py:376-463).
 
-    The reference loop is serial (decode, copy back, save, next batch).  Here batch k+1 is
-    enqueued (torbi_amd.DecodePipeline: alternating HIP streams) before batch k's indices are
-    copied back and saved, so loading/saving and the backtrace of one batch overlap the forward
-    pass of the next.  Outputs are identical.
+    The reference loop is serial (decode, copy back, save, next batch).  Here `GROUP_SIZE` consecutive
+    batches are decoded together (torbi_amd.DecodePipeline -> decode_batches: one time-resident forward
+    launch for the group when it has enough items), groups alternate between two HIP streams, and a
+    batch's indices are copied back and saved while the following group is collected and decoded.
+    Outputs are identical.
     """
     from .pipeline import DecodePipeline
+    import collections
     pipe = None
     if torch.cuda.is_available():
         device = torch.device('cuda', torch.cuda.current_device() if gpu is None else gpu)
-        pipe = DecodePipeline(device)
+        pipe = DecodePipeline(device, depth=2, group=GROUP_SIZE)
 
     def finish(item):
         indices, input_filenames, batch_frames, batch_chunks = item
@@ -268,7 +273,10 @@ def from_dataloader(
             for row, filename, frames in zip(rows, filenames, batch_frames.cpu()):
                 save_masked(row, filename, frames)
 
-    previous = None
+    # batches stay outstanding until a whole group behind them has been enqueued: the group being collected,
+    # the group being decoded and the batch being saved overlap
+    outstanding = collections.deque()
+    keep = 1 if pipe is None else pipe.group * (pipe.depth - 1) + 1
     model = {}
     for observation, batch_frames, batch_chunks, input_filenames in dataloader:
         indices = from_probabilities(
@@ -281,11 +289,11 @@ def from_dataloader(
             num_threads=num_threads,
             _pipeline=pipe,
             _model=model)
-        if previous is not None:
-            finish(previous)
-        previous = (indices, input_filenames, batch_frames, batch_chunks)
-    if previous is not None:
-        finish(previous)
+        outstanding.append((indices, input_filenames, batch_frames, batch_chunks))
+        while len(outstanding) > keep:
+            finish(outstanding.popleft())
+    while outstanding:
+        finish(outstanding.popleft())
 
 
 def save(tensor, file):

@@ -84,6 +84,17 @@ __device__ __forceinline__ void top_insert(u64 *list, u64 x) {
     }
 }
 
+#ifdef RESIDENT_STAMP
+// build-time instrumentation (tools/resident_stamps.py): per-wave cycle sums of the phases of a timestep
+constexpr int kPhases = 8;
+__device__ unsigned long long g_phase[1024 * 16 * kPhases];
+#define RSTAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); acc[i] += now_ - last; last = now_; }
+#define RCOUNT(i, n) acc[i] += (n)
+#else
+#define RSTAMP(i)
+#define RCOUNT(i, n)
+#endif
+
 // ---------------------------------------------------------------------------------------
 // The whole forward pass of 16 items.  grid = tiles of every batch of the group, block = 64 * KW,
 // dynamic LDS = lds_bytes(S).  MAXP = ceil(ceil(S/16) / KW) row-group passes per wave and timestep.
@@ -171,9 +182,14 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
     };
     __syncthreads();
     publish_top();
+#ifdef RESIDENT_STAMP
+    unsigned long long acc[kPhases] = {};
+    unsigned long long last = __builtin_readcyclecounter();
+#endif
 
     for (int t = 1; t < fmax; ++t) {
         __syncthreads();      // tile = posterior row t-1, mtop = its largest entries, `top` is empty
+        RSTAMP(0);
 
         // seeds and bound of this lane's four items: the kR largest posteriors are explicit candidates, the
         // (kR+1)-th bounds every other one.  Items that have ended (t >= frames) get thr = -inf: their bound
@@ -191,6 +207,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
             seedo[it][0] = o.x; seedo[it][1] = o.y; seedo[it][2] = o.z;
             thr[it] = live[it] ? v.w : -INFINITY;
         }
+        RSTAMP(1);
 
         // (an opaque zero keeps the row-group addresses of all MAXP passes from being hoisted out of the time loop,
         // where they would cost ~10 registers per pass)
@@ -248,6 +265,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
                 for (int it = 0; it < 4; ++it)
 #pragma unroll
                     for (int r = 0; r < kR; ++r) best[it] = fmaxf(best[it], seedv[it][r] + seedt[it][r]);
+                RSTAMP(2);
                 auto more = [&](const ListBlock<EPL> &blk) {
                     const float tn = group_bcast<G, 0>(blk.e[0].x);
                     return __any(jv && ((tn + thr[0] > best[0]) | (tn + thr[1] > best[1]) | (tn + thr[2] > best[2]) |
@@ -256,12 +274,15 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
                 const int Sp = (S + 15) / 16 * 16;
                 for (int kk = kBlk; kk < Sp; kk += 2 * kBlk) {
                     if (!more(nxt)) break;
+                    RCOUNT(7, 1);
                     consume(nxt);
                     load_list_block(nxt, row, kk + 2 * kBlk);
                     if (!more(cur)) break;
+                    RCOUNT(7, 1);
                     consume(cur);
                     load_list_block(cur, row, kk + 3 * kBlk);
                 }
+                RSTAMP(3);
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const float o = ob[it] + best[it];                     // post'[j] = obs[t,j] + max
@@ -269,9 +290,11 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
                     if (jv && live[it]) hist[((size_t)(bfirst + ioff[it]) * T + t) * S + jr] = o;
                     if (jv) top_insert(top + (4 * g + it) * kTop, top_key(o, jr));
                 }
+                RSTAMP(4);
             }
         }
         __syncthreads();      // every wave is done reading the tile and mtop, every output is in `top`
+        RSTAMP(5);
 #pragma unroll
         for (int p = 0; p < MAXP; ++p) {
             const int rg = wave + KW * p + opaque;
@@ -281,7 +304,12 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
                     make_float4(pend[p][0], pend[p][1], pend[p][2], pend[p][3]);
         }
         publish_top();
+        RSTAMP(6);
     }
+#ifdef RESIDENT_STAMP
+    if (lane == 0 && blockIdx.x < 1024)
+        for (int i = 0; i < kPhases; ++i) g_phase[((size_t)blockIdx.x * 16 + wave) * kPhases + i] = acc[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1176,3 +1176,10 @@ extern "C" int torbi_hip_debug_stamps(unsigned long long *host, size_t count) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pruned::g_stamps), count * sizeof(unsigned long long));
 }
 #endif
+
+#ifdef RESIDENT_STAMP
+// instrumentation build only (tools/resident_stamps.py); not part of include/torbi_hip.h
+extern "C" int torbi_hip_debug_phases(unsigned long long *host, size_t count) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(resident::g_phase), count * sizeof(unsigned long long));
+}
+#endif

@@ -78,21 +78,29 @@ def gather_indices(local: torch.Tensor, count: int, group=None, force: bool = Fa
 
 
 def decode_sharded(observation, batch_frames, transition, initial, group=None, gather=True,
-                   decode_fn: Optional[Callable] = None):
-    """Decode this rank's contiguous block of a batch every rank holds; optionally gather.
+                   decode_fn: Optional[Callable] = None, count: Optional[int] = None):
+    """Decode this rank's contiguous block of a batch; optionally gather.
 
-    `observation`/`batch_frames` are the FULL (B, T, S) / (B,) tensors (e.g. read from shared
-    storage by every rank); transition/initial are replicated (8.3 MB at S=1440 -- each rank
-    uploads its own copy, no broadcast needed).  Returns (B, T) indices on every rank when
-    `gather`, else this rank's (n_r, T) block.
+    Two ways to hand over the batch.  `count` None: `observation`/`batch_frames` are the FULL (B, T, S) /
+    (B,) tensors on every rank (e.g. read from shared storage) and each rank slices its block.  `count` = B:
+    they are ALREADY this rank's block `shard_bounds(B, size, rank)` -- nothing but the shard has to be
+    resident on the rank (1.47 GB per 512 x 500 x 1440 batch otherwise).  transition/initial are replicated
+    (8.3 MB at S=1440 -- each rank uploads its own copy, no broadcast needed).  Returns (B, T) indices on
+    every rank when `gather`, else this rank's (n_r, T) block.
     """
     if decode_fn is None:
         from .viterbi import decode as decode_fn
     rank, size = world(group)
-    lo, hi = shard_bounds(observation.shape[0], size, rank)
-    local = decode_fn(observation[lo:hi].contiguous(), batch_frames[lo:hi].contiguous(),
-                      transition, initial)
-    return gather_indices(local, observation.shape[0], group) if gather else local
+    if count is None:
+        count = observation.shape[0]
+        lo, hi = shard_bounds(count, size, rank)
+        observation, batch_frames = observation[lo:hi].contiguous(), batch_frames[lo:hi].contiguous()
+    else:
+        lo, hi = shard_bounds(count, size, rank)
+        if observation.shape[0] != hi - lo:
+            raise ValueError(f'rank {rank} of {size} owns {hi - lo} of {count} items; got {observation.shape[0]}')
+    local = decode_fn(observation, batch_frames, transition, initial)
+    return gather_indices(local, count, group) if gather else local
 
 
 def assign_batches(lengths: Sequence[int], batch_size: int, size: int) -> List[List[List[int]]]:
@@ -114,14 +122,25 @@ def assign_batches(lengths: Sequence[int], batch_size: int, size: int) -> List[L
     return [[batches[k] for k in sorted(ks)] for ks in plan]
 
 
+def assign_files(lengths: Sequence[int], batch_size: int, size: int) -> List[List[int]]:
+    """File positions per rank: the batches of `assign_batches`, flattened in order, a short trailing batch
+    last (so re-batching a rank's list `batch_size` at a time reproduces whole batches)."""
+    plan = assign_batches(lengths, batch_size, size)
+    return [[i for batch in sorted(batches, key=lambda b: (len(b) < batch_size, b[0])) for i in batch]
+            for batches in plan]
+
+
 def from_files_to_files(input_files, output_files, transition_file=None, initial_file=None,
                         log_probs=False, gpu=None, num_threads=None, lengths=None, group=None,
                         decode_files: Optional[Callable] = None):
-    """Multi-GPU form of torbi_amd.from_files_to_files: each rank decodes and saves whole
-    batches of its own; no collective besides the closing barrier.
+    """Multi-GPU form of torbi_amd.from_files_to_files: each rank decodes and saves the files of whole
+    batches of its own in ONE call of the single-GPU entry point (so the model is loaded and prepared once
+    per rank and consecutive batches share launch groups and streams); no collective besides the closing
+    barrier.
 
-    `lengths` (frames per file) lets batches be balanced by padded cost; without it batches
-    are dealt round-robin.  `gpu` defaults to this rank's current device.
+    `lengths` (frames per file) lets batches be balanced by padded cost and is handed on, so every rank
+    also forms its batches from files of similar length; without it batches are dealt round-robin.
+    `gpu` defaults to this rank's current device.  Returns the number of files this rank decoded.
     """
     from . import core
     rank, size = world(group)
@@ -130,12 +149,12 @@ def from_files_to_files(input_files, output_files, transition_file=None, initial
     if gpu is None and torch.cuda.is_available():
         gpu = torch.cuda.current_device()
     n = len(input_files)
-    if lengths is None:
-        lengths = [1] * n
-    mine = assign_batches(list(lengths), core.BATCH_SIZE, size)[rank]
-    for batch in mine:
-        decode_files([input_files[i] for i in batch], [output_files[i] for i in batch],
-                     transition_file, initial_file, log_probs, gpu, num_threads)
+    known = lengths is not None
+    mine = assign_files(list(lengths) if known else [1] * n, core.BATCH_SIZE, size)[rank]
+    if mine:
+        extra = {'lengths': [lengths[i] for i in mine]} if known else {}
+        decode_files([input_files[i] for i in mine], [output_files[i] for i in mine],
+                     transition_file, initial_file, log_probs, gpu, num_threads, **extra)
     if size > 1:
         dist.barrier(group=group)
-    return sum(len(b) for b in mine)
+    return len(mine)

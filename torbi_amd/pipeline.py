@@ -1,17 +1,21 @@
-"""Stream-level pipelining of consecutive decodes.
+"""Stream-level pipelining and grouping of consecutive decodes.
 
-One decode is a chain of ~500 dependent step launches followed by a latency-bound backtrace
-(one wave per item, ~1 ms at B=512, T=500).  Batches are independent, so the next batch's
-forward pass can run while the previous batch's backtrace drains and its launch gaps are
-filled: alternating decodes between two HIP streams (each with its own scratch) measured
-18.6 ms per 512x500x1440 decode against 20.3 ms on one stream, with identical results.
+The reference's driver is fully serial (load -> decode -> save, torbi/core.py:417-457).  Batches are
+independent, which buys two things here:
 
-The reference's driver is fully serial (load -> decode -> save, torbi/core.py:417-457).
-`DecodePipeline` keeps `decode`'s contract per call; only completion is deferred: the returned
-indices are valid once `wait(indices)` / `synchronize()` returns (or on the stream the pipeline
-used, for callers that chain more GPU work).
+* **groups** (`group` > 1): consecutive batches are collected and decoded by ONE call of
+  `torbi_amd.decode_batches` -- with enough items that is one time-resident forward launch for the whole
+  group (csrc/resident_forward.hpp: 16 items per workgroup, posterior rows resident in the LDS, no per-timestep
+  launches), 2.1x the per-timestep path on the 512 x 500 x 1440 benchmark with eight batches per group;
+* **streams** (`depth` > 1): consecutive decodes (or groups) alternate between HIP streams with private
+  scratch, so one's latency-bound backtrace and launch tails hide under the next one's forward pass
+  (18.6 ms per 512x500x1440 decode against 20.3 ms on one stream with the per-timestep path).
+
+`DecodePipeline` keeps `decode`'s contract per call; only completion is deferred: the returned indices are
+valid once `wait(indices)` / `synchronize()` returns (or on the stream the pipeline used, for callers that
+chain more GPU work).
 """
-from typing import List, Optional, Tuple
+from typing import Callable, List, Optional, Tuple
 
 import torch
 
@@ -19,61 +23,105 @@ from . import viterbi
 
 
 class DecodePipeline:
-    """Round-robin decodes over `depth` side streams, each with a private scratch buffer."""
+    """Decodes in groups of `group` batches, round-robin over `depth` side streams with private scratch."""
 
-    def __init__(self, device=None, depth: int = 2, reuse_preparation: bool = True):
+    def __init__(self, device=None, depth: int = 2, reuse_preparation: bool = True, group: int = 1,
+                 path: Optional[str] = None):
         if not torch.cuda.is_available():
             raise RuntimeError('DecodePipeline needs a HIP device; torbi_amd has no CPU path')
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None \
             else torch.device(device)
         self.depth = max(1, int(depth))
+        self.group = max(1, min(int(group), viterbi._lib.MAX_BATCHES))
+        self.path = path
         # each slot's scratch is private, so the per-transition preparation of one decode can serve the next
         # decode of the same slot when shape and transition tensor are unchanged (decode(reuse_preparation=))
         self.reuse_preparation = bool(reuse_preparation)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
-        self.scratch: List[Optional[torch.Tensor]] = [None] * self.depth
+        # scratch[slot][k]: workspace of the k-th batch of the group that runs on `slot`
+        self.scratch: List[List[Optional[torch.Tensor]]] = [[None] * self.group for _ in range(self.depth)]
         self.pending: List[Tuple[torch.Tensor, torch.cuda.Event]] = []
+        self.waiting: List[tuple] = []          # batches collected for the next group
         self.turn = 0
 
-    def _scratch(self, slot, nbytes):
-        buf = self.scratch[slot]
+    def _scratch(self, slot, k, nbytes):
+        buf = self.scratch[slot][k]
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
-            self.scratch[slot] = buf
+            self.scratch[slot][k] = buf
         return buf
 
-    def decode(self, observation, batch_frames, transition, initial, after=None) -> torch.Tensor:
+    def decode(self, observation, batch_frames, transition, initial, after: Optional[Callable] = None) -> torch.Tensor:
         """Enqueue one decode; arguments as `torbi_amd.decode` (tensors on `self.device`).
 
         `after(indices)` (optional) runs on the same side stream right after the decode, e.g. the
-        RCCL gather of a sharded batch or an asynchronous copy to pinned host memory.
+        RCCL gather of a sharded batch or an asynchronous copy to pinned host memory; its return value
+        replaces the indices handed back here only for `group` == 1.
         """
+        if self.group == 1:
+            return self._launch([(observation, batch_frames, transition, initial, after, None)])[0]
+        B, T, _ = observation.shape
+        indices = torch.empty((B, T), dtype=torch.int32, device=self.device)
+        # a group shares one transition / initial: a different model flushes what has been collected
+        if self.waiting and (self.waiting[0][2] is not transition or self.waiting[0][3] is not initial
+                             or self.waiting[0][0].shape[-1] != observation.shape[-1]):
+            self.flush()
+        self.waiting.append((observation, batch_frames, transition, initial, after, indices))
+        if len(self.waiting) >= self.group:
+            self.flush()
+        return indices
+
+    def flush(self) -> None:
+        """Launch the batches collected so far (a partial group)."""
+        if self.waiting:
+            batches, self.waiting = self.waiting, []
+            self._launch(batches)
+
+    def _launch(self, batches):
         slot = self.turn % self.depth
         self.turn += 1
         stream = self.streams[slot]
-        B, T, S = observation.shape
-        need = viterbi.workspace_bytes(B, T, S)
+        transition, initial = batches[0][2], batches[0][3]
         # the inputs may have been produced on the caller's stream
         stream.wait_stream(torch.cuda.current_stream(self.device))
+        results = []
         with torch.cuda.stream(stream):
-            scratch = self._scratch(slot, need)
-            indices = viterbi.decode(observation, batch_frames, transition, initial, workspace=scratch,
-                                     reuse_preparation=self.reuse_preparation)
-            if after is not None:
-                indices = after(indices)
+            if len(batches) == 1 and batches[0][5] is None:
+                observation, batch_frames, _, _, after, _ = batches[0]
+                B, T, S = observation.shape
+                scratch = self._scratch(slot, 0, viterbi.workspace_bytes(B, T, S))
+                indices = viterbi.decode(observation, batch_frames, transition, initial, workspace=scratch,
+                                         reuse_preparation=self.reuse_preparation, path=self.path)
+                if after is not None:
+                    indices = after(indices)
+                results.append(indices)
+            else:
+                spaces = [self._scratch(slot, k, viterbi.workspace_bytes(*b[0].shape)) for k, b in enumerate(batches)]
+                decoded = viterbi.decode_batches([b[0] for b in batches], [b[1] for b in batches], transition,
+                                                 initial, workspaces=spaces,
+                                                 reuse_preparation=self.reuse_preparation, path=self.path,
+                                                 out=[b[5] for b in batches])
+                for (_, _, _, _, after, _), indices in zip(batches, decoded):
+                    if after is not None:
+                        after(indices)
+                    results.append(indices)
             done = torch.cuda.Event()
             done.record(stream)
         # keep the inputs alive for the allocator until the side stream is done with them
-        for tensor in (observation, batch_frames, transition, initial):
-            if tensor.is_cuda:
-                tensor.record_stream(stream)
-        self.pending.append((indices, done))
-        if len(self.pending) > 4 * self.depth:
+        for observation, batch_frames, _, _, _, _ in batches:
+            for tensor in (observation, batch_frames, transition, initial):
+                if tensor.is_cuda:
+                    tensor.record_stream(stream)
+        for indices in results:
+            self.pending.append((indices, done))
+        if len(self.pending) > 4 * self.depth * self.group:
             self.pending = [(i, e) for i, e in self.pending if not e.query()]
-        return indices
+        return results
 
     def wait(self, indices: torch.Tensor) -> torch.Tensor:
         """Block the host until the decode that produced `indices` has finished."""
+        if any(entry[5] is indices for entry in self.waiting):
+            self.flush()
         for tensor, event in self.pending:
             if tensor is indices:
                 event.synchronize()
@@ -83,6 +131,7 @@ class DecodePipeline:
 
     def synchronize(self) -> None:
         """Block the host until every enqueued decode has finished."""
+        self.flush()
         for _, event in self.pending:
             event.synchronize()
         self.pending = []

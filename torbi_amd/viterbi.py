@@ -220,6 +220,7 @@ def decode_batches(
     workspaces=None,
     reuse_preparation: bool = False,
     path: Optional[str] = None,
+    out=None,
     _profile: Optional[list] = None,
 ):
     """`decode` for several batches that share `transition` and `initial`, in one call
@@ -237,6 +238,7 @@ def decode_batches(
         workspaces: optional list of uint8 scratch tensors, one per batch, each >= workspace_bytes(N_k, T_k, S)
         reuse_preparation: as `decode`, for the first workspace
         path: as `decode`
+        out: optional list of preallocated (N_k, T_k) int32 tensors to decode into
 
     Returns:
         list of (N_k, T_k) int32 index tensors on the device
@@ -266,7 +268,14 @@ def decode_batches(
                       for B, T, _ in shapes]
     if len(workspaces) != count:
         raise RuntimeError('decode_batches needs one workspace per batch')
-    indices = [torch.empty((B, T), dtype=torch.int32, device=device) for B, T, _ in shapes]
+    if out is None:
+        out = [None] * count
+    indices = [torch.empty((B, T), dtype=torch.int32, device=device) if given is None else given
+               for (B, T, _), given in zip(shapes, out)]
+    for (B, T, _), tensor in zip(shapes, indices):
+        if (tuple(tensor.shape) != (B, T) or tensor.dtype != torch.int32 or tensor.device != device
+                or not tensor.is_contiguous()):
+            raise RuntimeError('out tensors must be contiguous int32 (N_k, T_k) tensors on the compute device')
     table = (_lib.Batch * count)()
     for k, (B, T, _) in enumerate(shapes):
         ws = workspaces[k]
