@@ -521,7 +521,7 @@ def _oracle_for_file(observation, transition_probs, states):
     x = torch.log(torch.exp(x) + tiny).cpu().numpy()[None]
     trans = torch.log(transition_probs + tiny).numpy()
     init = np.full((states,), math.log(1. / states + tiny), dtype=np.float32)
-    return oracle.decode(x, [x.shape[1]], trans, init, num_threads=oracle.max_threads())[0]
+    return oracle.decode(x, [x.shape[1]], trans, init, num_threads=min(oracle.max_threads(), max(1, states // 16)))[0]
 
 
 def test_files_round_trip(tmp_path):
@@ -803,9 +803,9 @@ def _ragged_job(tmp_path, count, S, seed):
 def test_many_file_job_every_file_equals_the_oracle(tmp_path, forward):
     """2100 sequences of 100..900 frames over 256 states, batches of 512 in file order (five batches -> one launch
     group) and again length-bucketed: EVERY output file equals the oracle's decode of that file alone."""
-    if forward in ('dense', 'pruned'):
-        pytest.skip('auto (grouped, time-resident) and resident cover the job; the per-timestep paths see ragged '
-                    'batches in the other tests')
+    if forward != 'auto':
+        pytest.skip('once is enough (15 s of host work): AUTO decodes the five batches as one time-resident launch '
+                    'group; the per-timestep paths see ragged batches in the other tests')
     S, count = 256, 2100
     lengths, ins, outs, tf = _ragged_job(tmp_path, count, S, seed=4)
     torbi_amd.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, gpu=0)
@@ -825,8 +825,9 @@ def test_many_file_job_at_1440_states(tmp_path, forward):
     """BASELINE configs[3] at its own state count, 560 sequences (two batches: 512 + 48): in-order and
     length-bucketed batching write identical files, and 40 randomly chosen files equal the oracle's decode of
     that file alone (about 1 s of host time each)."""
-    if forward == 'dense':
-        pytest.skip('40 s per batch on the dense kernel; covered at 256 states')
+    if forward not in ('auto', 'pruned'):
+        pytest.skip('auto (launch group of two batches) and the per-timestep pruned path; the other paths see '
+                    'ragged batches in the other tests')
     S, count = 1440, 560
     lengths, ins, outs, tf = _ragged_job(tmp_path, count, S, seed=9)
     torbi_amd.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, gpu=0)

@@ -43,6 +43,7 @@ struct Batch {
     const int32_t *frames;   // (B)
     float *hist;             // (B,T,S) posterior history of this batch
     int32_t *out;            // (B,T) decoded indices (backtrace)
+    const int32_t *order;    // (B) items by descending length: tile k owns items order[16k .. 16k+15]
     int B, T;
     int tile0;               // first workgroup of this batch in the launch
     int item0;               // first item of this batch in the launch-wide item numbering (backtrace grid)
@@ -57,11 +58,37 @@ inline bool supported(int S) { return S >= 64 && S <= pruned::kMaxS16; }
 
 typedef unsigned long long u64;
 
-// dynamic LDS: posterior tile [S4][16] + running top lists (64-bit keys) + decoded top lists + frame counts
+// dynamic LDS: posterior tile [S4][16] + running top lists (64-bit keys) + decoded top lists + frame counts + items
 inline size_t lds_bytes(int S) {
     const size_t S4 = ((size_t)S + 3) / 4 * 4;
     return sizeof(float) * kNI * S4 + sizeof(u64) * kNI * kTop + (sizeof(float) + sizeof(int)) * kNI * kTop +
-           sizeof(int) * kNI;
+           2 * sizeof(int) * kNI;
+}
+
+// once per decode: order[rank] = item, items ranked by descending (clamped) length, ties by item number.  A tile of
+// 16 consecutive ranks then loops to the longest of 16 items of SIMILAR length -- a ragged batch costs recurrence
+// steps for its valid frames only (collate pads every item of a 512-batch to the batch maximum: reference
+// torbi/data/collate.py:24-31) -- and the longest tiles are dispatched first.  Results do not depend on the order.
+// grid = (ceil(max B / 256), batches), block = 256; O(B^2) compares, batches above kMaxOrdered items keep their order.
+constexpr int kMaxOrdered = 8192;
+struct OrderJob { const int32_t *frames; int32_t *order; int B, T; };
+struct OrderJobs { OrderJob job[kMaxBatches]; };
+
+__global__ __launch_bounds__(256) void order_items_kernel(OrderJobs jobs) {
+    const OrderJob &jb = jobs.job[blockIdx.y];
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    const int B = jb.B, T = jb.T;
+    if (b >= B) return;
+    if (B > kMaxOrdered) { jb.order[b] = b; return; }
+    int f = jb.frames[b];
+    f = f < 1 ? 1 : (f > T ? T : f);
+    int rank = 0;
+    for (int o = 0; o < B; ++o) {
+        int g = jb.frames[o];
+        g = g < 1 ? 1 : (g > T ? T : g);
+        rank += (g > f) || (g == f && o < b);
+    }
+    jb.order[rank] = b;
 }
 
 // order-preserving 64-bit key of (value, state): larger value first, then the lower state
@@ -99,7 +126,11 @@ __device__ unsigned long long g_phase[1024 * 16 * kPhases];
 // The whole forward pass of 16 items.  grid = tiles of every batch of the group, block = 64 * KW,
 // dynamic LDS = lds_bytes(S).  MAXP = ceil(ceil(S/16) / KW) row-group passes per wave and timestep.
 // ---------------------------------------------------------------------------------------
-template <int KW, int MAXP>
+// PIPE: the posterior reads of an entry pair are issued while the previous pair's adds/maxima run (two pairs of
+// ds_read_b128 in flight per wave, also across list blocks: the first pair of the next block is read before the
+// termination test decides whether it is needed) -- with one timestep per launch the scan was a third of the
+// kernel and this bought nothing (tools/prune_proto5.hip); here the scan IS the kernel.
+template <int KW, int MAXP, bool PIPE>
 __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, const float *__restrict__ tt,
                                                                    const float2 *__restrict__ sorted,
                                                                    const float *__restrict__ initial, int S, int SpP) {
@@ -110,6 +141,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
     float *mtopv = reinterpret_cast<float *>(top + kNI * kTop);       // [16][kTop] previous timestep's, decoded
     int *mtopi = reinterpret_cast<int *>(mtopv + kNI * kTop);         // their states, as offsets into tt (state * S)
     int *sframes = mtopi + kNI * kTop;                                // [16] frames per item (0 past the batch)
+    int *sitem = sframes + kNI;                                       // [16] item numbers (a valid one past the batch)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,11 +159,13 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
 
     if (tid < kNI) {
         int f = 0;
+        const int item = bat.order[b0 + tid < B ? b0 + tid : B - 1];
         if (b0 + tid < B) {
-            f = bat.frames[b0 + tid];
+            f = bat.frames[item];
             f = f < 1 ? 1 : (f > T ? T : f);
         }
         sframes[tid] = f;
+        sitem[tid] = item;
     }
     if (tid < kNI * kTop) top[tid] = 0ull;
     __syncthreads();
@@ -141,7 +175,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
 
     // t = 0: posterior row 0 = obs[b,0,:] + initial (viterbi.cpp:72-76) into the tile, the history and the top lists
     for (int item = 0; item < kNI; ++item) {
-        const int b = b0 + item < B ? b0 + item : B - 1;
+        const int b = sitem[item];
         const bool valid = b0 + item < B;
         const float *src = obs + (size_t)b * T * S;
         float *dst = hist + (size_t)b * T * S;
@@ -159,12 +193,10 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
     const int jl = (int)((0xFBAE9DC873261540ull >> (4 * (lane >> 2))) & 15);
     const char *ptile = reinterpret_cast<const char *>(lds) + 16 * g;
     const int nrg = (S + kRowGroup - 1) / kRowGroup;
-    const size_t istride = (size_t)T * S;
-    // items of this lane: 4g .. 4g+3; items past the batch read the last one's observations and store nothing
-    const int bfirst = b0 + 4 * g < B ? b0 + 4 * g : B - 1;
-    int ioff[4];
+    // items of this lane: tile items 4g .. 4g+3; items past the batch read a valid one's observations and store nothing
+    int ib[4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) ioff[it] = bfirst + it < B ? it : B - 1 - bfirst;
+    for (int it = 0; it < 4; ++it) ib[it] = sitem[4 * g + it];
 
     float pend[MAXP][4];
 
@@ -225,11 +257,8 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
                 load_list_block(cur, row, 0);
                 load_list_block(nxt, row, kBlk);
                 float ob[4];
-                {
-                    const float *osrc = obs + ((size_t)bfirst * T + t) * S + jr;
 #pragma unroll
-                    for (int it = 0; it < 4; ++it) ob[it] = osrc[ioff[it] * istride];
-                }
+                for (int it = 0; it < 4; ++it) ob[it] = obs[((size_t)ib[it] * T + t) * S + jr];
                 float seedt[4][kR];
 #pragma unroll
                 for (int it = 0; it < 4; ++it)
@@ -237,29 +266,60 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
                     for (int r = 0; r < kR; ++r) seedt[it][r] = tt[(unsigned)(seedo[it][r] + jr)];   // trans[jr][i_r]
 
                 float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                auto pair = [&](float t0, int o0, float t1, int o1) {
+                struct PairData { float4 p0, p1; float t0, t1; };
+                // entry pair H (0..7) of a block: owner lane O = H / 2 of the quad, its e[H % 2]
+                auto issue = [&](auto Hc, const ListBlock<EPL> &blk, PairData &d) {
+                    constexpr int H = decltype(Hc)::value, O = H / (EPL / 2), E = H % (EPL / 2);
+                    float t0 = group_bcast<G, O>(blk.e[E].x), t1 = group_bcast<G, O>(blk.e[E].z);
+                    const int o0 = group_bcast<G, O>(__float_as_int(blk.e[E].y));
+                    const int o1 = group_bcast<G, O>(__float_as_int(blk.e[E].w));
                     asm volatile("" : "+v"(t0), "+v"(t1));     // keep the broadcasts out of the adds (half-rate DPP adds)
-                    const float4 p0 = *reinterpret_cast<const float4 *>(ptile + o0);
-                    const float4 p1 = *reinterpret_cast<const float4 *>(ptile + o1);
-                    best[0] = fmaxf(fmaxf(best[0], t0 + p0.x), t1 + p1.x);
-                    best[1] = fmaxf(fmaxf(best[1], t0 + p0.y), t1 + p1.y);
-                    best[2] = fmaxf(fmaxf(best[2], t0 + p0.z), t1 + p1.z);
-                    best[3] = fmaxf(fmaxf(best[3], t0 + p0.w), t1 + p1.w);
+                    d.t0 = t0; d.t1 = t1;
+                    d.p0 = *reinterpret_cast<const float4 *>(ptile + o0);
+                    d.p1 = *reinterpret_cast<const float4 *>(ptile + o1);
                 };
-                auto owner = [&](auto Oc, const ListBlock<EPL> &blk) {
-                    constexpr int O = decltype(Oc)::value;
-#pragma unroll
-                    for (int h = 0; h < EPL / 2; ++h)
-                        pair(group_bcast<G, O>(blk.e[h].x), group_bcast<G, O>(__float_as_int(blk.e[h].y)),
-                             group_bcast<G, O>(blk.e[h].z), group_bcast<G, O>(__float_as_int(blk.e[h].w)));
+                auto math = [&](const PairData &d) {
+                    best[0] = fmaxf(fmaxf(best[0], d.t0 + d.p0.x), d.t1 + d.p1.x);
+                    best[1] = fmaxf(fmaxf(best[1], d.t0 + d.p0.y), d.t1 + d.p1.y);
+                    best[2] = fmaxf(fmaxf(best[2], d.t0 + d.p0.z), d.t1 + d.p1.z);
+                    best[3] = fmaxf(fmaxf(best[3], d.t0 + d.p0.w), d.t1 + d.p1.w);
                 };
-                auto consume = [&](const ListBlock<EPL> &blk) {
-                    owner(std::integral_constant<int, 0>(), blk);
-                    owner(std::integral_constant<int, 1>(), blk);
-                    owner(std::integral_constant<int, 2>(), blk);
-                    owner(std::integral_constant<int, 3>(), blk);
+                PairData ahead;            // PIPE: pair 0 of the block `consume` is about to be called on
+                // all 8 pairs of `blk`; PIPE: pair 0 is already in `ahead`, and pair 0 of `after` is left there
+                auto consume = [&](const ListBlock<EPL> &blk, const ListBlock<EPL> &after) {
+                    if (PIPE) {
+                        PairData other;
+#define TORBI_STAGE(H_, CUR_, NXT_)                                                   \
+                        issue(std::integral_constant<int, H_ + 1>(), blk, NXT_);      \
+                        __builtin_amdgcn_sched_barrier(0);                            \
+                        math(CUR_);                                                   \
+                        __builtin_amdgcn_sched_barrier(0);
+                        TORBI_STAGE(0, ahead, other)
+                        TORBI_STAGE(1, other, ahead)
+                        TORBI_STAGE(2, ahead, other)
+                        TORBI_STAGE(3, other, ahead)
+                        TORBI_STAGE(4, ahead, other)
+                        TORBI_STAGE(5, other, ahead)
+                        TORBI_STAGE(6, ahead, other)
+#undef TORBI_STAGE
+                        issue(std::integral_constant<int, 0>(), after, ahead);
+                        __builtin_amdgcn_sched_barrier(0);
+                        math(other);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        PairData d;
+                        issue(std::integral_constant<int, 0>(), blk, d); math(d);
+                        issue(std::integral_constant<int, 1>(), blk, d); math(d);
+                        issue(std::integral_constant<int, 2>(), blk, d); math(d);
+                        issue(std::integral_constant<int, 3>(), blk, d); math(d);
+                        issue(std::integral_constant<int, 4>(), blk, d); math(d);
+                        issue(std::integral_constant<int, 5>(), blk, d); math(d);
+                        issue(std::integral_constant<int, 6>(), blk, d); math(d);
+                        issue(std::integral_constant<int, 7>(), blk, d); math(d);
+                    }
                 };
-                consume(cur);
+                if (PIPE) issue(std::integral_constant<int, 0>(), cur, ahead);
+                consume(cur, nxt);
                 load_list_block(cur, row, 2 * kBlk);
 #pragma unroll
                 for (int it = 0; it < 4; ++it)
@@ -275,11 +335,11 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
                 for (int kk = kBlk; kk < Sp; kk += 2 * kBlk) {
                     if (!more(nxt)) break;
                     RCOUNT(7, 1);
-                    consume(nxt);
+                    consume(nxt, cur);
                     load_list_block(nxt, row, kk + 2 * kBlk);
                     if (!more(cur)) break;
                     RCOUNT(7, 1);
-                    consume(cur);
+                    consume(cur, nxt);
                     load_list_block(cur, row, kk + 3 * kBlk);
                 }
                 RSTAMP(3);
@@ -287,7 +347,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
                 for (int it = 0; it < 4; ++it) {
                     const float o = ob[it] + best[it];                     // post'[j] = obs[t,j] + max
                     pend[p][it] = o;
-                    if (jv && live[it]) hist[((size_t)(bfirst + ioff[it]) * T + t) * S + jr] = o;
+                    if (jv && live[it]) hist[((size_t)ib[it] * T + t) * S + jr] = o;
                     if (jv) top_insert(top + (4 * g + it) * kTop, top_key(o, jr));
                 }
                 RSTAMP(4);

@@ -507,6 +507,7 @@ struct ResidentWorkspace {
     float2 *sorted;
     float *tt;
     int32_t *row_range;
+    int32_t *order;       // [B] this batch's items by descending length
     int SpP, NPOW;
     size_t bytes;
 };
@@ -522,12 +523,15 @@ inline ResidentWorkspace carve_resident(void *base, int B, int T, int S) {
     const size_t sorted_bytes = align_up(sizeof(float2) * (size_t)S * w.SpP, 256);
     const size_t tt_bytes = align_up(sizeof(float) * (size_t)S * S, 256);
     const size_t range_bytes = align_up(sizeof(int32_t) * 2 * (size_t)S, 256);
+    const size_t order_bytes = align_up(sizeof(int32_t) * (size_t)B, 256);
     w.hist = reinterpret_cast<float *>(p);
     p += hist_bytes;
+    w.order = reinterpret_cast<int32_t *>(p);      // ahead of the preparation: its offset depends on B and T only
+    p += order_bytes;
     w.sorted = reinterpret_cast<float2 *>(p);
     w.tt = reinterpret_cast<float *>(p + sorted_bytes);
     w.row_range = reinterpret_cast<int32_t *>(p + sorted_bytes + tt_bytes);
-    w.bytes = hist_bytes + sorted_bytes + tt_bytes + range_bytes;
+    w.bytes = hist_bytes + order_bytes + sorted_bytes + tt_bytes + range_bytes;
     return w;
 }
 
@@ -810,30 +814,51 @@ struct HostBatch {
     int B, T;
 };
 
+// TORBI_HIP_RESIDENT_PIPE=0 selects the variant without software-pipelined posterior reads (experiments)
+inline bool resident_pipe() {
+    static const bool v = [] {
+        const char *e = getenv("TORBI_HIP_RESIDENT_PIPE");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+
+template <int KW, int MAXP, bool PIPE>
+hipError_t launch_resident_variant(const resident::Group &grp, int tiles, const ResidentWorkspace &w, const float *init,
+                                   int S, hipStream_t stream) {
+    const size_t lds = resident::lds_bytes(S);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resident::resident_forward_kernel<KW, MAXP, PIPE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((resident::resident_forward_kernel<KW, MAXP, PIPE>), dim3(tiles), dim3(64 * KW), lds, stream, grp,
+                       w.tt, w.sorted, init, S, w.SpP);
+    return hipGetLastError();
+}
+
 template <int KW, int MAXP>
 hipError_t launch_resident_kernel(const resident::Group &grp, int tiles, const ResidentWorkspace &w, const float *init,
                                   int S, hipStream_t stream) {
-    const size_t lds = resident::lds_bytes(S);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resident::resident_forward_kernel<KW, MAXP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((resident::resident_forward_kernel<KW, MAXP>), dim3(tiles), dim3(64 * KW), lds, stream, grp, w.tt,
-                       w.sorted, init, S, w.SpP);
-    return hipGetLastError();
+    return resident_pipe() ? launch_resident_variant<KW, MAXP, true>(grp, tiles, w, init, S, stream)
+                           : launch_resident_variant<KW, MAXP, false>(grp, tiles, w, init, S, stream);
 }
 
 // batches with B > 0 only; the preparation lives in the first batch's workspace
 hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const float *init, int S, hipStream_t s,
                         hipEvent_t *ev, int *launches, bool reuse) {
     resident::Group grp{};
+    resident::OrderJobs jobs{};
     grp.n = n;
-    int tiles = 0, items = 0;
+    int tiles = 0, items = 0, widest = 0;
     for (int k = 0; k < n; ++k) {
         resident::Batch &b = grp.batch[k];
+        const ResidentWorkspace wk = carve_resident(hb[k].workspace, hb[k].B, hb[k].T, S);
         b.obs = hb[k].obs;
         b.frames = hb[k].frames;
         b.out = hb[k].out;
-        b.hist = carve_resident(hb[k].workspace, hb[k].B, hb[k].T, S).hist;
+        b.hist = wk.hist;
+        b.order = wk.order;
+        jobs.job[k] = resident::OrderJob{hb[k].frames, wk.order, hb[k].B, hb[k].T};
+        widest = std::max(widest, hb[k].B);
         b.B = hb[k].B;
         b.T = hb[k].T;
         b.tile0 = tiles;
@@ -844,6 +869,7 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
     const ResidentWorkspace w = carve_resident(hb[0].workspace, hb[0].B, hb[0].T, S);
     if (ev) (void)hipEventRecord(ev[0], s);
     if (!reuse) launch_list_preparation(trans, w.sorted, w.row_range, w.tt, S, w.SpP, w.NPOW, resident::kNI, s);
+    hipLaunchKernelGGL(resident::order_items_kernel, dim3((widest + 255) / 256, n), dim3(256), 0, s, jobs);
     if (ev) (void)hipEventRecord(ev[3], s);
     hipError_t e;
     const int nrg = (S + resident::kRowGroup - 1) / resident::kRowGroup;
