@@ -1,4 +1,5 @@
-"""Fold the rocprofv3 CSVs written by tools/collect_profiles.sh into r01_pmc.json / r01_bench_kernel_stats.csv."""
+"""Fold the rocprofv3 CSVs written by tools/collect_profiles.sh into pmc.json / kernel_stats.csv (copied to
+profiles/rNN_pmc.json and profiles/rNN_bench_kernel_stats.csv by hand)."""
 import collections, csv, glob, json, os, shutil, sys
 
 out = sys.argv[1]
@@ -13,4 +14,4 @@ json.dump(summary, open(os.path.join(out, 'pmc.json'), 'w'), indent=1)
 for f in glob.glob(os.path.join(out, 'trace', '**', '*kernel_stats.csv'), recursive=True):
     shutil.copy(f, os.path.join(out, 'kernel_stats.csv'))
 print(json.dumps({k: {c: v['mean_per_dispatch'] for c, v in cs.items()} for k, cs in summary.items()
-                  if 'step' in k}, indent=1))
+                  if 'step' in k or 'resident' in k}, indent=1))

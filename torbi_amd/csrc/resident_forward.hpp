@@ -343,12 +343,17 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
                     load_list_block(cur, row, kk + 3 * kBlk);
                 }
                 RSTAMP(3);
+                // the four items' list thresholds are read together (one LDS round trip, not four in a row)
+                u64 last4[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) last4[it] = top[(4 * g + it) * kTop + kTop - 1];
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const float o = ob[it] + best[it];                     // post'[j] = obs[t,j] + max
                     pend[p][it] = o;
                     if (jv && live[it]) hist[((size_t)ib[it] * T + t) * S + jr] = o;
-                    if (jv) top_insert(top + (4 * g + it) * kTop, top_key(o, jr));
+                    const u64 key = top_key(o, jr);
+                    if (jv && key > last4[it]) top_insert(top + (4 * g + it) * kTop, key);
                 }
                 RSTAMP(4);
             }
