@@ -85,11 +85,12 @@ def algorithmic_bytes_per_timestep(S):
     return 8 * S + 8
 
 
-def profiled_traffic(kernel_prefix):
+def profiled_traffic(kernel_prefix, batches):
     """HBM-side bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
     (profiles/rNN_pmc.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).  FETCH_SIZE is
     doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950; both counters are in KiB and
-    include Infinity-Cache hits.  (None, None) when no summary names the kernel."""
+    include Infinity-Cache hits.  The summary was taken with `_meta.batches_per_forward_launch` batches per launch;
+    the figure is scaled to the `batches` this run puts into one.  (None, None) when no summary names the kernel."""
     folder = os.path.join(ROOT, 'profiles')
     try:
         names = sorted(f for f in os.listdir(folder) if f.endswith('_pmc.json'))
@@ -100,10 +101,11 @@ def profiled_traffic(kernel_prefix):
             pmc = json.load(open(os.path.join(folder, name)))
         except (OSError, ValueError):
             continue
+        taken_with = float(pmc.get('_meta', {}).get('batches_per_forward_launch', batches))
         for kernel, counters in pmc.items():
             if kernel_prefix in kernel and 'FETCH_SIZE' in counters and 'WRITE_SIZE' in counters:
                 return ((2.0 * counters['FETCH_SIZE']['mean_per_dispatch']
-                         + counters['WRITE_SIZE']['mean_per_dispatch']) * 1024.0, name)
+                         + counters['WRITE_SIZE']['mean_per_dispatch']) * 1024.0 * batches / taken_with, name)
     return None, None
 
 
@@ -327,7 +329,7 @@ class Bench:
         bytes_per_launch = timesteps_per_launch * algorithmic_bytes_per_timestep(S)
         achieved = bytes_per_launch / kernel_s / 1e9
         cells_per_launch = timesteps_per_launch * S * S
-        traffic, traffic_file = profiled_traffic(KERNELS[route])
+        traffic, traffic_file = profiled_traffic(KERNELS[route], covered)
         del spaces
         result['config'] = {
             'workload': (f'{S} states, {T} frames, batch={B} per GPU, fp32, dense transition'
@@ -345,7 +347,10 @@ class Bench:
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic if (B, T, S) == (512, 500, 1440) else None,
             'traffic_note': f'bytes per launch from profiles/{traffic_file} (2*FETCH_SIZE + WRITE_SIZE, Infinity-Cache '
-                            f'hits included)' if traffic_file else 'no PMC summary for this kernel committed',
+                            f'hits included, scaled to {covered} batches per launch): the excess over the algorithmic '
+                            f'bytes is the sorted transition lists streamed from the Infinity Cache (they do not fit the '
+                            f'4 MB L2s) and 4-byte strided observation reads'
+            if traffic_file else 'no PMC summary for this kernel committed',
             'kernel': KERNELS[route] + (f' (ONE launch = the whole forward pass of {covered} batches)'
                                         if route == 'resident' else ' (one launch = one timestep of one batch)'),
             'launch_us': kernel_s * 1e6, 'launches_per_group': launches, 'batches_per_launch': covered,
@@ -432,9 +437,46 @@ class Bench:
             del o5, t5, i5, f5, w5
         except RuntimeError as exc:     # out of memory next to the headline buffers: say so instead of dying
             out['c5'] = {'value': None, 'note': f'not measured: {exc}'}
-        # BASELINE configs[3] in miniature: 4096 ragged sequences, one GPU, decode only
-        out['c4_4096_files'] = self.c4_decode_only(4096, steps=0, quiet=True)
+        # BASELINE configs[3] in miniature: 16384 ragged sequences (32 batches, four launch groups), one GPU, decode only
+        out['c4_16384_files'] = self.c4_decode_only(16384, steps=0, quiet=True)
+        out['chunked_long_sequence'] = self.chunked_long_sequence(trans, init)
         return out
+
+    def chunked_long_sequence(self, trans, init):
+        """one long sequence (B = 1 is latency bound: ~4.7 us per frame whatever the GPU) cut at
+        low-entropy frames (torbi_amd/chunk.py = reference torbi/chunk.py) into pieces that are decoded as batch rows
+        and joined.  An approximation (results may differ from the unchunked decode at the cuts); reported: frames/s
+        both ways and the fraction of frames on which the two agree."""
+        torch = self.torch
+        import torbi_amd
+        from torbi_amd import data as tdata
+        dev, S, T = self.dev, trans.shape[0], 16000
+        gen = torch.Generator().manual_seed(11)
+        logits = torch.randn(T, S, generator=gen) * 2.0
+        centre = (S / 2 + S / 3 * torch.sin(torch.arange(T) / 150.0)).long().clamp(0, S - 1)
+        logits -= ((torch.arange(S)[None, :] - centre[:, None]).abs().float() / 10.0) ** 2
+        certain = (torch.arange(T) % 97) < 2                      # two adjacent near-certain frames every 97 frames
+        logits[certain, centre[certain]] += 60.0
+        sequence = torch.log_softmax(logits, dim=-1).clamp_(min=math.log(torch.finfo(torch.float32).tiny))
+        band = torch.from_numpy(self.synth.banded_transition(S, self.args.half_width)).to(dev)
+        whole = sequence[None].to(dev)
+        frames = torch.tensor([T], dtype=torch.int32, device=dev)
+        sec_whole, idx_whole = self.timed_decodes(lambda: torbi_amd.decode(whole, frames, band, init), 2)
+        t0 = time.perf_counter()
+        pieces = torbi_amd.chunk(sequence, min_chunk_size=200, entropy_threshold=0.5)
+        observation, batch_frames, batch_chunks, _ = tdata.collate([(pieces, 'sequence')])
+        cut_s = time.perf_counter() - t0
+        observation = observation.to(dev)
+        batch_frames = batch_frames.to(device=dev, dtype=torch.int32)
+        sec_chunks, idx_rows = self.timed_decodes(lambda: torbi_amd.decode(observation, batch_frames, band, init), 3)
+        joined = tdata.separate(idx_rows.cpu(), batch_chunks, batch_frames.cpu())[0]
+        agree = float((joined == idx_whole[0].cpu()).float().mean())
+        return {'value': T / sec_chunks, 'unit': 'timesteps/s', 'unchunked_value': T / sec_whole,
+                'ms_chunked': sec_chunks * 1e3, 'ms_unchunked': sec_whole * 1e3, 'pieces': len(pieces),
+                'longest_piece': int(batch_frames.max()), 'host_entropy_and_cut_ms': cut_s * 1e3,
+                'frames_agreeing_with_unchunked': agree,
+                'note': f'one sequence of {T} frames x {S} states, banded pitch transition, MIN_CHUNK_SIZE = 200: decode '
+                        f'time only (the cut points are found on the host like upstream, dataset.py:22-23)'}
 
     # ---- BASELINE configs[3]: ragged many-file job ----------------------------------------------------
     def c4_plan(self, files):

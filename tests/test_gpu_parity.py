@@ -840,3 +840,30 @@ def test_many_file_job_at_1440_states(tmp_path, forward):
     for k in np.random.default_rng(3).choice(count, size=40, replace=False):
         want = _oracle_for_file(torch.load(ins[k]), trans, S)
         assert np.array_equal(torch.load(outs[k]).numpy(), want), f'file {k} ({lengths[k]} frames)'
+
+
+def test_grouped_decode_pipeline_equals_the_oracle():
+    """DecodePipeline(group=3): batches are collected and decoded three per launch group; a different model, a
+    different state count, wait() on a batch that is still being collected, and synchronize() all flush what has
+    been collected; every batch equals the oracle."""
+    dev = torch.device('cuda:0')
+    pipe = torbi_amd.DecodePipeline(dev, depth=2, group=3)
+    models = {}
+    for S, seed in ((360, 3), (360, 4), (132, 5)):
+        models[(S, seed)] = (torch.tensor(synth.scores(2, (S, S), seed=seed), device=dev),
+                             torch.tensor(synth.scores(3, (S,), seed=seed), device=dev))
+    plan = [((360, 3), 64, 30), ((360, 3), 40, 17), ((360, 3), 96, 45), ((360, 3), 33, 8), ((360, 4), 64, 30),
+            ((360, 4), 20, 12), ((132, 5), 50, 9), ((132, 5), 48, 21), ((360, 3), 17, 5)]
+    jobs = []
+    for k, (key, B, T) in enumerate(plan):
+        trans, init = models[key]
+        obs = torch.tensor(synth.scores(1, (B, T, key[0]), seed=k), device=dev)
+        frames = torch.tensor(np.clip(synth.lengths(B, 1, T, seed=k), 1, T), device=dev)
+        jobs.append((obs, frames, trans, init, pipe.decode(obs, frames, trans, init)))
+        if k == 3:
+            pipe.wait(jobs[-1][4])          # still being collected: flushed and awaited
+    pipe.synchronize()
+    for obs, frames, trans, init, got in jobs:
+        want = oracle.decode(obs.cpu().numpy(), frames.cpu().numpy(), trans.cpu().numpy(), init.cpu().numpy(),
+                             num_threads=oracle.max_threads())
+        assert np.array_equal(got.cpu().numpy(), want)

@@ -86,7 +86,7 @@ def build(force=False, verbose=False):
         if os.path.getmtime(LIBRARY) >= newest:
             return LIBRARY
     cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-ffp-contract=off', '-fno-slp-vectorize', f'-I{INCLUDE}', '-o', LIBRARY + '.tmp', SOURCE]
+           '-ffp-contract=off', '-fno-slp-vectorize', '-Wno-pass-failed', f'-I{INCLUDE}', '-o', LIBRARY + '.tmp', SOURCE]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
