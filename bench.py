@@ -269,6 +269,8 @@ class Bench:
         pipe = self.torbi_amd.DecodePipeline(dev, depth=max(1, args.pipeline), reuse_preparation=args.reuse_preparation,
                                              group=group, path=path)
 
+        pipe.reserve(B, T, S)          # workspace allocation is not part of a decode
+
         def gather(idx):
             return self.distributed.gather_indices(idx, B * size, force=True) if self.collective else idx
 
@@ -519,6 +521,7 @@ class Bench:
             batches.append((flat[:len(b) * t * S].view(len(b), t, S), frames))
         pipe = self.torbi_amd.DecodePipeline(dev, depth=max(1, args.pipeline), group=group,
                                              path=None if args.forward == 'auto' else args.forward)
+        pipe.reserve(args.batch, tmax, S)
 
         def run():
             for observation, frames in batches:

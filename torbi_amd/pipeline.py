@@ -51,6 +51,14 @@ class DecodePipeline:
             self.scratch[slot][k] = buf
         return buf
 
+    def reserve(self, batch: int, frames: int, states: int) -> None:
+        """Allocate every slot's scratch for `group` batches of this shape now, so that no decode pays for a
+        device allocation later (a serving loop calls this once; bench.py does before it starts the clock)."""
+        need = viterbi.workspace_bytes(batch, frames, states)
+        for slot in range(self.depth):
+            for k in range(self.group):
+                self._scratch(slot, k, need)
+
     def decode(self, observation, batch_frames, transition, initial, after: Optional[Callable] = None) -> torch.Tensor:
         """Enqueue one decode; arguments as `torbi_amd.decode` (tensors on `self.device`).
 
