@@ -199,4 +199,91 @@ __global__ __launch_bounds__(64) void backtrace_prefetch_kernel(const float *__r
     backtrace_prefetch_item<NQ>(hist + (size_t)b * T * S, trans, frames[b], out + (size_t)b * T, T, S, threadIdx.x);
 }
 
+// ---------------------------------------------------------------------------------------
+// The same backtrace where the forward pass left SORTED transition rows (pruned / time-resident paths): per path
+// step the argmax_i fl(hist[t-1][i] + trans[j][i]) is found by walking row j in descending transition order, 64
+// entries per wave step, against the posterior row held in the LDS:
+//     every entry not yet examined has trans <= t_next (the next chunk's first entry) and hist <= hmax, so its
+//     candidate is <= fl(t_next + hmax); once that is < the best candidate seen, no unexamined entry can reach --
+//     or TIE -- the maximum, and the lowest prev-state among the examined maxima is the reference's backpointer
+//     (viterbi.cpp:94-100).
+// A step then moves the 4S-byte posterior row (prefetched one step ahead, coalesced) plus 0.5-1 KB of list instead
+// of the posterior row plus a 4S-byte transition row: with 4096 items in flight (a launch group of 8 batches) the
+// backtrace is bound by exactly that traffic.  List entries are {t, prev-state << shift}; (-inf) entries and the
+// row padding carry a stand-in prev-state, which matters only when EVERY candidate is -inf: the reference's scan
+// then keeps prev-state 0, and so does this.
+// One wave per item; dynamic LDS = 4 * ceil4(S) bytes per wave; S % 4 == 0, S <= 256 * NQ.
+// ---------------------------------------------------------------------------------------
+template <int NQ>
+__device__ __forceinline__ void backtrace_sorted_item(const float *__restrict__ h, const float2 *__restrict__ sorted,
+                                                      int SpP, int shift, int f, int32_t *__restrict__ o, int T, int S,
+                                                      int lane, float *__restrict__ hrow) {
+    f = f < 1 ? 1 : (f > T ? T : f);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 cur[NQ], nxt[NQ];
+    auto load_row = [&](float4 (&dst)[NQ], int r) {
+        const float *row = h + (size_t)r * S;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = 4 * lane + 256 * q;
+            dst[q] = i < S ? *reinterpret_cast<const float4 *>(row + i) : zero;
+        }
+    };
+    load_row(cur, f - 1);
+    load_row(nxt, f >= 2 ? f - 2 : 0);
+    // final state = first argmax of the last posterior row (viterbi.cpp:218)
+    int j = wave_first_argmax4<NQ>(cur, lane, S);
+    // every position t >= frames-1 holds the final state (viterbi.cpp:219-221)
+    for (int tt = f - 1 + lane; tt < T; tt += 64) o[tt] = j;
+    const int Sp = (S + 15) / 16 * 16;
+
+    for (int tt = f - 1; tt >= 1; --tt) {
+        // the list of the state just resolved (depends on j): first chunk on its way ...
+        const float2 *row = sorted + (size_t)j * SpP;
+        float2 ent = row[lane];
+        // ... while posterior row tt-1 (already in registers) goes to the LDS and row tt-2 is requested
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) cur[q] = nxt[q];
+        load_row(nxt, tt >= 2 ? tt - 2 : 0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = 4 * lane + 256 * q;
+            if (i < S) *reinterpret_cast<float4 *>(hrow + i) = cur[q];
+        }
+        const float hmax = wavered::wave_reduce_f32(lane_max<NQ>(cur, lane, S), wavered::MaxOp());
+        float bv = -INFINITY;
+        int bi = kSentinel;
+        float best = -INFINITY;
+        for (int k0 = 0; k0 < Sp; k0 += 64) {
+            const int kn = k0 + 64 + lane;
+            const float2 ahead = row[kn < SpP ? kn : SpP - 1];       // next chunk (its first entry bounds the rest)
+            if (k0 + lane < Sp) {
+                const int i = __float_as_int(ent.y) >> shift;
+                const float c = hrow[i] + ent.x;
+                if (c > bv || (c == bv && i < bi)) { bv = c; bi = i; }
+            }
+            best = wavered::wave_reduce_f32(bv, wavered::MaxOp());
+            const float tn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__float_as_int(ahead.x)));
+            ent = ahead;
+            if (k0 + 64 >= Sp || tn + hmax < best) break;
+        }
+        // lowest prev-state among the lanes that hold the maximum; all candidates -inf: prev-state 0
+        const int cand = (bv == best && bi != kSentinel) ? bi : kSentinel;
+        const int win = wavered::wave_min_i32(cand);
+        j = best == -INFINITY ? 0 : win;
+        if (lane == 0) o[tt - 1] = j;
+    }
+}
+
+template <int NQ>
+__global__ __launch_bounds__(64) void backtrace_sorted_kernel(const float *__restrict__ hist,
+                                                              const float2 *__restrict__ sorted, int SpP, int shift,
+                                                              const int32_t *__restrict__ frames,
+                                                              int32_t *__restrict__ out, int B, int T, int S) {
+    extern __shared__ __attribute__((aligned(16))) float hrow_lds[];
+    const int b = blockIdx.x;
+    backtrace_sorted_item<NQ>(hist + (size_t)b * T * S, sorted, SpP, shift, frames[b], out + (size_t)b * T, T, S,
+                              threadIdx.x, hrow_lds);
+}
+
 }  // namespace lazy

@@ -397,6 +397,16 @@ __global__ __launch_bounds__(64) void group_backtrace_prefetch_kernel(Group grp,
                                       bat.T, S, threadIdx.x);
 }
 
+template <int NQ>
+__global__ __launch_bounds__(64) void group_backtrace_sorted_kernel(Group grp, const float2 *__restrict__ sorted, int SpP,
+                                                                    int S) {
+    extern __shared__ __attribute__((aligned(16))) float hrow_lds[];
+    const Batch &bat = grp.batch[batch_of_item(grp, blockIdx.x)];
+    const int b = (int)blockIdx.x - bat.item0;
+    lazy::backtrace_sorted_item<NQ>(bat.hist + (size_t)b * bat.T * S, sorted, SpP, 6 /* offsets = state * 64 */,
+                                    bat.frames[b], bat.out + (size_t)b * bat.T, bat.T, S, threadIdx.x, hrow_lds);
+}
+
 template <int VEC>
 __global__ __launch_bounds__(64) void group_backtrace_kernel(Group grp, const float *__restrict__ trans, int S) {
     const Batch &bat = grp.batch[batch_of_item(grp, blockIdx.x)];

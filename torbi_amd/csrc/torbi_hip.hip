@@ -805,6 +805,38 @@ hipError_t launch_backtrace_on(const float *hist, const float *trans, const int3
     return hipGetLastError();
 }
 
+// backtrace over the SORTED transition rows the pruned / time-resident forward pass prepared (lazy_backtrace.hpp):
+// a path step reads the posterior row + 0.5-1 KB of list instead of the posterior row + a whole transition row.
+// TORBI_HIP_BACKTRACE=rows selects the transition-row form everywhere (experiments).
+inline bool backtrace_sorted_enabled() {
+    static const bool v = [] {
+        const char *e = getenv("TORBI_HIP_BACKTRACE");
+        return !(e && e[0] == 'r');
+    }();
+    return v;
+}
+
+hipError_t launch_backtrace_sorted(const float *hist, const float2 *sorted, int SpP, int items_per_tile,
+                                   const float *trans, const int32_t *frames, int32_t *out, int B, int T, int S,
+                                   hipStream_t stream) {
+    if (!backtrace_sorted_enabled() || S % 4 != 0 || S > 256 * 16)
+        return launch_backtrace_on(hist, trans, frames, out, B, T, S, stream);
+    const int shift = items_per_tile == pruned::kNB ? 6 : 5;      // list offsets = prev-state * 4 * items per tile
+    const size_t lds = sizeof(float) * (size_t)S;
+#define TORBI_BTS_CASE(NQ_)                                                                              \
+    if (S <= 256 * NQ_) {                                                                                \
+        hipLaunchKernelGGL(lazy::backtrace_sorted_kernel<NQ_>, dim3(B), dim3(64), lds, stream, hist, sorted, SpP, \
+                           shift, frames, out, B, T, S);                                                 \
+        return hipGetLastError();                                                                        \
+    }
+    TORBI_BTS_CASE(2)
+    TORBI_BTS_CASE(6)
+    TORBI_BTS_CASE(8)
+    TORBI_BTS_CASE(16)
+#undef TORBI_BTS_CASE
+    return hipErrorInvalidValue;
+}
+
 // ---- time-resident path: several batches, one forward launch, one backtrace launch -------------------------
 struct HostBatch {
     const float *obs;
@@ -880,7 +912,18 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
     if (ev) (void)hipEventRecord(ev[1], s);
     if (e != hipSuccess) return e;
     const bool vec = (S % 4 == 0) && ((reinterpret_cast<uintptr_t>(trans) & 15) == 0);
-    if (vec && S <= 512)
+    const size_t row_lds = sizeof(float) * (size_t)S;
+    if (S % 4 == 0 && backtrace_sorted_enabled()) {
+        if (S <= 512)
+            hipLaunchKernelGGL(resident::group_backtrace_sorted_kernel<2>, dim3(items), dim3(64), row_lds, s, grp,
+                               w.sorted, w.SpP, S);
+        else if (S <= 1536)
+            hipLaunchKernelGGL(resident::group_backtrace_sorted_kernel<6>, dim3(items), dim3(64), row_lds, s, grp,
+                               w.sorted, w.SpP, S);
+        else
+            hipLaunchKernelGGL(resident::group_backtrace_sorted_kernel<8>, dim3(items), dim3(64), row_lds, s, grp,
+                               w.sorted, w.SpP, S);
+    } else if (vec && S <= 512)
         hipLaunchKernelGGL(resident::group_backtrace_prefetch_kernel<2>, dim3(items), dim3(64), 0, s, grp, trans, S);
     else if (vec && S <= 1536)
         hipLaunchKernelGGL(resident::group_backtrace_prefetch_kernel<6>, dim3(items), dim3(64), 0, s, grp, trans, S);
@@ -909,7 +952,8 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
         const PrunedWorkspace w = carve_pruned(workspace, B, T, S, cus);
         e = launch_pruned_forward(obs, frames, trans, init, w, B, T, S, s, launches, reuse, collect);
         if (ev) (void)hipEventRecord(ev[1], s);
-        if (e == hipSuccess) e = launch_backtrace_on(w.hist, trans, frames, out, B, T, S, s);
+        if (e == hipSuccess)
+            e = launch_backtrace_sorted(w.hist, w.sorted, w.plan.SpP, w.plan.NI, trans, frames, out, B, T, S, s);
     } else if (route == ROUTE_DENSE) {
         const DenseWorkspace w = carve_dense(workspace, B, T, S, cus);
         e = launch_dense_forward(obs, frames, trans, init, w, B, T, S, s, launches, reuse);
