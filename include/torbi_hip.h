@@ -130,6 +130,7 @@ int torbi_hip_viterbi_decode(const float *observation, const int32_t *batch_fram
  */
 #define TORBI_HIP_REUSE_TRANSITION 1u
 #define TORBI_HIP_COLLECT_STATS 2u     /* a PRUNED decode also leaves scan statistics: torbi_hip_scan_stats */
+#define TORBI_HIP_SHORTEST_FIRST 256u  /* RESIDENT: workgroups in ascending order of their items' lengths (default: longest first) */
 int torbi_hip_viterbi_decode_ex(const float *observation, const int32_t *batch_frames,
                                 const float *transition, const float *initial,
                                 int32_t *indices_out, void *workspace, size_t workspace_bytes,

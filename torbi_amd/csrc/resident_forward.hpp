@@ -52,6 +52,7 @@ struct Batch {
 struct Group {
     Batch batch[kMaxBatches];
     int n;
+    const int32_t *tile_map;   // [tiles of the group] workgroup -> (batch << 20 | tile of that batch), longest first
 };
 
 inline bool supported(int S) { return S >= 64 && S <= pruned::kMaxS16; }
@@ -71,8 +72,8 @@ inline size_t lds_bytes(int S) {
 // torbi/data/collate.py:24-31) -- and the longest tiles are dispatched first.  Results do not depend on the order.
 // grid = (ceil(max B / 256), batches), block = 256; O(B^2) compares, batches above kMaxOrdered items keep their order.
 constexpr int kMaxOrdered = 8192;
-struct OrderJob { const int32_t *frames; int32_t *order; int B, T; };
-struct OrderJobs { OrderJob job[kMaxBatches]; };
+struct OrderJob { const int32_t *frames; int32_t *order; int B, T, tile0; };
+struct OrderJobs { OrderJob job[kMaxBatches]; int ascending; int n; int tiles; int32_t *tile_map; };
 
 __global__ __launch_bounds__(256) void order_items_kernel(OrderJobs jobs) {
     const OrderJob &jb = jobs.job[blockIdx.y];
@@ -88,7 +89,41 @@ __global__ __launch_bounds__(256) void order_items_kernel(OrderJobs jobs) {
         g = g < 1 ? 1 : (g > T ? T : g);
         rank += (g > f) || (g == f && o < b);
     }
-    jb.order[rank] = b;
+    jb.order[jobs.ascending ? B - 1 - rank : rank] = b;
+}
+
+// ... and the group's TILES by descending length of their longest item: workgroup w decodes tile_map[w].  The GPU hands
+// workgroup i to shader engine i mod 32 and waits, in launch order, for a free CU THERE (tools/dispatch_probe.hip,
+// tools/resident_wgtime.py): with batch-major numbering the rank-c tiles of all batches -- all of one length -- meet on
+// one engine, the engine of the longest tiles is the one the first workgroup beyond the 256th waits for, and nothing
+// behind it starts until those finish (measured: 28.3 ms for a ragged 16-batch group that has 16.5 ms of work per CU).
+// Ranked across the whole group, every engine holds an even spread of lengths and frees a CU early.
+// One thread per tile; grid = ceil(tiles / 256); O(tiles^2) compares.  Runs after order_items_kernel.
+__global__ __launch_bounds__(256) void order_tiles_kernel(OrderJobs jobs) {
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= jobs.tiles) return;
+    auto tile_length = [&](int k, int j) {
+        const OrderJob &jb = jobs.job[k];
+        // the longest item of tile j: its first in descending order, its last (within the batch) in ascending order
+        const int last = 16 * j + 15 < jb.B ? 16 * j + 15 : jb.B - 1;
+        int f = jb.frames[jb.order[jobs.ascending ? last : 16 * j]];
+        return f < 1 ? 1 : (f > jb.T ? jb.T : f);
+    };
+    int k = 0;
+    for (int q = 1; q < jobs.n; ++q)
+        if (w >= jobs.job[q].tile0) k = q;
+    const int j = w - jobs.job[k].tile0;
+    const int mine = tile_length(k, j);
+    int rank = 0;
+    for (int q = 0; q < jobs.n; ++q) {
+        const int nt = (jobs.job[q].B + 15) / 16;
+        for (int t = 0; t < nt; ++t) {
+            const int other = tile_length(q, t);
+            const int ow = jobs.job[q].tile0 + t;
+            rank += (other > mine) || (other == mine && ow < w);
+        }
+    }
+    jobs.tile_map[jobs.ascending ? jobs.tiles - 1 - rank : rank] = (k << 20) | j;
 }
 
 // order-preserving 64-bit key of (value, state): larger value first, then the lower state
@@ -115,6 +150,7 @@ __device__ __forceinline__ void top_insert(u64 *list, u64 x) {
 // build-time instrumentation (tools/resident_stamps.py): per-wave cycle sums of the phases of a timestep
 constexpr int kPhases = 8;
 __device__ unsigned long long g_phase[1024 * 16 * kPhases];
+__device__ unsigned long long g_wgtime[1024 * 4];        // per workgroup: start, end (100 MHz wall clock), steps, -
 #define RSTAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); acc[i] += now_ - last; last = now_; }
 #define RCOUNT(i, n) acc[i] += (n)
 #else
@@ -145,17 +181,17 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef RESIDENT_STAMP
+    const unsigned long long wg_start = wall_clock64();
+#endif
 
-    // which batch this workgroup belongs to
-    int k = 0;
-#pragma unroll 1
-    for (int q = 1; q < grp.n; ++q)
-        if ((int)blockIdx.x >= grp.batch[q].tile0) k = q;
-    const Batch &bat = grp.batch[k];
+    // which tile of which batch this workgroup decodes
+    const int code = grp.tile_map[blockIdx.x];
+    const Batch &bat = grp.batch[code >> 20];
     const float *__restrict__ obs = bat.obs;
     float *__restrict__ hist = bat.hist;
     const int B = bat.B, T = bat.T;
-    const int b0 = ((int)blockIdx.x - bat.tile0) * kNI;
+    const int b0 = (code & 0xfffff) * kNI;
 
     if (tid < kNI) {
         int f = 0;
@@ -374,6 +410,11 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
 #ifdef RESIDENT_STAMP
     if (lane == 0 && blockIdx.x < 1024)
         for (int i = 0; i < kPhases; ++i) g_phase[((size_t)blockIdx.x * 16 + wave) * kPhases + i] = acc[i];
+    if (tid == 0 && blockIdx.x < 1024) {
+        g_wgtime[4 * blockIdx.x] = wg_start;
+        g_wgtime[4 * blockIdx.x + 1] = wall_clock64();
+        g_wgtime[4 * blockIdx.x + 2] = (unsigned long long)fmax;
+    }
 #endif
 }
 

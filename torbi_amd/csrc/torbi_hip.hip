@@ -425,7 +425,7 @@ inline int requested_path(unsigned flags) {
     const unsigned f = (flags >> 4) & 7u;
     return f ? (int)f - 1 : default_path();
 }
-constexpr unsigned kKnownFlags = TORBI_HIP_REUSE_TRANSITION | TORBI_HIP_COLLECT_STATS | (7u << 4);
+constexpr unsigned kKnownFlags = TORBI_HIP_REUSE_TRANSITION | TORBI_HIP_COLLECT_STATS | (7u << 4) | TORBI_HIP_SHORTEST_FIRST;
 inline bool flags_ok(unsigned flags) {
     return !(flags & ~kKnownFlags) && ((flags >> 4) & 7u) <= (unsigned)TORBI_HIP_FORWARD_RESIDENT + 1u;
 }
@@ -502,12 +502,14 @@ inline PrunedWorkspace carve_pruned(void *base, int B, int T, int S, int cus) {
 }
 
 // the time-resident path shares the sorted lists / transposed matrix layout of the pruned path (16-item tiles)
+constexpr int kMaxGroupTiles = 16384;     // 16-item tiles one launch group may hold (262 144 items)
 struct ResidentWorkspace {
     float *hist;
     float2 *sorted;
     float *tt;
     int32_t *row_range;
     int32_t *order;       // [B] this batch's items by descending length
+    int32_t *tile_map;    // [kMaxGroupTiles] workgroup -> tile of the launch group (first batch's workspace)
     int SpP, NPOW;
     size_t bytes;
 };
@@ -523,10 +525,11 @@ inline ResidentWorkspace carve_resident(void *base, int B, int T, int S) {
     const size_t sorted_bytes = align_up(sizeof(float2) * (size_t)S * w.SpP, 256);
     const size_t tt_bytes = align_up(sizeof(float) * (size_t)S * S, 256);
     const size_t range_bytes = align_up(sizeof(int32_t) * 2 * (size_t)S, 256);
-    const size_t order_bytes = align_up(sizeof(int32_t) * (size_t)B, 256);
+    const size_t order_bytes = align_up(sizeof(int32_t) * (size_t)B, 256) + sizeof(int32_t) * kMaxGroupTiles;
     w.hist = reinterpret_cast<float *>(p);
     p += hist_bytes;
-    w.order = reinterpret_cast<int32_t *>(p);      // ahead of the preparation: its offset depends on B and T only
+    w.tile_map = reinterpret_cast<int32_t *>(p);   // ahead of the preparation: offsets depend on B and T only
+    w.order = w.tile_map + kMaxGroupTiles;
     p += order_bytes;
     w.sorted = reinterpret_cast<float2 *>(p);
     w.tt = reinterpret_cast<float *>(p + sorted_bytes);
@@ -876,9 +879,10 @@ hipError_t launch_resident_kernel(const resident::Group &grp, int tiles, const R
 
 // batches with B > 0 only; the preparation lives in the first batch's workspace
 hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const float *init, int S, hipStream_t s,
-                        hipEvent_t *ev, int *launches, bool reuse) {
+                        hipEvent_t *ev, int *launches, bool reuse, bool ascending = false) {
     resident::Group grp{};
     resident::OrderJobs jobs{};
+    jobs.ascending = ascending ? 1 : 0;
     grp.n = n;
     int tiles = 0, items = 0, widest = 0;
     for (int k = 0; k < n; ++k) {
@@ -889,7 +893,7 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
         b.out = hb[k].out;
         b.hist = wk.hist;
         b.order = wk.order;
-        jobs.job[k] = resident::OrderJob{hb[k].frames, wk.order, hb[k].B, hb[k].T};
+        jobs.job[k] = resident::OrderJob{hb[k].frames, wk.order, hb[k].B, hb[k].T, tiles};
         widest = std::max(widest, hb[k].B);
         b.B = hb[k].B;
         b.T = hb[k].T;
@@ -899,9 +903,15 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
         items += hb[k].B;
     }
     const ResidentWorkspace w = carve_resident(hb[0].workspace, hb[0].B, hb[0].T, S);
+    if (tiles > kMaxGroupTiles) return hipErrorInvalidValue;
+    grp.tile_map = w.tile_map;
+    jobs.n = n;
+    jobs.tiles = tiles;
+    jobs.tile_map = w.tile_map;
     if (ev) (void)hipEventRecord(ev[0], s);
     if (!reuse) launch_list_preparation(trans, w.sorted, w.row_range, w.tt, S, w.SpP, w.NPOW, resident::kNI, s);
     hipLaunchKernelGGL(resident::order_items_kernel, dim3((widest + 255) / 256, n), dim3(256), 0, s, jobs);
+    hipLaunchKernelGGL(resident::order_tiles_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, jobs);
     if (ev) (void)hipEventRecord(ev[3], s);
     hipError_t e;
     const int nrg = (S + resident::kRowGroup - 1) / resident::kRowGroup;
@@ -1102,7 +1112,7 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
         int launches = 0;
         hipError_t e;
         if (together) {
-            e = run_resident(hb, n, transition, initial, S, s, pe.ev, &launches, reuse);
+            e = run_resident(hb, n, transition, initial, S, s, pe.ev, &launches, reuse, (flags & TORBI_HIP_SHORTEST_FIRST) != 0);
             phase_ms[3] = (float)ROUTE_RESIDENT;
         } else {
             // one batch after the other, each on the path it would take alone; phases of the LAST batch only
@@ -1117,7 +1127,9 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
         phase_ms[5] = (float)(together ? n : 1);
         return (int)e;
     }
-    if (together) return (int)run_resident(hb, n, transition, initial, S, s, nullptr, nullptr, reuse);
+    if (together)
+        return (int)run_resident(hb, n, transition, initial, S, s, nullptr, nullptr, reuse,
+                                 (flags & TORBI_HIP_SHORTEST_FIRST) != 0);
     for (int k = 0; k < n; ++k) {
         const hipError_t e = run_decode(hb[k].obs, hb[k].frames, transition, initial, hb[k].out, hb[k].workspace,
                                         hb[k].B, hb[k].T, S, device, s, nullptr, nullptr, reuse,
@@ -1251,5 +1263,8 @@ extern "C" int torbi_hip_debug_stamps(unsigned long long *host, size_t count) {
 // instrumentation build only (tools/resident_stamps.py); not part of include/torbi_hip.h
 extern "C" int torbi_hip_debug_phases(unsigned long long *host, size_t count) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(resident::g_phase), count * sizeof(unsigned long long));
+}
+extern "C" int torbi_hip_debug_wgtime(unsigned long long *host, size_t count) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(resident::g_wgtime), count * sizeof(unsigned long long));
 }
 #endif

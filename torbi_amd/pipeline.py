@@ -105,10 +105,14 @@ class DecodePipeline:
                 results.append(indices)
             else:
                 spaces = [self._scratch(slot, k, viterbi.workspace_bytes(*b[0].shape)) for k, b in enumerate(batches)]
+                # consecutive launch groups alternate between shortest-tiles-first and longest-tiles-first: the
+                # long workgroups of one group then start on the CUs the short ones of the other have just left
+                # (4 ragged groups over two streams: 37.1 ms against 39.5 ms all longest-first)
                 decoded = viterbi.decode_batches([b[0] for b in batches], [b[1] for b in batches], transition,
                                                  initial, workspaces=spaces,
                                                  reuse_preparation=self.reuse_preparation, path=self.path,
-                                                 out=[b[5] for b in batches])
+                                                 out=[b[5] for b in batches],
+                                                 shortest_first=self.depth > 1 and self.turn % 2 == 1)
                 for (_, _, _, _, after, _), indices in zip(batches, decoded):
                     if after is not None:
                         after(indices)

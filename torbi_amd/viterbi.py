@@ -221,6 +221,7 @@ def decode_batches(
     reuse_preparation: bool = False,
     path: Optional[str] = None,
     out=None,
+    shortest_first: bool = False,
     _profile: Optional[list] = None,
 ):
     """`decode` for several batches that share `transition` and `initial`, in one call
@@ -294,6 +295,8 @@ def decode_batches(
     if _reusable(workspaces[first], transition, (tuple(shapes), chosen, stream), reuse_preparation) \
             and (chosen == 'resident' or count == 1):
         flags |= 1
+    if shortest_first:
+        flags |= 256                               # TORBI_HIP_SHORTEST_FIRST
     phases = (ctypes.c_float * 6)() if _profile is not None else None
     _lib.check(lib.torbi_hip_viterbi_decode_batches(table, count, trans.data_ptr(), init.data_ptr(), S, index,
                                                     ctypes.c_void_p(stream), flags, phases),
