@@ -132,7 +132,7 @@ def assign_files(lengths: Sequence[int], batch_size: int, size: int) -> List[Lis
 
 def from_files_to_files(input_files, output_files, transition_file=None, initial_file=None,
                         log_probs=False, gpu=None, num_threads=None, lengths=None, group=None,
-                        decode_files: Optional[Callable] = None):
+                        decode_files: Optional[Callable] = None, num_workers: Optional[int] = None):
     """Multi-GPU form of torbi_amd.from_files_to_files: each rank decodes and saves the files of whole
     batches of its own in ONE call of the single-GPU entry point (so the model is loaded and prepared once
     per rank and consecutive batches share launch groups and streams); no collective besides the closing
@@ -153,6 +153,8 @@ def from_files_to_files(input_files, output_files, transition_file=None, initial
     mine = assign_files(list(lengths) if known else [1] * n, core.BATCH_SIZE, size)[rank]
     if mine:
         extra = {'lengths': [lengths[i] for i in mine]} if known else {}
+        if num_workers is not None:
+            extra['num_workers'] = num_workers      # DataLoader workers for torch.load (reference default 0)
         decode_files([input_files[i] for i in mine], [output_files[i] for i in mine],
                      transition_file, initial_file, log_probs, gpu, num_threads, **extra)
     if size > 1:
