@@ -430,13 +430,15 @@ inline bool flags_ok(unsigned flags) {
     return !(flags & ~kKnownFlags) && ((flags >> 4) & 7u) <= (unsigned)TORBI_HIP_FORWARD_RESIDENT + 1u;
 }
 
+constexpr int kMaxGroupTiles = 16384;     // 16-item tiles one launch group may hold (262 144 items)
 inline int tiles_of(int B) { return (B + resident::kNI - 1) / resident::kNI; }
+inline bool resident_fits(int S, int tiles) { return resident::supported(S) && tiles <= kMaxGroupTiles; }
 
 // route of ONE batch.  AUTO: the time-resident kernel when the batch alone gives at least half the CUs a
 // workgroup, else the per-timestep pruned pass where supported, else the dense (max,+) GEMM, else generic.
 inline Route route_for(int path, int B, int S, int cus) {
-    if (path == TORBI_HIP_FORWARD_RESIDENT && resident::supported(S)) return ROUTE_RESIDENT;
-    if (path == TORBI_HIP_FORWARD_AUTO && resident::supported(S) && 2 * tiles_of(B) >= cus) return ROUTE_RESIDENT;
+    if (path == TORBI_HIP_FORWARD_RESIDENT && resident_fits(S, tiles_of(B))) return ROUTE_RESIDENT;
+    if (path == TORBI_HIP_FORWARD_AUTO && resident_fits(S, tiles_of(B)) && 2 * tiles_of(B) >= cus) return ROUTE_RESIDENT;
     if (path != TORBI_HIP_FORWARD_DENSE && pruned::supported(B, S)) return ROUTE_PRUNED;
     return use_dense(B, S) ? ROUTE_DENSE : ROUTE_GENERIC;
 }
@@ -502,7 +504,6 @@ inline PrunedWorkspace carve_pruned(void *base, int B, int T, int S, int cus) {
 }
 
 // the time-resident path shares the sorted lists / transposed matrix layout of the pruned path (16-item tiles)
-constexpr int kMaxGroupTiles = 16384;     // 16-item tiles one launch group may hold (262 144 items)
 struct ResidentWorkspace {
     float *hist;
     float2 *sorted;
@@ -1104,7 +1105,7 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int path = requested_path(flags);
     const bool reuse = (flags & TORBI_HIP_REUSE_TRANSITION) != 0;
-    const bool together = resident::supported(S) &&
+    const bool together = resident_fits(S, tiles) &&
                           (path == TORBI_HIP_FORWARD_RESIDENT || (path == TORBI_HIP_FORWARD_AUTO && 2 * tiles >= cus));
     if (phase_ms) {
         PhaseEvents pe;

@@ -125,6 +125,8 @@ class DecodePipeline:
                 if tensor.is_cuda:
                     tensor.record_stream(stream)
         for indices in results:
+            if indices.is_cuda:
+                indices.record_stream(stream)       # preallocated on the caller's stream, written on this one
             self.pending.append((indices, done))
         if len(self.pending) > 4 * self.depth * self.group:
             self.pending = [(i, e) for i, e in self.pending if not e.query()]

@@ -80,7 +80,7 @@ def _resolve_path(trans, transition, B, S, device, path, tiles, measure):
         tuner = _tuner_for(transition, S, device)
         if tuner is not None:
             chosen = tuner.choose()
-    if chosen == 'pruned' and 64 <= S <= 2048 and 2 * tiles >= compute_units(device):
+    if chosen == 'pruned' and 64 <= S <= 2048 and tiles <= 16384 and 2 * tiles >= compute_units(device):
         chosen = 'resident'          # enough items to give the compute units a workgroup of 16 each
     return chosen, tuner
 
