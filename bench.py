@@ -393,6 +393,8 @@ class Bench:
             if extra:
                 out[name].update(extra)
 
+        # BASELINE configs[3] on this one GPU: 40 000 ragged sequences (79 batches, ten launch groups), decode only
+        out['c4_40000_files'] = self.c4_decode_only(40000, steps=0, quiet=True)
         ws = torch.empty(v.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(obs, frames, trans, init, workspace=ws, path='pruned'), 3)
         record('serial', sec, B * T, S, 'headline batch, ONE batch at a time on one stream: per-timestep launches of '
@@ -419,7 +421,17 @@ class Bench:
                'pitch transition; path = what AUTO settled on', {'forward_path': ROUTES[int(prof[3])]})
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(peaked, frames, trans, init, workspace=ws), 3, warmup=4)
         record('peaked_dense_transition', sec, B * T, S, 'the same peaked rows with the dense random transition (AUTO)')
-        del peaked, band
+        # the same workload as a launch group of 8 batches (what from_files_to_files sees): AUTO's choice for the group
+        spaces = [torch.empty(v.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev) for _ in range(8)]
+        prof = []
+        v.decode_batches([peaked] * 8, [frames] * 8, band, init, workspaces=spaces, _profile=prof)
+        sec, _ = self.timed_decodes(lambda: v.decode_batches([peaked] * 8, [frames] * 8, band, init, workspaces=spaces), 2)
+        record('peaked_banded_launch_group', sec, 8 * B * T, S,
+               'eight batches of the peaked rows + banded pitch transition in one call', {'forward_path': ROUTES[int(prof[3])]})
+        sec, _ = self.timed_decodes(lambda: v.decode_batches([peaked] * 8, [frames] * 8, band, init, workspaces=spaces,
+                                                             path='resident'), 2)
+        record('peaked_banded_launch_group_resident', sec, 8 * B * T, S, 'the same, time-resident kernel forced')
+        del peaked, band, spaces
         c = float(torch.tensor(math.log(1.0 / S), dtype=torch.float32))
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode_uniform(obs, frames, c, init), 3)
         out['uniform'] = {'value': B * T / sec, 'unit': 'timesteps/s', 'ms_per_decode': sec * 1e3,
@@ -446,8 +458,6 @@ class Bench:
             del o5, t5, i5, f5, w5
         except RuntimeError as exc:     # out of memory next to the headline buffers: say so instead of dying
             out['c5'] = {'value': None, 'note': f'not measured: {exc}'}
-        # BASELINE configs[3] on this one GPU: 40 000 ragged sequences (79 batches, ten launch groups), decode only
-        out['c4_40000_files'] = self.c4_decode_only(40000, steps=0, quiet=True)
         out['chunked_long_sequence'] = self.chunked_long_sequence(trans, init)
         return out
 
@@ -621,10 +631,18 @@ def main():
         sys.exit(self_launch(args))
     bench = Bench(args)
     result = bench.run_c4() if args.workload == 'c4' else bench.run_c3()
-    if bench.rank == 0:
-        print(json.dumps(result), flush=True)
     if bench.collective:
         bench.dist.destroy_process_group()
+    # RCCL announces itself through C stdio ("Librccl path : ..."), which would otherwise be flushed at exit, AFTER
+    # the result: flush it now so that the JSON line is the last thing on stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    if bench.rank == 0:
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == '__main__':

@@ -609,6 +609,17 @@ def test_decode_batches_auto_goes_resident_when_the_group_fills_the_chip():
     assert int(prof[3]) == 2 and int(prof[5]) == 1
     for k in range(2):
         np.testing.assert_array_equal(got[k].cpu().numpy(), want[k])
+    # a narrow band goes to the dense kernel one batch at a time, to the time-resident kernel as a full group
+    band = synth.banded_transition(S, 12.0)
+    d_band = torch.as_tensor(band).to(dev)
+    got = viterbi.decode_batches(obs_list, frame_list, d_band, d_init, path='auto', _profile=prof)
+    assert int(prof[3]) == 3 and int(prof[5]) == 8
+    for k in (0, 7):
+        ref = oracle.decode(obs_list[k].cpu().numpy(), frame_list[k].cpu().numpy(), band, init,
+                            num_threads=oracle.max_threads())
+        np.testing.assert_array_equal(got[k].cpu().numpy(), ref)
+    viterbi.decode_batches(obs_list[:1], frame_list[:1], d_band, d_init, path='auto', _profile=prof)
+    assert int(prof[3]) == 1
 
 
 @pytest.mark.parametrize('B', [40, 270])

@@ -74,15 +74,31 @@ def _resolve_path(trans, transition, B, S, device, path, tiles, measure):
     if forced != 'auto':
         return forced, None
     chosen = _choose_path(trans, transition, B, S)
+    banded = chosen == 'dense'
     tuner = None
     if chosen == 'pruned' and B >= 32 and measure:
         # both value-only recurrences are available and nothing is forced: pick by measurement (see _Tuner)
         tuner = _tuner_for(transition, S, device)
         if tuner is not None:
             chosen = tuner.choose()
-    if chosen == 'pruned' and 64 <= S <= 2048 and tiles <= 16384 and 2 * tiles >= compute_units(device):
-        chosen = 'resident'          # enough items to give the compute units a workgroup of 16 each
+    if 64 <= S <= 2048 and tiles <= 16384 and 2 * tiles >= compute_units(device):
+        # enough items to give the compute units a workgroup of 16 each: the time-resident kernel -- also for a
+        # narrow band (its lists end at the band edge, so the scan is short whatever the posteriors look like:
+        # 58 M against 32 M timesteps/s for eight batches of peaked rows with the pitch transition) -- unless
+        # measurements on this matrix have shown that pruning does not work on the caller's data
+        if banded or (chosen == 'pruned' and not _pruning_known_bad(transition, S)):
+            chosen = 'resident'
     return chosen, tuner
+
+
+def _pruning_known_bad(transition: torch.Tensor, states: int) -> bool:
+    """A path tuner of this matrix has timed both value-only recurrences and the dense kernel won."""
+    version = _version_of(transition)
+    known = _tuners.get(id(transition)) if version is not None else None
+    if known is None or known[0]() is not transition or known[1:3] != (version, states):
+        return False
+    times = known[3].time
+    return times['pruned'] is not None and times['dense'] is not None and times['dense'] < times['pruned']
 
 
 def compute_units(device) -> int:
