@@ -40,7 +40,7 @@ class DecodePipeline:
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
         # scratch[slot][k]: workspace of the k-th batch of the group that runs on `slot`
         self.scratch: List[List[Optional[torch.Tensor]]] = [[None] * self.group for _ in range(self.depth)]
-        self.pending: List[Tuple[torch.Tensor, torch.cuda.Event]] = []
+        self.pending: List[tuple] = []           # (indices, completion event, inputs kept alive until then)
         self.waiting: List[tuple] = []          # batches collected for the next group
         self.turn = 0
 
@@ -119,35 +119,37 @@ class DecodePipeline:
                     results.append(indices)
             done = torch.cuda.Event()
             done.record(stream)
-        # keep the inputs alive for the allocator until the side stream is done with them
-        for observation, batch_frames, _, _, _, _ in batches:
-            for tensor in (observation, batch_frames, transition, initial):
-                if tensor.is_cuda:
-                    tensor.record_stream(stream)
+        # Inputs and indices were allocated on the caller's stream and are used on this one: `pending` holds them until
+        # `done` has completed, so the allocator cannot hand their memory out early.  (record_stream() would do the
+        # same by deferring every free behind an event; on a job that frees a batch per decode that cost the
+        # many-file benchmark a third of its rate.)
+        self._prune()
+        keep = [(b[0], b[1]) for b in batches] + [(transition, initial)]
         for indices in results:
-            if indices.is_cuda:
-                indices.record_stream(stream)       # preallocated on the caller's stream, written on this one
-            self.pending.append((indices, done))
-        if len(self.pending) > 4 * self.depth * self.group:
-            self.pending = [(i, e) for i, e in self.pending if not e.query()]
+            self.pending.append((indices, done, keep))
         return results
+
+    def _prune(self) -> None:
+        """Forget the decodes that have completed (and let go of their inputs)."""
+        self.pending = [entry for entry in self.pending if not entry[1].query()]
 
     def wait(self, indices: torch.Tensor) -> torch.Tensor:
         """Block the host until the decode that produced `indices` has finished."""
         if any(entry[5] is indices for entry in self.waiting):
             self.flush()
-        for tensor, event in self.pending:
-            if tensor is indices:
-                event.synchronize()
+        for entry in self.pending:
+            if entry[0] is indices:
+                entry[1].synchronize()
                 break
+        self._prune()
         viterbi.collect_measurements()
         return indices
 
     def synchronize(self) -> None:
         """Block the host until every enqueued decode has finished."""
         self.flush()
-        for _, event in self.pending:
-            event.synchronize()
+        for entry in self.pending:
+            entry[1].synchronize()
         self.pending = []
         for stream in self.streams:
             stream.synchronize()
