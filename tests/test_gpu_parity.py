@@ -878,3 +878,23 @@ def test_grouped_decode_pipeline_equals_the_oracle():
         want = oracle.decode(obs.cpu().numpy(), frames.cpu().numpy(), trans.cpu().numpy(), init.cpu().numpy(),
                              num_threads=oracle.max_threads())
         assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('B', [8200, 1000])
+def test_time_resident_tile_orders_do_not_change_results(B):
+    """The time-resident kernel forms its 16-item tiles from items ranked by length and ranks the tiles across the
+    launch group (longest or shortest first); batches above 8192 items keep their order.  None of it may show in
+    the indices: ragged lengths, partial last tile, both orders, against the oracle."""
+    dev = torch.device('cuda:0')
+    T, S = 7, 64
+    obs, trans, init = synth.problem(B, T, S, seed=B)
+    frames = synth.lengths(B, 1, T, seed=3)
+    want = oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())
+    d = [torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)]
+    small = _device_problem(37, 5, S, seed=9, dev=dev)
+    want_small = oracle.decode(small[0], small[1], trans, init)
+    for shortest_first in (False, True):
+        got = viterbi.decode_batches([d[0], torch.as_tensor(small[0]).to(dev)], [d[1], torch.as_tensor(small[1]).to(dev)],
+                                     d[2], d[3], path='resident', shortest_first=shortest_first)
+        np.testing.assert_array_equal(got[0].cpu().numpy(), want)
+        np.testing.assert_array_equal(got[1].cpu().numpy(), want_small)
