@@ -1,4 +1,4 @@
-"""Randomised parity stress (GPU box): random shapes, lengths, -inf densities and tie levels under the three forward
+"""Randomised parity stress (GPU box): random shapes, lengths, -inf densities and tie levels under the four forward
 paths against the C oracle.   python tools/stress.py [cases] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -34,12 +34,12 @@ for c in range(cases):
     frames = rng.integers(1, T + 1, size=B).astype(np.int32)
     want = oracle.decode(obs.astype(np.float32), frames, trans.astype(np.float32), init.astype(np.float32), num_threads=oracle.max_threads())
     args = [torch.as_tensor(np.ascontiguousarray(x)).to(dev) for x in (obs.astype(np.float32), frames, trans.astype(np.float32), init.astype(np.float32))]
-    for path in ('auto', 'dense', 'pruned'):
+    for path in ('auto', 'dense', 'pruned', 'resident'):
         viterbi.set_forward_path(path)
         got = torbi_amd.decode(*args).cpu().numpy()
         if not np.array_equal(got, want):
             bad += 1
             print('MISMATCH', dict(B=B, T=T, S=S, kind=int(kind), path=path, used=viterbi.forward_path(B, S)), int((got != want).sum()))
 viterbi.set_forward_path('auto')
-print(f'{cases} cases x 3 paths, {bad} mismatches, {time.time() - t0:.0f} s')
+print(f'{cases} cases x 4 paths, {bad} mismatches, {time.time() - t0:.0f} s')
 sys.exit(1 if bad else 0)

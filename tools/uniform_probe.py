@@ -1,0 +1,23 @@
+"""Uniform-transition decode (the reference's transition=None default): time and HBM fraction.  (GPU box)"""
+import math, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torbi_amd
+from torbi_amd import viterbi, synth
+dev = torch.device('cuda:0')
+for B, T, S in ((512, 500, 1440), (4096, 250, 1440), (512, 500, 1024), (128, 2000, 4096)):
+    obs = viterbi.fill_synthetic((B, T, S), synth.STREAM_OBSERVATION, device=dev)
+    init = viterbi.fill_synthetic((S,), synth.STREAM_INITIAL, device=dev)
+    frames = torch.full((B,), T, dtype=torch.int32, device=dev)
+    c = float(torch.tensor(math.log(1.0 / S), dtype=torch.float32))
+    for _ in range(2):
+        torbi_amd.decode_uniform(obs, frames, c, init)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        torbi_amd.decode_uniform(obs, frames, c, init)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    print(f'{B} x {T} x {S}: {dt * 1e3:.3f} ms, {B * T / dt / 1e6:.0f} M timesteps/s, '
+          f'{B * T * (4 * S + 4) / dt / 8e12 * 100:.1f} % of 8 TB/s, {dt / (T - 1) * 1e6:.2f} us per timestep')
