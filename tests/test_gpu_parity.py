@@ -898,3 +898,31 @@ def test_time_resident_tile_orders_do_not_change_results(B):
                                      d[2], d[3], path='resident', shortest_first=shortest_first)
         np.testing.assert_array_equal(got[0].cpu().numpy(), want)
         np.testing.assert_array_equal(got[1].cpu().numpy(), want_small)
+
+
+def test_command_line_decodes_files_like_the_reference_cli(tmp_path, forward):
+    """`python -m torbi_amd --input_files ... --output_files ... --transition_file ... --log_probs --gpu 0`
+    (the reference's flags, torbi/__main__.py:16-49) writes the oracle's decode of every file."""
+    if forward != 'auto':
+        pytest.skip('a child process: the fixture does not reach it')
+    import subprocess
+    import sys
+    S = 48
+    gen = torch.Generator().manual_seed(5)
+    ins, outs = [], []
+    for k, n in enumerate([11, 3, 29]):
+        f = tmp_path / f'in{k}.pt'
+        torch.save(torch.rand(n, S, generator=gen).log_softmax(-1), f)
+        ins.append(str(f))
+        outs.append(str(tmp_path / f'out{k}.pt'))
+    tf = tmp_path / 'transition.pt'
+    torch.save(torch.rand(S, S, generator=gen).softmax(-1), tf)
+    root = __import__('conftest').ROOT
+    run = subprocess.run([sys.executable, '-m', 'torbi_amd', '--input_files', *ins, '--output_files', *outs,
+                          '--transition_file', str(tf), '--log_probs', '--gpu', '0', '--num_threads', '2'],
+                         cwd=root, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-2000:]
+    for fin, fout in zip(ins, outs):
+        got = torch.load(fout)
+        assert got.dtype == torch.int32
+        assert np.array_equal(got.numpy(), _oracle_for_file(torch.load(fin), torch.load(tf), S))

@@ -335,3 +335,17 @@ def test_bench_starts_its_own_ranks_and_dry_runs_without_a_gpu():
     assert line['n_gpus'] == 2 and line['scaling'] == 'strong'
     assert line['decode_only']['batches_per_rank'] == [3, 3]
     assert line['decode_only']['valid_timesteps'] == float(synth.lengths(3000, 100, 900).sum())
+
+
+def test_command_line_takes_the_reference_flags(monkeypatch, tmp_path):
+    """reference torbi/__main__.py:16-49: same flag names and types; the call goes to from_files_to_files."""
+    from torbi_amd import __main__ as cli
+    seen = {}
+    monkeypatch.setattr(torbi_amd, 'from_files_to_files', lambda **kwargs: seen.update(kwargs))
+    assert cli.main(['--input_files', 'a.pt', 'b.pt', '--output_files', 'x.pt', 'y.pt', '--transition_file', 't.pt',
+                     '--initial_file', 'i.pt', '--log_probs', '--gpu', '3', '--num_threads', '4', '--config', 'ignored.py']) == 0
+    assert [str(p) for p in seen['input_files']] == ['a.pt', 'b.pt'] and [str(p) for p in seen['output_files']] == ['x.pt', 'y.pt']
+    assert str(seen['transition_file']) == 't.pt' and str(seen['initial_file']) == 'i.pt'
+    assert seen['log_probs'] is True and seen['gpu'] == 3 and seen['num_threads'] == 4
+    with pytest.raises(SystemExit):
+        cli.main(['--output_files', 'x.pt'])              # --input_files is required, as upstream
