@@ -167,18 +167,21 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
                                      float *phase_ms);
 
 /*
- * Scan statistics of the last PRUNED decode that ran with TORBI_HIP_COLLECT_STATS on `workspace`
- * (zeros otherwise; for adaptive path selection;
- * torbi_amd/viterbi.py uses them): copies 128 uint32 to `stats_out` (DEVICE pointer) on `stream`:
- *   stats_out[0..63]   sum over (sampled timestep, tile) of the deepest scan among the tile's waves, in
- *                      16-entry list blocks (a launch lasts as long as its deepest wave)
- *   stats_out[64..127] number of (timestep, tile) pairs counted (every 8th timestep is sampled)
- * sum(first half) / sum(second half) = blocks on the critical path of a launch: about 11 of the
- * S/16 = 90 on the 1440-state benchmark; near S/16 nothing is being pruned and the dense path is
- * faster.  TORBI_HIP_EUNSUPPORTED when (B, S) does not take the pruned path.
+ * Scan statistics for adaptive path selection (torbi_amd/viterbi.py uses them): copies 128 uint32 to `stats_out`
+ * (DEVICE pointer) on `stream`.  `flags` = the path flag of the decode in question:
+ *   PRUNED (a decode run with TORBI_HIP_COLLECT_STATS on `workspace`; zeros otherwise):
+ *     stats_out[0..63]   sum over (sampled timestep, tile) of the deepest scan among the tile's waves, in 16-entry
+ *                        list blocks (a launch lasts as long as its deepest wave)
+ *     stats_out[64..127] number of (timestep, tile) pairs counted (every 8th timestep is sampled)
+ *   RESIDENT (always collected; `workspace` = the FIRST batch's workspace of the launch group):
+ *     stats_out[0]       list blocks walked by the sampled wave passes (every 16th timestep)
+ *     stats_out[64]      wave passes counted;            the other entries are zero
+ * sum(first half) / sum(second half) = list blocks per scan: about 11 of the S/16 = 90 on the 1440-state benchmark;
+ * near S/16 nothing is being pruned and the dense path is faster.  TORBI_HIP_EUNSUPPORTED when the shape takes
+ * neither path.
  */
 int torbi_hip_scan_stats(const void *workspace, size_t workspace_bytes, int B, int T, int S,
-                         unsigned *stats_out, int device, void *stream);
+                         unsigned *stats_out, int device, void *stream, unsigned flags);
 
 /*
  * The operator for a UNIFORM transition matrix (every entry == log_transition), i.e. the

@@ -926,3 +926,34 @@ def test_command_line_decodes_files_like_the_reference_cli(tmp_path, forward):
         got = torch.load(fout)
         assert got.dtype == torch.int32
         assert np.array_equal(got.numpy(), _oracle_for_file(torch.load(fin), torch.load(tf), S))
+
+
+def test_auto_leaves_the_time_resident_kernel_when_nothing_is_pruned(forward):
+    """A flat transition matrix gives the pruning bound nothing to work with: the time-resident kernel walks every
+    list to its end.  The scan statistics of the first AUTO launch group say so (torbi_hip_scan_stats), and later
+    groups with the same matrix go to the dense kernel; a matrix with spread stays time-resident.  Same indices."""
+    if forward != 'auto':
+        pytest.skip('path forced')
+    dev = torch.device('cuda:0')
+    S, T, B, n = 360, 10, 272, 8
+    obs_list, frame_list = [], []
+    for k in range(n):
+        obs, frames, _, _ = _device_problem(B, T, S, seed=70 + k, dev=dev)
+        obs_list.append(torch.as_tensor(obs).to(dev))
+        frame_list.append(torch.as_tensor(frames).to(dev))
+    _, spread, init = synth.problem(1, 1, S, seed=2)
+    flat = np.full((S, S), np.float32(-1.25))
+    d_init = torch.as_tensor(init).to(dev)
+    for matrix, later in ((flat, 1), (spread, 3)):
+        d_matrix = torch.as_tensor(matrix).to(dev)
+        want = [oracle.decode(obs_list[k].cpu().numpy(), frame_list[k].cpu().numpy(), matrix, init,
+                              num_threads=oracle.max_threads()) for k in (0, n - 1)]
+        routes = []
+        for _ in range(3):
+            prof = []
+            got = viterbi.decode_batches(obs_list, frame_list, d_matrix, d_init, _profile=prof)
+            torch.cuda.synchronize()
+            routes.append(int(prof[3]))
+            np.testing.assert_array_equal(got[0].cpu().numpy(), want[0])
+            np.testing.assert_array_equal(got[n - 1].cpu().numpy(), want[1])
+        assert routes[0] == 3 and routes[-1] == later, routes

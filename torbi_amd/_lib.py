@@ -41,7 +41,7 @@ SYMBOLS = {
         _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
         _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint]),
     'torbi_hip_scan_stats': (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
-                                        _c.c_int, _c.c_void_p]),
+                                        _c.c_int, _c.c_void_p, _c.c_uint]),
     'torbi_hip_set_forward_path': (_c.c_int, [_c.c_int]),
     'torbi_hip_forward_path': (_c.c_int, [_c.c_int, _c.c_int]),
     'torbi_hip_forward_path_on': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_uint]),

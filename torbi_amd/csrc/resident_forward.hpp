@@ -53,6 +53,7 @@ struct Group {
     Batch batch[kMaxBatches];
     int n;
     const int32_t *tile_map;   // [tiles of the group] workgroup -> (batch << 20 | tile of that batch), longest first
+    unsigned *stats;           // [128] scan statistics: [0] list blocks walked, [64] wave passes counted (sampled)
 };
 
 inline bool supported(int S) { return S >= 64 && S <= pruned::kMaxS16; }
@@ -73,7 +74,7 @@ inline size_t lds_bytes(int S) {
 // grid = (ceil(max B / 256), batches), block = 256; O(B^2) compares, batches above kMaxOrdered items keep their order.
 constexpr int kMaxOrdered = 8192;
 struct OrderJob { const int32_t *frames; int32_t *order; int B, T, tile0; };
-struct OrderJobs { OrderJob job[kMaxBatches]; int ascending; int n; int tiles; int32_t *tile_map; };
+struct OrderJobs { OrderJob job[kMaxBatches]; int ascending; int n; int tiles; int32_t *tile_map; unsigned *stats; };
 
 __global__ __launch_bounds__(256) void order_items_kernel(OrderJobs jobs) {
     const OrderJob &jb = jobs.job[blockIdx.y];
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(256) void order_items_kernel(OrderJobs jobs) {
 // One thread per tile; grid = ceil(tiles / 256); O(tiles^2) compares.  Runs after order_items_kernel.
 __global__ __launch_bounds__(256) void order_tiles_kernel(OrderJobs jobs) {
     const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w < 128) jobs.stats[w] = 0u;                 // the forward launch that follows accumulates into them
     if (w >= jobs.tiles) return;
     auto tile_length = [&](int k, int j) {
         const OrderJob &jb = jobs.job[k];
@@ -235,6 +237,9 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
     for (int it = 0; it < 4; ++it) ib[it] = sitem[4 * g + it];
 
     float pend[MAXP][4];
+    // scan statistics for adaptive path selection (every 16th timestep): how many 16-entry list blocks a wave pass
+    // walks.  The benchmark needs 10.6 of the 90 a row holds; near 90 nothing is being pruned and the dense kernel wins.
+    unsigned stat_blocks = 0, stat_passes = 0;
 
     // publish the largest entries of the row the tile holds (decoded; states as offsets into tt) and empty the
     // running lists for the next row's outputs
@@ -355,6 +360,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
                     }
                 };
                 if (PIPE) issue(std::integral_constant<int, 0>(), cur, ahead);
+                int nblk = 1;                              // wave-uniform
                 consume(cur, nxt);
                 load_list_block(cur, row, 2 * kBlk);
 #pragma unroll
@@ -371,13 +377,16 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
                 for (int kk = kBlk; kk < Sp; kk += 2 * kBlk) {
                     if (!more(nxt)) break;
                     RCOUNT(7, 1);
+                    ++nblk;
                     consume(nxt, cur);
                     load_list_block(nxt, row, kk + 2 * kBlk);
                     if (!more(cur)) break;
                     RCOUNT(7, 1);
+                    ++nblk;
                     consume(cur, nxt);
                     load_list_block(cur, row, kk + 3 * kBlk);
                 }
+                if ((t & 15) == 1) { stat_blocks += (unsigned)nblk; stat_passes += 1u; }
                 RSTAMP(3);
                 // the four items' list thresholds are read together (one LDS round trip, not four in a row)
                 u64 last4[4];
@@ -406,6 +415,10 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
         }
         publish_top();
         RSTAMP(6);
+    }
+    if (lane == 0 && stat_passes) {
+        atomicAdd(&grp.stats[0], stat_blocks);
+        atomicAdd(&grp.stats[64], stat_passes);
     }
 #ifdef RESIDENT_STAMP
     if (lane == 0 && blockIdx.x < 1024)

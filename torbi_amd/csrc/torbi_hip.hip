@@ -511,6 +511,7 @@ struct ResidentWorkspace {
     int32_t *row_range;
     int32_t *order;       // [B] this batch's items by descending length
     int32_t *tile_map;    // [kMaxGroupTiles] workgroup -> tile of the launch group (first batch's workspace)
+    unsigned *stats;      // [128] scan statistics of the last launch group (first batch's workspace)
     int SpP, NPOW;
     size_t bytes;
 };
@@ -526,11 +527,12 @@ inline ResidentWorkspace carve_resident(void *base, int B, int T, int S) {
     const size_t sorted_bytes = align_up(sizeof(float2) * (size_t)S * w.SpP, 256);
     const size_t tt_bytes = align_up(sizeof(float) * (size_t)S * S, 256);
     const size_t range_bytes = align_up(sizeof(int32_t) * 2 * (size_t)S, 256);
-    const size_t order_bytes = align_up(sizeof(int32_t) * (size_t)B, 256) + sizeof(int32_t) * kMaxGroupTiles;
+    const size_t order_bytes = align_up(sizeof(int32_t) * (size_t)B, 256) + sizeof(int32_t) * (kMaxGroupTiles + 128);
     w.hist = reinterpret_cast<float *>(p);
     p += hist_bytes;
     w.tile_map = reinterpret_cast<int32_t *>(p);   // ahead of the preparation: offsets depend on B and T only
-    w.order = w.tile_map + kMaxGroupTiles;
+    w.stats = reinterpret_cast<unsigned *>(w.tile_map + kMaxGroupTiles);
+    w.order = w.tile_map + kMaxGroupTiles + 128;
     p += order_bytes;
     w.sorted = reinterpret_cast<float2 *>(p);
     w.tt = reinterpret_cast<float *>(p + sorted_bytes);
@@ -906,6 +908,8 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
     const ResidentWorkspace w = carve_resident(hb[0].workspace, hb[0].B, hb[0].T, S);
     if (tiles > kMaxGroupTiles) return hipErrorInvalidValue;
     grp.tile_map = w.tile_map;
+    grp.stats = w.stats;
+    jobs.stats = w.stats;
     jobs.n = n;
     jobs.tiles = tiles;
     jobs.tile_map = w.tile_map;
@@ -1141,14 +1145,19 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
 }
 
 int torbi_hip_scan_stats(const void *workspace, size_t workspace_bytes, int B, int T, int S,
-                         unsigned *stats_out, int device, void *stream) {
-    if (B < 1 || T < 1 || S < 1 || !workspace || !stats_out) return TORBI_HIP_EINVAL;
-    if (!pruned::supported(B, S)) return TORBI_HIP_EUNSUPPORTED;
+                         unsigned *stats_out, int device, void *stream, unsigned flags) {
+    if (B < 1 || T < 1 || S < 1 || !workspace || !stats_out || !flags_ok(flags)) return TORBI_HIP_EINVAL;
     DeviceGuard guard(device);
     if (guard.err != hipSuccess) return (int)guard.err;
     if (workspace_bytes < need_bytes(B, T, S, cu_count(device))) return TORBI_HIP_EWORKSPACE;
-    const PrunedWorkspace w = carve_pruned(const_cast<void *>(workspace), B, T, S, cu_count(device));
-    return (int)hipMemcpyAsync(stats_out, w.stats, sizeof(unsigned) * 2 * pruned::kStatSlots, hipMemcpyDeviceToDevice,
+    const unsigned *stats;
+    if (requested_path(flags) == TORBI_HIP_FORWARD_RESIDENT && resident::supported(S))
+        stats = carve_resident(const_cast<void *>(workspace), B, T, S).stats;
+    else if (pruned::supported(B, S))
+        stats = carve_pruned(const_cast<void *>(workspace), B, T, S, cu_count(device)).stats;
+    else
+        return TORBI_HIP_EUNSUPPORTED;
+    return (int)hipMemcpyAsync(stats_out, stats, sizeof(unsigned) * 2 * pruned::kStatSlots, hipMemcpyDeviceToDevice,
                                static_cast<hipStream_t>(stream));
 }
 

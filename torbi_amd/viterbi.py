@@ -86,19 +86,56 @@ def _resolve_path(trans, transition, B, S, device, path, tiles, measure):
         # narrow band (its lists end at the band edge, so the scan is short whatever the posteriors look like:
         # 58 M against 32 M timesteps/s for eight batches of peaked rows with the pitch transition) -- unless
         # measurements on this matrix have shown that pruning does not work on the caller's data
-        if banded or (chosen == 'pruned' and not _pruning_known_bad(transition, S)):
-            chosen = 'resident'
+        # the scan statistics of an earlier time-resident launch with this matrix say that hardly anything is pruned
+        # (see _watch_resident).  Whether the per-timestep pruned kernel beats the dense one is NOT the question here:
+        # on peaked rows with a dense matrix it does not, and the time-resident kernel still runs at twice the dense
+        # kernel's rate (tools/peaked_group_probe.py: 17.6-27.6 M against 12.6 M timesteps/s).
+        if banded or chosen in ('pruned', 'dense'):
+            chosen = 'dense' if (not banded and _resident_is_losing(transition, S)) else 'resident'
     return chosen, tuner
 
 
-def _pruning_known_bad(transition: torch.Tensor, states: int) -> bool:
-    """A path tuner of this matrix has timed both value-only recurrences and the dense kernel won."""
+RESIDENT_GATE = 0.45     # fraction of a row's S/16 list blocks per scan above which the dense kernel wins
+_group_depth = {}        # id(transition) -> [weakref, version, states, blocks or None, pending (pinned stats, event)]
+
+
+def _depth_record(transition: torch.Tensor, states: int):
     version = _version_of(transition)
-    known = _tuners.get(id(transition)) if version is not None else None
-    if known is None or known[0]() is not transition or known[1:3] != (version, states):
+    if version is None:
+        return None
+    known = _group_depth.get(id(transition))
+    if known is None or known[0]() is not transition or known[1:3] != [version, states]:
+        if len(_group_depth) > 64:
+            for key in [k for k, v in list(_group_depth.items()) if v[0]() is None]:
+                _group_depth.pop(key, None)
+        known = [weakref.ref(transition), version, states, None, None]
+        _group_depth[id(transition)] = known
+    return known
+
+
+def _resident_is_losing(transition: torch.Tensor, states: int) -> bool:
+    """Time-resident launches with this matrix walk so many list blocks per scan that the dense kernel is faster
+    (flat or nearly flat matrices: nothing to prune).  Read without blocking from the statistics the kernel leaves."""
+    known = _depth_record(transition, states)
+    if known is None:
         return False
-    times = known[3].time
-    return times['pruned'] is not None and times['dense'] is not None and times['dense'] < times['pruned']
+    if known[3] is None and known[4] is not None and known[4][1].query():
+        known[3] = critical_blocks(known[4][0])
+        known[4] = None
+    return known[3] is not None and known[3] > RESIDENT_GATE * states / 16.0
+
+
+def _watch_resident(transition, workspace, batch, frames, states) -> None:
+    """After a time-resident launch chosen by AUTO: once per matrix, copy the scan statistics it leaves in its first
+    workspace to pinned host memory (asynchronously; looked at by a later call, never waited for)."""
+    known = _depth_record(transition, states)
+    if known is None or known[3] is not None or known[4] is not None:
+        return
+    stats = torch.empty((128,), dtype=torch.int32, pin_memory=True)
+    stats.copy_(scan_stats(workspace, batch, frames, states, path='resident'), non_blocking=True)
+    done = torch.cuda.Event()
+    done.record(torch.cuda.current_stream(workspace.device))
+    known[4] = (stats, done)
 
 
 def compute_units(device) -> int:
@@ -180,6 +217,8 @@ def decode(
     index = device.index if device.index is not None else torch.cuda.current_device()
     stream = torch.cuda.current_stream(device).cuda_stream
     chosen, tuner = _resolve_path(trans, transition, B, S, device, path, (B + 15) // 16, _profile is None)
+    if chosen == 'resident':
+        tuner = None                     # the per-timestep tuner has nothing to learn from a time-resident launch
     begin = None
     if tuner is not None and not tuner.settled():
         begin = torch.cuda.Event(enable_timing=True)
@@ -208,6 +247,8 @@ def decode(
         _lib.check(lib.torbi_hip_viterbi_decode_profiled(*args, flags, phases),
                    'torbi_hip_viterbi_decode_profiled')
         _profile[:] = list(phases)
+    if chosen == 'resident' and (_forced_path if path is None else path) == 'auto':
+        _watch_resident(transition, workspace, B, T, S)
     return indices if home == device else indices.to(home)
 
 
@@ -319,6 +360,9 @@ def decode_batches(
                'torbi_hip_viterbi_decode_batches')
     if _profile is not None:
         _profile[:] = list(phases)
+    if chosen == 'resident' and (_forced_path if path is None else path) == 'auto':
+        B0, T0, _ = shapes[first]
+        _watch_resident(transition, workspaces[first], B0, T0, S)
     return indices
 
 
@@ -430,15 +474,17 @@ def set_forward_path(path: str = 'auto') -> None:
                'torbi_hip_set_forward_path')
 
 
-def scan_stats(workspace: torch.Tensor, batch: int, frames: int, states: int) -> Optional[torch.Tensor]:
-    """Enqueue a copy of the scan statistics the last pruned decode left in `workspace`
-    (include/torbi_hip.h, torbi_hip_scan_stats): a (128,) int32 device tensor, valid once the
-    current stream reaches it; None when the shape does not take the pruned path."""
+def scan_stats(workspace: torch.Tensor, batch: int, frames: int, states: int,
+               path: str = 'pruned') -> Optional[torch.Tensor]:
+    """Enqueue a copy of the scan statistics the last pruned (or, `path='resident'`, time-resident) decode left in
+    `workspace` (include/torbi_hip.h, torbi_hip_scan_stats): a (128,) int32 device tensor, valid once the
+    current stream reaches it; None when the shape takes neither path."""
     lib = _lib.load()
     out = torch.empty((128,), dtype=torch.int32, device=workspace.device)
     rc = lib.torbi_hip_scan_stats(workspace.data_ptr(), workspace.numel(), batch, frames, states, out.data_ptr(),
                                   workspace.device.index or 0,
-                                  ctypes.c_void_p(torch.cuda.current_stream(workspace.device).cuda_stream))
+                                  ctypes.c_void_p(torch.cuda.current_stream(workspace.device).cuda_stream),
+                                  _path_flag(path))
     if rc == -5:
         return None
     _lib.check(rc, 'torbi_hip_scan_stats')
