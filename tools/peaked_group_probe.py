@@ -22,3 +22,15 @@ for width in (12.0, 3.0, 40.0):
             viterbi.decode_batches([peaked] * n, frames, trans, init, workspaces=ws, path=path)
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print(f'peak width {width}: {path:9s} {n * B * T / dt / 1e6:7.2f} M timesteps/s  ({dt * 1e3:.1f} ms per group)')
+# observation spread sweep on the synthetic benchmark inputs (DESIGN.md 4.5 for the per-timestep kernels)
+base = viterbi.fill_synthetic((B, T, S), 1, device=dev)
+for scale in (1.0, 4.0, 16.0, 64.0):
+    scaled = base * scale
+    for path in ('resident', 'dense'):
+        for _ in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            viterbi.decode_batches([scaled] * n, frames, trans, init, workspaces=ws, path=path)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        stats = viterbi.scan_stats(ws[0], B, T, S, path='resident') if path == 'resident' else None
+        depth = f', {viterbi.critical_blocks(stats):.1f} of {S // 16} list blocks per scan' if stats is not None else ''
+        print(f'observations x{scale}: {path:9s} {n * B * T / dt / 1e6:7.2f} M timesteps/s{depth}')
