@@ -929,26 +929,26 @@ def test_command_line_decodes_files_like_the_reference_cli(tmp_path, forward):
 
 
 def test_auto_leaves_the_time_resident_kernel_when_nothing_is_pruned(forward):
-    """Observations that spread far wider than the transitions leave the pruning bound nothing to work with
-    (DESIGN.md 4.5): the time-resident kernel walks most of every list.  The scan statistics of the first AUTO launch
-    group say so (torbi_hip_scan_stats), and later groups with the same matrix go to the dense kernel; with the
-    benchmark's spread the groups stay time-resident.  Same indices either way."""
+    """Transitions that fall with the prev-state exactly as fast as the posteriors rise make every candidate of a row
+    nearly equal: the pruning bound never bites and the time-resident kernel walks every list to its end.  The scan
+    statistics of the first AUTO launch group say so (torbi_hip_scan_stats), and later groups with the same matrix
+    go to the dense kernel; with the benchmark's inputs the groups stay time-resident.  Same indices either way."""
     if forward != 'auto':
         pytest.skip('path forced')
     dev = torch.device('cuda:0')
     S, T, B, n = 360, 10, 272, 8
-    _, matrix, init = synth.problem(1, 1, S, seed=2)
+    noise_obs, noise_trans, init = synth.problem(B * n, T, S, seed=2)
+    ramp = (np.arange(S, dtype=np.float32) * np.float32(0.25))
+    cases = {'anti': ((noise_obs * np.float32(2 ** -6) + ramp[None, None, :]).astype(np.float32),
+                      (noise_trans * np.float32(2 ** -6) - ramp[None, :]).astype(np.float32), 1),
+             'benchmark': (noise_obs, noise_trans, 3)}
     d_init = torch.as_tensor(init).to(dev)
-    for scale, later in ((np.float32(64.0), 1), (np.float32(1.0), 3)):
-        obs_list, frame_list, want = [], [], {}
-        for k in range(n):
-            obs, frames, _, _ = _device_problem(B, T, S, seed=70 + k, dev=dev)
-            obs = (obs * scale).astype(np.float32)
-            obs_list.append(torch.as_tensor(obs).to(dev))
-            frame_list.append(torch.as_tensor(frames).to(dev))
-            if k in (0, n - 1):
-                want[k] = oracle.decode(obs, frames, matrix, init, num_threads=oracle.max_threads())
-        d_matrix = torch.as_tensor(matrix).to(dev)          # a new tensor: a new record of scan statistics
+    for name, (obs_all, matrix, later) in cases.items():
+        obs_list = [torch.as_tensor(np.ascontiguousarray(obs_all[k * B:(k + 1) * B])).to(dev) for k in range(n)]
+        frame_list = [torch.as_tensor(np.clip(synth.lengths(B, 1, T, seed=k), 1, T)).to(dev) for k in range(n)]
+        want = {k: oracle.decode(obs_all[k * B:(k + 1) * B], frame_list[k].cpu().numpy(), matrix, init,
+                                 num_threads=oracle.max_threads()) for k in (0, n - 1)}
+        d_matrix = torch.as_tensor(matrix).to(dev)
         routes = []
         for _ in range(3):
             prof = []
@@ -956,5 +956,5 @@ def test_auto_leaves_the_time_resident_kernel_when_nothing_is_pruned(forward):
             torch.cuda.synchronize()
             routes.append(int(prof[3]))
             for k in want:
-                np.testing.assert_array_equal(got[k].cpu().numpy(), want[k])
-        assert routes[0] == 3 and routes[-1] == later, routes
+                np.testing.assert_array_equal(got[k].cpu().numpy(), want[k], err_msg=name)
+        assert routes[0] == 3 and routes[-1] == later, (name, routes)

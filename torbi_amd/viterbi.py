@@ -95,7 +95,9 @@ def _resolve_path(trans, transition, B, S, device, path, tiles, measure):
     return chosen, tuner
 
 
-RESIDENT_GATE = 0.45     # fraction of a row's S/16 list blocks per scan above which the dense kernel wins
+# fraction of a row's S/16 list blocks per scan above which the dense kernel wins (tools/peaked_group_probe.py at 1440
+# states: 11 blocks -> 53 M timesteps/s, 19 -> 36 M, 31 -> 23 M, 44 -> 17 M; the dense kernel 12.7 M whatever the data)
+RESIDENT_GATE = 0.65
 _group_depth = {}        # id(transition) -> [weakref, version, states, blocks or None, pending (pinned stats, event)]
 
 
