@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz lane-instructions/s
 METRIC = 'timesteps decoded/sec, 1440 states batch=512'
 KERNELS = {'resident': 'resident::resident_forward_kernel', 'pruned': 'pruned::step_pruned_kernel',
-           'dense': 'dense::step_dense_kernel', 'generic': 'step_rows'}
-ROUTES = {0: 'generic', 1: 'dense', 2: 'pruned', 3: 'resident'}
+           'dense': 'dense::step_dense_kernel', 'generic': 'step_rows', 'rows': 'rowscan::step_rows_sorted_kernel'}
+ROUTES = {0: 'generic', 1: 'dense', 2: 'pruned', 3: 'resident', 4: 'rows'}
 
 
 def parse_args(argv=None):

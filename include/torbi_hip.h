@@ -75,8 +75,10 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
 
 /*
  * Forward-recurrence paths (all give identical indices):
- *   GENERIC   B <= 16 or S < 64 (and 17 <= B < 32 with shapes PRUNED does not take): trellis kernels
- *             shaped like the reference's
+ *   GENERIC   S < 64, S > 4096 with B < 32, or DENSE named for a batch below 32 items: trellis kernels shaped like
+ *             the reference's
+ *   ROWS      B <= 16, 64 <= S <= 4096: the pruned recurrence with one wave per (item, next-state), 64 list
+ *             entries per wave step (small_batch_forward.hpp); one launch per timestep
  *   DENSE     value-only (max,+) GEMM, every (prev, next) cell evaluated, one launch per timestep
  *   PRUNED    value-only, exact: sorted transition rows + per-item top posteriors bound the cells
  *             that can still win, the rest are never touched (B >= 17, 64 <= S <= 4096); one launch
@@ -86,14 +88,15 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
  *             16 items per compute unit: the path for many items in flight -- several batches through
  *             torbi_hip_viterbi_decode_batches, or one batch of >= 8 * compute-units items.
  * AUTO takes RESIDENT when the call's items fill at least half the compute units with workgroups of
- * 16, else PRUNED where supported, else DENSE, else GENERIC.
+ * 16, else PRUNED / ROWS where supported, else DENSE, else GENERIC.
  *
  * A call selects a path in its `flags` (TORBI_HIP_PATH_FLAG); calls without one use the process-wide
  * default (torbi_hip_set_forward_path, initially the environment variable
  * TORBI_HIP_FORWARD=dense|pruned|resident, else AUTO).  A path that does not cover the shape falls
  * back as AUTO would.  A workspace of torbi_hip_workspace_bytes() fits every path.
  * torbi_hip_forward_path_on reports what a (B, S) batch would run on `device` with `flags`:
- * 0 generic, 1 dense, 2 pruned, 3 resident; torbi_hip_forward_path is the same for device 0, flags 0.
+ * 0 generic, 1 dense, 2 pruned, 3 resident, 4 rows; torbi_hip_forward_path is the same for device 0, flags 0.
+ * (TORBI_HIP_FORWARD_PRUNED names the pruned recurrence in its per-timestep form: tiles for B >= 17, rows below.)
  */
 #define TORBI_HIP_FORWARD_AUTO 0
 #define TORBI_HIP_FORWARD_DENSE 1
@@ -149,7 +152,7 @@ int torbi_hip_viterbi_decode_ex(const float *observation, const int32_t *batch_f
  * phase_ms: NULL, or a HOST pointer to 6 floats -- the call then brackets its phases with hipEvents on
  * `stream` and SYNCHRONISES it (bench.py):
  *   [0] forward recurrence incl. preparation, ms   [1] argmax + backtrace, ms
- *   [2] forward kernel launches                    [3] route that ran (0 generic .. 3 resident)
+ *   [2] forward kernel launches                    [3] route that ran (0 generic .. 4 rows)
  *   [4] per-transition preparation alone, ms       [5] batches the forward launch(es) covered
  * (for batches decoded one after the other [0],[1],[2],[4] describe the LAST batch).
  */

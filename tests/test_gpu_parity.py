@@ -138,8 +138,10 @@ def test_dense_path_edge_shapes(shape):
 
 def test_forward_path_selection(forward):
     resident = forward == 'resident'
-    assert viterbi.forward_path(4, 1440) == ('resident' if resident else 'generic')
+    assert viterbi.forward_path(4, 1440) == {'resident': 'resident', 'dense': 'generic'}.get(forward, 'rows')
+    assert viterbi.forward_path(16, 4096) == ('generic' if forward == 'dense' else 'rows')
     assert viterbi.forward_path(4, 40) == 'generic'                # S < 64: no value-only path
+    assert viterbi.forward_path(4, 4100) == 'generic'
     assert viterbi.forward_path(128, 4096) == ('dense' if forward == 'dense' else 'pruned')   # 8-item tiles
     assert viterbi.forward_path(128, 4100) == 'dense'              # posterior tile does not fit the LDS
     assert viterbi.forward_path(512, 1440) == {'dense': 'dense', 'resident': 'resident'}.get(forward, 'pruned')

@@ -1,0 +1,74 @@
+// small_batch_forward.hpp -- exact forward recurrence for SMALL batches (B <= 16), one launch per timestep.
+//
+// The generic row kernels (torbi_hip.hip, step_rows*_kernel) stream the whole S x S transition matrix through the
+// chip for every timestep of every item -- 8.3 MB at S = 1440: 5.2 us per launch at B = 1 (rocprofv3), the matrix
+// does not fit the 4 MB L2s.  Here every wave owns ONE next-state j of ONE item and walks row j's SORTED list
+// (pruned_forward.hpp: sort_rows_kernel) in chunks of 64 entries, one entry per lane, against the item's posterior row
+// staged in the LDS: candidate = fl(post[i_k] + t_k); every entry not yet examined has t <= t_next (the next chunk's
+// first entry) and post <= pmax, so once fl(t_next + pmax) <= best the maximum is final (monotone rounding; values
+// only -- the backpointer is recomputed along the decoded path by lazy_backtrace.hpp).  With one item per wave there
+// is no lock-step across items: a row needs one chunk on the benchmark inputs (52 entries on average), i.e. 0.5 KB of
+// list instead of a 5.76 KB transition row.  Posterior rows are bit-identical to the reference's (viterbi.cpp:78-108).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "wave_reduce.hpp"
+
+namespace rowscan {
+
+constexpr int kRowsPerBlock = 4;      // one wave per next-state, four per workgroup
+
+inline bool supported(int B, int S) { return B >= 1 && B <= 16 && S >= 64 && S <= 4096; }
+
+// One timestep of every item.  grid = (ceil(S / 4), B), block = 256, dynamic LDS = 4 * S bytes.
+// List entries are {t, prev-state << shift} (sort_rows_kernel with row_bytes = 1 << shift).
+__global__ __launch_bounds__(256) void step_rows_sorted_kernel(const float *__restrict__ obs,
+                                                               const int32_t *__restrict__ frames,
+                                                               const float2 *__restrict__ sorted, float *__restrict__ hist,
+                                                               int B, int T, int S, int t, int SpP, int shift) {
+    extern __shared__ __attribute__((aligned(16))) float prow[];
+    __shared__ float xmax[kRowsPerBlock];
+    const int b = blockIdx.y;
+    int f = frames[b];
+    f = f < 1 ? 1 : (f > T ? T : f);
+    if (t >= f) return;                                       // block-uniform: the item has ended
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = blockIdx.x * kRowsPerBlock + wave;
+    const int jr = j < S ? j : S - 1;
+    // the first list chunk and the observation do not depend on the posterior: request them first
+    const float2 *row = sorted + (size_t)jr * SpP;
+    float2 ent = row[lane];
+    const float *item = hist + (size_t)b * T * S;
+    const float ob = obs[((size_t)b * T + t) * S + jr];
+    // posterior row t-1 -> LDS, and its maximum
+    const float *prev = item + (size_t)(t - 1) * S;
+    float lm = -INFINITY;
+    for (int i = tid; i < S; i += 256) {
+        const float v = prev[i];
+        prow[i] = v;
+        lm = __builtin_fmaxf(lm, v);
+    }
+    const float wm = wavered::wave_reduce_f32(lm, wavered::MaxOp());
+    if (lane == 0) xmax[wave] = wm;
+    __syncthreads();
+    const float pmax = __builtin_fmaxf(__builtin_fmaxf(xmax[0], xmax[1]), __builtin_fmaxf(xmax[2], xmax[3]));
+
+    const int Sp = (S + 15) / 16 * 16;
+    float bv = -INFINITY, best = -INFINITY;
+    for (int k0 = 0; k0 < Sp; k0 += 64) {
+        const int kn = k0 + 64 + lane;
+        const float2 ahead = row[kn < SpP ? kn : SpP - 1];        // next chunk (its first entry bounds the rest)
+        if (k0 + lane < Sp) bv = __builtin_fmaxf(bv, prow[__float_as_int(ent.y) >> shift] + ent.x);
+        best = wavered::wave_reduce_f32(bv, wavered::MaxOp());
+        const float tn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__float_as_int(ahead.x)));
+        ent = ahead;
+        if (k0 + 64 >= Sp || tn + pmax <= best) break;
+    }
+    if (lane == 0 && j < S) hist[((size_t)b * T + t) * S + j] = ob + best;          // post'[j] = obs[t,j] + max
+}
+
+}  // namespace rowscan

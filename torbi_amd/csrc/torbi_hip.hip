@@ -29,6 +29,7 @@
 #include "uniform_decode.hpp"
 #include "pruned_forward.hpp"
 #include "resident_forward.hpp"
+#include "small_batch_forward.hpp"
 
 namespace {
 
@@ -401,7 +402,7 @@ inline int cu_count(int device) {
 
 // Which forward recurrence runs.  GENERIC materialises the int32 trellis like the reference does; the other three
 // keep the posterior history and recompute backpointers along the decoded path (lazy_backtrace.hpp).
-enum Route { ROUTE_GENERIC = 0, ROUTE_DENSE = 1, ROUTE_PRUNED = 2, ROUTE_RESIDENT = 3 };
+enum Route { ROUTE_GENERIC = 0, ROUTE_DENSE = 1, ROUTE_PRUNED = 2, ROUTE_RESIDENT = 3, ROUTE_ROWS = 4 };
 
 inline bool use_dense(int B, int S) { return B >= 32 && S >= 64; }
 
@@ -440,6 +441,7 @@ inline Route route_for(int path, int B, int S, int cus) {
     if (path == TORBI_HIP_FORWARD_RESIDENT && resident_fits(S, tiles_of(B))) return ROUTE_RESIDENT;
     if (path == TORBI_HIP_FORWARD_AUTO && resident_fits(S, tiles_of(B)) && 2 * tiles_of(B) >= cus) return ROUTE_RESIDENT;
     if (path != TORBI_HIP_FORWARD_DENSE && pruned::supported(B, S)) return ROUTE_PRUNED;
+    if (path != TORBI_HIP_FORWARD_DENSE && rowscan::supported(B, S)) return ROUTE_ROWS;
     return use_dense(B, S) ? ROUTE_DENSE : ROUTE_GENERIC;
 }
 
@@ -541,6 +543,31 @@ inline ResidentWorkspace carve_resident(void *base, int B, int T, int S) {
     return w;
 }
 
+// small batches (B <= 16): history + sorted rows (small_batch_forward.hpp)
+struct RowsWorkspace {
+    float *hist;
+    float2 *sorted;
+    int32_t *row_range;
+    int SpP, NPOW;
+    size_t bytes;
+};
+
+inline RowsWorkspace carve_rows(void *base, int B, int T, int S) {
+    RowsWorkspace w;
+    char *p = static_cast<char *>(base);
+    const int Sp = (S + 15) / 16 * 16;
+    w.SpP = Sp + pruned::kPad;
+    w.NPOW = 64;
+    while (w.NPOW < S) w.NPOW *= 2;
+    const size_t sorted_bytes = align_up(sizeof(float2) * (size_t)S * w.SpP, 256);
+    w.hist = reinterpret_cast<float *>(p);
+    p += history_bytes(B, T, S);
+    w.sorted = reinterpret_cast<float2 *>(p);
+    w.row_range = reinterpret_cast<int32_t *>(p + sorted_bytes);
+    w.bytes = history_bytes(B, T, S) + sorted_bytes + align_up(sizeof(int32_t) * 2 * (size_t)S, 256);
+    return w;
+}
+
 struct DenseWorkspace {
     dense::Plan plan;
     float *hist;       // [B][T][S]      posterior history (replaces the int32 trellis)
@@ -593,6 +620,7 @@ inline size_t need_bytes(int B, int T, int S, int cus) {
     if (use_dense(B, S)) need = std::max(need, carve_dense(nullptr, B, T, S, cus).bytes);
     if (pruned::supported(B, S)) need = std::max(need, carve_pruned(nullptr, B, T, S, cus).bytes);
     if (resident::supported(S)) need = std::max(need, carve_resident(nullptr, B, T, S).bytes);
+    if (rowscan::supported(B, S)) need = std::max(need, carve_rows(nullptr, B, T, S).bytes);
     return need;
 }
 
@@ -974,6 +1002,26 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
         e = launch_dense_forward(obs, frames, trans, init, w, B, T, S, s, launches, reuse);
         if (ev) (void)hipEventRecord(ev[1], s);
         if (e == hipSuccess) e = launch_backtrace_on(w.hist, trans, frames, out, B, T, S, s);
+    } else if (route == ROUTE_ROWS) {
+        const RowsWorkspace w = carve_rows(workspace, B, T, S);
+        if (!reuse)       // per-transition preparation: descending rows, prev-states as byte offsets of a 16-item tile row
+            hipLaunchKernelGGL(pruned::sort_rows_kernel, dim3(S), dim3(256), sizeof(float) * 2 * (size_t)w.NPOW, s, trans,
+                               w.sorted, w.row_range, S, w.SpP, w.NPOW, pruned::kNB * 4);
+        {
+            const size_t n = (size_t)B * S;
+            const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+            hipLaunchKernelGGL(pruned::init_history_kernel, dim3(grid), dim3(256), 0, s, obs, init, w.hist, B, T, S);
+        }
+        int n = 0;
+        for (int t = 1; t < T; ++t, ++n)
+            hipLaunchKernelGGL(rowscan::step_rows_sorted_kernel,
+                               dim3((S + rowscan::kRowsPerBlock - 1) / rowscan::kRowsPerBlock, B), dim3(256),
+                               sizeof(float) * (size_t)S, s, obs, frames, w.sorted, w.hist, B, T, S, t, w.SpP, 6);
+        if (launches) *launches = n;
+        e = hipGetLastError();
+        if (ev) (void)hipEventRecord(ev[1], s);
+        if (e == hipSuccess)
+            e = launch_backtrace_sorted(w.hist, w.sorted, w.SpP, pruned::kNB, trans, frames, out, B, T, S, s);
     } else {
         const Workspace w = carve(workspace, B, T, S);
         e = launch_forward(obs, frames, trans, init, w, B, T, S, s, launches);
@@ -1202,6 +1250,7 @@ int torbi_hip_viterbi_decode_profiled(const float *observation, const int32_t *b
         if (guard.err != hipSuccess) return (int)guard.err;
         // AUTO in the batches entry counts the tiles of the whole group; for one batch that is route_for()
         const Route r = route_for(TORBI_HIP_FORWARD_AUTO, B > 0 ? B : 1, S, cu_count(device));
+        // (PRUNED names the pruned recurrence in whichever per-timestep form covers the batch size: tiles or rows)
         f = (f & ~(7u << 4)) | TORBI_HIP_PATH_FLAG(r == ROUTE_RESIDENT ? TORBI_HIP_FORWARD_RESIDENT
                                                    : r == ROUTE_DENSE ? TORBI_HIP_FORWARD_DENSE
                                                                       : TORBI_HIP_FORWARD_PRUNED);

@@ -522,12 +522,12 @@ def _choose_path(trans: torch.Tensor, original: torch.Tensor, batch: int, states
     return 'dense' if 0.0 < reach < BANDED_RANGE else 'pruned'
 
 
-ROUTES = {0: 'generic', 1: 'dense', 2: 'pruned', 3: 'resident'}
+ROUTES = {0: 'generic', 1: 'dense', 2: 'pruned', 3: 'resident', 4: 'rows'}
 
 
 def forward_path(batch: int, states: int, path: Optional[str] = None, device: int = 0) -> str:
     """Which forward recurrence the library runs for one (batch, states) problem under `path` (None = the process
-    default): 'generic', 'dense', 'pruned' or 'resident'."""
+    default): 'generic', 'dense', 'pruned', 'resident' or 'rows' (the pruned recurrence for batches of <= 16 items)."""
     code = _lib.load().torbi_hip_forward_path_on(int(batch), int(states), int(device),
                                                  _path_flag(_forced_path if path is None else path))
     if code < 0:
