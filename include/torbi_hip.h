@@ -78,7 +78,8 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
  *   GENERIC   S < 64, S > 4096 with B < 32, or DENSE named for a batch below 32 items: trellis kernels shaped like
  *             the reference's
  *   ROWS      B <= 16, 64 <= S <= 4096: the pruned recurrence with one wave per (item, next-state), 64 list
- *             entries per wave step (small_batch_forward.hpp); one launch per timestep
+ *             entries per wave step (small_batch_forward.hpp); one launch per timestep.  AUTO takes it for
+ *             B >= 8 or S > 2048 (below that both it and GENERIC are bound by the gap between launches)
  *   DENSE     value-only (max,+) GEMM, every (prev, next) cell evaluated, one launch per timestep
  *   PRUNED    value-only, exact: sorted transition rows + per-item top posteriors bound the cells
  *             that can still win, the rest are never touched (B >= 17, 64 <= S <= 4096); one launch

@@ -138,8 +138,9 @@ def test_dense_path_edge_shapes(shape):
 
 def test_forward_path_selection(forward):
     resident = forward == 'resident'
-    assert viterbi.forward_path(4, 1440) == {'resident': 'resident', 'dense': 'generic'}.get(forward, 'rows')
-    assert viterbi.forward_path(16, 4096) == ('generic' if forward == 'dense' else 'rows')
+    assert viterbi.forward_path(4, 1440) == {'resident': 'resident', 'pruned': 'rows'}.get(forward, 'generic')
+    assert viterbi.forward_path(16, 1440) == {'resident': 'resident', 'dense': 'generic'}.get(forward, 'rows')
+    assert viterbi.forward_path(2, 4096) == ('generic' if forward == 'dense' else 'rows')
     assert viterbi.forward_path(4, 40) == 'generic'                # S < 64: no value-only path
     assert viterbi.forward_path(4, 4100) == 'generic'
     assert viterbi.forward_path(128, 4096) == ('dense' if forward == 'dense' else 'pruned')   # 8-item tiles

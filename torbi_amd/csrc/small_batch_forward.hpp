@@ -23,6 +23,12 @@ constexpr int kRowsPerBlock = 4;      // one wave per next-state, four per workg
 
 inline bool supported(int B, int S) { return B >= 1 && B <= 16 && S >= 64 && S <= 4096; }
 
+// Where it beats the generic row kernels (tools/small_batch_probe.py, T = 500).  Both are bound by the ~4.4 us between
+// dependent launches at B = 1, S = 1440 (rows 2.20 + 0.53 ms backtrace over the sorted rows against 2.30 + 0.13 ms trellis
+// chase); the list walk wins once a launch carries real work: B = 16, S = 1440: 6.0 vs 6.8 ms; B = 1, S = 4096: 5.8 vs
+// 7.5 ms; B = 8, S = 4096: 14.9 vs 28.1 ms.  AUTO takes the kernel there; TORBI_HIP_FORWARD_PRUNED names it for any B <= 16.
+inline bool profitable(int B, int S) { return supported(B, S) && (S > 2048 || B >= 8); }
+
 // One timestep of every item.  grid = (ceil(S / 4), B), block = 256, dynamic LDS = 4 * S bytes.
 // List entries are {t, prev-state << shift} (sort_rows_kernel with row_bytes = 1 << shift).
 __global__ __launch_bounds__(256) void step_rows_sorted_kernel(const float *__restrict__ obs,

@@ -441,7 +441,9 @@ inline Route route_for(int path, int B, int S, int cus) {
     if (path == TORBI_HIP_FORWARD_RESIDENT && resident_fits(S, tiles_of(B))) return ROUTE_RESIDENT;
     if (path == TORBI_HIP_FORWARD_AUTO && resident_fits(S, tiles_of(B)) && 2 * tiles_of(B) >= cus) return ROUTE_RESIDENT;
     if (path != TORBI_HIP_FORWARD_DENSE && pruned::supported(B, S)) return ROUTE_PRUNED;
-    if (path != TORBI_HIP_FORWARD_DENSE && rowscan::supported(B, S)) return ROUTE_ROWS;
+    if ((path == TORBI_HIP_FORWARD_PRUNED && rowscan::supported(B, S)) ||
+        (path != TORBI_HIP_FORWARD_DENSE && rowscan::profitable(B, S)))
+        return ROUTE_ROWS;
     return use_dense(B, S) ? ROUTE_DENSE : ROUTE_GENERIC;
 }
 
