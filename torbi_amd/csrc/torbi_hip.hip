@@ -1244,19 +1244,10 @@ int torbi_hip_viterbi_decode_profiled(const float *observation, const int32_t *b
                                       void *stream, unsigned flags, float *phase_ms) {
     if (!phase_ms || !flags_ok(flags)) return TORBI_HIP_EINVAL;
     const torbi_hip_batch one{observation, batch_frames, indices_out, workspace, workspace_bytes, B, T};
-    // a single batch through the batches entry: same routing as torbi_hip_viterbi_decode_ex for this shape
+    // a single batch through the batches entry: same routing as torbi_hip_viterbi_decode_ex for this shape (AUTO
+    // there counts the 16-item tiles of the group, which for one batch is what route_for() does)
     unsigned f = flags;
     if (((flags >> 4) & 7u) == 0) f |= TORBI_HIP_PATH_FLAG(default_path());
-    if (requested_path(f) == TORBI_HIP_FORWARD_AUTO) {
-        DeviceGuard guard(device);
-        if (guard.err != hipSuccess) return (int)guard.err;
-        // AUTO in the batches entry counts the tiles of the whole group; for one batch that is route_for()
-        const Route r = route_for(TORBI_HIP_FORWARD_AUTO, B > 0 ? B : 1, S, cu_count(device));
-        // (PRUNED names the pruned recurrence in whichever per-timestep form covers the batch size: tiles or rows)
-        f = (f & ~(7u << 4)) | TORBI_HIP_PATH_FLAG(r == ROUTE_RESIDENT ? TORBI_HIP_FORWARD_RESIDENT
-                                                   : r == ROUTE_DENSE ? TORBI_HIP_FORWARD_DENSE
-                                                                      : TORBI_HIP_FORWARD_PRUNED);
-    }
     return torbi_hip_viterbi_decode_batches(&one, 1, transition, initial, S, device, stream, f, phase_ms);
 }
 
