@@ -263,12 +263,13 @@ def test_non_contiguous_inputs_are_accepted():
     assert np.array_equal(got, want)
 
 
-def test_preparation_reuse_follows_the_transition_and_the_shape():
+@pytest.mark.parametrize('B', [48, 12])
+def test_preparation_reuse_follows_the_transition_and_the_shape(B):
     """decode(workspace=..., reuse_preparation=True) skips the per-transition preparation only when the
     workspace's previous decode had the same shape, path and transition version (include/torbi_hip.h,
-    TORBI_HIP_REUSE_TRANSITION); everything else rebuilds it."""
+    TORBI_HIP_REUSE_TRANSITION); everything else rebuilds it.  (B = 12: the small-batch kernels.)"""
     dev = torch.device('cuda:0')
-    B, T, S = 48, 7, 360
+    T, S = 7, 360
     obs, trans, init = synth.problem(B, T, S, seed=5)
     obs2 = synth.problem(B, T, S, seed=6)[0]
     frames = synth.lengths(B, 1, T, seed=2)
