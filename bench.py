@@ -231,17 +231,11 @@ class Bench:
         return trans, init
 
     def balanced_groups(self, steps, group):
-        """Sizes of the launch groups `steps` consecutive batches are decoded in.  Whole groups of `group` (8 x 512
-        items = one 16-item workgroup per CU) when they divide the steps; otherwise fewer, LARGER, equally full groups
-        (up to 1.5 x `group`, at most 16 batches): a group with more tiles than CUs is cut into two time segments
-        (csrc/torbi_hip.hip, resident_segments) whose partly filled tail the other stream's group fills, so 20 steps
-        run as 10 + 10 in 2.5 chip-filling rounds where 7 + 7 + 6 would take 3."""
+        """Group sizes for `steps` consecutive batches: as few launch groups as `group` allows, equally full
+        (20 steps, group 8 -> 7 + 7 + 6 rather than 8 + 8 + 4: a half-empty last group costs a full one's time)."""
         if group <= 1:
             return [1] * steps
-        if steps % group == 0:
-            return [group] * (steps // group)
-        cap = min(16, group + group // 2)
-        n = max(1, math.ceil(steps / cap))
+        n = max(1, math.ceil(steps / group))
         base, extra = divmod(steps, n)
         return [base + (1 if k < extra else 0) for k in range(n)]
 
@@ -275,14 +269,12 @@ class Bench:
         frames = torch.full((B,), T, dtype=torch.int32, device=dev)
         uniform_c = float(torch.tensor(math.log(1.0 / S), dtype=torch.float32))
         group = 1 if args.transition == 'uniform' else max(1, args.group)
-        # the largest launch group of the warm-up and of the timed steps (balanced_groups may go above --group)
-        widest = max(self.balanced_groups(args.steps, group) + self.balanced_groups(max(args.warmup, 1), group))
         # distinct observations for the batches of a launch group (rank-specific streams; shared model)
         obs = [v.fill_synthetic((B, T, S), synth.STREAM_OBSERVATION, seed=rank * 64 + k, device=dev)
-               for k in range(widest)]
+               for k in range(group)]
         path = None if args.forward == 'auto' else args.forward
         pipe = self.torbi_amd.DecodePipeline(dev, depth=max(1, args.pipeline), reuse_preparation=args.reuse_preparation,
-                                             group=widest, path=path)
+                                             group=group, path=path)
 
         pipe.reserve(B, T, S)          # workspace allocation is not part of a decode
 
@@ -296,7 +288,7 @@ class Bench:
                     if args.transition == 'uniform':
                         last = gather(self.torbi_amd.decode_uniform(obs[0], frames, uniform_c, init))
                     else:
-                        last = pipe.decode(obs[j % widest], frames, trans, init, after=gather)
+                        last = pipe.decode(obs[j % group], frames, trans, init, after=gather)
                     k += 1
                 pipe.flush()
             return last
@@ -308,7 +300,7 @@ class Bench:
         self.fence(pipe)
         elapsed = self.max_over_ranks(time.perf_counter() - t0)
         value = float(B) * T * args.steps * size / elapsed
-        last_obs = obs[(self.balanced_groups(args.steps, group)[-1] - 1) % widest]
+        last_obs = obs[(self.balanced_groups(args.steps, group)[-1] - 1) % group]
 
         result = {
             'metric': METRIC, 'value': value, 'unit': 'timesteps/s', 'n_gpus': size, 'steps': args.steps,
@@ -333,7 +325,7 @@ class Bench:
         spaces = [torch.empty(v.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev) for _ in range(g)]
         prof, fwd_ms, bt_ms, prep_ms = [], 0.0, 0.0, 0.0
         for _ in range(3):
-            v.decode_batches([obs[k % widest] for k in range(g)], [frames] * g, trans, init, workspaces=spaces,
+            v.decode_batches([obs[k % group] for k in range(g)], [frames] * g, trans, init, workspaces=spaces,
                              path=path, _profile=prof)
             fwd_ms += prof[0] / 3
             bt_ms += prof[1] / 3
@@ -342,12 +334,11 @@ class Bench:
         launches = max(int(prof[2]), 1)
         covered = max(int(prof[5]), 1)                     # batches one forward launch (chain) covers
         kernel_s = (fwd_ms - prep_ms) * 1e-3 / launches
-        # a time-resident launch covers its batches' timesteps of one time segment (`launches` segments per group)
-        timesteps_per_launch = float(covered) * B * (T / launches if route == 'resident' else 1)
+        timesteps_per_launch = float(covered) * B * (T if route == 'resident' else 1)
         bytes_per_launch = timesteps_per_launch * algorithmic_bytes_per_timestep(S)
         achieved = bytes_per_launch / kernel_s / 1e9
         cells_per_launch = timesteps_per_launch * S * S
-        traffic, traffic_file = profiled_traffic(KERNELS[route], covered / launches if route == 'resident' else covered)
+        traffic, traffic_file = profiled_traffic(KERNELS[route], covered)
         del spaces
         result['config'] = {
             'workload': (f'{S} states, {T} frames, batch={B} per GPU, fp32, dense transition'
@@ -369,8 +360,7 @@ class Bench:
                             f'bytes is the sorted transition lists streamed from the Infinity Cache (they do not fit the '
                             f'4 MB L2s) and 4-byte strided observation reads'
             if traffic_file else 'no PMC summary for this kernel committed',
-            'kernel': KERNELS[route] + ((f' (ONE launch = the whole forward pass of {covered} batches)' if launches == 1 else
-                                         f' (one launch = 1/{launches} of the timesteps of {covered} batches)')
+            'kernel': KERNELS[route] + (f' (ONE launch = the whole forward pass of {covered} batches)'
                                         if route == 'resident' else ' (one launch = one timestep of one batch)'),
             'launch_us': kernel_s * 1e6, 'launches_per_group': launches, 'batches_per_launch': covered,
             'algorithmic_bytes_per_launch': bytes_per_launch,

@@ -972,23 +972,3 @@ def test_auto_leaves_the_time_resident_kernel_when_nothing_is_pruned(forward):
             for k in want:
                 np.testing.assert_array_equal(got[k].cpu().numpy(), want[k], err_msg=name)
         assert routes[0] == 3 and routes[-1] == later, (name, routes)
-
-
-@pytest.mark.parametrize('T', [2, 9, 30])
-def test_time_segments_of_a_launch_group_hand_the_posterior_over(T, forward):
-    """A launch group with more 16-item tiles than the device has CUs is decoded as two launches over consecutive time
-    ranges (torbi_hip.hip, resident_segments); the history row at the boundary carries the posterior from one to the
-    next.  4200 ragged items (263 tiles), items that end before, at and after the boundary, against the oracle."""
-    if forward != 'auto':
-        pytest.skip('names its path itself: once is enough')
-    dev = torch.device('cuda:0')
-    B, S = 4200, 64
-    obs, trans, init = synth.problem(B, T, S, seed=T)
-    frames = synth.lengths(B, 1, T, seed=T + 1)
-    frames[:3] = [T, 1, max(1, T // 2)]
-    want = oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())
-    prof = []
-    got = viterbi.decode_batches([torch.as_tensor(obs).to(dev)], [torch.as_tensor(frames).to(dev)],
-                                 torch.as_tensor(trans).to(dev), torch.as_tensor(init).to(dev), path='resident', _profile=prof)
-    assert int(prof[3]) == 3 and int(prof[2]) == min(2, T - 1)          # route, forward launches
-    np.testing.assert_array_equal(got[0].cpu().numpy(), want)

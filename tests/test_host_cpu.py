@@ -327,7 +327,7 @@ def test_bench_starts_its_own_ranks_and_dry_runs_without_a_gpu():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['dry_run'] is True and line['value'] is None
-    assert line['steps'] == 20 and line['warmup'] == 5 and line['config']['launch_groups'] == [10, 10]
+    assert line['steps'] == 20 and line['warmup'] == 5 and line['config']['launch_groups'] == [7, 7, 6]
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', 'c4', '--files', '3000'],
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-2000:]

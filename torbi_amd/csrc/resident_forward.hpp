@@ -171,8 +171,7 @@ __device__ unsigned long long g_wgtime[1024 * 4];        // per workgroup: start
 template <int KW, int MAXP, bool PIPE>
 __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, const float *__restrict__ tt,
                                                                    const float2 *__restrict__ sorted,
-                                                                   const float *__restrict__ initial, int S, int SpP,
-                                                                   int t_lo, int t_hi) {
+                                                                   const float *__restrict__ initial, int S, int SpP) {
     constexpr int G = 4, EPL = kBlk / G;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int S4 = (S + 3) / 4 * 4;
@@ -211,37 +210,18 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
     int fmax = 0;
 #pragma unroll
     for (int it = 0; it < kNI; ++it) fmax = max(fmax, sframes[it]);
-    // This launch covers timesteps [t_lo, t_hi) of every tile (a launch group's forward pass may be cut into time
-    // segments, one launch each: see run_resident in torbi_hip.hip).  Tiles that end before t_lo have nothing to do.
-    if (t_lo > 1 && fmax <= t_lo) return;
-    fmax = min(fmax, t_hi);
 
-    if (t_lo <= 1) {
-        // t = 0: posterior row 0 = obs[b,0,:] + initial (viterbi.cpp:72-76) into the tile, the history, the top lists
-        for (int item = 0; item < kNI; ++item) {
-            const int b = sitem[item];
-            const bool valid = b0 + item < B;
-            const float *src = obs + (size_t)b * T * S;
-            float *dst = hist + (size_t)b * T * S;
-            for (int i = tid; i < S; i += 64 * KW) {
-                const float v = src[i] + initial[i];
-                lds[i * kNI + item] = v;
-                if (valid) dst[i] = v;
-                top_insert(top + item * kTop, top_key(v, i));
-            }
-        }
-    } else {
-        // a later segment: posterior row t_lo - 1 comes back from the history the previous launch wrote (an item
-        // that ended earlier hands over its last row: its column only has to hold valid numbers)
-        for (int item = 0; item < kNI; ++item) {
-            const int fi = sframes[item] > 0 ? sframes[item] : 1;
-            const int r = t_lo - 1 < fi - 1 ? t_lo - 1 : fi - 1;
-            const float *src = hist + ((size_t)sitem[item] * T + r) * S;
-            for (int i = tid; i < S; i += 64 * KW) {
-                const float v = src[i];
-                lds[i * kNI + item] = v;
-                top_insert(top + item * kTop, top_key(v, i));
-            }
+    // t = 0: posterior row 0 = obs[b,0,:] + initial (viterbi.cpp:72-76) into the tile, the history and the top lists
+    for (int item = 0; item < kNI; ++item) {
+        const int b = sitem[item];
+        const bool valid = b0 + item < B;
+        const float *src = obs + (size_t)b * T * S;
+        float *dst = hist + (size_t)b * T * S;
+        for (int i = tid; i < S; i += 64 * KW) {
+            const float v = src[i] + initial[i];
+            lds[i * kNI + item] = v;
+            if (valid) dst[i] = v;
+            top_insert(top + item * kTop, top_key(v, i));
         }
     }
 
@@ -280,7 +260,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
     unsigned long long last = __builtin_readcyclecounter();
 #endif
 
-    for (int t = t_lo > 1 ? t_lo : 1; t < fmax; ++t) {
+    for (int t = 1; t < fmax; ++t) {
         __syncthreads();      // tile = posterior row t-1, mtop = its largest entries, `top` is empty
         RSTAMP(0);
 

@@ -891,48 +891,27 @@ inline bool resident_pipe() {
     return v;
 }
 
-// The forward pass of a launch group as `segments` launches over consecutive time ranges (the history row at a
-// boundary hands the posterior over; the kernel boundary makes it visible).
 template <int KW, int MAXP, bool PIPE>
 hipError_t launch_resident_variant(const resident::Group &grp, int tiles, const ResidentWorkspace &w, const float *init,
-                                   int S, hipStream_t stream, int t_max, int segments) {
+                                   int S, hipStream_t stream) {
     const size_t lds = resident::lds_bytes(S);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resident::resident_forward_kernel<KW, MAXP, PIPE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    const int span = (t_max - 1 + segments - 1) / segments;          // timesteps 1 .. t_max-1 in `segments` ranges
-    for (int k = 0; k < segments; ++k) {
-        const int lo = 1 + k * span, hi = k + 1 == segments ? t_max : 1 + (k + 1) * span;
-        if (k > 0 && lo >= t_max) break;
-        hipLaunchKernelGGL((resident::resident_forward_kernel<KW, MAXP, PIPE>), dim3(tiles), dim3(64 * KW), lds, stream,
-                           grp, w.tt, w.sorted, init, S, w.SpP, lo, hi);
-    }
+    hipLaunchKernelGGL((resident::resident_forward_kernel<KW, MAXP, PIPE>), dim3(tiles), dim3(64 * KW), lds, stream, grp,
+                       w.tt, w.sorted, init, S, w.SpP);
     return hipGetLastError();
 }
 
 template <int KW, int MAXP>
 hipError_t launch_resident_kernel(const resident::Group &grp, int tiles, const ResidentWorkspace &w, const float *init,
-                                  int S, hipStream_t stream, int t_max, int segments) {
-    return resident_pipe() ? launch_resident_variant<KW, MAXP, true>(grp, tiles, w, init, S, stream, t_max, segments)
-                           : launch_resident_variant<KW, MAXP, false>(grp, tiles, w, init, S, stream, t_max, segments);
-}
-
-// A launch group with more 16-item tiles than the device has CUs runs in waves of workgroups, and the last, partly
-// filled wave costs a whole forward pass.  Cut in two time segments the tail is half as long, and with launch groups
-// alternating between two streams the other group's workgroups fill it (20 batches of 512: 2.5 instead of 3 rounds).
-// TORBI_HIP_RESIDENT_SEGMENTS=n forces a count (experiments).
-inline int resident_segments(int tiles, int cus, int t_max) {
-    static const int forced = [] {
-        const char *e = getenv("TORBI_HIP_RESIDENT_SEGMENTS");
-        return e ? atoi(e) : 0;
-    }();
-    int n = forced > 0 ? forced : (tiles > cus ? 2 : 1);
-    if (n > t_max - 1) n = t_max - 1 > 0 ? t_max - 1 : 1;
-    return n;
+                                  int S, hipStream_t stream) {
+    return resident_pipe() ? launch_resident_variant<KW, MAXP, true>(grp, tiles, w, init, S, stream)
+                           : launch_resident_variant<KW, MAXP, false>(grp, tiles, w, init, S, stream);
 }
 
 // batches with B > 0 only; the preparation lives in the first batch's workspace
-hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const float *init, int S, int cus, hipStream_t s,
+hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const float *init, int S, hipStream_t s,
                         hipEvent_t *ev, int *launches, bool reuse, bool ascending = false) {
     resident::Group grp{};
     resident::OrderJobs jobs{};
@@ -971,13 +950,10 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
     if (ev) (void)hipEventRecord(ev[3], s);
     hipError_t e;
     const int nrg = (S + resident::kRowGroup - 1) / resident::kRowGroup;
-    int t_max = 1;
-    for (int k = 0; k < n; ++k) t_max = std::max(t_max, hb[k].T);
-    const int segments = resident_segments(tiles, cus, t_max);
-    if (nrg <= 72) e = launch_resident_kernel<12, 6>(grp, tiles, w, init, S, s, t_max, segments);
-    else if (nrg <= 96) e = launch_resident_kernel<12, 8>(grp, tiles, w, init, S, s, t_max, segments);
-    else e = launch_resident_kernel<12, 11>(grp, tiles, w, init, S, s, t_max, segments);
-    if (launches) *launches = segments;
+    if (nrg <= 72) e = launch_resident_kernel<12, 6>(grp, tiles, w, init, S, s);
+    else if (nrg <= 96) e = launch_resident_kernel<12, 8>(grp, tiles, w, init, S, s);
+    else e = launch_resident_kernel<12, 11>(grp, tiles, w, init, S, s);
+    if (launches) *launches = 1;
     if (ev) (void)hipEventRecord(ev[1], s);
     if (e != hipSuccess) return e;
     const bool vec = (S % 4 == 0) && ((reinterpret_cast<uintptr_t>(trans) & 15) == 0);
@@ -1013,7 +989,7 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
     const Route route = route_for(path, B, S, cus);
     if (route == ROUTE_RESIDENT) {
         const HostBatch hb{obs, frames, out, workspace, B, T};
-        return run_resident(&hb, 1, trans, init, S, cus, s, ev, launches, reuse);
+        return run_resident(&hb, 1, trans, init, S, s, ev, launches, reuse);
     }
     if (ev) (void)hipEventRecord(ev[0], s);
     if (ev) (void)hipEventRecord(ev[3], s);
@@ -1191,8 +1167,7 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
         int launches = 0;
         hipError_t e;
         if (together) {
-            e = run_resident(hb, n, transition, initial, S, cus, s, pe.ev, &launches, reuse,
-                             (flags & TORBI_HIP_SHORTEST_FIRST) != 0);
+            e = run_resident(hb, n, transition, initial, S, s, pe.ev, &launches, reuse, (flags & TORBI_HIP_SHORTEST_FIRST) != 0);
             phase_ms[3] = (float)ROUTE_RESIDENT;
         } else {
             // one batch after the other, each on the path it would take alone; phases of the LAST batch only
@@ -1208,7 +1183,7 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
         return (int)e;
     }
     if (together)
-        return (int)run_resident(hb, n, transition, initial, S, cus, s, nullptr, nullptr, reuse,
+        return (int)run_resident(hb, n, transition, initial, S, s, nullptr, nullptr, reuse,
                                  (flags & TORBI_HIP_SHORTEST_FIRST) != 0);
     for (int k = 0; k < n; ++k) {
         const hipError_t e = run_decode(hb[k].obs, hb[k].frames, transition, initial, hb[k].out, hb[k].workspace,
