@@ -822,7 +822,7 @@ def _ragged_job(tmp_path, count, S, seed, shortest=100, longest=900):
     return lengths, ins, outs, tf
 
 
-def test_many_file_job_every_file_equals_the_oracle(tmp_path, forward):
+def test_many_file_job_every_file_equals_the_oracle(tmp_path, forward, monkeypatch):
     """BASELINE configs[3] scaled down fivefold in time: 2100 sequences of 20..180 frames over 256 states, batches of 512
     in file order (five batches -> one launch group) and again length-bucketed: EVERY output file equals the oracle's
     decode of that file alone."""
@@ -841,6 +841,14 @@ def test_many_file_job_every_file_equals_the_oracle(tmp_path, forward):
     outs2 = [tmp_path / f'bucketed{k}.pt' for k in range(count)]
     torbi_amd.from_files_to_files(ins, outs2, transition_file=tf, log_probs=True, gpu=0, lengths=lengths)
     for a, b in zip(outs, outs2):
+        assert torch.equal(torch.load(a), torch.load(b))
+    # ... and with the reference's host path (torch.load + collate in a DataLoader, saves on the calling thread)
+    # instead of the direct file reader (torbi_amd/fastio.py) and the saver threads
+    monkeypatch.setattr(torbi_amd.core, 'DIRECT_FILE_IO', False)
+    monkeypatch.setattr(torbi_amd.core, 'SAVE_THREADS', 0)
+    outs3 = [tmp_path / f'loader{k}.pt' for k in range(count)]
+    torbi_amd.from_files_to_files(ins, outs3, transition_file=tf, log_probs=True, gpu=0, num_workers=2)
+    for a, b in zip(outs, outs3):
         assert torch.equal(torch.load(a), torch.load(b))
 
 

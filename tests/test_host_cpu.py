@@ -313,6 +313,102 @@ def test_from_dataloader_joins_chunked_files(tmp_path, monkeypatch):
         assert got.dtype == torch.int32 and got.tolist() == want
 
 
+# ---- direct file reader (torbi_amd/fastio.py): same batches as torch.load + collate ------------------------------
+
+def _write_ragged_files(folder, lengths, states=12, seed=0):
+    generator = torch.Generator().manual_seed(seed)
+    files = []
+    for k, n in enumerate(lengths):
+        f = str(folder / f'in{k}.pt')
+        torch.save(torch.rand(n, states, generator=generator), f)
+        files.append(f)
+    return files
+
+
+def _same_batches(ours, theirs):
+    ours, theirs = list(ours), list(theirs)
+    assert len(ours) == len(theirs)
+    for a, b in zip(ours, theirs):
+        assert a[0].dtype == b[0].dtype and torch.equal(a[0], b[0])
+        assert a[1].dtype == b[1].dtype and torch.equal(a[1], b[1])
+        assert list(a[2]) == list(b[2]) and tuple(a[3]) == tuple(b[3])
+
+
+def test_file_batches_equal_the_loader_batches(tmp_path):
+    """The payload of every file lands in its row, the rest of the row is collate's zero padding
+    (reference collate.py:24-31), lengths / chunk counts / names as the DataLoader yields them."""
+    from torbi_amd import fastio
+    files = _write_ragged_files(tmp_path, [5, 1, 9, 3, 7, 2, 8, 4])
+    assert fastio.payload(files[2])[:2] == (9, 12)
+    for batch_size in (1, 3, 8, 20):
+        _same_batches(fastio.FileBatches(files, batch_size, threads=3, pin_memory=False),
+                      torbi_amd.data.loader(files, num_workers=0, batch_size=batch_size, pin_memory=False))
+    batches = fastio.open_batches(files, 3, threads=2)
+    assert isinstance(batches, fastio.FileBatches) and len(batches) == 3
+
+
+def test_file_batches_equal_the_reference_collate(tmp_path):
+    """The reference's own collate output (tests/golden/generate_api.py) from files holding its inputs."""
+    from torbi_amd import fastio
+    files = []
+    for k in range(4):
+        f = str(tmp_path / f'{k}.pt')
+        torch.save(torch.as_tensor(API[f'collate/item{k}']), f)
+        files.append(f)
+    (observation, batch_frames, batch_chunks, names), = list(fastio.FileBatches(files, 4, pin_memory=False))
+    assert observation.dtype == torch.float32 and np.array_equal(observation.numpy(), API['collate/observation'])
+    assert batch_frames.dtype == torch.int64 and batch_frames.tolist() == API['collate/batch_frames'].tolist()
+    assert list(batch_chunks) == API['collate/batch_chunks'].tolist() and list(names) == files
+
+
+def test_file_batches_leave_unusual_files_to_torch_load(tmp_path, monkeypatch):
+    """Views with a storage offset are read in place; other dtypes, non-contiguous tensors and the legacy
+    container make their batch go through torch.load + collate; chunked decoding keeps the reference's loader."""
+    from torbi_amd import fastio
+    files = _write_ragged_files(tmp_path, [6, 4, 7, 3, 5, 2])
+    base = torch.rand(20, 12, generator=torch.Generator().manual_seed(5))
+    torch.save(base[4:9], files[1])                                   # storage offset 48, 5 frames
+    assert fastio.payload(files[1])[:2] == (5, 12)
+    _same_batches(fastio.FileBatches(files, 3, threads=2, pin_memory=False),
+                  torbi_amd.data.loader(files, num_workers=0, batch_size=3, pin_memory=False))
+    torch.save(base[:3].double(), files[3])
+    torch.save(base[:12, :12].t(), files[4])                          # stride (1, 12)
+    torch.save(base[:2].clone(), files[5], _use_new_zipfile_serialization=False)
+    for odd in files[3:]:
+        with pytest.raises(fastio.UnsupportedFile):
+            fastio.payload(odd)
+    _same_batches(fastio.FileBatches(files, 3, threads=2, pin_memory=False),
+                  torbi_amd.data.loader(files, num_workers=0, batch_size=3, pin_memory=False))
+    assert fastio.open_batches(files, 3) is None                      # last file: legacy container
+    assert fastio.open_batches(files[:3], 3) is not None
+    monkeypatch.setattr(torbi_amd.core, 'MIN_CHUNK_SIZE', 8)
+    assert fastio.open_batches(files[:3], 3) is None
+    assert fastio.open_batches([], 3) is None
+
+
+def test_from_dataloader_saves_every_file_from_direct_batches(tmp_path, monkeypatch):
+    """from_dataloader over FileBatches with saver threads: every output holds its own row's valid frames
+    (core.py:449-457); a stand-in decode labels positions, no GPU involved."""
+    from torbi_amd import fastio
+    lengths = [5, 1, 9, 3, 7, 2, 8]
+    files = _write_ragged_files(tmp_path, lengths)
+    mapping = {f: str(tmp_path / f'out{k}.pt') for k, f in enumerate(files)}
+
+    def fake_from_probabilities(observation, batch_frames, **_):
+        rows, frames = observation.shape[:2]
+        return (1000 * torch.arange(rows)[:, None] + torch.arange(frames)[None, :]).to(torch.int32)
+
+    monkeypatch.setattr(torbi_amd.core, 'from_probabilities', fake_from_probabilities)
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: False)
+    for threads in (0, 3):
+        monkeypatch.setattr(torbi_amd.core, 'SAVE_THREADS', threads)
+        torbi_amd.from_dataloader(fastio.FileBatches(files, 3, threads=2, pin_memory=False), mapping)
+        for k, f in enumerate(files):
+            got = torch.load(mapping[f])
+            assert got.dtype == torch.int32 and got.tolist() == [1000 * (k % 3) + t for t in range(lengths[k])]
+            os.remove(mapping[f])
+
+
 def test_bench_starts_its_own_ranks_and_dry_runs_without_a_gpu():
     """`python bench.py --gpus 2` without a launcher: bench.py starts the two ranks itself (child process, gloo
     rendezvous on 127.0.0.1) and, with no HIP device, prints a dry-run line carrying the launch plan."""

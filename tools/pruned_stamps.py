@@ -1,7 +1,7 @@
 """Per-phase timeline of pruned::step_pruned_kernel (instrumented build, -DPRUNED_STAMP).
 
     python tools/pruned_stamps.py build        # here (hipcc cross-compiles): tools/libtorbi_hip_stamp.so
-    python tools/pruned_stamps.py              # on the GPU box
+    python tools/pruned_stamps.py [B T S]      # on the GPU box (default 512 40 1440; 128 40 4096 = configs[4] tiles)
 """
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,7 +19,7 @@ import numpy as np, torch
 import torbi_amd._lib as _lib
 _lib.LIBRARY = LIB
 import torbi_amd
-B, T, S = 512, 40, 1440
+B, T, S = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (512, 40, 1440)))
 dev = torch.device('cuda:0')
 from torbi_amd import viterbi
 obs = viterbi.fill_synthetic((B, T, S), 1, device=dev); trans = viterbi.fill_synthetic((S, S), 2, device=dev)

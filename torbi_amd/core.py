@@ -23,6 +23,11 @@ ENTROPY_THRESHOLD = 0.5
 # batches of a many-file job decoded per launch group (torbi_amd.DecodePipeline / decode_batches): 8 x 512 items
 # give every compute unit of an MI355X one 16-item workgroup of the time-resident kernel
 GROUP_SIZE = 8
+# from_files_to_files reads plain float32 observation files straight into pinned batch buffers (torbi_amd/fastio.py)
+# instead of torch.load + collate in DataLoader workers; False = the reference's loader for every file
+DIRECT_FILE_IO = True
+# threads that write the per-file outputs while the next launch group is decoded (0 = save on the calling thread)
+SAVE_THREADS = 4
 
 
 def _compute_device(gpu, observation):
@@ -211,7 +216,13 @@ def from_files_to_files(
         lengths      frames per input file, when known: batches are then formed from files
                      of similar length (longest first), which removes most of the padding a
                      ragged collection costs (every padded frame is a full recurrence step)
-        num_workers  DataLoader workers for torch.load (reference default 0, loader.py:19-25)
+        num_workers  DataLoader workers for torch.load (reference default 0, loader.py:19-25); reader threads
+                     of the direct file reader (below)
+
+    Plain float32 files are not taken through `torch.load` + `collate` at all: their payload is read from the
+    `torch.save` container straight into its row of a pinned batch buffer (torbi_amd/fastio.py; same tuples, same
+    zero padding), and outputs are written by `SAVE_THREADS` threads while the next batches are decoded.  Files
+    the direct reader does not take (other dtypes or layouts, chunked decoding) go the reference's way.
     """
     transition, initial = _load_model(transition_file, initial_file, log_probs, clamp=True)
     mapping = dict(zip(input_files, output_files))
@@ -222,8 +233,12 @@ def from_files_to_files(
         order = sorted(range(len(input_files)), key=lambda k: (-int(lengths[k]), k))
         input_files = [input_files[k] for k in order]
 
+    batches = None
+    if DIRECT_FILE_IO:
+        from . import fastio
+        batches = fastio.open_batches(input_files, BATCH_SIZE, threads=num_workers)
     from_dataloader(
-        dataloader=_data.loader(input_files, num_workers=num_workers),
+        dataloader=batches if batches is not None else _data.loader(input_files, num_workers=num_workers),
         output_files=mapping,
         transition=transition,
         initial=initial,
@@ -254,7 +269,19 @@ def from_dataloader(
     """
     from .pipeline import DecodePipeline
     import collections
+    from concurrent.futures import ThreadPoolExecutor
     pipe = None
+    savers = ThreadPoolExecutor(max_workers=SAVE_THREADS) if SAVE_THREADS > 0 else None
+    written = collections.deque()
+
+    def write(function, *args):
+        if savers is None:
+            function(*args)
+            return
+        written.append(savers.submit(function, *args))
+        while len(written) > 4096:            # bound the queue; surfaces a failed save early
+            written.popleft().result()
+
     if torch.cuda.is_available():
         device = torch.device('cuda', torch.cuda.current_device() if gpu is None else gpu)
         pipe = DecodePipeline(device, depth=2, group=GROUP_SIZE)
@@ -268,32 +295,38 @@ def from_dataloader(
         if any(int(count) != 1 for count in batch_chunks):
             # files that were cut into pieces (torbi_amd/chunk.py): join each file's rows again (core.py:438-448)
             for joined, filename in zip(_data.separate(rows, batch_chunks, batch_frames.cpu()), filenames):
-                save(joined, filename)
+                write(save, joined, filename)
         else:
-            for row, filename, frames in zip(rows, filenames, batch_frames.cpu()):
-                save_masked(row, filename, frames)
+            for row, filename, frames in zip(rows, filenames, batch_frames.cpu().tolist()):
+                write(save_masked, row, filename, frames)
 
     # batches stay outstanding until a whole group behind them has been enqueued: the group being collected,
     # the group being decoded and the batch being saved overlap
     outstanding = collections.deque()
     keep = 1 if pipe is None else pipe.group * (pipe.depth - 1) + 1
     model = {}
-    for observation, batch_frames, batch_chunks, input_filenames in dataloader:
-        indices = from_probabilities(
-            observation=observation,
-            batch_frames=batch_frames,
-            transition=transition,
-            initial=initial,
-            log_probs=log_probs,
-            gpu=gpu,
-            num_threads=num_threads,
-            _pipeline=pipe,
-            _model=model)
-        outstanding.append((indices, input_filenames, batch_frames, batch_chunks))
-        while len(outstanding) > keep:
+    try:
+        for observation, batch_frames, batch_chunks, input_filenames in dataloader:
+            indices = from_probabilities(
+                observation=observation,
+                batch_frames=batch_frames,
+                transition=transition,
+                initial=initial,
+                log_probs=log_probs,
+                gpu=gpu,
+                num_threads=num_threads,
+                _pipeline=pipe,
+                _model=model)
+            outstanding.append((indices, input_filenames, batch_frames, batch_chunks))
+            while len(outstanding) > keep:
+                finish(outstanding.popleft())
+        while outstanding:
             finish(outstanding.popleft())
-    while outstanding:
-        finish(outstanding.popleft())
+        while written:
+            written.popleft().result()
+    finally:
+        if savers is not None:
+            savers.shutdown(wait=True)
 
 
 def save(tensor, file):
