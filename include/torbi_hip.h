@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TORBI_HIP_ABI_VERSION 5
+#define TORBI_HIP_ABI_VERSION 6
 
 #define TORBI_HIP_OK 0
 #define TORBI_HIP_EINVAL (-1)      /* null pointer / non-positive dimension            */
@@ -51,6 +51,7 @@ extern "C" {
 #define TORBI_HIP_ERANGE (-3)      /* dimension too large for this build               */
 #define TORBI_HIP_ENODEVICE (-4)   /* no usable HIP device / wrong architecture        */
 #define TORBI_HIP_EUNSUPPORTED (-5) /* shape not covered by this specialised entry point */
+#define TORBI_HIP_EIO_BASE (-100)  /* torbi_hip_read_rows: item k could not be read in full -> -(100 + k) */
 
 /* Build/ABI version of the loaded library (== TORBI_HIP_ABI_VERSION). */
 int torbi_hip_abi_version(void);
@@ -239,6 +240,19 @@ int torbi_hip_epsilon_clamp(float *x, uint64_t count, int device, void *stream);
  */
 int torbi_hip_fill_synthetic(float *dst, uint64_t count, uint64_t start, int stream_id,
                              int seed, int device, void *stream);
+
+/*
+ * Host side of a many-file job (no device is touched; all pointers are HOST pointers): item k's `bytes[k]`
+ * bytes at `offsets[k]` of the open file `fds[k]` are read into `rows[k]`, and the `zero_bytes[k]` bytes behind
+ * them are cleared, by `threads` native threads.  Replaces torch.load + pad_sequence per batch (reference
+ * torbi/data/dataset.py:18-20, torbi/data/collate.py:24-31): the float32 payload of a torch.save()d observation
+ * goes from the page cache to its row of the (pinned) batch buffer in one pass, outside the Python interpreter
+ * (torbi_amd/fastio.py finds the payloads and builds the same batch tuples as the reference's collate).
+ * Returns TORBI_HIP_OK, TORBI_HIP_EINVAL, or TORBI_HIP_EIO_BASE - k for the first item k that could not be read in
+ * full (*error_out, if given, holds its errno; 0 = the file ended early).
+ */
+int torbi_hip_read_rows(const int *fds, const int64_t *offsets, const int64_t *bytes, void *const *rows,
+                        const int64_t *zero_bytes, int count, int threads, int *error_out);
 
 #ifdef __cplusplus
 }

@@ -347,6 +347,31 @@ def test_file_batches_equal_the_loader_batches(tmp_path):
     assert isinstance(batches, fastio.FileBatches) and len(batches) == 3
 
 
+def test_payload_found_from_the_head_of_the_file_equals_the_central_directory_route(tmp_path):
+    """fastio.payload_of_open_file walks the local headers in the first 4 KB (torch leaves record sizes to data
+    descriptors); fastio.payload asks the zip central directory.  Same answer, also for a view with a storage
+    offset; a file cut short is reported by the native reader, not decoded."""
+    from torbi_amd import fastio
+    f = str(tmp_path / 'x.pt')
+    base = torch.rand(40, 12, generator=torch.Generator().manual_seed(3))
+    for tensor in (torch.rand(500, 1440), torch.rand(1, 3), torch.rand(33, 4096), base[4:9], base[39:]):
+        torch.save(tensor, f)
+        fd = os.open(f, os.O_RDONLY)
+        try:
+            found = fastio.payload_of_open_file(fd)
+        finally:
+            os.close(fd)
+        assert found == fastio.payload(f) and found[:2] == tuple(tensor.shape)
+        raw = np.fromfile(f, dtype=np.uint8)[found[2]:found[2] + 4 * tensor.numel()].view(np.float32)
+        assert np.array_equal(raw.reshape(tensor.shape), tensor.numpy())
+    torch.save(torch.rand(50, 12), f)
+    frames, states, start = fastio.payload(f)
+    with open(f, 'r+b') as handle:
+        handle.truncate(start + 4 * 12 * 20)
+    with pytest.raises(OSError, match='in full'):
+        list(fastio.FileBatches([f], 4, pin_memory=False))
+
+
 def test_file_batches_equal_the_reference_collate(tmp_path):
     """The reference's own collate output (tests/golden/generate_api.py) from files holding its inputs."""
     from torbi_amd import fastio

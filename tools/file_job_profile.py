@@ -1,0 +1,35 @@
+"""cProfile of the calling thread of torbi_amd.from_files_to_files on a ragged many-file job in /dev/shm.
+python tools/file_job_profile.py [files] [threads]"""
+import cProfile, os, pstats, shutil, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torbi_amd
+from torbi_amd import synth
+
+files = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+threads = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+S = 1440
+lengths = synth.lengths(files, 100, 900).tolist()
+folder = tempfile.mkdtemp(prefix='torbi_job_', dir='/dev/shm')
+try:
+    gen = torch.Generator().manual_seed(1)
+    block = torch.rand(900, S, generator=gen).log_softmax(-1)
+    ins, outs = [], []
+    for k, n in enumerate(lengths):
+        f = os.path.join(folder, f'in{k}.pt'); torch.save(torch.roll(block, k, dims=0)[:n].clone(), f)
+        ins.append(f); outs.append(os.path.join(folder, f'out{k}.pt'))
+    tf = os.path.join(folder, 'transition.pt'); torch.save(torch.rand(S, S, generator=gen).softmax(-1), tf)
+    for attempt in range(2):
+        torch.cuda.synchronize()
+        prof = cProfile.Profile()
+        t0 = time.perf_counter()
+        prof.enable()
+        torbi_amd.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, lengths=lengths, gpu=0, num_workers=threads)
+        torch.cuda.synchronize()
+        prof.disable()
+        dt = time.perf_counter() - t0
+        print(f'run {attempt}: {dt:.2f} s, {sum(lengths) / dt / 1e6:.2f} M frames/s', flush=True)
+        pstats.Stats(prof).sort_stats('cumulative').print_stats(28)
+finally:
+    shutil.rmtree(folder, ignore_errors=True)

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(_HERE)
 SOURCE = os.path.join(_HERE, 'csrc', 'torbi_hip.hip')
 INCLUDE = os.path.join(ROOT, 'include')
 LIBRARY = os.path.join(_HERE, 'libtorbi_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every symbol include/torbi_hip.h declares: name -> (restype, argtypes)
 _c = ctypes
@@ -49,6 +49,8 @@ SYMBOLS = {
         _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p,
         _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint]),
     'torbi_hip_epsilon_clamp': (_c.c_int, [_c.c_void_p, _c.c_uint64, _c.c_int, _c.c_void_p]),
+    'torbi_hip_read_rows': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int,
+                                       _c.c_int, _c.POINTER(_c.c_int)]),
     'torbi_hip_fill_synthetic': (_c.c_int, [
         _c.c_void_p, _c.c_uint64, _c.c_uint64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
 }
@@ -86,7 +88,7 @@ def build(force=False, verbose=False):
         if os.path.getmtime(LIBRARY) >= newest:
             return LIBRARY
     cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-ffp-contract=off', '-fno-slp-vectorize', '-Wno-pass-failed', f'-I{INCLUDE}', '-o', LIBRARY + '.tmp', SOURCE]
+           '-ffp-contract=off', '-fno-slp-vectorize', '-Wno-pass-failed', '-pthread', f'-I{INCLUDE}', '-o', LIBRARY + '.tmp', SOURCE]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

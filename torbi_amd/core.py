@@ -25,7 +25,7 @@ ENTROPY_THRESHOLD = 0.5
 GROUP_SIZE = 8
 # from_files_to_files reads plain float32 observation files straight into pinned batch buffers (torbi_amd/fastio.py)
 # instead of torch.load + collate in DataLoader workers; False = the reference's loader for every file
-DIRECT_FILE_IO = True
+DIRECT_FILE_IO = os.environ.get('TORBI_DIRECT_FILE_IO', '1') != '0'
 # threads that write the per-file outputs while the next launch group is decoded (0 = save on the calling thread)
 SAVE_THREADS = 4
 

@@ -7,14 +7,16 @@ takes a few milliseconds on an MI355X, so a many-file job is bound by exactly th
 
 `FileBatches` yields the same `(observation, batch_frames, batch_chunks, input_files)` tuples as
 `data.loader(...)`'s collate (zero padding included), but a file's float32 payload is `pread` from its place in the
-`torch.save` container directly into its row of the pinned batch buffer: one pass over the bytes, threads instead
-of processes (the reads release the GIL), the next batch assembled while the current one is copied and decoded.
+`torch.save` container directly into its row of the pinned batch buffer by native threads
+(`torbi_hip_read_rows`, csrc/file_rows.hpp): one pass over the bytes, outside the interpreter, the next batch
+assembled while the current one is copied and decoded.
 
 Only what `torch.save` writes for a plain contiguous float32 CPU tensor is taken this way (an uncompressed zip
-container: `<name>/data.pkl` + `<name>/data/<key>`); anything else -- another dtype or layout, the legacy
-non-zip format, chunked decoding (`core.MIN_CHUNK_SIZE`) -- makes `open_batches` return None and the caller uses
-`data.loader` like the reference.
+container: `<name>/data.pkl` + `<name>/data/<key>`); a batch holding anything else -- another dtype or layout, the
+legacy non-zip format -- is loaded with `torch.load` + `collate` like the reference does, and with chunked decoding
+(`core.MIN_CHUNK_SIZE`) `open_batches` returns None and the caller uses `data.loader`.
 """
+import ctypes
 import io
 import os
 import pickle
@@ -22,10 +24,11 @@ import queue
 import struct
 import threading
 import zipfile
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
+
+from . import _lib
 
 
 class UnsupportedFile(Exception):
@@ -52,21 +55,99 @@ class _LayoutUnpickler(pickle.Unpickler):
         return pid          # ('storage', storage type, key, location, numel)
 
 
+_layouts = {}          # data.pkl bytes -> (storage type, key, offset, size, stride): files of one shape share them
+
+
+def _tensor_record(pickled):
+    known = _layouts.get(pickled)
+    if known is None:
+        record = _LayoutUnpickler(io.BytesIO(pickled)).load()
+        if not (isinstance(record, tuple) and record and record[0] == 'tensor'):
+            raise UnsupportedFile('not a tensor')
+        _, storage, offset, size, stride = record
+        known = (storage[1], str(storage[2]), offset, size, stride)
+        if len(_layouts) > 4096:
+            _layouts.clear()
+        _layouts[pickled] = known
+    storage_type, key, offset, size, stride = known
+    if storage_type != 'FloatStorage' or len(size) != 2 or stride != (size[1], 1):
+        raise UnsupportedFile('not a contiguous float32 (frames, states) tensor')
+    return key, offset, size
+
+
+def _scan_head(head):
+    """Members of a torch.save container from its first bytes alone: {name: (data offset, size)}, walking the local
+    file headers up to the first storage record (torch writes data.pkl, three small records, then the payload; all
+    stored).  torch's writer leaves the sizes to a data descriptor behind each record, so a record's end is where
+    the next descriptor signature stands and agrees with the distance walked.  None when the walk meets anything
+    else (compression, a record that does not end inside `head`)."""
+    members, at = {}, 0
+    while at + 30 <= len(head) and head[at:at + 4] == b'PK\x03\x04':
+        flags, method = struct.unpack_from('<HH', head, at + 6)
+        packed, size, name_bytes, extra_bytes = struct.unpack_from('<IIHH', head, at + 18)
+        data = at + 30 + name_bytes + extra_bytes
+        if method != 0 or at + 30 + name_bytes > len(head):
+            return None
+        name = head[at + 30:at + 30 + name_bytes].split(b'/', 1)[-1]
+        if name.startswith(b'data/'):
+            members[name] = (data, None)
+            return members
+        if flags & 8:
+            # sizes follow the data: signature, crc32, packed size, size (4 bytes each, 8 in the zip64 form)
+            mark = data
+            while True:
+                mark = head.find(b'PK\x07\x08', mark)
+                if mark < 0 or mark + 24 > len(head):
+                    return None
+                if struct.unpack_from('<I', head, mark + 12)[0] == mark - data:
+                    size, after = mark - data, mark + 16
+                    break
+                if struct.unpack_from('<Q', head, mark + 16)[0] == mark - data:
+                    size, after = mark - data, mark + 24
+                    break
+                mark += 4
+        else:
+            if packed != size or size == 0xFFFFFFFF:
+                return None
+            after = data + size
+        members[name] = (data, size)
+        at = after
+    return None
+
+
+def payload_of_open_file(fd):
+    """(frames, states, byte offset of the float32 payload) of the torch.save()d tensor behind `fd`: one 4 KB read
+    and a walk over the local headers.  LookupError when that does not get there (`payload` then goes through the
+    central directory)."""
+    head = os.pread(fd, 4096, 0)
+    members = _scan_head(head)
+    if members is None or b'data.pkl' not in members:
+        raise LookupError
+    start, size = members[b'data.pkl']
+    if start + size > len(head):
+        raise LookupError
+    if b'byteorder' in members:
+        at, n = members[b'byteorder']
+        if head[at:at + n].strip() != b'little':
+            raise UnsupportedFile('byte order')
+    key, offset, shape = _tensor_record(bytes(head[start:start + size]))
+    entry = members.get(b'data/' + key.encode())
+    if entry is None:
+        raise LookupError
+    return shape[0], shape[1], entry[0] + 4 * offset        # (a file cut short shows up as a failed read)
+
+
 def payload(path):
-    """(frames, states, byte offset of the float32 payload) of a `torch.save`d (frames, states) tensor."""
+    """(frames, states, byte offset of the float32 payload) of a `torch.save`d (frames, states) tensor, through
+    the container's central directory."""
     try:
         with open(path, 'rb') as handle:
             archive = zipfile.ZipFile(handle)
             members = {info.filename.split('/', 1)[-1]: info for info in archive.infolist()}
             if 'byteorder' in members and archive.read(members['byteorder']).strip() != b'little':
                 raise UnsupportedFile('byte order')
-            record = _LayoutUnpickler(io.BytesIO(archive.read(members['data.pkl']))).load()
-            if not (isinstance(record, tuple) and record and record[0] == 'tensor'):
-                raise UnsupportedFile('not a tensor')
-            _, storage, offset, size, stride = record
-            if storage[1] != 'FloatStorage' or len(size) != 2 or stride != (size[1], 1):
-                raise UnsupportedFile('not a contiguous float32 (frames, states) tensor')
-            info = members['data/' + str(storage[2])]
+            key, offset, size = _tensor_record(archive.read(members['data.pkl']))
+            info = members['data/' + key]
             if info.compress_type != zipfile.ZIP_STORED:
                 raise UnsupportedFile('compressed payload')
             handle.seek(info.header_offset)
@@ -82,25 +163,23 @@ def payload(path):
         raise UnsupportedFile(str(exc)) from exc
 
 
-def _read_into(path, start, row):
-    """pread the payload at `start` into the numpy view `row` (contiguous float32)."""
-    view = memoryview(row).cast('B')
+def _open_payload(path):
+    """(fd, frames, states, payload offset); the caller closes the descriptor."""
     fd = os.open(path, os.O_RDONLY)
     try:
-        done = 0
-        while done < len(view):
-            got = os.preadv(fd, [view[done:]], start + done)
-            if got <= 0:
-                raise OSError(f'short read from {path}')
-            done += got
-    finally:
+        try:
+            return (fd,) + payload_of_open_file(fd)
+        except (LookupError, struct.error, pickle.UnpicklingError):
+            return (fd,) + payload(path)
+    except BaseException:
         os.close(fd)
+        raise
 
 
 class FileBatches:
     """Iterator over `(observation, batch_frames, batch_chunks, input_files)` for consecutive groups of
     `batch_size` files; the observation is a (rows, longest, states) float32 tensor in pinned memory when a HIP
-    device is present.  `threads` readers fill a batch; one batch is prepared ahead of the consumer."""
+    device is present.  `threads` native readers fill a batch; `ahead` batches are prepared ahead of the consumer."""
 
     def __init__(self, input_files, batch_size, threads=None, pin_memory=None, ahead=1):
         self.input_files = list(input_files)
@@ -112,31 +191,41 @@ class FileBatches:
     def __len__(self):
         return (len(self.input_files) + self.batch_size - 1) // self.batch_size
 
-    def _assemble(self, pool, files):
+    def _assemble(self, files):
+        opened = []
         try:
-            layouts = list(pool.map(payload, files))
-            if any(layout[1] != layouts[0][1] for layout in layouts):
-                raise UnsupportedFile('files of one batch differ in their number of states')
-        except UnsupportedFile:
-            # a file the direct reader does not take: this batch goes the reference's way (torch.load + collate)
-            from . import data
-            observation, batch_frames, batch_chunks, names = data.collate(
-                [(torch.load(file, map_location='cpu'), file) for file in files])
-            return (observation.pin_memory() if self.pin_memory else observation), batch_frames, batch_chunks, names
-        states = layouts[0][1]
-        longest = max(layout[0] for layout in layouts)
-        observation = torch.empty((len(files), longest, states), dtype=torch.float32, pin_memory=self.pin_memory)
-        rows = observation.numpy()
-
-        def fill(k):
-            frames, _, start = layouts[k]
-            if frames:
-                _read_into(files[k], start, rows[k, :frames])
-            rows[k, frames:] = 0.0             # collate's zero padding (collate.py:24-31)
-
-        list(pool.map(fill, range(len(files))))
-        batch_frames = torch.tensor([layout[0] for layout in layouts])
-        return observation, batch_frames, [1] * len(files), tuple(files)
+            try:
+                for file in files:
+                    opened.append(_open_payload(file))
+                if any(entry[2] != opened[0][2] for entry in opened):
+                    raise UnsupportedFile('files of one batch differ in their number of states')
+            except UnsupportedFile:
+                # a file the direct reader does not take: this batch goes the reference's way (torch.load + collate)
+                from . import data
+                observation, batch_frames, batch_chunks, names = data.collate(
+                    [(torch.load(file, map_location='cpu'), file) for file in files])
+                return (observation.pin_memory() if self.pin_memory else observation), batch_frames, batch_chunks, names
+            count, states = len(files), opened[0][2]
+            longest = max(entry[1] for entry in opened)
+            observation = torch.empty((count, longest, states), dtype=torch.float32, pin_memory=self.pin_memory)
+            row_bytes = 4 * longest * states
+            fds = np.array([entry[0] for entry in opened], dtype=np.int32)
+            frames = np.array([entry[1] for entry in opened], dtype=np.int64)
+            offsets = np.array([entry[3] for entry in opened], dtype=np.int64)
+            sizes = 4 * states * frames                                                      # payload bytes
+            rows = observation.data_ptr() + row_bytes * np.arange(count, dtype=np.int64)     # row addresses
+            zeros = row_bytes - sizes                                      # collate's zero padding (collate.py:24-31)
+            error = ctypes.c_int(0)
+            code = _lib.load().torbi_hip_read_rows(
+                fds.ctypes.data, offsets.ctypes.data, sizes.ctypes.data, rows.ctypes.data, zeros.ctypes.data,
+                count, min(self.threads, count), ctypes.byref(error))
+            if code <= -100:
+                raise OSError(error.value, f'could not read {files[-(code + 100)]} in full')
+            _lib.check(code, 'torbi_hip_read_rows')
+            return observation, torch.from_numpy(frames.copy()), [1] * count, tuple(files)
+        finally:
+            for entry in opened:
+                os.close(entry[0])
 
     def __iter__(self):
         groups = [self.input_files[k:k + self.batch_size] for k in range(0, len(self.input_files), self.batch_size)]
@@ -145,17 +234,16 @@ class FileBatches:
 
         def produce():
             try:
-                with ThreadPoolExecutor(max_workers=self.threads) as pool:
-                    for files in groups:
-                        if stop.is_set():
-                            return
-                        item = self._assemble(pool, files)
-                        while not stop.is_set():
-                            try:
-                                ready.put(item, timeout=0.1)
-                                break
-                            except queue.Full:
-                                continue
+                for files in groups:
+                    if stop.is_set():
+                        return
+                    item = self._assemble(files)
+                    while not stop.is_set():
+                        try:
+                            ready.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
                 ready.put(None)
             except BaseException as exc:      # surfaces in the consumer
                 ready.put(exc)
