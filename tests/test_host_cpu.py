@@ -427,11 +427,34 @@ def test_from_dataloader_saves_every_file_from_direct_batches(tmp_path, monkeypa
     monkeypatch.setattr(torch.cuda, 'is_available', lambda: False)
     for threads in (0, 3):
         monkeypatch.setattr(torbi_amd.core, 'SAVE_THREADS', threads)
+        monkeypatch.setattr(torbi_amd.core, 'DIRECT_FILE_IO', threads == 3)     # save_indices / save_masked
         torbi_amd.from_dataloader(fastio.FileBatches(files, 3, threads=2, pin_memory=False), mapping)
         for k, f in enumerate(files):
             got = torch.load(mapping[f])
             assert got.dtype == torch.int32 and got.tolist() == [1000 * (k % 3) + t for t in range(lengths[k])]
             os.remove(mapping[f])
+
+
+def test_save_indices_writes_what_torch_load_expects(tmp_path):
+    """fastio.save_indices leaves a torch.save container (reference output format, torbi/core.py:466-473): torch.load
+    returns the int32 vector in every mode, the zip checksums hold, other inputs go through torch.save."""
+    import zipfile
+    from torbi_amd import fastio
+    generator = torch.Generator().manual_seed(2)
+    for n in (1, 2, 17, 500, 900, 500):
+        x = torch.randint(0, 1440, (n,), dtype=torch.int32, generator=generator)
+        f = tmp_path / f'o{n}.pt'
+        fastio.save_indices(x, f)
+        for kwargs in ({}, {'weights_only': True}, {'mmap': True}):
+            got = torch.load(f, **kwargs)
+            assert got.dtype == torch.int32 and got.shape == (n,) and torch.equal(got, x)
+        assert zipfile.ZipFile(f).testzip() is None
+    rows = torch.arange(40, dtype=torch.int32).reshape(4, 10)
+    fastio.save_indices(rows[2][:7], tmp_path / 'view.pt')                 # a view into a batch of rows
+    assert torch.load(tmp_path / 'view.pt').tolist() == list(range(20, 27))
+    for odd in (torch.zeros((0,), dtype=torch.int32), torch.arange(6, dtype=torch.int64), rows):
+        fastio.save_indices(odd, tmp_path / 'odd.pt')
+        assert torch.equal(torch.load(tmp_path / 'odd.pt'), odd)
 
 
 def test_bench_starts_its_own_ranks_and_dry_runs_without_a_gpu():

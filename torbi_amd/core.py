@@ -27,7 +27,7 @@ GROUP_SIZE = 8
 # instead of torch.load + collate in DataLoader workers; False = the reference's loader for every file
 DIRECT_FILE_IO = os.environ.get('TORBI_DIRECT_FILE_IO', '1') != '0'
 # threads that write the per-file outputs while the next launch group is decoded (0 = save on the calling thread)
-SAVE_THREADS = 4
+SAVE_THREADS = 2
 
 
 def _compute_device(gpu, observation):
@@ -282,6 +282,16 @@ def from_dataloader(
         while len(written) > 4096:            # bound the queue; surfaces a failed save early
             written.popleft().result()
 
+    if DIRECT_FILE_IO:
+        # same file contents as save / save_masked (core.py:466-473), written from a prebuilt container image
+        from .fastio import save_indices
+
+        def store(tensor, file, length):
+            save_indices(tensor if length is None else tensor[..., :length], file)
+    else:
+        def store(tensor, file, length):
+            save(tensor, file) if length is None else save_masked(tensor, file, length)
+
     if torch.cuda.is_available():
         device = torch.device('cuda', torch.cuda.current_device() if gpu is None else gpu)
         pipe = DecodePipeline(device, depth=2, group=GROUP_SIZE)
@@ -295,10 +305,10 @@ def from_dataloader(
         if any(int(count) != 1 for count in batch_chunks):
             # files that were cut into pieces (torbi_amd/chunk.py): join each file's rows again (core.py:438-448)
             for joined, filename in zip(_data.separate(rows, batch_chunks, batch_frames.cpu()), filenames):
-                write(save, joined, filename)
+                write(store, joined, filename, None)
         else:
             for row, filename, frames in zip(rows, filenames, batch_frames.cpu().tolist()):
-                write(save_masked, row, filename, frames)
+                write(store, row, filename, frames)
 
     # batches stay outstanding until a whole group behind them has been enqueued: the group being collected,
     # the group being decoded and the batch being saved overlap
