@@ -586,19 +586,28 @@ class Bench:
             tf = os.path.join(folder, 'transition.pt')
             if self.rank == 0:
                 torch.save(torch.rand(S, S, generator=gen).softmax(-1), tf)
-            self.fence()
-            t0 = time.perf_counter()
-            workers = min(16, max(1, (os.cpu_count() or 2) // (2 * self.size)))
-            self.distributed.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, lengths=lengths,
-                                                 num_workers=workers)
-            self.fence()
-            elapsed = self.max_over_ranks(time.perf_counter() - t0)
+            workers = min(32, max(1, (os.cpu_count() or 2) // (2 * self.size)))
+            seconds = []
+            for _ in range(2):      # first call: pinned host blocks, device scratch and code objects are new
+                self.fence()
+                t0 = time.perf_counter()
+                self.distributed.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, lengths=lengths,
+                                                     num_workers=workers)
+                self.fence()
+                seconds.append(self.max_over_ranks(time.perf_counter() - t0))
+            elapsed = seconds[-1]
             ok = all(os.path.exists(f) for f in outs)
-            return {'value': sum(lengths) / elapsed, 'unit': 'timesteps/s', 'seconds': elapsed, 'sequences': files,
+            direct = bool(getattr(self.torbi_amd.core, 'DIRECT_FILE_IO', False))
+            return {'value': sum(lengths) / elapsed, 'unit': 'timesteps/s', 'seconds': elapsed,
+                    'first_call_seconds': seconds[0], 'sequences': files,
                     'outputs_written': ok,
-                    'loader_workers': workers,
-                    'note': 'torch.load + collate + H2D + epsilon clamp + decode + D2H + torch.save, length-bucketed '
-                            f'batches, files in {folder.rsplit("/", 1)[0]}: host-bound (torch.load / torch.save)'}
+                    'reader_threads': workers,
+                    'host_path': 'direct reader (payloads pread into pinned batch rows by native threads, outputs from '
+                                 'a prebuilt container image)' if direct else 'torch.load + collate in DataLoader workers, torch.save',
+                    'gb_per_s_from_files': sum(lengths) * S * 4 / elapsed / 1e9,
+                    'note': 'files -> pinned batches -> H2D -> epsilon clamp -> decode -> D2H -> one output file per input, '
+                            f'length-bucketed batches, files in {folder.rsplit("/", 1)[0]}; value = the second call '
+                            '(steady state of a long job), first_call_seconds = the same job cold'}
         finally:
             if self.rank == 0:
                 shutil.rmtree(folder, ignore_errors=True)
