@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 SOURCE = os.path.join(_HERE, 'csrc', 'torbi_hip.hip')
 INCLUDE = os.path.join(ROOT, 'include')
-LIBRARY = os.path.join(_HERE, 'libtorbi_hip.so')
+# TORBI_HIP_LIBRARY: an alternative build of the library (tools/variants_probe.py: -D experiments)
+LIBRARY = os.environ.get('TORBI_HIP_LIBRARY') or os.path.join(_HERE, 'libtorbi_hip.so')
 ABI_VERSION = 6
 
 # every symbol include/torbi_hip.h declares: name -> (restype, argtypes)

@@ -30,7 +30,10 @@
 
 namespace pruned {
 
-constexpr int kR = 3;        // explicit top candidates per item; thr = (kR+1)-th largest posterior
+#ifndef TORBI_KR
+#define TORBI_KR 3
+#endif
+constexpr int kR = TORBI_KR;  // explicit top candidates per item; thr = (kR+1)-th largest posterior
 constexpr int kNB = 16;      // batch items per tile for S <= 2048 (4 item groups per next-state); 8 above (2 groups)
 constexpr int kBlk = 16;     // list entries per termination test
 constexpr int kPad = 4 * kBlk;  // (-inf) entries after every list row: prefetches never leave the row

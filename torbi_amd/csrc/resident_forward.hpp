@@ -148,6 +148,13 @@ __device__ __forceinline__ void top_insert(u64 *list, u64 x) {
     }
 }
 
+// build-time ablations for tools/variants_probe.py (timing only, results are wrong): bit 0 fixed scan depth of 11 blocks
+// (no termination test), 1 no posterior reads from the LDS, 2 no quad broadcasts, 3 no history stores, 4 no top-list
+// inserts, 5 no observation loads, 6 no seeds
+#ifndef RESIDENT_ABL
+#define RESIDENT_ABL 0
+#endif
+
 #ifdef RESIDENT_STAMP
 // build-time instrumentation (tools/resident_stamps.py): per-wave cycle sums of the phases of a timestep
 constexpr int kPhases = 8;
@@ -274,11 +281,19 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
         for (int it = 0; it < 4; ++it) {
             const int item = 4 * g + it;
             live[it] = t < sframes[item];
-            const float4 v = *reinterpret_cast<const float4 *>(mtopv + item * kTop);
-            const int4 o = *reinterpret_cast<const int4 *>(mtopi + item * kTop);
-            seedv[it][0] = v.x; seedv[it][1] = v.y; seedv[it][2] = v.z;
-            seedo[it][0] = o.x; seedo[it][1] = o.y; seedo[it][2] = o.z;
-            thr[it] = live[it] ? v.w : -INFINITY;
+            if constexpr (kTop == 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(mtopv + item * kTop);
+                const int4 o = *reinterpret_cast<const int4 *>(mtopi + item * kTop);
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+                const int oo[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                for (int r = 0; r < kR; ++r) { seedv[it][r] = vv[r]; seedo[it][r] = oo[r]; }
+                thr[it] = live[it] ? vv[kR] : -INFINITY;
+            } else {
+#pragma unroll
+                for (int r = 0; r < kR; ++r) { seedv[it][r] = mtopv[item * kTop + r]; seedo[it][r] = mtopi[item * kTop + r]; }
+                thr[it] = live[it] ? mtopv[item * kTop + kR] : -INFINITY;
+            }
         }
         RSTAMP(1);
 
@@ -299,25 +314,37 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
                 load_list_block(nxt, row, kBlk);
                 float ob[4];
 #pragma unroll
-                for (int it = 0; it < 4; ++it) ob[it] = obs[((size_t)ib[it] * T + t) * S + jr];
+                for (int it = 0; it < 4; ++it) ob[it] = (RESIDENT_ABL & 32) ? 0.5f * it : obs[((size_t)ib[it] * T + t) * S + jr];
                 float seedt[4][kR];
 #pragma unroll
                 for (int it = 0; it < 4; ++it)
 #pragma unroll
-                    for (int r = 0; r < kR; ++r) seedt[it][r] = tt[(unsigned)(seedo[it][r] + jr)];   // trans[jr][i_r]
+                    for (int r = 0; r < kR; ++r)
+                        seedt[it][r] = (RESIDENT_ABL & 64) ? -1.0f : tt[(unsigned)(seedo[it][r] + jr)];   // trans[jr][i_r]
 
                 float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                 struct PairData { float4 p0, p1; float t0, t1; };
                 // entry pair H (0..7) of a block: owner lane O = H / 2 of the quad, its e[H % 2]
                 auto issue = [&](auto Hc, const ListBlock<EPL> &blk, PairData &d) {
                     constexpr int H = decltype(Hc)::value, O = H / (EPL / 2), E = H % (EPL / 2);
-                    float t0 = group_bcast<G, O>(blk.e[E].x), t1 = group_bcast<G, O>(blk.e[E].z);
-                    const int o0 = group_bcast<G, O>(__float_as_int(blk.e[E].y));
-                    const int o1 = group_bcast<G, O>(__float_as_int(blk.e[E].w));
+                    float t0, t1;
+                    int o0, o1;
+                    if (RESIDENT_ABL & 4) {
+                        t0 = blk.e[E].x; t1 = blk.e[E].z; o0 = __float_as_int(blk.e[E].y); o1 = __float_as_int(blk.e[E].w);
+                    } else {
+                        t0 = group_bcast<G, O>(blk.e[E].x); t1 = group_bcast<G, O>(blk.e[E].z);
+                        o0 = group_bcast<G, O>(__float_as_int(blk.e[E].y));
+                        o1 = group_bcast<G, O>(__float_as_int(blk.e[E].w));
+                    }
                     asm volatile("" : "+v"(t0), "+v"(t1));     // keep the broadcasts out of the adds (half-rate DPP adds)
                     d.t0 = t0; d.t1 = t1;
-                    d.p0 = *reinterpret_cast<const float4 *>(ptile + o0);
-                    d.p1 = *reinterpret_cast<const float4 *>(ptile + o1);
+                    if (RESIDENT_ABL & 2) {
+                        d.p0 = make_float4(__int_as_float(o0), t1, t0, t1);
+                        d.p1 = make_float4(__int_as_float(o1), t0, t1, t0);
+                    } else {
+                        d.p0 = *reinterpret_cast<const float4 *>(ptile + o0);
+                        d.p1 = *reinterpret_cast<const float4 *>(ptile + o1);
+                    }
                 };
                 auto math = [&](const PairData &d) {
                     best[0] = fmaxf(fmaxf(best[0], d.t0 + d.p0.x), d.t1 + d.p1.x);
@@ -363,17 +390,21 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
                 int nblk = 1;                              // wave-uniform
                 consume(cur, nxt);
                 load_list_block(cur, row, 2 * kBlk);
+                auto fold_seeds = [&]() {
 #pragma unroll
-                for (int it = 0; it < 4; ++it)
+                    for (int it = 0; it < 4; ++it)
 #pragma unroll
-                    for (int r = 0; r < kR; ++r) best[it] = fmaxf(best[it], seedv[it][r] + seedt[it][r]);
-                RSTAMP(2);
+                        for (int r = 0; r < kR; ++r) best[it] = fmaxf(best[it], seedv[it][r] + seedt[it][r]);
+                };
                 auto more = [&](const ListBlock<EPL> &blk) {
+                    if (RESIDENT_ABL & 1) return nblk < 11;
                     const float tn = group_bcast<G, 0>(blk.e[0].x);
-                    return __any(jv && ((tn + thr[0] > best[0]) | (tn + thr[1] > best[1]) | (tn + thr[2] > best[2]) |
-                                        (tn + thr[3] > best[3])));
+                    return (bool)__any(jv && ((tn + thr[0] > best[0]) | (tn + thr[1] > best[1]) | (tn + thr[2] > best[2]) |
+                                              (tn + thr[3] > best[3])));
                 };
                 const int Sp = (S + 15) / 16 * 16;
+                fold_seeds();
+                RSTAMP(2);
                 for (int kk = kBlk; kk < Sp; kk += 2 * kBlk) {
                     if (!more(nxt)) break;
                     RCOUNT(7, 1);
@@ -396,9 +427,9 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
                 for (int it = 0; it < 4; ++it) {
                     const float o = ob[it] + best[it];                     // post'[j] = obs[t,j] + max
                     pend[p][it] = o;
-                    if (jv && live[it]) hist[((size_t)ib[it] * T + t) * S + jr] = o;
+                    if (jv && live[it] && !(RESIDENT_ABL & 8)) hist[((size_t)ib[it] * T + t) * S + jr] = o;
                     const u64 key = top_key(o, jr);
-                    if (jv && key > last4[it]) top_insert(top + (4 * g + it) * kTop, key);
+                    if (jv && key > last4[it] && !(RESIDENT_ABL & 16)) top_insert(top + (4 * g + it) * kTop, key);
                 }
                 RSTAMP(4);
             }
