@@ -17,10 +17,14 @@ if sys.argv[1] == 'build':
                            f'{ROOT}/torbi_amd/csrc/torbi_hip.hip'])
 else:
     args = os.environ.get('PROBE_ARGS', '8 200').split()
+    script = os.environ.get('PROBE_SCRIPT', 'resident_probe.py')        # e.g. uniform_probe.py (every line is shown)
     for rep in range(int(os.environ.get('PROBE_REPS', '2'))):
         for name in sys.argv[2:]:
             env = dict(os.environ, TORBI_HIP_LIBRARY=lib(name))
-            out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'resident_probe.py'), *args], env=env,
+            out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', script), *args], env=env,
                                  capture_output=True, text=True).stdout
+            if script != 'resident_probe.py':
+                print(f'{name}:\n{out}', flush=True)
+                continue
             line = [l for l in out.splitlines() if l.startswith(f'resident x{args[0]}')]
             print(f'{name:12s}', line[-1] if line else out[-300:], flush=True)

@@ -32,6 +32,10 @@
 #include "small_batch_forward.hpp"
 #include "file_rows.hpp"
 
+#ifndef TORBI_UNIFORM_DEPTH
+#define TORBI_UNIFORM_DEPTH 4      // observation rows in flight per item in the uniform-transition kernel
+#endif
+
 namespace {
 
 constexpr int kWave = 64;
@@ -1232,9 +1236,9 @@ int torbi_hip_viterbi_decode_uniform(const float *observation, const int32_t *ba
                            observation, batch_frames, initial, log_transition, indices_out, B, T, S); \
         return (int)hipGetLastError();                                                              \
     }
-    TORBI_UNIFORM_CASE(1, 4)
-    TORBI_UNIFORM_CASE(2, 4)
-    TORBI_UNIFORM_CASE(4, 4)
+    TORBI_UNIFORM_CASE(1, TORBI_UNIFORM_DEPTH)
+    TORBI_UNIFORM_CASE(2, TORBI_UNIFORM_DEPTH)
+    TORBI_UNIFORM_CASE(4, TORBI_UNIFORM_DEPTH)
 #undef TORBI_UNIFORM_CASE
     return TORBI_HIP_EUNSUPPORTED;
 }
