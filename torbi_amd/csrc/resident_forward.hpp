@@ -150,9 +150,13 @@ __device__ __forceinline__ void top_insert(u64 *list, u64 x) {
 
 // build-time ablations for tools/variants_probe.py (timing only, results are wrong): bit 0 fixed scan depth of 11 blocks
 // (no termination test), 1 no posterior reads from the LDS, 2 no quad broadcasts, 3 no history stores, 4 no top-list
-// inserts, 5 no observation loads, 6 no seeds
+// inserts, 5 no observation loads, 6 no seeds.  RESIDENT_EXTRA_VALU=n adds n independent v_add_f32 per entry pair (results
+// unchanged): how much of the run time is the vector instruction stream
 #ifndef RESIDENT_ABL
 #define RESIDENT_ABL 0
+#endif
+#ifndef RESIDENT_EXTRA_VALU
+#define RESIDENT_EXTRA_VALU 0
 #endif
 
 #ifdef RESIDENT_STAMP
@@ -323,6 +327,9 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
                         seedt[it][r] = (RESIDENT_ABL & 64) ? -1.0f : tt[(unsigned)(seedo[it][r] + jr)];   // trans[jr][i_r]
 
                 float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#if RESIDENT_EXTRA_VALU
+                float dummy[4] = {0.f, 0.f, 0.f, 0.f};
+#endif
                 struct PairData { float4 p0, p1; float t0, t1; };
                 // entry pair H (0..7) of a block: owner lane O = H / 2 of the quad, its e[H % 2]
                 auto issue = [&](auto Hc, const ListBlock<EPL> &blk, PairData &d) {
@@ -347,6 +354,11 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
                     }
                 };
                 auto math = [&](const PairData &d) {
+#if RESIDENT_EXTRA_VALU
+                    // probe: extra independent full-rate adds per entry pair (is the vector ALU the limit?)
+#pragma unroll
+                    for (int x = 0; x < RESIDENT_EXTRA_VALU; ++x) asm volatile("v_add_f32 %0, %0, %1" : "+v"(dummy[x & 3]) : "v"(d.t0));
+#endif
                     best[0] = fmaxf(fmaxf(best[0], d.t0 + d.p0.x), d.t1 + d.p1.x);
                     best[1] = fmaxf(fmaxf(best[1], d.t0 + d.p0.y), d.t1 + d.p1.y);
                     best[2] = fmaxf(fmaxf(best[2], d.t0 + d.p0.z), d.t1 + d.p1.z);
@@ -425,6 +437,9 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
                 for (int it = 0; it < 4; ++it) last4[it] = top[(4 * g + it) * kTop + kTop - 1];
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
+#if RESIDENT_EXTRA_VALU
+                    if (dummy[it] == 12345.678f) best[it] = 0.f;
+#endif
                     const float o = ob[it] + best[it];                     // post'[j] = obs[t,j] + max
                     pend[p][it] = o;
                     if (jv && live[it] && !(RESIDENT_ABL & 8)) hist[((size_t)ib[it] * T + t) * S + jr] = o;
