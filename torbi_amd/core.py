@@ -315,6 +315,7 @@ def from_dataloader(
     outstanding = collections.deque()
     keep = 1 if pipe is None else pipe.group * (pipe.depth - 1) + 1
     model = {}
+    starved = getattr(dataloader, 'more_ready', None)
     try:
         for observation, batch_frames, batch_chunks, input_filenames in dataloader:
             indices = from_probabilities(
@@ -328,6 +329,8 @@ def from_dataloader(
                 _pipeline=pipe,
                 _model=model)
             outstanding.append((indices, input_filenames, batch_frames, batch_chunks))
+            if pipe is not None and starved is not None and not starved():
+                pipe.flush()      # the reader is the slower side: decode what has arrived instead of waiting for a full group
             while len(outstanding) > keep:
                 finish(outstanding.popleft())
         while outstanding:

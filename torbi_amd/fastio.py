@@ -187,6 +187,13 @@ class FileBatches:
         self.threads = max(1, int(threads if threads else min(32, (os.cpu_count() or 4))))
         self.pin_memory = torch.cuda.is_available() if pin_memory is None else bool(pin_memory)
         self.ahead = max(1, int(ahead))
+        self._ready = None
+
+    def more_ready(self):
+        """True while the batch after the one just yielded is already assembled (or the job is over).  The many-file
+        driver launches a partial group instead of waiting for a full one when the reader is the slower side."""
+        ready = self._ready
+        return ready is None or not ready.empty()
 
     def __len__(self):
         return (len(self.input_files) + self.batch_size - 1) // self.batch_size
@@ -229,7 +236,7 @@ class FileBatches:
 
     def __iter__(self):
         groups = [self.input_files[k:k + self.batch_size] for k in range(0, len(self.input_files), self.batch_size)]
-        ready = queue.Queue(maxsize=self.ahead)
+        ready = self._ready = queue.Queue(maxsize=self.ahead)
         stop = threading.Event()
 
         def produce():
