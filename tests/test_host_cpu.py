@@ -457,6 +457,26 @@ def test_save_indices_writes_what_torch_load_expects(tmp_path):
         assert torch.equal(torch.load(tmp_path / 'odd.pt'), odd)
 
 
+def test_save_index_rows_writes_a_batch_of_outputs(tmp_path):
+    """fastio.save_index_rows (native writer threads, torbi_hip_write_files): every file holds its row's first
+    `length` indices (core.py:449-457); rows the image route does not take fall back to torch.save; a path that cannot
+    be created raises."""
+    from torbi_amd import fastio
+    rows = torch.randint(0, 1440, (40, 90), dtype=torch.int32, generator=torch.Generator().manual_seed(4))
+    lengths = [1 + (7 * k) % 90 for k in range(40)]
+    files = [tmp_path / f'o{k}.pt' for k in range(40)]
+    fastio.save_index_rows(rows, files, lengths, threads=3)
+    for k in range(40):
+        got = torch.load(files[k])
+        assert got.dtype == torch.int32 and torch.equal(got, rows[k, :lengths[k]])
+    wide = rows.to(torch.int64)
+    fastio.save_index_rows(wide[:3], files[:3], [5, None, 0])
+    assert torch.equal(torch.load(files[0]), wide[0, :5]) and torch.equal(torch.load(files[1]), wide[1])
+    assert torch.load(files[2]).numel() == 0
+    with pytest.raises(OSError):
+        fastio.save_index_rows(rows[:1], [tmp_path / 'missing' / 'x.pt'], [4])
+
+
 def test_bench_starts_its_own_ranks_and_dry_runs_without_a_gpu():
     """`python bench.py --gpus 2` without a launcher: bench.py starts the two ranks itself (child process, gloo
     rendezvous on 127.0.0.1) and, with no HIP device, prints a dry-run line carrying the launch plan."""

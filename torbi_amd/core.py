@@ -284,7 +284,7 @@ def from_dataloader(
 
     if DIRECT_FILE_IO:
         # same file contents as save / save_masked (core.py:466-473), written from a prebuilt container image
-        from .fastio import save_indices
+        from .fastio import save_indices, save_index_rows as save_rows
 
         def store(tensor, file, length):
             save_indices(tensor if length is None else tensor[..., :length], file)
@@ -306,6 +306,8 @@ def from_dataloader(
             # files that were cut into pieces (torbi_amd/chunk.py): join each file's rows again (core.py:438-448)
             for joined, filename in zip(_data.separate(rows, batch_chunks, batch_frames.cpu()), filenames):
                 write(store, joined, filename, None)
+        elif DIRECT_FILE_IO:
+            write(save_rows, rows, filenames, batch_frames.cpu().tolist())       # one task: the whole batch, native threads
         else:
             for row, filename, frames in zip(rows, filenames, batch_frames.cpu().tolist()):
                 write(store, row, filename, frames)

@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <thread>
 #include <vector>
+#include <fcntl.h>
 #include <unistd.h>
 
 namespace filerows {
@@ -63,6 +64,61 @@ inline int read_rows(const int *fds, const int64_t *offsets, const int64_t *byte
     pool.reserve((size_t)threads - 1);
     for (int t = 1; t < threads; ++t) pool.emplace_back(work, &job);
     work(&job);
+    for (auto &t : pool) t.join();
+    if (error_out) *error_out = job.error.load();
+    const int failed = job.failed.load();
+    return failed ? -failed : 0;
+}
+
+// ---- the other direction: one small file per decoded sequence (torbi/core.py:449-457 saves them one by one) -------
+struct WriteJob {
+    const char *const *paths;
+    const void *const *data;
+    const int64_t *bytes;
+    int n;
+    std::atomic<int> next{0};
+    std::atomic<int> failed{0};
+    std::atomic<int> error{0};
+};
+
+inline void write_work(WriteJob *job) {
+    for (;;) {
+        const int k = job->next.fetch_add(1, std::memory_order_relaxed);
+        if (k >= job->n) return;
+        int err = 0;
+        const int fd = open(job->paths[k], O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+        if (fd < 0) {
+            err = errno ? errno : EIO;
+        } else {
+            const char *src = static_cast<const char *>(job->data[k]);
+            int64_t left = job->bytes[k];
+            while (left > 0) {
+                const ssize_t put = write(fd, src, (size_t)left);
+                if (put < 0 && errno == EINTR) continue;
+                if (put <= 0) { err = errno ? errno : EIO; break; }
+                src += put;
+                left -= put;
+            }
+            if (close(fd) != 0 && !err) err = errno ? errno : EIO;
+        }
+        if (err) {
+            int expected = 0;
+            if (job->failed.compare_exchange_strong(expected, k + 1)) job->error.store(err);
+        }
+    }
+}
+
+// 0, or -(1 + index) of a file that could not be written (its errno in *error_out)
+inline int write_files(const char *const *paths, const void *const *data, const int64_t *bytes, int n, int threads,
+                       int *error_out) {
+    WriteJob job;
+    job.paths = paths; job.data = data; job.bytes = bytes; job.n = n;
+    if (threads > n) threads = n;
+    if (threads < 1) threads = 1;
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)threads - 1);
+    for (int t = 1; t < threads; ++t) pool.emplace_back(write_work, &job);
+    write_work(&job);
     for (auto &t : pool) t.join();
     if (error_out) *error_out = job.error.load();
     const int failed = job.failed.load();

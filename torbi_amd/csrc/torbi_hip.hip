@@ -1081,7 +1081,7 @@ const char *torbi_hip_error_string(int code) {
         default: break;
     }
     if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
-    if (code <= TORBI_HIP_EIO_BASE) return "torbi_hip_read_rows: an item could not be read in full (index = -(code + 100))";
+    if (code <= TORBI_HIP_EIO_BASE) return "torbi_hip_read_rows / torbi_hip_write_files: item -(code + 100) could not be read or written in full";
     return "unknown torbi_hip error";
 }
 
@@ -1317,6 +1317,17 @@ int torbi_hip_read_rows(const int *fds, const int64_t *offsets, const int64_t *b
         if (fds[k] < 0 || offsets[k] < 0 || bytes[k] < 0 || zero_bytes[k] < 0 || (!rows[k] && bytes[k] + zero_bytes[k] > 0))
             return TORBI_HIP_EINVAL;
     const int rc = filerows::read_rows(fds, offsets, bytes, rows, zero_bytes, count, threads, error_out);
+    return rc == 0 ? TORBI_HIP_OK : TORBI_HIP_EIO_BASE + rc + 1;      // -(100 + index)
+}
+
+int torbi_hip_write_files(const char *const *paths, const void *const *data, const int64_t *bytes, int count, int threads,
+                          int *error_out) {
+    if (count < 0 || threads < 1) return TORBI_HIP_EINVAL;
+    if (count == 0) return TORBI_HIP_OK;
+    if (!paths || !data || !bytes) return TORBI_HIP_EINVAL;
+    for (int k = 0; k < count; ++k)
+        if (!paths[k] || bytes[k] < 0 || (!data[k] && bytes[k] > 0)) return TORBI_HIP_EINVAL;
+    const int rc = filerows::write_files(paths, data, bytes, count, threads, error_out);
     return rc == 0 ? TORBI_HIP_OK : TORBI_HIP_EIO_BASE + rc + 1;      // -(100 + index)
 }
 

@@ -343,11 +343,25 @@ def _container_image(length):
 def save_indices(indices, file):
     """Write a 1-D int32 CPU tensor so that torch.load(file) returns it (what the reference's save / save_masked
     leave on disk, torbi/core.py:466-473); anything else goes through torch.save."""
+    out = _filled_image(indices)
+    if out is None:
+        torch.save(indices.clone(), file)
+        return
+    fd = os.open(os.fspath(file), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666)
+    try:
+        view, done = memoryview(out), 0
+        while done < len(out):
+            done += os.write(fd, view[done:])
+    finally:
+        os.close(fd)
+
+
+def _filled_image(indices):
+    """The container bytes for one 1-D int32 CPU tensor (see save_indices), or None for anything else."""
     import zlib
     if not (isinstance(indices, torch.Tensor) and indices.dtype == torch.int32 and indices.dim() == 1
             and indices.device.type == 'cpu' and indices.numel() > 0):
-        torch.save(indices.clone(), file)
-        return
+        return None
     length = indices.numel()
     with _images_lock:
         known = _images.get(length)
@@ -362,10 +376,31 @@ def save_indices(indices, file):
     crc = struct.pack('<I', zlib.crc32(body) & 0xffffffff)
     for at in crc_at:
         out[at:at + 4] = crc
-    fd = os.open(os.fspath(file), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666)
-    try:
-        view, done = memoryview(out), 0
-        while done < len(out):
-            done += os.write(fd, view[done:])
-    finally:
-        os.close(fd)
+    return out
+
+
+def save_index_rows(rows, files, lengths, threads=8):
+    """`save_indices(rows[k][:lengths[k]], files[k])` for a whole batch: the containers are put together here and
+    written by native threads in one call (`torbi_hip_write_files`)."""
+    images, names = [], []
+    for row, file, length in zip(rows, files, lengths):
+        piece = row if length is None else row[..., :length]
+        image = _filled_image(piece)
+        if image is None:
+            torch.save(piece.clone(), file)
+            continue
+        images.append(image)
+        names.append(os.fsencode(os.fspath(file)))
+    count = len(images)
+    if not count:
+        return
+    paths = (ctypes.c_char_p * count)(*names)
+    buffers = [(ctypes.c_char * len(image)).from_buffer(image) for image in images]
+    data = (ctypes.c_void_p * count)(*[ctypes.addressof(buffer) for buffer in buffers])
+    sizes = np.array([len(image) for image in images], dtype=np.int64)
+    error = ctypes.c_int(0)
+    code = _lib.load().torbi_hip_write_files(paths, data, sizes.ctypes.data, count, max(1, min(int(threads), count)),
+                                             ctypes.byref(error))
+    if code <= -100:
+        raise OSError(error.value, f'could not write {os.fsdecode(names[-(code + 100)])}')
+    _lib.check(code, 'torbi_hip_write_files')
