@@ -459,6 +459,11 @@ class Bench:
         except RuntimeError as exc:     # out of memory next to the headline buffers: say so instead of dying
             out['c5'] = {'value': None, 'note': f'not measured: {exc}'}
         out['chunked_long_sequence'] = self.chunked_long_sequence(trans, init)
+        try:
+            # configs[3] from files to files (2 048 sequences: torch.save()d inputs in /dev/shm -> one output file each)
+            out['c4_files_end_to_end'] = self.c4_end_to_end(2048)
+        except (OSError, RuntimeError) as exc:
+            out['c4_files_end_to_end'] = {'value': None, 'note': f'not measured: {exc}'}
         return out
 
     def chunked_long_sequence(self, trans, init):
