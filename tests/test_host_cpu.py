@@ -60,12 +60,16 @@ def test_decode_validates_like_the_reference_operator():
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
 def test_no_gpu_fails_loudly_instead_of_falling_back():
+    """A GPU request without a HIP device raises; it is never served by the CPU operator (which only `gpu=None`
+    selects, like upstream -- tests/test_cpu_twin.py)."""
     obs = torch.full((1, 3, 3), 1 / 3)
     with pytest.raises(RuntimeError, match='no CPU'):
-        torbi_amd.from_probabilities(obs)
+        torbi_amd.from_probabilities(obs, gpu=0)
     with pytest.raises(RuntimeError, match='HIP device'):
         torbi_amd.decode(torch.zeros(1, 3, 3), torch.tensor([3], dtype=torch.int32),
                          torch.zeros(3, 3), torch.zeros(3))
+    with pytest.raises(RuntimeError, match='HIP device'):
+        torbi_amd.DecodePipeline()
 
 
 def test_product_never_imports_the_oracle():

@@ -21,7 +21,7 @@ FLAGS = {
     'initial_file': dict(type=pathlib.Path, default=None,
                          help='(states,) initial distribution; uniform when omitted'),
     'log_probs': dict(action='store_true', help='the files already hold natural-log probabilities'),
-    'gpu': dict(type=int, default=None, help='HIP device index (default: the current device; there is no CPU decoder)'),
+    'gpu': dict(type=int, default=None, help='HIP device index (default: the CPU operator, like upstream)'),
     'num_threads': dict(type=int, default=1, help='accepted for compatibility with the reference CLI; unused'),
 }
 

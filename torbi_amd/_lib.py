@@ -1,7 +1,8 @@
 """ctypes binding of libtorbi_hip.so (C ABI declared in include/torbi_hip.h).
 
 The library is built IN-TREE by `torbi_amd._lib.build()` (hipcc --offload-arch=gfx950) and is
-the only compute path of this package: there is no CPU or eager-PyTorch fallback.  A missing
+the only compute path of a GPU request: there is no CPU or eager-PyTorch fallback (the CPU operator that `gpu=None`
+selects lives in its own library, libtorbi_cpu.so, see build_cpu / load_cpu).  A missing
 library, a missing symbol or an ABI mismatch raises at first use.
 """
 import ctypes
@@ -68,6 +69,12 @@ class Batch(_c.Structure):
 
 _LIB = None
 
+# the host twin (include/torbi_cpu.h): a separate library, g++ -fopenmp, no HIP dependency
+CPU_SOURCE = os.path.join(_HERE, 'csrc', 'torbi_cpu.cpp')
+CPU_LIBRARY = os.path.join(_HERE, 'libtorbi_cpu.so')
+CPU_ABI_VERSION = 1
+_CPU_LIB = None
+
 
 class TorbiHipError(RuntimeError):
     """A non-zero return code from libtorbi_hip.so."""
@@ -126,3 +133,38 @@ def check(code, what='torbi_hip call'):
     if code != 0:
         msg = load().torbi_hip_error_string(code)
         raise TorbiHipError(f'{what} failed with code {code}: {msg.decode() if msg else "?"}')
+
+
+def build_cpu(force=False, verbose=False):
+    """Compile csrc/torbi_cpu.cpp into torbi_amd/libtorbi_cpu.so (in-tree; the CPU operator of gpu=None callers)."""
+    deps = [CPU_SOURCE, os.path.join(INCLUDE, 'torbi_cpu.h')]
+    if not force and os.path.exists(CPU_LIBRARY) and os.path.getmtime(CPU_LIBRARY) >= max(os.path.getmtime(d) for d in deps):
+        return CPU_LIBRARY
+    cxx = os.environ.get('CXX') or shutil.which('g++') or 'g++'
+    cmd = [cxx, '-O3', '-std=c++17', '-fopenmp', '-fPIC', '-shared', '-ffp-contract=off', f'-I{INCLUDE}', '-o',
+           CPU_LIBRARY + '.tmp', CPU_SOURCE]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(CPU_LIBRARY + '.tmp', CPU_LIBRARY)
+    global _CPU_LIB
+    _CPU_LIB = None
+    return CPU_LIBRARY
+
+
+def load_cpu():
+    """Load libtorbi_cpu.so and bind its entry points; raises if it has not been built."""
+    global _CPU_LIB
+    if _CPU_LIB is not None:
+        return _CPU_LIB
+    if not os.path.exists(CPU_LIBRARY):
+        raise FileNotFoundError(f'{CPU_LIBRARY} is missing: run `python -c "import __graft_entry__ as g; g.build()"`')
+    lib = ctypes.CDLL(CPU_LIBRARY)
+    lib.torbi_cpu_abi_version.restype = _c.c_int
+    lib.torbi_cpu_abi_version.argtypes = []
+    lib.torbi_cpu_viterbi_decode.restype = _c.c_int
+    lib.torbi_cpu_viterbi_decode.argtypes = [_c.c_void_p] * 5 + [_c.c_int] * 4
+    if lib.torbi_cpu_abi_version() != CPU_ABI_VERSION:
+        raise RuntimeError('libtorbi_cpu.so ABI mismatch: rebuild')
+    _CPU_LIB = lib
+    return lib

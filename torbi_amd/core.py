@@ -30,18 +30,45 @@ DIRECT_FILE_IO = os.environ.get('TORBI_DIRECT_FILE_IO', '1') != '0'
 SAVE_THREADS = 2
 
 
-def _compute_device(gpu, observation):
-    if gpu is None:
-        if observation.is_cuda:
-            return observation.device
-        if not torch.cuda.is_available():
-            raise RuntimeError(
-                'torbi_amd has no CPU decoder: from_probabilities(gpu=None) decodes on the '
-                'current HIP device and needs one (the reference would run its CPU operator)')
-        return torch.device('cuda', torch.cuda.current_device())
+def _compute_device(gpu):
     if gpu == 'mps':
         raise RuntimeError('the MPS backend of the reference is out of scope on MI355X')
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            f'from_probabilities(gpu={gpu!r}) needs a HIP device and PyTorch-ROCm reports none; there is no CPU '
+            'fallback for a GPU request (gpu=None selects the CPU operator, like upstream)')
     return torch.device(f'cuda:{gpu}')
+
+
+def _from_probabilities_cpu(observation, batch_frames, transition, initial, log_probs, num_threads):
+    """`gpu=None`: the reference's CPU route (torbi/core.py:145-201 with device = 'cpu'), decoded by the host twin of
+    the operator (include/torbi_cpu.h).  Same steps in the same order, materialised uniform defaults included."""
+    from .viterbi import decode_cpu
+    batch, frames, states = observation.shape
+    device = torch.device('cpu')
+    tiny = torch.finfo(torch.float32).tiny
+    if batch_frames is None:
+        batch_frames = torch.full((batch,), frames, dtype=torch.int32, device=device)
+    batch_frames = batch_frames.to(dtype=torch.int32, device=device)
+    if initial is None:
+        initial = torch.full((states,), math.log((1. / states) + tiny), dtype=torch.float32, device=device)
+    else:
+        if not log_probs:
+            initial = torch.log(initial)
+        initial = initial.to(device)
+    if transition is None:
+        transition = torch.full((states, states), math.log(1. / states), dtype=torch.float32, device=device)
+    else:
+        if not log_probs:
+            transition = torch.log(transition)
+        transition = transition.to(device)
+    if not log_probs:
+        observation = torch.log(observation)
+    observation = observation.to(device=device, dtype=torch.float32)
+    torch.exp_(observation)
+    observation += tiny
+    torch.log_(observation)
+    return decode_cpu(observation, batch_frames, transition, initial, num_threads=num_threads)
 
 
 _transition_cache = {}        # id(caller's tensor) -> (weakref, version, log_probs, device, prepared tensor)
@@ -75,7 +102,7 @@ def from_probabilities(
     _pipeline=None,
     _model: Optional[dict] = None
 ) -> torch.Tensor:
-    """Viterbi-decode a batch of per-frame state distributions on the HIP device.
+    """Viterbi-decode a batch of per-frame state distributions on HIP device `gpu` (or on the CPU: `gpu=None`).
 
     Same steps, in the same order, as reference torbi/core.py:110-208: `batch_frames` defaults to
     every frame (int32); a missing `initial` becomes log(1/S + tiny) and a missing `transition`
@@ -90,16 +117,18 @@ def from_probabilities(
             O(states)-per-frame kernel, same indices)
         initial: (states,) distribution over the first frame's states; None = uniform
         log_probs: the tensors are already natural-log probabilities
-        gpu: HIP device index.  None (CPU decoding upstream) means the device the observation is
-            on, else the current one, and the indices come back on the host as upstream's do
-        num_threads: upstream's CPU thread count; has no meaning here
+        gpu: HIP device index.  None selects the CPU operator like upstream (torbi/core.py:147-150): its host twin
+            (`decode_cpu`, include/torbi_cpu.h), same indices.  A GPU request without a device raises
+        num_threads: worker threads of the CPU operator (upstream: torch's global thread count,
+            torbi/viterbi.py:51-52); ignored on the GPU
 
     Returns:
         (batch, frames) int32 indices of the most likely state sequence of every item
     """
+    if gpu is None:
+        return _from_probabilities_cpu(observation, batch_frames, transition, initial, log_probs, num_threads)
     batch, frames, states = observation.shape
-    device = _compute_device(gpu, observation)
-    to_host = gpu is None and not observation.is_cuda
+    device = _compute_device(gpu)
     tiny = torch.finfo(torch.float32).tiny
 
     if batch_frames is None:
@@ -149,7 +178,7 @@ def from_probabilities(
         return _pipeline.decode(observation, batch_frames, transition, initial)
     else:
         indices = decode(observation, batch_frames, transition, initial, num_threads=num_threads)
-    return indices.cpu() if to_host else indices
+    return indices
 
 
 def from_file(
@@ -236,7 +265,8 @@ def from_files_to_files(
     batches = None
     if DIRECT_FILE_IO:
         from . import fastio
-        batches = fastio.open_batches(input_files, BATCH_SIZE, threads=num_workers)
+        batches = fastio.open_batches(input_files, BATCH_SIZE, threads=num_workers,
+                                      pin_memory=gpu is not None and torch.cuda.is_available())
     from_dataloader(
         dataloader=batches if batches is not None else _data.loader(input_files, num_workers=num_workers),
         output_files=mapping,
@@ -292,9 +322,8 @@ def from_dataloader(
         def store(tensor, file, length):
             save(tensor, file) if length is None else save_masked(tensor, file, length)
 
-    if torch.cuda.is_available():
-        device = torch.device('cuda', torch.cuda.current_device() if gpu is None else gpu)
-        pipe = DecodePipeline(device, depth=2, group=GROUP_SIZE)
+    if gpu is not None and torch.cuda.is_available():
+        pipe = DecodePipeline(torch.device('cuda', gpu), depth=2, group=GROUP_SIZE)
 
     def finish(item):
         indices, input_filenames, batch_frames, batch_chunks = item

@@ -1,0 +1,203 @@
+// torbi_cpu.cpp -- host twin of the MI355X decoder behind include/torbi_cpu.h.
+//
+// The operator the reference registers for the CPU key (viterbi_decode_cpu, torbi/csrc/viterbi.cpp:182-234), written
+// the way the HIP side is: the forward pass keeps VALUES only,
+//     post'[j] = fl(obs[t,j] + max_i fl(post[i] + trans[j,i]))                       (viterbi.cpp:81-104)
+// as a (max,+) row product vectorised over prev-states with a block of items sharing every transition row, the
+// posterior rows are kept as the (B,T,S) history, and the backpointer -- lowest prev-state attaining the maximum
+// (viterbi.cpp:94-100) -- is recomputed only for the states on the decoded path (viterbi.cpp:140-160 reads exactly
+// those).  Same two roundings per cell in the same order, max is exact, so indices are bit-identical to the reference
+// operator for inputs without NaN.  Not the test oracle (oracle/viterbi_oracle.c restates the reference's own loop
+// structure) and not a fallback of the HIP path: torbi_amd calls it only where a caller asks for the CPU (gpu=None).
+#include "torbi_cpu.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <omp.h>
+#include <vector>
+
+namespace {
+
+constexpr int kBlock = 8;      // items that share a pass over the transition matrix
+constexpr int kLanes = 16;     // floats per accumulator (one 512-bit register; two 256-bit ones)
+constexpr float kNegInf = -std::numeric_limits<float>::infinity();
+
+inline int clamp_frames(int f, int T) { return f < 1 ? 1 : (f > T ? T : f); }
+
+// out[b][j] = obs[b][j] + max_i (post[b][i] + trans[j][i]) for next-states [j0, j1) and NB items.  The item loop is
+// innermost: every 16-float piece of a transition row is loaded once and added to NB posterior rows.
+template <int NB>
+__attribute__((target_clones("avx512f", "avx2", "default")))
+void step_rows(const float *const *post, const float *const *obs, float *const *out, const float *trans, int S, int j0,
+               int j1) {
+    const int whole = S / kLanes * kLanes;
+    for (int j = j0; j < j1; ++j) {
+        const float *tr = trans + (size_t)j * S;
+        float acc[NB][kLanes];
+        for (int b = 0; b < NB; ++b)
+            for (int l = 0; l < kLanes; ++l) acc[b][l] = kNegInf;
+        for (int i = 0; i < whole; i += kLanes) {
+            for (int b = 0; b < NB; ++b) {
+                const float *p = post[b] + i;
+#pragma omp simd
+                for (int l = 0; l < kLanes; ++l) {
+                    const float c = p[l] + tr[i + l];
+                    acc[b][l] = c > acc[b][l] ? c : acc[b][l];
+                }
+            }
+        }
+        for (int b = 0; b < NB; ++b) {
+            float m = kNegInf;
+            for (int l = 0; l < kLanes; ++l) m = acc[b][l] > m ? acc[b][l] : m;
+            for (int i = whole; i < S; ++i) {
+                const float c = post[b][i] + tr[i];
+                m = c > m ? c : m;
+            }
+            out[b][j] = obs[b][j] + m;
+        }
+    }
+}
+
+void step_rows_any(int nb, const float *const *post, const float *const *obs, float *const *out, const float *trans, int S,
+                   int j0, int j1) {
+    switch (nb) {
+        case 8: step_rows<8>(post, obs, out, trans, S, j0, j1); break;
+        case 7: step_rows<7>(post, obs, out, trans, S, j0, j1); break;
+        case 6: step_rows<6>(post, obs, out, trans, S, j0, j1); break;
+        case 5: step_rows<5>(post, obs, out, trans, S, j0, j1); break;
+        case 4: step_rows<4>(post, obs, out, trans, S, j0, j1); break;
+        case 3: step_rows<3>(post, obs, out, trans, S, j0, j1); break;
+        case 2: step_rows<2>(post, obs, out, trans, S, j0, j1); break;
+        case 1: step_rows<1>(post, obs, out, trans, S, j0, j1); break;
+        default: break;
+    }
+}
+
+// lowest index of the maximum of v[0..n)   (first-max semantics of the reference's argmax, viterbi.cpp:218)
+inline int first_argmax(const float *v, int n) {
+    int k = 0;
+    float m = v[0];
+    for (int i = 1; i < n; ++i)
+        if (v[i] > m) { m = v[i]; k = i; }
+    return k;
+}
+
+// the backpointer of state j at a timestep whose previous posterior row is `prev`: lowest i attaining
+// max_i (prev[i] + trans[j][i]); a running maximum from i = 0 replaced on strict > (viterbi.cpp:94-100)
+__attribute__((target_clones("avx512f", "avx2", "default")))
+int backpointer(const float *prev, const float *tr, int S) {
+    float m = kNegInf;
+#pragma omp simd reduction(max : m)
+    for (int i = 0; i < S; ++i) {
+        const float c = prev[i] + tr[i];
+        m = c > m ? c : m;
+    }
+    for (int i = 0; i < S; ++i)
+        if (prev[i] + tr[i] == m) return i;
+    return 0;       // every candidate is NaN-free -inf: the reference's running maximum never leaves index 0
+}
+
+void backtrace_item(const float *hist, const float *trans, int32_t *out, int f, int T, int S) {
+    int j = first_argmax(hist + (size_t)(f - 1) * S, S);
+    for (int t = f - 1; t < T; ++t) out[t] = j;              // every position t >= frames-1 (viterbi.cpp:219-221)
+    for (int t = f - 1; t >= 1; --t) {
+        j = backpointer(hist + (size_t)(t - 1) * S, trans + (size_t)j * S, S);
+        out[t - 1] = j;
+    }
+}
+
+struct Block {
+    int first, count;       // items [first, first + count)
+    int longest;            // frames of its longest item
+};
+
+// the forward pass of one block over next-states [j0, j1) of timestep t (items that have ended are left out)
+inline void block_step(const Block &blk, const int *frames, const float *obs, float *hist, const float *trans, int T, int S,
+                       int t, int j0, int j1) {
+    const float *post[kBlock], *ob[kBlock];
+    float *out[kBlock];
+    int nb = 0;
+    for (int k = 0; k < blk.count; ++k) {
+        const int b = blk.first + k;
+        if (t >= frames[b]) continue;
+        const size_t base = (size_t)b * T * S;
+        post[nb] = hist + base + (size_t)(t - 1) * S;
+        ob[nb] = obs + base + (size_t)t * S;
+        out[nb] = hist + base + (size_t)t * S;
+        ++nb;
+    }
+    step_rows_any(nb, post, ob, out, trans, S, j0, j1);
+}
+
+}  // namespace
+
+extern "C" {
+
+int torbi_cpu_abi_version(void) { return TORBI_CPU_ABI_VERSION; }
+
+int torbi_cpu_viterbi_decode(const float *observation, const int32_t *batch_frames, const float *transition,
+                             const float *initial, int32_t *indices_out, int B, int T, int S, int num_threads) {
+    if (B < 0 || T < 1 || S < 1) return TORBI_CPU_EINVAL;
+    if (B == 0) return TORBI_CPU_OK;
+    if (!observation || !batch_frames || !transition || !initial || !indices_out) return TORBI_CPU_EINVAL;
+    const int threads = num_threads > 0 ? num_threads : omp_get_max_threads();
+
+    float *hist = static_cast<float *>(std::aligned_alloc(64, ((size_t)B * T * S * sizeof(float) + 63) / 64 * 64));
+    if (!hist) return TORBI_CPU_ENOMEM;
+    std::vector<int> frames((size_t)B);
+    for (int b = 0; b < B; ++b) frames[b] = clamp_frames(batch_frames[b], T);
+
+    std::vector<Block> blocks;
+    for (int first = 0; first < B; first += kBlock) {
+        Block blk{first, std::min(kBlock, B - first), 0};
+        for (int k = 0; k < blk.count; ++k) blk.longest = std::max(blk.longest, frames[first + k]);
+        blocks.push_back(blk);
+    }
+    const int nblocks = (int)blocks.size();
+
+    // t = 0: post = obs[0] + initial                                             (viterbi.cpp:72-76)
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int b = 0; b < B; ++b) {
+        const float *o = observation + (size_t)b * T * S;
+        float *h = hist + (size_t)b * T * S;
+        for (int i = 0; i < S; ++i) h[i] = o[i] + initial[i];
+    }
+
+    if (nblocks >= threads || threads == 1) {
+        // enough item blocks to go round: a thread takes whole blocks through all their timesteps, no barriers
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+        for (int n = 0; n < nblocks; ++n) {
+            const Block &blk = blocks[n];
+            for (int t = 1; t < blk.longest; ++t)
+                block_step(blk, frames.data(), observation, hist, transition, T, S, t, 0, S);
+            for (int k = 0; k < blk.count; ++k) {
+                const int b = blk.first + k;
+                backtrace_item(hist + (size_t)b * T * S, transition, indices_out + (size_t)b * T, frames[b], T, S);
+            }
+        }
+    } else {
+        // few items: the next-states of every timestep are split among the threads (one barrier per timestep)
+        for (int n = 0; n < nblocks; ++n) {
+            const Block &blk = blocks[n];
+#pragma omp parallel num_threads(threads)
+            {
+                const int me = omp_get_thread_num(), team = omp_get_num_threads();
+                const int j0 = (int)((long long)S * me / team), j1 = (int)((long long)S * (me + 1) / team);
+                for (int t = 1; t < blk.longest; ++t) {
+                    block_step(blk, frames.data(), observation, hist, transition, T, S, t, j0, j1);
+#pragma omp barrier
+                }
+            }
+        }
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+        for (int b = 0; b < B; ++b)
+            backtrace_item(hist + (size_t)b * T * S, transition, indices_out + (size_t)b * T, frames[b], T, S);
+    }
+    std::free(hist);
+    return TORBI_CPU_OK;
+}
+
+}  // extern "C"

@@ -270,7 +270,7 @@ class FileBatches:
             worker.join(timeout=5.0)
 
 
-def open_batches(input_files, batch_size, threads=None):
+def open_batches(input_files, batch_size, threads=None, pin_memory=None):
     """A `FileBatches` over `input_files` when the direct reader applies, else None (the caller falls back to
     `data.loader`).  The first and the last file are looked at; a batch holding a file in between that does not
     fit is loaded with `torch.load` + `collate`."""
@@ -282,7 +282,7 @@ def open_batches(input_files, batch_size, threads=None):
         payload(input_files[-1])
     except UnsupportedFile:
         return None
-    return FileBatches(input_files, batch_size, threads=threads)
+    return FileBatches(input_files, batch_size, threads=threads, pin_memory=pin_memory)
 
 
 # ---- outputs: one small torch.save container per file ------------------------------------------------------------

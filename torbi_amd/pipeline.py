@@ -43,7 +43,7 @@ class DecodePipeline:
     def __init__(self, device=None, depth: int = 2, reuse_preparation: bool = True, group: int = 1,
                  path: Optional[str] = None):
         if not torch.cuda.is_available():
-            raise RuntimeError('DecodePipeline needs a HIP device; torbi_amd has no CPU path')
+            raise RuntimeError('DecodePipeline needs a HIP device; there is no CPU fallback')
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None \
             else torch.device(device)
         self.depth = max(1, int(depth))

@@ -18,7 +18,7 @@ def _require_gpu():
     if not torch.cuda.is_available():
         raise RuntimeError(
             'torbi_amd.decode needs a HIP device (PyTorch-ROCm reports none). This package has '
-            'no CPU compute path; the reference CPU implementation is only restated under '
+            'no CPU fallback (decode_cpu is the CPU operator); the reference CPU implementation is only restated under '
             'oracle/ as a test oracle.')
 
 
@@ -176,7 +176,7 @@ def decode(
             (reference torbi/csrc/viterbi.cpp:81-86)
         initial: :math:`(S)` float32 log initial distribution
         num_threads: accepted for signature compatibility (reference torbi/viterbi.py:51-52
-            sets the CPU thread count); ignored -- there is no CPU path here
+            sets the CPU thread count); ignored on the GPU (`decode_cpu` takes it)
         reuse_preparation: with `workspace`, a promise that nothing else has written to the
             workspace since the previous decode that used it; when that decode had the same shape,
             forward path and transition tensor (same storage, same version, same stream) the
@@ -252,6 +252,38 @@ def decode(
     if chosen == 'resident' and (_forced_path if path is None else path) == 'auto':
         _watch_resident(transition, workspace, B, T, S)
     return indices if home == device else indices.to(home)
+
+
+def decode_cpu(
+    observation: torch.Tensor,
+    batch_frames: torch.Tensor,
+    transition: torch.Tensor,
+    initial: torch.Tensor,
+    num_threads: Optional[int] = None,
+) -> torch.Tensor:
+    """The same operator on the host: the twin of the reference's CPU registration (torbi/csrc/viterbi.cpp:182-234,
+    237-239) behind include/torbi_cpu.h, for callers that ask for the CPU (`from_probabilities(gpu=None)`).
+
+    Arguments as `decode`, CPU tensors; `num_threads` OpenMP threads (None / 0 = the runtime's default; the reference
+    sets torch's global thread count instead, torbi/viterbi.py:51-52).  Decoded indices are bit-identical to the
+    reference CPU operator and to `decode`.  This is an explicit entry point, not a fallback: `decode` never routes here.
+    """
+    B, T, S = _check_inputs(observation, batch_frames, transition, initial)
+    for name, tensor in (('observation', observation), ('batch_frames', batch_frames), ('transition', transition),
+                         ('initial', initial)):
+        if tensor.device.type != 'cpu':
+            raise RuntimeError(f'decode_cpu takes CPU tensors; {name} is on {tensor.device}')
+    obs, frames = observation.contiguous(), batch_frames.contiguous()
+    trans, init = transition.contiguous(), initial.contiguous()
+    indices = torch.empty((B, T), dtype=torch.int32)
+    if B == 0:
+        return indices
+    code = _lib.load_cpu().torbi_cpu_viterbi_decode(obs.data_ptr(), frames.data_ptr(), trans.data_ptr(), init.data_ptr(),
+                                                    indices.data_ptr(), B, T, S, int(num_threads or 0))
+    if code != 0:
+        raise RuntimeError(f'torbi_cpu_viterbi_decode failed with code {code}'
+                           + (' (out of memory for the posterior history)' if code == -6 else ''))
+    return indices
 
 
 def _reusable(workspace, transition, shape_state, wanted) -> bool:
