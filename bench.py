@@ -460,6 +460,20 @@ class Bench:
             out['c5'] = {'value': None, 'note': f'not measured: {exc}'}
         out['chunked_long_sequence'] = self.chunked_long_sequence(trans, init)
         try:
+            # the CPU operator gpu=None callers get (include/torbi_cpu.h): 64 items of the headline batch on the host's cores
+            n = min(64, B)
+            host = [x.cpu() for x in (obs[:n], frames[:n], trans, init)]
+            t0 = time.perf_counter()
+            cpu_indices = self.torbi_amd.decode_cpu(*host)
+            sec = time.perf_counter() - t0
+            gpu_indices = self.torbi_amd.decode(obs[:n].contiguous(), frames[:n].contiguous(), trans, init).cpu()
+            out['cpu_twin'] = {'value': n * T / sec, 'unit': 'timesteps/s', 'seconds': sec, 'items': n,
+                               'threads': 'OpenMP default', 'equals_gpu_indices': bool(torch.equal(cpu_indices, gpu_indices)),
+                               'note': 'torbi_amd.decode_cpu, the host twin of the operator that gpu=None selects (not '
+                                       'the cpu_baseline, which times the reference operator)'}
+        except (OSError, RuntimeError) as exc:
+            out['cpu_twin'] = {'value': None, 'note': f'not measured: {exc}'}
+        try:
             # configs[3] from files to files (2 048 sequences: torch.save()d inputs in /dev/shm -> one output file each)
             out['c4_files_end_to_end'] = self.c4_end_to_end(2048)
         except (OSError, RuntimeError) as exc:

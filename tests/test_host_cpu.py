@@ -255,7 +255,9 @@ def test_chunk_cut_points_equal_the_reference(monkeypatch):
     monkeypatch.setattr(torbi_amd.core, 'MIN_CHUNK_SIZE', size)
     for k in range(4):
         x = torch.as_tensor(API[f'files_chunk/in{k}'])
-        assert np.array_equal(chunk_module.entropy(x).numpy(), API[f'chunk/entropy{k}'])
+        # entropy values to the last bits of the host's exp / log / sum kernels (they differ between an AVX2 and an
+        # AVX-512 build of torch's CPU ops); the cut points below are the contract and stay exact
+        np.testing.assert_allclose(chunk_module.entropy(x).numpy(), API[f'chunk/entropy{k}'], rtol=2e-5, atol=1e-12)
         assert chunk_module.split(x, size, thr) == API[f'chunk/split{k}'].tolist()
         pieces = torbi_amd.chunk(x)                     # defaults read from core at call time
         assert [p.shape[0] for p in pieces] == API[f'chunk/pieces{k}'].tolist()
