@@ -168,3 +168,28 @@ def test_gpu_requests_never_reach_the_twin(monkeypatch):
     sources = [f for f in os.listdir(os.path.join(ROOT, 'torbi_amd', 'csrc')) if f != 'torbi_cpu.cpp']
     for name in sources:
         assert 'torbi_cpu' not in open(os.path.join(ROOT, 'torbi_amd', 'csrc', name)).read(), name
+
+
+def test_command_line_without_gpu_decodes_on_the_cpu_like_upstream(tmp_path):
+    """`python -m torbi_amd --input_files ... --output_files ... --transition_file ... --log_probs` (reference
+    torbi/__main__.py:16-49; no --gpu = the CPU operator): the reference's own output files."""
+    import subprocess
+    import sys
+    count = int(API['files_plain/count'])
+    ins, outs = [], []
+    for k in range(count):
+        f = tmp_path / f'in{k}.pt'
+        torch.save(torch.as_tensor(API[f'files_plain/in{k}']), f)
+        ins.append(str(f))
+        outs.append(str(tmp_path / f'out{k}.pt'))
+    tf = tmp_path / 'transition.pt'
+    torch.save(torch.as_tensor(API['files_plain/transition']), tf)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''), CUDA_VISIBLE_DEVICES='',
+               HIP_VISIBLE_DEVICES='')
+    done = subprocess.run([sys.executable, '-m', 'torbi_amd', '--input_files', *ins, '--output_files', *outs,
+                           '--transition_file', str(tf), '--log_probs', '--num_threads', '2'],
+                          cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0, done.stderr[-2000:]
+    for k, f in enumerate(outs):
+        got = torch.load(f)
+        np.testing.assert_array_equal(got.numpy(), API[f'files_plain/out{k}'], err_msg=f'file {k}')
