@@ -1,5 +1,5 @@
 """Randomised parity stress (GPU box): random shapes, lengths, -inf densities and tie levels under the four forward
-paths against the C oracle.   python tools/stress.py [cases] [seed]"""
+paths (and the CPU twin) against the C oracle.   python tools/stress.py [cases] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -34,6 +34,11 @@ for c in range(cases):
     frames = rng.integers(1, T + 1, size=B).astype(np.int32)
     want = oracle.decode(obs.astype(np.float32), frames, trans.astype(np.float32), init.astype(np.float32), num_threads=oracle.max_threads())
     args = [torch.as_tensor(np.ascontiguousarray(x)).to(dev) for x in (obs.astype(np.float32), frames, trans.astype(np.float32), init.astype(np.float32))]
+    twin = torbi_amd.decode_cpu(*[torch.as_tensor(np.ascontiguousarray(x)) for x in (obs.astype(np.float32), frames, trans.astype(np.float32), init.astype(np.float32))],
+                                num_threads=int(rng.integers(1, 9))).numpy()
+    if not np.array_equal(twin, want):
+        bad += 1
+        print('MISMATCH', dict(B=B, T=T, S=S, kind=int(kind), path='cpu twin'), int((twin != want).sum()))
     for path in ('auto', 'dense', 'pruned', 'resident'):
         viterbi.set_forward_path(path)
         got = torbi_amd.decode(*args).cpu().numpy()
@@ -41,5 +46,5 @@ for c in range(cases):
             bad += 1
             print('MISMATCH', dict(B=B, T=T, S=S, kind=int(kind), path=path, used=viterbi.forward_path(B, S)), int((got != want).sum()))
 viterbi.set_forward_path('auto')
-print(f'{cases} cases x 4 paths, {bad} mismatches, {time.time() - t0:.0f} s')
+print(f'{cases} cases x (4 HIP paths + the CPU twin), {bad} mismatches, {time.time() - t0:.0f} s')
 sys.exit(1 if bad else 0)
