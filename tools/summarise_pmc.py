@@ -10,8 +10,13 @@ for f in glob.glob(os.path.join(out, 'pmc_*', '**', '*counter_collection.csv'), 
         pmc[name][r['Counter_Name']].append(float(r['Counter_Value']))
 summary = {k: {c: {'mean_per_dispatch': sum(v) / len(v), 'dispatches': len(v)} for c, v in cs.items()}
            for k, cs in pmc.items()}
+try:      # how many batches one forward launch of the profiled command covered (bench.py scales `traffic` by it)
+    groups = json.load(open(os.path.join(out, 'bench_under_trace.json')))['config']['launch_groups']
+    summary['_meta'] = {'batches_per_forward_launch': int(groups[0]), 'units': 'FETCH_SIZE / WRITE_SIZE in KiB per dispatch'}
+except (OSError, ValueError, KeyError, IndexError):
+    pass
 json.dump(summary, open(os.path.join(out, 'pmc.json'), 'w'), indent=1)
 for f in glob.glob(os.path.join(out, 'trace', '**', '*kernel_stats.csv'), recursive=True):
     shutil.copy(f, os.path.join(out, 'kernel_stats.csv'))
 print(json.dumps({k: {c: v['mean_per_dispatch'] for c, v in cs.items()} for k, cs in summary.items()
-                  if 'step' in k or 'resident' in k}, indent=1))
+                  if k != '_meta' and ('step' in k or 'resident' in k)}, indent=1))
