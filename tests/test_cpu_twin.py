@@ -193,3 +193,16 @@ def test_command_line_without_gpu_decodes_on_the_cpu_like_upstream(tmp_path):
     for k, f in enumerate(outs):
         got = torch.load(f)
         np.testing.assert_array_equal(got.numpy(), API[f'files_plain/out{k}'], err_msg=f'file {k}')
+
+
+def test_dispatcher_registration_serves_cpu_tensors():
+    """reference torbi/viterbi.py:53 on CPU tensors: torch.ops.torbi.viterbi_decode reaches the host twin (the CPU key
+    the reference registers at torbi/csrc/viterbi.cpp:237-239); int64 lengths are rejected like upstream."""
+    from torbi_amd import torch_op
+    op = torch_op.register()
+    obs, trans, init = synth.problem(3, 9, 20, seed=8)
+    frames = np.array([9, 4, 1], dtype=np.int32)
+    got = op(torch.as_tensor(obs), torch.as_tensor(frames), torch.as_tensor(trans), torch.as_tensor(init))
+    assert got.dtype == torch.int32 and np.array_equal(got.numpy(), oracle.decode(obs, frames, trans, init))
+    with pytest.raises(RuntimeError, match='expected scalar type'):
+        op(torch.as_tensor(obs), torch.as_tensor(frames.astype(np.int64)), torch.as_tensor(trans), torch.as_tensor(init))
