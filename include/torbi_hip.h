@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TORBI_HIP_ABI_VERSION 7
+#define TORBI_HIP_ABI_VERSION 8
 
 #define TORBI_HIP_OK 0
 #define TORBI_HIP_EINVAL (-1)      /* null pointer / non-positive dimension            */
@@ -231,6 +231,13 @@ int torbi_hip_read_posterior(const void *workspace, size_t workspace_bytes,
  * equality with the three torch ops on the same device.
  */
 int torbi_hip_epsilon_clamp(float *x, uint64_t count, int device, void *stream);
+
+/*
+ * The same for PROBABILITY inputs: out <- log(exp(log(p)) + FLT_MIN), i.e. upstream's torch.log(observation)
+ * (torbi/core.py:189-191, out of place) and the clamp behind it in one pass instead of four.  `probabilities`
+ * is not written; both pointers 16-byte aligned.
+ */
+int torbi_hip_log_epsilon_clamp(const float *probabilities, float *out, uint64_t count, int device, void *stream);
 
 /*
  * Measurement helper (not part of the reference interface): fills dst[0..count) with the

@@ -358,6 +358,33 @@ def test_fused_epsilon_clamp_is_bit_identical_to_the_torch_ops():
     assert torch.equal(got.view(torch.int32), want.view(torch.int32))
 
 
+def test_fused_log_and_epsilon_clamp_is_bit_identical_to_the_torch_ops():
+    """reference torbi/core.py:189-197 on probability inputs: log, exp_, += tiny, log_ -- one pass here, out of place
+    (the caller's probabilities are not touched), NaN for negative inputs like torch.log."""
+    dev = torch.device('cuda:0')
+    gen = torch.Generator(device=dev).manual_seed(1)
+    p = torch.rand(8_000_003, device=dev, generator=gen)
+    p[:14] = torch.tensor([0.0, 1.0, 1e-45, 1e-38, 1.1754944e-38, 1e-30, 0.5, 0.99999994, 2.0, 1e30, float('inf'),
+                           3e-39, 1e-20, 0.25], device=dev)
+    p[14] = -1.0
+    p[100:1_000_100] = torch.softmax(torch.randn(1000, 1000, device=dev, generator=gen) * 8.0, dim=-1).reshape(-1)
+    keep = p.clone()
+    want = torch.log(p)
+    torch.exp_(want)
+    want += torch.finfo(torch.float32).tiny
+    torch.log_(want)
+    got = viterbi.log_epsilon_clamp(p)
+    assert got is not None and got.data_ptr() != p.data_ptr() and torch.equal(p.view(torch.int32), keep.view(torch.int32))
+    same = (got.view(torch.int32) == want.view(torch.int32)) | (torch.isnan(got) & torch.isnan(want))
+    assert bool(same.all())
+    assert viterbi.log_epsilon_clamp(p[1:]) is None and viterbi.log_epsilon_clamp(p.double()) is None     # torch ops instead
+    # ... and through from_probabilities: device-resident probabilities decode like host ones
+    obs = torch.softmax(torch.randn(3, 17, 40, generator=torch.Generator().manual_seed(2)) * 3.0, dim=-1)
+    a = torbi_amd.from_probabilities(obs.clone(), gpu=0)
+    b = torbi_amd.from_probabilities(obs.to(dev), gpu=0)
+    assert torch.equal(a.cpu(), b.cpu())
+
+
 def test_posterior_rows_match_oracle_bitwise():
     B, T, S = 5, 23, 300
     obs, trans, init = synth.problem(B, T, S, seed=77)

@@ -16,7 +16,7 @@ SOURCE = os.path.join(_HERE, 'csrc', 'torbi_hip.hip')
 INCLUDE = os.path.join(ROOT, 'include')
 # TORBI_HIP_LIBRARY: an alternative build of the library (tools/variants_probe.py: -D experiments)
 LIBRARY = os.environ.get('TORBI_HIP_LIBRARY') or os.path.join(_HERE, 'libtorbi_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # every symbol include/torbi_hip.h declares: name -> (restype, argtypes)
 _c = ctypes
@@ -51,6 +51,7 @@ SYMBOLS = {
         _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p,
         _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint]),
     'torbi_hip_epsilon_clamp': (_c.c_int, [_c.c_void_p, _c.c_uint64, _c.c_int, _c.c_void_p]),
+    'torbi_hip_log_epsilon_clamp': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_int, _c.c_void_p]),
     'torbi_hip_read_rows': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int,
                                        _c.c_int, _c.POINTER(_c.c_int)]),
     'torbi_hip_write_files': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.POINTER(_c.c_int)]),

@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Union
 import torch
 
 from . import data as _data
-from .viterbi import decode, decode_uniform, epsilon_clamp_, _version_of
+from .viterbi import decode, decode_uniform, epsilon_clamp_, log_epsilon_clamp, _version_of
 
 # reference torbi/config/defaults.py:80,83
 BATCH_SIZE = 512
@@ -160,16 +160,24 @@ def from_probabilities(
         if _model is not None:
             _model.update(initial=initial, transition=transition, uniform=uniform)
 
-    # Ensure observation probabilities are in log space (core.py:189-191)
+    # Ensure observation probabilities are in log space (core.py:189-191).  Probabilities that already live on the
+    # compute device go through log() and the epsilon round trip below in one pass (same values, tested bitwise)
+    clamped = None
     if not log_probs:
-        observation = torch.log(observation)
+        if observation.device == device:
+            clamped = log_epsilon_clamp(observation)
+        if clamped is None:
+            observation = torch.log(observation)
     # non_blocking: a pinned host batch (data.loader) is copied asynchronously, so the copy of batch k+1
     # runs under the decode of batch k; pageable sources fall back to the synchronous path by themselves
     observation = observation.to(device=device, dtype=torch.float32, non_blocking=True)
 
     # Add epsilon for stability (core.py:193-197; in place, like the reference): exp_, += tiny,
     # log_ as ONE elementwise pass on the device
-    epsilon_clamp_(observation)
+    if clamped is not None:
+        observation = clamped
+    else:
+        epsilon_clamp_(observation)
 
     if uniform is not None:
         indices = decode_uniform(observation, batch_frames, uniform, initial)

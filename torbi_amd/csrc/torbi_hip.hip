@@ -361,6 +361,28 @@ __global__ __launch_bounds__(256) void epsilon_clamp_kernel(float *__restrict__ 
         x[e] = logf(expf(x[e]) + tiny);
 }
 
+// y = log(exp(log(p)) + tiny): the log() of probability inputs (torbi/core.py:189-191) and the epsilon clamp behind it
+// (core.py:193-197) in one pass, out of place like upstream's torch.log
+__global__ __launch_bounds__(256) void log_epsilon_clamp_kernel(const float *__restrict__ p, float *__restrict__ y,
+                                                                uint64_t count) {
+    const float tiny = 1.17549435e-38f;
+    const uint64_t n4 = count / 4;
+    const float4 *p4 = reinterpret_cast<const float4 *>(p);
+    float4 *y4 = reinterpret_cast<float4 *>(y);
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4;
+         e += (uint64_t)gridDim.x * blockDim.x) {
+        float4 v = p4[e];
+        v.x = logf(expf(logf(v.x)) + tiny);
+        v.y = logf(expf(logf(v.y)) + tiny);
+        v.z = logf(expf(logf(v.z)) + tiny);
+        v.w = logf(expf(logf(v.w)) + tiny);
+        y4[e] = v;
+    }
+    for (uint64_t e = n4 * 4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count;
+         e += (uint64_t)gridDim.x * blockDim.x)
+        y[e] = logf(expf(logf(p[e])) + tiny);
+}
+
 // deterministic synthetic scores, same function as torbi_amd/synth.py::scores
 __global__ __launch_bounds__(256) void fill_synthetic_kernel(float *__restrict__ dst,
                                                              uint64_t count, uint64_t start,
@@ -1290,6 +1312,19 @@ int torbi_hip_epsilon_clamp(float *x, uint64_t count, int device, void *stream) 
     const int grid = (int)(blocks < 16384 ? blocks : 16384);
     hipLaunchKernelGGL(epsilon_clamp_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), x,
                        count);
+    return (int)hipGetLastError();
+}
+
+int torbi_hip_log_epsilon_clamp(const float *probabilities, float *out, uint64_t count, int device, void *stream) {
+    if (count == 0) return TORBI_HIP_OK;
+    if (!probabilities || !out || ((reinterpret_cast<uintptr_t>(probabilities) | reinterpret_cast<uintptr_t>(out)) & 15))
+        return TORBI_HIP_EINVAL;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return (int)guard.err;
+    const uint64_t blocks = (count / 4 + 255) / 256 + 1;
+    const int grid = (int)(blocks < 16384 ? blocks : 16384);
+    hipLaunchKernelGGL(log_epsilon_clamp_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), probabilities,
+                       out, count);
     return (int)hipGetLastError();
 }
 

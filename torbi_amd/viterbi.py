@@ -647,6 +647,22 @@ def epsilon_clamp_(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def log_epsilon_clamp(probabilities: torch.Tensor) -> Optional[torch.Tensor]:
+    """`log(exp(log(p)) + tiny)` of a float32 HIP tensor in ONE pass, out of place: upstream's `torch.log(observation)`
+    (torbi/core.py:189-191) followed by the epsilon round trip (core.py:193-197), bit-identical to the four torch ops
+    on the same device (tested).  None for tensors the fused kernel does not take (the caller runs the torch ops)."""
+    p = probabilities
+    if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.data_ptr() % 16 == 0):
+        return None
+    out = torch.empty_like(p)
+    if out.data_ptr() % 16:
+        return None
+    stream = torch.cuda.current_stream(p.device).cuda_stream
+    _lib.check(_lib.load().torbi_hip_log_epsilon_clamp(p.data_ptr(), out.data_ptr(), p.numel(), p.device.index or 0,
+                                                       ctypes.c_void_p(stream)), 'torbi_hip_log_epsilon_clamp')
+    return out
+
+
 def fill_synthetic(shape, stream_id, seed=0, device=None, start=0):
     """Device-side torbi_amd.synth.scores(): deterministic fp32 scores in (-16, 0]."""
     _require_gpu()
