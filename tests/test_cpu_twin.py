@@ -197,12 +197,28 @@ def test_command_line_without_gpu_decodes_on_the_cpu_like_upstream(tmp_path):
 
 def test_dispatcher_registration_serves_cpu_tensors():
     """reference torbi/viterbi.py:53 on CPU tensors: torch.ops.torbi.viterbi_decode reaches the host twin (the CPU key
-    the reference registers at torbi/csrc/viterbi.cpp:237-239); int64 lengths are rejected like upstream."""
-    from torbi_amd import torch_op
-    op = torch_op.register()
-    obs, trans, init = synth.problem(3, 9, 20, seed=8)
-    frames = np.array([9, 4, 1], dtype=np.int32)
-    got = op(torch.as_tensor(obs), torch.as_tensor(frames), torch.as_tensor(trans), torch.as_tensor(init))
-    assert got.dtype == torch.int32 and np.array_equal(got.numpy(), oracle.decode(obs, frames, trans, init))
-    with pytest.raises(RuntimeError, match='expected scalar type'):
-        op(torch.as_tensor(obs), torch.as_tensor(frames.astype(np.int64)), torch.as_tensor(trans), torch.as_tensor(init))
+    the reference registers at torbi/csrc/viterbi.cpp:237-239); int64 lengths are rejected like upstream.  In a process
+    of its own: the registration claims the `torbi` operator namespace, which the reference's own library (loaded by the
+    oracle tests as a checker) claims too."""
+    import subprocess
+    import sys
+    script = """
+import numpy as np, torch
+import oracle
+from torbi_amd import synth, torch_op
+op = torch_op.register()
+obs, trans, init = synth.problem(3, 9, 20, seed=8)
+frames = np.array([9, 4, 1], dtype=np.int32)
+got = op(torch.as_tensor(obs), torch.as_tensor(frames), torch.as_tensor(trans), torch.as_tensor(init))
+assert got.dtype == torch.int32 and np.array_equal(got.numpy(), oracle.decode(obs, frames, trans, init))
+try:
+    op(torch.as_tensor(obs), torch.as_tensor(frames.astype(np.int64)), torch.as_tensor(trans), torch.as_tensor(init))
+except RuntimeError as exc:
+    assert 'expected scalar type' in str(exc)
+else:
+    raise AssertionError('int64 lengths were accepted')
+print('dispatcher ok')
+"""
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    done = subprocess.run([sys.executable, '-c', script], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0 and 'dispatcher ok' in done.stdout, done.stderr[-2000:]

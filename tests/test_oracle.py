@@ -70,9 +70,19 @@ def test_tail_is_filled_with_final_state():
     assert (got[0, 3:] == got[0, 3]).all()
 
 
+def _torbi_namespace_taken():
+    # torbi_amd.torch_op.register() (dispatcher tests) defines torbi::viterbi_decode in this process; the reference's
+    # own library defines it too and aborts when loaded second
+    import sys
+    module = sys.modules.get('torbi_amd.torch_op')
+    return module is not None and module._LIBRARY is not None
+
+
 @pytest.mark.skipif(not oracle.ref_available(), reason='oracle/_ref not built (no /root/reference)')
 @pytest.mark.parametrize('seed', range(6))
 def test_oracle_equals_reference_operator_on_fresh_inputs(seed):
+    if _torbi_namespace_taken():
+        pytest.skip('torbi::viterbi_decode was registered by torbi_amd.torch_op in this process')
     rng = np.random.default_rng(seed)
     B, T, S = int(rng.integers(1, 5)), int(rng.integers(1, 40)), int(rng.integers(1, 300))
     obs, trans, init = synth.problem(B, T, S, seed=1000 + seed)
