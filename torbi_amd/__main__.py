@@ -1,4 +1,4 @@
-"""`python -m torbi_amd`: decode observation files to index files on an MI355X.
+"""`python -m torbi_amd`: decode observation files to index files on an MI355X (--gpu N) or on the CPU.
 
 Flag names and meanings are those of the reference CLI (torbi/__main__.py:16-49) so scripts written
 for it keep working; the decode itself is torbi_amd.from_files_to_files.
@@ -22,7 +22,7 @@ FLAGS = {
                          help='(states,) initial distribution; uniform when omitted'),
     'log_probs': dict(action='store_true', help='the files already hold natural-log probabilities'),
     'gpu': dict(type=int, default=None, help='HIP device index (default: the CPU operator, like upstream)'),
-    'num_threads': dict(type=int, default=1, help='accepted for compatibility with the reference CLI; unused'),
+    'num_threads': dict(type=int, default=1, help='worker threads of the CPU operator (no --gpu); ignored on a HIP device'),
 }
 
 
