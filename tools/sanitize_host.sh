@@ -1,5 +1,5 @@
 #!/bin/bash
-# AddressSanitizer + UBSan over the host-side native code (CPU only; GPU sanitizers are not available on this pool):
+# AddressSanitizer + UBSan (and ThreadSanitizer for the reader / writer threads) over the host-side native code (CPU only; GPU sanitizers are not available on this pool):
 # the file reader / writer threads (csrc/file_rows.hpp) through tools/file_rows_check.cpp, and the CPU twin
 # (csrc/torbi_cpu.cpp) against the oracle.   bash tools/sanitize_host.sh
 set -e
@@ -8,6 +8,8 @@ W=$(mktemp -d)
 cd "$R/tools"
 g++ -O1 -g -std=c++17 -pthread -fsanitize=address,undefined -fno-omit-frame-pointer -o "$W/file_rows_check" file_rows_check.cpp
 "$W/file_rows_check"
+g++ -O1 -g -std=c++17 -pthread -fsanitize=thread -o "$W/file_rows_check_tsan" file_rows_check.cpp      # the reader / writer threads
+"$W/file_rows_check_tsan"
 rm -f /tmp/torbi_file_rows_check_*
 g++ -O1 -g -fopenmp -fPIC -shared -std=c++17 -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer \
     -I"$R/include" -o "$W/libtorbi_cpu_asan.so" "$R/torbi_amd/csrc/torbi_cpu.cpp"
