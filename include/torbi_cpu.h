@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TORBI_CPU_ABI_VERSION 1
+#define TORBI_CPU_ABI_VERSION 2
 #define TORBI_CPU_OK 0
 #define TORBI_CPU_EINVAL (-1)   /* null pointer / non-positive dimension */
 #define TORBI_CPU_ENOMEM (-6)   /* the posterior history could not be allocated */
@@ -44,6 +44,20 @@ int torbi_cpu_abi_version(void);
  */
 int torbi_cpu_viterbi_decode(const float *observation, const int32_t *batch_frames, const float *transition,
                              const float *initial, int32_t *indices_out, int B, int T, int S, int num_threads);
+
+/*
+ * Host side of the many-file job for callers WITHOUT a HIP runtime (gpu=None): the same two entry points as
+ * torbi_hip_read_rows / torbi_hip_write_files (include/torbi_hip.h; same arguments, same return codes:
+ * 0, TORBI_CPU_EINVAL, or -(100 + index) of the first item that could not be read / written in full with its errno
+ * in *error_out).  They replace torch.load + pad_sequence (torbi/data/dataset.py:18-20, collate.py:24-31) and the
+ * per-file torch.save (torbi/core.py:466-473) of the reference's loop; plain pread / write on native threads, so
+ * libtorbi_cpu.so keeps linking nothing but libgomp / libstdc++.
+ */
+#define TORBI_CPU_EIO_BASE (-100)
+int torbi_cpu_read_rows(const int *fds, const int64_t *offsets, const int64_t *bytes, void *const *rows,
+                        const int64_t *zero_bytes, int count, int threads, int *error_out);
+int torbi_cpu_write_files(const char *const *paths, const void *const *data, const int64_t *bytes, int count,
+                          int threads, int *error_out);
 
 #ifdef __cplusplus
 }

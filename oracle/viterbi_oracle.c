@@ -9,7 +9,7 @@
  *   (a) the reference's only known-answer test (tests/test_core.py:7-25 -> [1,2,2]),
  *   (b) committed golden vectors in tests/golden/ that were produced by the
  *       reference's own C++ operator (csrc/ops.cpp + csrc/viterbi.cpp compiled
- *       unchanged into oracle/_ref/, see oracle/build_ref.py and
+ *       unchanged into oracle/_ref/, see oracle/build.py and
  *       tests/golden/generate.py), and
  *   (c) when oracle/_ref/ is present, the reference operator itself on fresh
  *       seeded inputs.

@@ -1,0 +1,143 @@
+"""BASELINE configs[3] at FULL size on one GPU, and the RCCL branch of torbi_amd.distributed with one rank.
+
+The 8-GPU run of configs[3] is the driver's; what one box can establish is (a) that the whole 40 000-sequence job
+decodes correctly through the launch-group pipeline it would use on every rank, and (b) that the code a rank runs when
+torch.distributed IS initialised over "nccl" (= RCCL) -- init with a device id, all_gather_into_tensor on device
+tensors, gathers issued from the pipeline's side streams, the closing barrier of the file flow -- runs at all and
+returns the oracle's indices.  (CPU tests cover the same code over gloo with two ranks: tests/test_distributed_cpu.py.)
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import torbi_amd
+from torbi_amd import synth, viterbi
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _path_score(obs, trans, init, idx, frames):
+    """Score of each decoded path, accumulated in the recurrence's own fp32 order (viterbi.cpp:84,102)."""
+    B, T, S = obs.shape
+    ar = torch.arange(B, device=obs.device)
+    first = idx[:, 0].long()
+    score = obs[ar, 0, first] + init[first]
+    for t in range(1, T):
+        prev, cur = idx[:, t - 1].long(), idx[:, t].long()
+        score = torch.where(t < frames, obs[ar, t, cur] + (score + trans[cur, prev]), score)
+    return score
+
+
+def test_configs3_full_size_job_on_one_gpu():
+    """BASELINE configs[3], every sequence of it, on ONE GPU: 40 000 sequences of 100..900 frames over 1440 states in
+    file order = 79 batches of 512 padded to the batch maximum (reference loader.py:19-25, collate.py:24-31), decoded
+    in launch groups of 8 through DecodePipeline like from_files_to_files does (reference loop: core.py:417-457).
+
+    Too large for the oracle as a whole (20 M frames), so per batch:
+      (1) every decoded path, re-scored in the recurrence's own operation order, attains the maximum of its item's
+          final posterior row bit for bit, its last state is that row's first argmax, and the tail is filled;
+      (2) 64 sequences drawn from the whole job equal the oracle's decode of that sequence alone."""
+    dev = torch.device('cuda:0')
+    S, count, batch = 1440, 40000, 512
+    lengths = synth.lengths(count, 100, 900)
+    batches = [np.arange(k, min(k + batch, count)) for k in range(0, count, batch)]
+    assert len(batches) == 79
+    trans = viterbi.fill_synthetic((S, S), synth.STREAM_TRANSITION, device=dev)
+    init = viterbi.fill_synthetic((S,), synth.STREAM_INITIAL, device=dev)
+    group = 8
+    pool = [torch.empty((batch * 900 * S,), dtype=torch.float32, device=dev) for _ in range(group)]
+    pipe = torbi_amd.DecodePipeline(dev, depth=2, group=group)
+    pipe.reserve(batch, 900, S)
+    rng = np.random.default_rng(40000)
+    picked = set(rng.choice(count, size=64, replace=False).tolist())
+    samples = []                                    # (sequence number, observation on the host, decoded indices)
+    lib = torbi_amd._lib.load()
+    total = 0
+    for first in range(0, len(batches), group):
+        members = batches[first:first + group]
+        jobs = []
+        for k, files in enumerate(members):
+            n, longest = len(files), int(lengths[files].max())
+            # the batch's own synthetic scores (a fresh stream per batch), laid over the head of a pool buffer
+            flat = pool[k][:n * longest * S]
+            torbi_amd._lib.check(lib.torbi_hip_fill_synthetic(flat.data_ptr(), flat.numel(), 0, synth.STREAM_OBSERVATION,
+                                                              1000 + first + k, 0, None), 'fill')
+            obs = flat.view(n, longest, S)
+            frames = torch.as_tensor(lengths[files].astype(np.int32)).to(dev)
+            jobs.append((files, obs, frames, pipe.decode(obs, frames, trans, init)))
+        pipe.synchronize()
+        slot = (pipe.turn - 1) % pipe.depth                       # the slot whose scratch holds this group's history
+        for k, (files, obs, frames, idx) in enumerate(jobs):
+            n, longest = obs.shape[0], obs.shape[1]
+            post = viterbi.read_posterior(pipe.scratch[slot][k], frames, n, longest, S, path='resident')
+            assert int(idx.min()) >= 0 and int(idx.max()) < S
+            assert torch.equal(_path_score(obs, trans, init, idx, frames), post.max(dim=1).values), f'batch {first + k}'
+            last = idx[torch.arange(n, device=dev), (frames - 1).long()]
+            assert torch.equal(last.long(), post.argmax(dim=1))
+            tail = torch.arange(longest, device=dev)[None, :] >= (frames - 1)[:, None]
+            assert bool((idx == last[:, None])[tail].all())
+            total += int(frames.sum())
+            for row, seq in enumerate(files.tolist()):
+                if seq in picked:
+                    f = int(lengths[seq])
+                    samples.append((seq, obs[row, :f].cpu().numpy(), idx[row].cpu().numpy()))
+    assert total == int(lengths.sum()) and len(samples) == 64
+    trans_h, init_h = trans.cpu().numpy(), init.cpu().numpy()
+    for seq, obs_h, got in samples:
+        f = obs_h.shape[0]
+        want = oracle.decode(obs_h[None], [f], trans_h, init_h, num_threads=oracle.max_threads(), mode=1)[0]
+        np.testing.assert_array_equal(got[:f], want, err_msg=f'sequence {seq} ({f} frames)')
+
+
+def _child_env(**extra):
+    env = dict(os.environ)
+    for name in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'TORBI_FORCE_DIST', 'TORBI_HIP_FORWARD'):
+        env.pop(name, None)
+    env.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.update(extra)
+    return env
+
+
+def test_rccl_branch_with_one_rank():
+    """The code a rank runs under torch.distributed over RCCL, on the one GPU of this box: a FRESH child process
+    (nothing in it has touched the GPU before the rendezvous) with WORLD_SIZE=1 and TORBI_FORCE_DIST=1 initialises
+    the "nccl" backend and runs decode_sharded(gather=True), gather_indices(force=True) from a DecodePipeline
+    `after=` hook (side streams, single launches and launch groups) and distributed.from_files_to_files on 600
+    files; everything is compared with the oracle inside the child (tests/nccl_child.py)."""
+    run = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'nccl_child.py')], cwd=ROOT,
+                         env=_child_env(WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', TORBI_FORCE_DIST='1'),
+                         capture_output=True, text=True, timeout=1500)
+    assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
+    report = json.loads([line for line in run.stdout.splitlines() if line.startswith('{')][-1])
+    assert report['decode_sharded'] == 'ok' and report['pipeline_after_hook'] == 'ok'
+    assert report['from_files_to_files'] == '600 files ok' and report['all_gather_calls'] == 12
+
+
+def test_bench_with_the_collective_forced_prints_the_same_rate():
+    """`bench.py --gpus 1` under TORBI_FORCE_DIST=1 (nccl initialised, every batch's indices all-gathered inside the
+    timed region, barrier + all_reduce around it) must measure what it measures without: the collective path costs
+    nothing it should not.  Two child processes, 8 timed steps each."""
+    rates = {}
+    for force in ('0', '1'):
+        run = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '8', '--warmup', '8',
+                              '--no-secondary', '--no-cpu-baseline'], cwd=ROOT, env=_child_env(TORBI_FORCE_DIST=force),
+                             capture_output=True, text=True, timeout=900)
+        assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
+        line = json.loads([text for text in run.stdout.splitlines() if text.startswith('{')][-1])
+        assert line['n_gpus'] == 1 and line['steps'] == 8 and line['value'] > 0
+        rates[force] = line['value']
+    assert abs(rates['1'] - rates['0']) / rates['0'] < 0.05, rates

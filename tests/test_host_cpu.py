@@ -374,8 +374,21 @@ def test_payload_found_from_the_head_of_the_file_equals_the_central_directory_ro
     frames, states, start = fastio.payload(f)
     with open(f, 'r+b') as handle:
         handle.truncate(start + 4 * 12 * 20)
-    with pytest.raises(OSError, match='in full'):
+    # a file cut short: the head route refuses it (the tensor does not fit the file), the batch goes the reference's way
+    # and torch.load raises as it would upstream; the native reader reports a short read should a file shrink later
+    with pytest.raises(RuntimeError):
         list(fastio.FileBatches([f], 4, pin_memory=False))
+    import ctypes
+    read_rows, _ = torbi_amd._lib.host_io(False)
+    fd = os.open(f, os.O_RDONLY)
+    try:
+        row = np.zeros(50 * 12, np.float32)
+        args = [np.array([fd], np.int32), np.array([start], np.int64), np.array([4 * 12 * 50], np.int64),
+                np.array([row.ctypes.data], np.int64), np.array([0], np.int64)]
+        error = ctypes.c_int(0)
+        assert read_rows(*[a.ctypes.data for a in args], 1, 1, ctypes.byref(error)) == -100 and error.value == 0
+    finally:
+        os.close(fd)
 
 
 def test_file_batches_equal_the_reference_collate(tmp_path):
@@ -519,3 +532,64 @@ def test_command_line_takes_the_reference_flags(monkeypatch, tmp_path):
     assert seen['log_probs'] is True and seen['gpu'] == 3 and seen['num_threads'] == 4
     with pytest.raises(SystemExit):
         cli.main(['--output_files', 'x.pt'])              # --input_files is required, as upstream
+
+
+def test_cpu_route_of_the_many_file_job_never_needs_the_hip_library(tmp_path):
+    """`from_files_to_files(gpu=None)` (what `python -m torbi_amd` without --gpu runs) takes its native reader and writer
+    from libtorbi_cpu.so (include/torbi_cpu.h: torbi_cpu_read_rows / torbi_cpu_write_files): with the HIP library out
+    of reach (TORBI_HIP_LIBRARY names a file that does not exist) the job still runs through the direct file path and
+    writes the CPU operator's indices."""
+    import subprocess
+    import sys
+    files = _write_ragged_files(tmp_path, [6, 4, 7, 3, 5, 2, 9])
+    outs = [str(tmp_path / f'out{k}.pt') for k in range(len(files))]
+    code = ('import sys, torch\n'
+            f'sys.path.insert(0, {ROOT!r})\n'
+            'import torbi_amd\n'
+            'from torbi_amd import _lib, fastio\n'
+            'torbi_amd.core.BATCH_SIZE = 3\n'
+            f'files, outs = {files!r}, {outs!r}\n'
+            'assert isinstance(fastio.open_batches(files, 3, gpu=False), fastio.FileBatches)\n'
+            'torbi_amd.from_files_to_files(files, outs, log_probs=True, gpu=None, num_threads=2)\n'
+            'assert _lib._LIB is None, "the CPU route loaded libtorbi_hip.so"\n'
+            'for f, o in zip(files, outs):\n'
+            '    want = torbi_amd.from_probabilities(torch.load(f)[None], log_probs=True, gpu=None)[0]\n'
+            '    assert torch.equal(torch.load(o), want)\n'
+            'print("ok")\n')
+    env = dict(os.environ, TORBI_HIP_LIBRARY=str(tmp_path / 'no_such_library.so'))
+    run = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300, env=env)
+    assert run.returncode == 0 and run.stdout.strip().endswith('ok'), run.stderr[-2000:]
+
+
+def test_file_batches_producer_lets_go_when_the_consumer_leaves_early(tmp_path):
+    """A consumer that stops after the first batch (an exception in its loop, a break) must not leave the reader
+    thread blocked on a full queue: sentinel and exceptions are handed over with the same stop-aware loop as batches."""
+    import threading
+    import time
+    from torbi_amd import fastio
+    files = _write_ragged_files(tmp_path, [3, 4, 5, 6, 7, 8, 9, 10])
+    before = {t.name for t in threading.enumerate()}
+    t0 = time.perf_counter()
+    for _ in fastio.FileBatches(files, 1, threads=2, pin_memory=False, gpu=False):
+        break
+    assert time.perf_counter() - t0 < 3.0          # no 5 s join timeout
+    time.sleep(0.3)
+    assert 'torbi-file-batches' not in {t.name for t in threading.enumerate()} - before
+
+
+def test_head_route_rejects_a_header_that_promises_more_than_the_file_holds(tmp_path):
+    """payload_of_open_file checks the tensor the pickle describes against the file size like payload() checks it
+    against the storage record: a container cut inside its payload is UnsupportedFile (the batch then goes through
+    torch.load, which raises like the reference would), not a silent read of trailer bytes."""
+    from torbi_amd import fastio
+    f = str(tmp_path / 'x.pt')
+    torch.save(torch.rand(50, 12), f)
+    frames, states, start = fastio.payload(f)
+    with open(f, 'r+b') as handle:
+        handle.truncate(start + 4 * 12 * 20)
+    fd = os.open(f, os.O_RDONLY)
+    try:
+        with pytest.raises(fastio.UnsupportedFile):
+            fastio.payload_of_open_file(fd)
+    finally:
+        os.close(fd)

@@ -73,7 +73,7 @@ _LIB = None
 # the host twin (include/torbi_cpu.h): a separate library, g++ -fopenmp, no HIP dependency
 CPU_SOURCE = os.path.join(_HERE, 'csrc', 'torbi_cpu.cpp')
 CPU_LIBRARY = os.path.join(_HERE, 'libtorbi_cpu.so')
-CPU_ABI_VERSION = 1
+CPU_ABI_VERSION = 2
 _CPU_LIB = None
 
 
@@ -138,11 +138,11 @@ def check(code, what='torbi_hip call'):
 
 def build_cpu(force=False, verbose=False):
     """Compile csrc/torbi_cpu.cpp into torbi_amd/libtorbi_cpu.so (in-tree; the CPU operator of gpu=None callers)."""
-    deps = [CPU_SOURCE, os.path.join(INCLUDE, 'torbi_cpu.h')]
+    deps = [CPU_SOURCE, os.path.join(INCLUDE, 'torbi_cpu.h'), os.path.join(os.path.dirname(CPU_SOURCE), 'file_rows.hpp')]
     if not force and os.path.exists(CPU_LIBRARY) and os.path.getmtime(CPU_LIBRARY) >= max(os.path.getmtime(d) for d in deps):
         return CPU_LIBRARY
     cxx = os.environ.get('CXX') or shutil.which('g++') or 'g++'
-    cmd = [cxx, '-O3', '-std=c++17', '-fopenmp', '-fPIC', '-shared', '-ffp-contract=off', f'-I{INCLUDE}', '-o',
+    cmd = [cxx, '-O3', '-std=c++17', '-fopenmp', '-pthread', '-fPIC', '-shared', '-ffp-contract=off', f'-I{INCLUDE}', '-o',
            CPU_LIBRARY + '.tmp', CPU_SOURCE]
     if verbose:
         print(' '.join(cmd))
@@ -165,7 +165,30 @@ def load_cpu():
     lib.torbi_cpu_abi_version.argtypes = []
     lib.torbi_cpu_viterbi_decode.restype = _c.c_int
     lib.torbi_cpu_viterbi_decode.argtypes = [_c.c_void_p] * 5 + [_c.c_int] * 4
+    # host side of the many-file job (same signatures as torbi_hip_read_rows / torbi_hip_write_files)
+    lib.torbi_cpu_read_rows.restype = _c.c_int
+    lib.torbi_cpu_read_rows.argtypes = SYMBOLS['torbi_hip_read_rows'][1]
+    lib.torbi_cpu_write_files.restype = _c.c_int
+    lib.torbi_cpu_write_files.argtypes = SYMBOLS['torbi_hip_write_files'][1]
     if lib.torbi_cpu_abi_version() != CPU_ABI_VERSION:
         raise RuntimeError('libtorbi_cpu.so ABI mismatch: rebuild')
     _CPU_LIB = lib
     return lib
+
+
+def host_io(gpu: bool):
+    """(read_rows, write_files) of the many-file job's host side.  A GPU job takes them from libtorbi_hip.so (the
+    library it needs anyway; include/torbi_hip.h), a CPU job (`gpu=None`) from libtorbi_cpu.so -- the same host code
+    (csrc/file_rows.hpp) behind include/torbi_cpu.h, so the CPU route never needs the HIP runtime."""
+    if gpu:
+        lib = load()
+        return lib.torbi_hip_read_rows, lib.torbi_hip_write_files
+    lib = load_cpu()
+    return lib.torbi_cpu_read_rows, lib.torbi_cpu_write_files
+
+
+def check_io(code, what):
+    """Return codes of the host I/O entry points (both libraries use the same numbering)."""
+    if code != 0:
+        raise TorbiHipError(f'{what} failed with code {code}: '
+                            + ('invalid argument' if code == -1 else 'an item could not be read or written in full'))

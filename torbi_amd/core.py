@@ -274,7 +274,7 @@ def from_files_to_files(
     if DIRECT_FILE_IO:
         from . import fastio
         batches = fastio.open_batches(input_files, BATCH_SIZE, threads=num_workers,
-                                      pin_memory=gpu is not None and torch.cuda.is_available())
+                                      pin_memory=gpu is not None and torch.cuda.is_available(), gpu=gpu is not None)
     from_dataloader(
         dataloader=batches if batches is not None else _data.loader(input_files, num_workers=num_workers),
         output_files=mapping,
@@ -322,7 +322,9 @@ def from_dataloader(
 
     if DIRECT_FILE_IO:
         # same file contents as save / save_masked (core.py:466-473), written from a prebuilt container image
-        from .fastio import save_indices, save_index_rows as save_rows
+        import functools
+        from .fastio import save_indices, save_index_rows
+        save_rows = functools.partial(save_index_rows, gpu=gpu is not None)
 
         def store(tensor, file, length):
             save_indices(tensor if length is None else tensor[..., :length], file)

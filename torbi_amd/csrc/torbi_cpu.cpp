@@ -10,8 +10,11 @@
 // operator for inputs without NaN.  Not the test oracle (oracle/viterbi_oracle.c restates the reference's own loop
 // structure) and not a fallback of the HIP path: torbi_amd calls it only where a caller asks for the CPU (gpu=None).
 #include "torbi_cpu.h"
+#include "file_rows.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -68,14 +71,6 @@ void step_rows(const float *const *post, const float *const *obs, float *const *
 void step_rows_any(int nb, const float *const *post, const float *const *obs, float *const *out, const float *trans, int S,
                    int j0, int j1) {
     switch (nb) {
-        case 16: step_rows<16>(post, obs, out, trans, S, j0, j1); break;
-        case 15: step_rows<15>(post, obs, out, trans, S, j0, j1); break;
-        case 14: step_rows<14>(post, obs, out, trans, S, j0, j1); break;
-        case 13: step_rows<13>(post, obs, out, trans, S, j0, j1); break;
-        case 12: step_rows<12>(post, obs, out, trans, S, j0, j1); break;
-        case 11: step_rows<11>(post, obs, out, trans, S, j0, j1); break;
-        case 10: step_rows<10>(post, obs, out, trans, S, j0, j1); break;
-        case 9: step_rows<9>(post, obs, out, trans, S, j0, j1); break;
         case 8: step_rows<8>(post, obs, out, trans, S, j0, j1); break;
         case 7: step_rows<7>(post, obs, out, trans, S, j0, j1); break;
         case 6: step_rows<6>(post, obs, out, trans, S, j0, j1); break;
@@ -120,6 +115,23 @@ void backtrace_item(const float *hist, const float *trans, int32_t *out, int f, 
         out[t - 1] = j;
     }
 }
+
+// barrier of one team of threads inside a flat parallel region (an `omp barrier` would stop every team)
+struct alignas(64) TeamBarrier {
+    std::atomic<unsigned> arrived{0}, phase{0};
+    void wait(int size, unsigned &my_phase) {
+        if (size <= 1) return;
+        const unsigned next = ++my_phase;
+        if (arrived.fetch_add(1u, std::memory_order_acq_rel) + 1u == (unsigned)size) {
+            arrived.store(0u, std::memory_order_relaxed);
+            phase.store(next, std::memory_order_release);
+        } else {
+            int spins = 0;
+            while (phase.load(std::memory_order_acquire) != next)
+                if (++spins > 4096) { std::this_thread::yield(); spins = 0; }
+        }
+    }
+};
 
 struct Block {
     int first, count;       // items [first, first + count)
@@ -196,30 +208,57 @@ int torbi_cpu_viterbi_decode(const float *observation, const int32_t *batch_fram
             }
         }
     } else {
-        const int levels = omp_get_max_active_levels();
-        omp_set_max_active_levels(std::max(levels, 2));
-#pragma omp parallel for num_threads(teams) schedule(dynamic, 1)
-        for (int n = 0; n < nblocks; ++n) {
-            const Block &blk = blocks[n];
-#pragma omp parallel num_threads(team_size)
-            {
-                const int me = omp_get_thread_num(), team = omp_get_num_threads();
-                const int j0 = (int)((long long)S * me / team), j1 = (int)((long long)S * (me + 1) / team);
-                for (int t = 1; t < blk.longest; ++t) {
-                    block_step(blk, frames.data(), observation, hist, transition, T, S, t, j0, j1);
-#pragma omp barrier
-                }
-#pragma omp for schedule(dynamic, 1)
-                for (int k = 0; k < blk.count; ++k) {
-                    const int b = blk.first + k;
-                    backtrace_item(hist + (size_t)b * T * S, transition, indices_out + (size_t)b * T, frames[b], T, S);
+        // ONE flat parallel region (nothing process-wide is touched: no nested parallelism, no omp_set_* call): thread id ->
+        // (team, place in the team); a team takes item blocks team, team + teams, ... and meets at its own barrier
+        std::vector<TeamBarrier> barriers((size_t)teams);
+#pragma omp parallel num_threads(teams * team_size)
+        {
+            const int nth = omp_get_num_threads(), id = omp_get_thread_num();
+            const int nteams = std::min(teams, nth), size = nth / nteams;      // what the runtime actually gave us
+            const int team = id / size, me = id % size;
+            if (team < nteams) {
+                TeamBarrier &bar = barriers[(size_t)team];
+                unsigned phase = 0;
+                const int j0 = (int)((long long)S * me / size), j1 = (int)((long long)S * (me + 1) / size);
+                for (int n = team; n < nblocks; n += nteams) {
+                    const Block &blk = blocks[n];
+                    for (int t = 1; t < blk.longest; ++t) {
+                        block_step(blk, frames.data(), observation, hist, transition, T, S, t, j0, j1);
+                        bar.wait(size, phase);
+                    }
+                    for (int k = me; k < blk.count; k += size) {
+                        const int b = blk.first + k;
+                        backtrace_item(hist + (size_t)b * T * S, transition, indices_out + (size_t)b * T, frames[b], T, S);
+                    }
                 }
             }
         }
-        omp_set_max_active_levels(levels);
     }
     std::free(hist);
     return TORBI_CPU_OK;
+}
+
+int torbi_cpu_read_rows(const int *fds, const int64_t *offsets, const int64_t *bytes, void *const *rows,
+                        const int64_t *zero_bytes, int count, int threads, int *error_out) {
+    if (count < 0 || threads < 1) return TORBI_CPU_EINVAL;
+    if (count == 0) return TORBI_CPU_OK;
+    if (!fds || !offsets || !bytes || !rows || !zero_bytes) return TORBI_CPU_EINVAL;
+    for (int k = 0; k < count; ++k)
+        if (fds[k] < 0 || offsets[k] < 0 || bytes[k] < 0 || zero_bytes[k] < 0 || (!rows[k] && bytes[k] + zero_bytes[k] > 0))
+            return TORBI_CPU_EINVAL;
+    const int rc = filerows::read_rows(fds, offsets, bytes, rows, zero_bytes, count, threads, error_out);
+    return rc == 0 ? TORBI_CPU_OK : TORBI_CPU_EIO_BASE + rc + 1;      // -(100 + index)
+}
+
+int torbi_cpu_write_files(const char *const *paths, const void *const *data, const int64_t *bytes, int count, int threads,
+                          int *error_out) {
+    if (count < 0 || threads < 1) return TORBI_CPU_EINVAL;
+    if (count == 0) return TORBI_CPU_OK;
+    if (!paths || !data || !bytes) return TORBI_CPU_EINVAL;
+    for (int k = 0; k < count; ++k)
+        if (!paths[k] || bytes[k] < 0 || (!data[k] && bytes[k] > 0)) return TORBI_CPU_EINVAL;
+    const int rc = filerows::write_files(paths, data, bytes, count, threads, error_out);
+    return rc == 0 ? TORBI_CPU_OK : TORBI_CPU_EIO_BASE + rc + 1;      // -(100 + index)
 }
 
 }  // extern "C"

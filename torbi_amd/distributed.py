@@ -53,13 +53,17 @@ def shard_bounds(count: int, size: int, rank: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_indices(local: torch.Tensor, count: int, group=None, force: bool = False) -> torch.Tensor:
+def gather_indices(local: torch.Tensor, count: int, group=None, force: Optional[bool] = None) -> torch.Tensor:
     """All-gather the per-rank (n_r, T) int32 index blocks into the full (count, T) tensor.
 
     Shards may differ by one row, so blocks are padded to the largest shard for the
-    collective and trimmed afterwards.
+    collective and trimmed afterwards.  With one rank there is nothing to gather and `local` is returned as it is,
+    unless `force` (default: the environment's TORBI_FORCE_DIST=1, the switch `init_from_env` also reads) asks for the
+    collective anyway -- that is how the RCCL branch is exercised on a single GPU.
     """
     rank, size = world(group)
+    if force is None:
+        force = os.environ.get('TORBI_FORCE_DIST') == '1'
     if size == 1 and not (force and dist.is_available() and dist.is_initialized()):
         return local
     frames = local.shape[1]

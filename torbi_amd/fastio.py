@@ -134,7 +134,13 @@ def payload_of_open_file(fd):
     entry = members.get(b'data/' + key.encode())
     if entry is None:
         raise LookupError
-    return shape[0], shape[1], entry[0] + 4 * offset        # (a file cut short shows up as a failed read)
+    # the storage record's size is only in the descriptor behind it; what can be checked from here is that the tensor
+    # the pickle describes fits between the payload's start and the end of the file (torch.load would raise on a
+    # header that promises more than the record holds; a file cut short also shows up as a failed read)
+    start = entry[0] + 4 * offset
+    if start + 4 * shape[0] * shape[1] > os.fstat(fd).st_size:
+        raise UnsupportedFile('payload shorter than the tensor')
+    return shape[0], shape[1], start
 
 
 def payload(path):
@@ -181,7 +187,9 @@ class FileBatches:
     `batch_size` files; the observation is a (rows, longest, states) float32 tensor in pinned memory when a HIP
     device is present.  `threads` native readers fill a batch; `ahead` batches are prepared ahead of the consumer."""
 
-    def __init__(self, input_files, batch_size, threads=None, pin_memory=None, ahead=1):
+    def __init__(self, input_files, batch_size, threads=None, pin_memory=None, ahead=1, gpu=None):
+        # which library reads the rows: libtorbi_hip.so for a GPU job, libtorbi_cpu.so for gpu=None (no HIP runtime needed)
+        self.gpu = torch.cuda.is_available() if gpu is None else bool(gpu)
         self.input_files = list(input_files)
         self.batch_size = int(batch_size)
         self.threads = max(1, int(threads if threads else min(32, (os.cpu_count() or 4))))
@@ -223,12 +231,12 @@ class FileBatches:
             rows = observation.data_ptr() + row_bytes * np.arange(count, dtype=np.int64)     # row addresses
             zeros = row_bytes - sizes                                      # collate's zero padding (collate.py:24-31)
             error = ctypes.c_int(0)
-            code = _lib.load().torbi_hip_read_rows(
-                fds.ctypes.data, offsets.ctypes.data, sizes.ctypes.data, rows.ctypes.data, zeros.ctypes.data,
-                count, min(self.threads, count), ctypes.byref(error))
+            read_rows, _ = _lib.host_io(self.gpu)
+            code = read_rows(fds.ctypes.data, offsets.ctypes.data, sizes.ctypes.data, rows.ctypes.data, zeros.ctypes.data,
+                             count, min(self.threads, count), ctypes.byref(error))
             if code <= -100:
                 raise OSError(error.value, f'could not read {files[-(code + 100)]} in full')
-            _lib.check(code, 'torbi_hip_read_rows')
+            _lib.check_io(code, 'read_rows')
             return observation, torch.from_numpy(frames.copy()), [1] * count, tuple(files)
         finally:
             for entry in opened:
@@ -239,21 +247,24 @@ class FileBatches:
         ready = self._ready = queue.Queue(maxsize=self.ahead)
         stop = threading.Event()
 
+        def hand_over(item):
+            # never blocks past `stop`: a consumer that left early (an exception in its loop, a break) is not waited for
+            while not stop.is_set():
+                try:
+                    ready.put(item, timeout=0.1)
+                    return
+                except queue.Full:
+                    continue
+
         def produce():
             try:
                 for files in groups:
                     if stop.is_set():
                         return
-                    item = self._assemble(files)
-                    while not stop.is_set():
-                        try:
-                            ready.put(item, timeout=0.1)
-                            break
-                        except queue.Full:
-                            continue
-                ready.put(None)
+                    hand_over(self._assemble(files))
+                hand_over(None)
             except BaseException as exc:      # surfaces in the consumer
-                ready.put(exc)
+                hand_over(exc)
 
         worker = threading.Thread(target=produce, name='torbi-file-batches', daemon=True)
         worker.start()
@@ -270,7 +281,7 @@ class FileBatches:
             worker.join(timeout=5.0)
 
 
-def open_batches(input_files, batch_size, threads=None, pin_memory=None):
+def open_batches(input_files, batch_size, threads=None, pin_memory=None, gpu=None):
     """A `FileBatches` over `input_files` when the direct reader applies, else None (the caller falls back to
     `data.loader`).  The first and the last file are looked at; a batch holding a file in between that does not
     fit is loaded with `torch.load` + `collate`."""
@@ -282,7 +293,11 @@ def open_batches(input_files, batch_size, threads=None, pin_memory=None):
         payload(input_files[-1])
     except UnsupportedFile:
         return None
-    return FileBatches(input_files, batch_size, threads=threads, pin_memory=pin_memory)
+    try:
+        _lib.host_io(torch.cuda.is_available() if gpu is None else bool(gpu))
+    except (OSError, AttributeError):
+        return None            # the native reader's library is not built: the reference's loader does the job
+    return FileBatches(input_files, batch_size, threads=threads, pin_memory=pin_memory, gpu=gpu)
 
 
 # ---- outputs: one small torch.save container per file ------------------------------------------------------------
@@ -379,7 +394,7 @@ def _filled_image(indices):
     return out
 
 
-def save_index_rows(rows, files, lengths, threads=8):
+def save_index_rows(rows, files, lengths, threads=8, gpu=None):
     """`save_indices(rows[k][:lengths[k]], files[k])` for a whole batch: the containers are put together here and
     written by native threads in one call (`torbi_hip_write_files`)."""
     images, names = [], []
@@ -399,8 +414,8 @@ def save_index_rows(rows, files, lengths, threads=8):
     data = (ctypes.c_void_p * count)(*[ctypes.addressof(buffer) for buffer in buffers])
     sizes = np.array([len(image) for image in images], dtype=np.int64)
     error = ctypes.c_int(0)
-    code = _lib.load().torbi_hip_write_files(paths, data, sizes.ctypes.data, count, max(1, min(int(threads), count)),
-                                             ctypes.byref(error))
+    _, write_files = _lib.host_io(torch.cuda.is_available() if gpu is None else bool(gpu))
+    code = write_files(paths, data, sizes.ctypes.data, count, max(1, min(int(threads), count)), ctypes.byref(error))
     if code <= -100:
         raise OSError(error.value, f'could not write {os.fsdecode(names[-(code + 100)])}')
-    _lib.check(code, 'torbi_hip_write_files')
+    _lib.check_io(code, 'write_files')

@@ -56,13 +56,22 @@ class DecodePipeline:
         # scratch[slot][k]: workspace of the k-th batch of the group that runs on `slot`
         self.scratch: List[List[Optional[torch.Tensor]]] = [[None] * self.group for _ in range(self.depth)]
         self.pending: List[tuple] = []           # (indices, completion event, inputs kept alive until then)
+        self.last_done: List[Optional[torch.cuda.Event]] = [None] * self.depth    # completion of a slot's latest launch
+        self.retired: List[tuple] = []           # (outgrown scratch buffer, the event it may still be in use until)
         self.waiting: List[tuple] = []          # batches collected for the next group
         self.turn = 0
 
     def _scratch(self, slot, k, nbytes):
+        """Scratch buffer k of `slot`, at least `nbytes`: allocated on (and only ever used on) the slot's side stream, so
+        the caching allocator's stream bookkeeping is right; a buffer that is outgrown stays alive until the slot's
+        latest launch -- which may still be reading its history -- has completed."""
         buf = self.scratch[slot][k]
         if buf is None or buf.numel() < nbytes:
-            buf = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+            if buf is not None and self.last_done[slot] is not None:
+                self.retired.append((buf, self.last_done[slot]))
+            self.retired = [entry for entry in self.retired if not entry[1].query()]
+            with torch.cuda.stream(self.streams[slot]):
+                buf = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
             self.scratch[slot][k] = buf
         return buf
 
@@ -134,6 +143,7 @@ class DecodePipeline:
                     results.append(indices)
             done = torch.cuda.Event()
             done.record(stream)
+            self.last_done[slot] = done
         # Inputs and indices were allocated on the caller's stream and are used on this one: `pending` holds them until
         # `done` has completed, so the allocator cannot hand their memory out early.  (record_stream() would do the
         # same by deferring every free behind an event; on a job that frees a batch per decode that cost the
