@@ -30,9 +30,10 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz lane-instructions/s
 METRIC = 'timesteps decoded/sec, 1440 states batch=512'
-KERNELS = {'resident': 'resident::resident_forward_kernel', 'pruned': 'pruned::step_pruned_kernel',
+KERNELS = {'resident': 'resident::resident_forward_kernel', 'cluster': 'resident::resident_forward_kernel',
+           'pruned': 'pruned::step_pruned_kernel',
            'dense': 'dense::step_dense_kernel', 'generic': 'step_rows', 'rows': 'rowscan::step_rows_sorted_kernel'}
-ROUTES = {0: 'generic', 1: 'dense', 2: 'pruned', 3: 'resident', 4: 'rows'}
+ROUTES = {0: 'generic', 1: 'dense', 2: 'pruned', 3: 'resident', 4: 'rows', 5: 'cluster'}
 
 
 def parse_args(argv=None):
@@ -56,9 +57,13 @@ def parse_args(argv=None):
     ap.add_argument('--reuse-preparation', action='store_true',
                     help='let consecutive decodes share the per-transition preparation (sorted rows / packed panels) '
                          'as a serving loop would; off by default: every timed launch group does all of its work')
-    ap.add_argument('--forward', choices=['auto', 'dense', 'pruned', 'resident'], default='auto',
+    ap.add_argument('--forward', choices=['auto', 'dense', 'pruned', 'resident', 'cluster'], default='auto',
                     help='forward-recurrence path (include/torbi_hip.h); every path gives identical indices')
     ap.add_argument('--pipeline', type=int, default=2, help='HIP streams the launch groups alternate between')
+    ap.add_argument('--groups', choices=['balanced', 'full'], default='full',
+                    help='how --steps batches are cut into launch groups: balanced = equally full groups (20 -> 7 + 7 + 6), '
+                         'full = as many full groups as possible, the rest as one smaller group (20 -> 8 + 8 + 4; a group below '
+                         'half the chip runs in the cluster form)')
     ap.add_argument('--group', type=int, default=8,
                     help='batches decoded per launch group (1 = every batch on its own: per-timestep launches)')
     ap.add_argument('--transition', choices=['dense', 'banded', 'uniform'], default='dense',
@@ -235,6 +240,8 @@ class Bench:
         (20 steps, group 8 -> 7 + 7 + 6 rather than 8 + 8 + 4: a half-empty last group costs a full one's time)."""
         if group <= 1:
             return [1] * steps
+        if getattr(self.args, 'groups', 'balanced') == 'full':
+            return [group] * (steps // group) + ([steps % group] if steps % group else [])
         n = max(1, math.ceil(steps / group))
         base, extra = divmod(steps, n)
         return [base + (1 if k < extra else 0) for k in range(n)]
@@ -334,7 +341,7 @@ class Bench:
         launches = max(int(prof[2]), 1)
         covered = max(int(prof[5]), 1)                     # batches one forward launch (chain) covers
         kernel_s = (fwd_ms - prep_ms) * 1e-3 / launches
-        timesteps_per_launch = float(covered) * B * (T if route == 'resident' else 1)
+        timesteps_per_launch = float(covered) * B * (T if route in ('resident', 'cluster') else 1)
         bytes_per_launch = timesteps_per_launch * algorithmic_bytes_per_timestep(S)
         achieved = bytes_per_launch / kernel_s / 1e9
         cells_per_launch = timesteps_per_launch * S * S
@@ -361,7 +368,7 @@ class Bench:
                             f'4 MB L2s) and 4-byte strided observation reads'
             if traffic_file else 'no PMC summary for this kernel committed',
             'kernel': KERNELS[route] + (f' (ONE launch = the whole forward pass of {covered} batches)'
-                                        if route == 'resident' else ' (one launch = one timestep of one batch)'),
+                                        if route in ('resident', 'cluster') else ' (one launch = one timestep of one batch)'),
             'launch_us': kernel_s * 1e6, 'launches_per_group': launches, 'batches_per_launch': covered,
             'algorithmic_bytes_per_launch': bytes_per_launch,
             'note': 'the (max,+) recurrence holds S/4 = 360 cells per algorithmic byte: kernels that evaluate every cell '

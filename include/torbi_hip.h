@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TORBI_HIP_ABI_VERSION 8
+#define TORBI_HIP_ABI_VERSION 9
 
 #define TORBI_HIP_OK 0
 #define TORBI_HIP_EINVAL (-1)      /* null pointer / non-positive dimension            */
@@ -104,6 +104,7 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
 #define TORBI_HIP_FORWARD_DENSE 1
 #define TORBI_HIP_FORWARD_PRUNED 2
 #define TORBI_HIP_FORWARD_RESIDENT 3
+#define TORBI_HIP_FORWARD_CLUSTER 4
 #define TORBI_HIP_PATH_FLAG(path) (((unsigned)(path) + 1u) << 4)   /* bits 4..6 of `flags`; 0 = process default */
 int torbi_hip_set_forward_path(int path);
 int torbi_hip_forward_path(int B, int S);

@@ -15,12 +15,14 @@ from conftest import SMALL_NAMES, LARGE_NAMES
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=['auto', 'dense', 'pruned', 'resident'])
+@pytest.fixture(autouse=True, params=['auto', 'dense', 'pruned', 'resident', 'cluster'])
 def forward(request):
-    """Every test runs four times: with the automatic path choice (pruned, or dense for narrow-band
+    """Every test runs five times: with the automatic path choice (pruned, or dense for narrow-band
     matrices), with the dense (max,+) GEMM forced, with the exact pruned pass forced wherever it is
-    supported, and with the time-resident kernel forced wherever it is supported (64 <= S <= 2048, ANY
-    batch size).  Small batches take the generic kernels on the first three."""
+    supported, with the time-resident kernel forced wherever it is supported (64 <= S <= 2048, ANY
+    batch size) -- whole 16-item tiles per workgroup -- and with its cluster form (the next-states of a tile
+    split over up to 16 workgroups that exchange their slices of every posterior row inside the launch).
+    Small batches take the generic kernels on the first three."""
     viterbi.set_forward_path(request.param)
     yield request.param
     viterbi.set_forward_path('auto')
@@ -137,20 +139,24 @@ def test_dense_path_edge_shapes(shape):
 
 
 def test_forward_path_selection(forward):
-    resident = forward == 'resident'
-    assert viterbi.forward_path(4, 1440) == {'resident': 'resident', 'pruned': 'rows'}.get(forward, 'generic')
-    assert viterbi.forward_path(16, 1440) == {'resident': 'resident', 'dense': 'generic'}.get(forward, 'rows')
+    assert viterbi.forward_path(4, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'pruned': 'rows'}.get(forward, 'generic')
+    assert viterbi.forward_path(16, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'dense': 'generic'}.get(forward, 'rows')
     assert viterbi.forward_path(2, 4096) == ('generic' if forward == 'dense' else 'rows')
     assert viterbi.forward_path(4, 40) == 'generic'                # S < 64: no value-only path
     assert viterbi.forward_path(4, 4100) == 'generic'
     assert viterbi.forward_path(128, 4096) == ('dense' if forward == 'dense' else 'pruned')   # 8-item tiles
     assert viterbi.forward_path(128, 4100) == 'dense'              # posterior tile does not fit the LDS
-    assert viterbi.forward_path(512, 1440) == {'dense': 'dense', 'resident': 'resident'}.get(forward, 'pruned')
-    assert viterbi.forward_path(64, 130) == {'dense': 'dense', 'resident': 'resident'}.get(forward, 'pruned')
-    # AUTO: a batch that gives at least half the compute units a 16-item workgroup is decoded time-resident
-    big = 8 * viterbi.compute_units('cuda:0')
-    assert viterbi.forward_path(big, 1440, path='auto') == 'resident'
-    assert viterbi.forward_path(big, 2052, path='auto') == 'pruned'
+    assert viterbi.forward_path(512, 1440) == {'dense': 'dense', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'pruned')
+    assert viterbi.forward_path(64, 130) == {'dense': 'dense', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'pruned')
+    # AUTO: a batch that gives at least half the compute units a 16-item workgroup is decoded time-resident with whole
+    # tiles per workgroup, one that is too large for one round of the per-timestep kernel in clusters
+    cus = viterbi.compute_units('cuda:0')
+    assert viterbi.forward_path(16 * cus, 1440, path='auto') == 'resident'
+    assert viterbi.forward_path(16 * cus, 1440, path='cluster') == 'resident'     # nothing to split
+    assert viterbi.forward_path(8 * cus, 1440, path='auto') == 'cluster'          # half the chip: two workgroups per tile
+    assert viterbi.forward_path(8 * cus, 2052, path='auto') == 'pruned'
+    assert viterbi.forward_path(3 * cus, 1440, path='auto') == 'cluster'
+    assert viterbi.forward_path(2 * cus, 1440, path='auto') == 'pruned'
     # the path travels with the call: naming one never changes the process default
     assert viterbi.forward_path(512, 1440, path='dense') == 'dense'
     assert viterbi.workspace_bytes(512, 500, 1440) >= 512 * 500 * 1440 * 4
@@ -638,8 +644,9 @@ def test_decode_batches_auto_goes_resident_when_the_group_fills_the_chip(forward
     assert int(prof[3]) == 3 and int(prof[5]) == 8 and int(prof[2]) == 1
     for k in range(8):
         np.testing.assert_array_equal(got[k].cpu().numpy(), want[k])
+    # a group that fills less than half the chip: still ONE launch, tiles split over clusters of workgroups
     got = viterbi.decode_batches(obs_list[:2], frame_list[:2], d_trans, d_init, path='auto', _profile=prof)
-    assert int(prof[3]) == 2 and int(prof[5]) == 1
+    assert int(prof[3]) == 5 and int(prof[5]) == 2 and int(prof[2]) == 1
     for k in range(2):
         np.testing.assert_array_equal(got[k].cpu().numpy(), want[k])
     # a narrow band goes to the dense kernel one batch at a time, to the time-resident kernel as a full group
@@ -653,6 +660,10 @@ def test_decode_batches_auto_goes_resident_when_the_group_fills_the_chip(forward
         np.testing.assert_array_equal(got[k].cpu().numpy(), ref)
     viterbi.decode_batches(obs_list[:1], frame_list[:1], d_band, d_init, path='auto', _profile=prof)
     assert int(prof[3]) == 1
+    got = viterbi.decode_batches(obs_list[:3], frame_list[:3], d_band, d_init, path='auto', _profile=prof)
+    assert int(prof[3]) == 5 and int(prof[5]) == 3
+    ref = oracle.decode(obs_list[2].cpu().numpy(), frame_list[2].cpu().numpy(), band, init, num_threads=oracle.max_threads())
+    np.testing.assert_array_equal(got[2].cpu().numpy(), ref)
 
 
 @pytest.mark.parametrize('B', [40, 270])

@@ -180,9 +180,15 @@ def test_auto_path_choice_reads_the_transition_structure_once_per_version():
         assert viterbi._resolve_path(dense, dense, 64, S, 'cuda:0', None, 4, False) == ('dense', None)
         assert viterbi._resolve_path(dense, dense, 64, S, 'cuda:0', 'auto', 4, False) == ('pruned', None)
         assert viterbi._resolve_path(dense, dense, 64, S, 'cuda:0', 'resident', 4, False) == ('resident', None)
-        # enough 16-item tiles to give half the compute units a workgroup: AUTO decodes time-resident
-        assert viterbi._resolve_path(dense, dense, 2048, S, 'cuda:0', 'auto', 128, False) == ('resident', None)
-        assert viterbi._resolve_path(band, band, 2048, S, 'cuda:0', 'auto', 128, False) == ('resident', None)
+        # enough 16-item tiles to give half the compute units a workgroup: AUTO decodes time-resident ('cluster' = the
+        # library picks the form: whole tiles per workgroup here, clusters of workgroups per tile below half the chip)
+        assert viterbi._resolve_path(dense, dense, 2048, S, 'cuda:0', 'auto', 128, False) == ('cluster', None)
+        assert viterbi._resolve_path(band, band, 2048, S, 'cuda:0', 'auto', 128, False) == ('cluster', None)
+        # a launch group below half the chip, one batch beyond one round of the per-timestep kernel: clusters; one
+        # 512-item batch: the per-timestep pruned kernel
+        assert viterbi._resolve_path(dense, dense, 512, S, 'cuda:0', 'auto', 64, False, count=2) == ('cluster', None)
+        assert viterbi._resolve_path(dense, dense, 768, S, 'cuda:0', 'auto', 48, False) == ('cluster', None)
+        assert viterbi._resolve_path(dense, dense, 512, S, 'cuda:0', 'auto', 32, False) == ('pruned', None)
     finally:
         viterbi._forced_path = old
         viterbi._compute_units.clear()
@@ -510,7 +516,7 @@ def test_bench_starts_its_own_ranks_and_dry_runs_without_a_gpu():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['dry_run'] is True and line['value'] is None
-    assert line['steps'] == 20 and line['warmup'] == 5 and line['config']['launch_groups'] == [7, 7, 6]
+    assert line['steps'] == 20 and line['warmup'] == 5 and line['config']['launch_groups'] == [8, 8, 4]
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', 'c4', '--files', '3000'],
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -28,12 +28,13 @@ init = viterbi.fill_synthetic((S,), 3, device=dev)
 obs = [viterbi.fill_synthetic((B, T, S), 1, seed=k, device=dev) for k in range(n)]
 frames = [torch.full((B,), T, dtype=torch.int32, device=dev) for _ in range(n)]
 prof = []
+PATH = os.environ.get('STAMP_PATH', 'resident')          # 'cluster': the cluster form (n = 1: R = 8 at 512 items)
 for _ in range(2):
-    viterbi.decode_batches(obs, frames, trans, init, path='resident', _profile=prof)
+    viterbi.decode_batches(obs, frames, trans, init, path=PATH, _profile=prof)
 torch.cuda.synchronize()
 lib = _lib.load()
-KW, KP = 12, 8
-nwg = n * B // 16
+KW, KP = 12, 12
+nwg = min(1024, n * B // 16 * (max(1, 256 // (n * B // 16)) if PATH == 'cluster' else 1))
 buf = (ctypes.c_ulonglong * (nwg * 16 * KP))()
 lib.torbi_hip_debug_phases.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 rc = lib.torbi_hip_debug_phases(buf, nwg * 16 * KP)
@@ -47,6 +48,11 @@ print(f'rc {rc}; forward {prof[0]:.3f} ms for {n} batches x {T} frames; {tot / s
 for i, name in enumerate(names):
     v = acc[:, :, i].mean() / steps
     print(f'{name:38s} {v:9.0f} ticks/step  {100 * v * steps / tot:5.1f} %')
+if PATH == 'cluster':
+    for i, name in zip((8, 9, 10, 11), ('drain of the slice stores', 'wait for the other members\' flags', 'slices -> tile, top lists',
+                                        'barrier E (tile complete)')):
+        v = acc[:, :, i].mean() / steps
+        print(f'{name:38s} {v:9.0f} ticks/step  (cluster; not in the percentages above)')
 blocks = acc[:, :, 7].mean() / steps
 print(f'extra list blocks per wave and timestep: {blocks:.1f} over {np.ceil(90 / KW):.0f} passes -> '
       f'{16 * (1 + blocks / (90 / KW)):.0f} entries per row group on average')

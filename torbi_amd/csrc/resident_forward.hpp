@@ -38,6 +38,8 @@ constexpr int kNI = 16;            // batch items per workgroup (4 item groups o
 constexpr int kMaxBatches = 16;    // batches one launch can carry
 constexpr int kRowGroup = 16;      // next-states per wave pass (64 lanes / 4 lanes per next-state)
 
+typedef unsigned long long u64;
+
 struct Batch {
     const float *obs;        // (B,T,S)
     const int32_t *frames;   // (B)
@@ -56,16 +58,39 @@ struct Group {
     unsigned *stats;           // [128] scan statistics: [0] list blocks walked, [64] wave passes counted (sampled)
 };
 
+// CLUSTER form: R workgroups (a cluster) share one 16-item tile.  Every member keeps the WHOLE posterior tile in its
+// LDS but scans only its share of the next-states; after a timestep the members exchange their slices of the new row
+// through `xchg` (write-through stores, one flag per member and timestep, MI355X_MICROARCH.md "handoff-flag" /
+// cdna_hip_programming.md Guideline 16 R1) -- no kernel boundary, no grid-wide barrier, the clusters drift freely.
+// That puts a single 512-item batch (32 tiles) on 256 compute units.  Membership is by ARRIVAL (a ticket drawn at
+// kernel entry): nothing depends on dispatch order or placement, and a cluster whose last members have not been
+// dispatched yet only waits -- every cluster that is complete runs to its end and frees its compute units.
+constexpr int kMaxR = 16;                // members per cluster
+constexpr int kMaxTop = 4;               // list entries per item a member publishes (>= KR + 1 of every instantiation)
+// bytes of one exchange slot: a posterior row of the tile + the members' partial top lists
+__host__ __device__ inline size_t cluster_slot_bytes(int S) {
+    return ((size_t)S + 3) / 4 * 4 * kNI * sizeof(float) + (size_t)kMaxR * kNI * kMaxTop * sizeof(u64);
+}
+struct Cluster {
+    float *xchg;           // [tiles][2] slots by timestep parity: the members' slices of the newest posterior row
+                           // [S4][16] floats, then their partial top lists [kMaxR][16 * kMaxTop] 64-bit keys
+    unsigned *flags;       // [tiles][kMaxR] newest timestep each member has published (zeroed before the launch)
+    unsigned *control;     // [0] tickets drawn (zeroed before the launch); give-ups are counted in Group::stats[127]
+    int R;
+};
+
 inline bool supported(int S) { return S >= 64 && S <= pruned::kMaxS16; }
 
-typedef unsigned long long u64;
-
 // dynamic LDS: posterior tile [S4][16] + running top lists (64-bit keys) + decoded top lists + frame counts + items
-inline size_t lds_bytes(int S) {
+// + 4 control words (cluster ticket, gave-up flag)
+inline size_t lds_bytes(int S, int ktop = kTop) {
     const size_t S4 = ((size_t)S + 3) / 4 * 4;
-    return sizeof(float) * kNI * S4 + sizeof(u64) * kNI * kTop + (sizeof(float) + sizeof(int)) * kNI * kTop +
-           2 * sizeof(int) * kNI;
+    return sizeof(float) * kNI * S4 + sizeof(u64) * kNI * ktop + (sizeof(float) + sizeof(int)) * kNI * ktop +
+           2 * sizeof(int) * kNI + 4 * sizeof(int);
 }
+
+// row groups (16 next-states) member m of R scans: [m * nrg / R, (m + 1) * nrg / R)
+__host__ __device__ inline int cluster_first_group(int m, int nrg, int R) { return (int)((long long)m * nrg / R); }
 
 // once per decode: order[rank] = item, items ranked by descending (clamped) length, ties by item number.  A tile of
 // 16 consecutive ranks then loops to the longest of 16 items of SIMILAR length -- a ragged batch costs recurrence
@@ -137,15 +162,32 @@ __device__ __forceinline__ u64 top_key(float v, int state) {
 
 // insert into a kTop-entry list kept in descending order by a cascade of LDS atomic maxima: the displaced key
 // moves one rank down, so every rank ends with the maximum of what passed through it
+// (a key that is already in the list is dropped: the members of a cluster see each other's keys more than once)
+template <int KTOP = kTop>
 __device__ __forceinline__ void top_insert(u64 *list, u64 x) {
-    if (x <= list[kTop - 1]) return;
+    if (x <= list[KTOP - 1]) return;
 #pragma unroll
-    for (int r = 0; r < kTop; ++r) {
+    for (int r = 0; r < KTOP; ++r) {
         if (x != 0ull) {
             const u64 old = atomicMax(&list[r], x);
-            x = old < x ? old : x;
+            x = old < x ? old : (old == x ? 0ull : x);
         }
     }
+}
+
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+// 16-byte write-through (sc1) store / L1-bypassing (sc1) load at byte `offset` of a buffer: the payload side of the
+// cluster hand-off (a plain store would stay in the producer XCD's L2, a plain load could hit a stale L1 line)
+__device__ __forceinline__ void store_through(__amdgpu_buffer_rsrc_t buffer, int offset, float4 v) {
+    v4u x = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(x, buffer, offset, 0, 16);
+}
+__device__ __forceinline__ float4 load_through(__amdgpu_buffer_rsrc_t buffer, int offset) {
+    const v4u x = __builtin_amdgcn_raw_buffer_load_b128(buffer, offset, 0, 16);
+    return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
 }
 
 // build-time ablations for tools/variants_probe.py (timing only, results are wrong): bit 0 fixed scan depth of 11 blocks
@@ -161,7 +203,7 @@ __device__ __forceinline__ void top_insert(u64 *list, u64 x) {
 
 #ifdef RESIDENT_STAMP
 // build-time instrumentation (tools/resident_stamps.py): per-wave cycle sums of the phases of a timestep
-constexpr int kPhases = 8;
+constexpr int kPhases = 12;     // 0..6 timestep phases, 7 extra list blocks, 8..11 cluster: drain, flag wait, slices, barrier
 __device__ unsigned long long g_phase[1024 * 16 * kPhases];
 __device__ unsigned long long g_wgtime[1024 * 4];        // per workgroup: start, end (100 MHz wall clock), steps, -
 #define RSTAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); acc[i] += now_ - last; last = now_; }
@@ -179,11 +221,13 @@ __device__ unsigned long long g_wgtime[1024 * 4];        // per workgroup: start
 // ds_read_b128 in flight per wave, also across list blocks: the first pair of the next block is read before the
 // termination test decides whether it is needed) -- with one timestep per launch the scan was a third of the
 // kernel and this bought nothing (tools/prune_proto5.hip); here the scan IS the kernel.
-template <int KW, int MAXP, bool PIPE>
-__global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, const float *__restrict__ tt,
+// KR: seeds per item (explicit candidates; thr = the (KR+1)-th largest posterior).  CLUSTER: see struct Cluster.
+template <int KW, int MAXP, bool PIPE, int KR = kR, bool CLUSTER = false>
+__global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cluster clu, const float *__restrict__ tt,
                                                                    const float2 *__restrict__ sorted,
                                                                    const float *__restrict__ initial, int S, int SpP) {
     constexpr int G = 4, EPL = kBlk / G;
+    constexpr int kR = KR, kTop = KR + 1;                             // (shadow the namespace-wide defaults)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int S4 = (S + 3) / 4 * 4;
     u64 *top = reinterpret_cast<u64 *>(lds + (size_t)kNI * S4);       // [16][kTop] this timestep's largest outputs
@@ -191,6 +235,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
     int *mtopi = reinterpret_cast<int *>(mtopv + kNI * kTop);         // their states, as offsets into tt (state * S)
     int *sframes = mtopi + kNI * kTop;                                // [16] frames per item (0 past the batch)
     int *sitem = sframes + kNI;                                       // [16] item numbers (a valid one past the batch)
+    int *smisc = sitem + kNI;                                         // [0] cluster ticket, [1] gave up waiting
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -198,8 +243,21 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
     const unsigned long long wg_start = wall_clock64();
 #endif
 
-    // which tile of which batch this workgroup decodes
-    const int code = grp.tile_map[blockIdx.x];
+    // which tile of which batch this workgroup decodes; CLUSTER: by arrival -- ticket / R is the cluster (= tile),
+    // ticket % R the member
+    int cid = blockIdx.x, member = 0;
+    const int R = CLUSTER ? clu.R : 1;
+    if constexpr (CLUSTER) {
+        if (tid == 0) {
+            smisc[0] = (int)__hip_atomic_fetch_add(clu.control, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            smisc[1] = 0;
+        }
+        __syncthreads();
+        const int ticket = __builtin_amdgcn_readfirstlane(smisc[0]);
+        cid = ticket / R;
+        member = ticket - cid * R;
+    }
+    const int code = grp.tile_map[cid];
     const Batch &bat = grp.batch[code >> 20];
     const float *__restrict__ obs = bat.obs;
     float *__restrict__ hist = bat.hist;
@@ -232,7 +290,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
             const float v = src[i] + initial[i];
             lds[i * kNI + item] = v;
             if (valid) dst[i] = v;
-            top_insert(top + item * kTop, top_key(v, i));
+            top_insert<kTop>(top + item * kTop, top_key(v, i));
         }
     }
 
@@ -242,12 +300,37 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
     const int jl = (int)((0xFBAE9DC873261540ull >> (4 * (lane >> 2))) & 15);
     const char *ptile = reinterpret_cast<const char *>(lds) + 16 * g;
     const int nrg = (S + kRowGroup - 1) / kRowGroup;
+    // this workgroup's row groups: all of them, or its share as member of a cluster
+    const int rg_lo = CLUSTER ? cluster_first_group(member, nrg, R) : 0;
+    const int rg_hi = CLUSTER ? cluster_first_group(member + 1, nrg, R) : nrg;
+    // CLUSTER: bytes of a posterior row of the tile and of a whole slot of the exchange buffer (slot = 2 * cid + parity)
+    const unsigned xrow = (unsigned)S4 * kNI * (unsigned)sizeof(float);
+    const unsigned xbytes = (unsigned)cluster_slot_bytes(S);
+    static_assert(kTop <= kMaxTop, "a member publishes at most kMaxTop list entries per item");
     // items of this lane: tile items 4g .. 4g+3; items past the batch read a valid one's observations and store nothing
     int ib[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) ib[it] = sitem[4 * g + it];
 
     float pend[MAXP][4];
+    // A cluster member whose waves scan ONE row group per timestep (MAXP == 1) meets the same sorted rows every
+    // timestep: their first two list blocks stay in registers, and the next timestep's observations are requested
+    // before the wait for the other members (everything a pass needs that does not depend on the exchange).
+    constexpr bool FIXED = CLUSTER && MAXP == 1;
+    ListBlock<EPL> head0, head1;
+    float obnext[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (FIXED) {
+        const int rg = rg_lo + wave;
+        const int jj = kRowGroup * rg + jl;
+        const int jr = (rg < rg_hi && jj < S) ? jj : S - 1;
+        const float2 *row = sorted + (size_t)jr * SpP + EPL * g;
+        load_list_block(head0, row, 0);
+        load_list_block(head1, row, kBlk);
+        if (fmax > 1) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) obnext[it] = obs[((size_t)ib[it] * T + 1) * S + jr];
+        }
+    }
     // scan statistics for adaptive path selection (every 16th timestep): how many 16-entry list blocks a wave pass
     // walks.  The benchmark needs 10.6 of the 90 a row holds; near 90 nothing is being pruned and the dense kernel wins.
     unsigned stat_blocks = 0, stat_passes = 0;
@@ -307,18 +390,26 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
         asm volatile("" : "+s"(opaque));
 #pragma unroll
         for (int p = 0; p < MAXP; ++p) {
-            const int rg = wave + KW * p + opaque;          // wave-uniform
-            if (rg < nrg) {
+            const int rg = rg_lo + wave + KW * p + opaque;  // wave-uniform
+            if (rg < rg_hi) {
                 const int jj = kRowGroup * rg + jl;
                 const bool jv = jj < S;
                 const int jr = jv ? jj : S - 1;
                 const float2 *row = sorted + (size_t)jr * SpP + EPL * g;
                 ListBlock<EPL> cur, nxt;
-                load_list_block(cur, row, 0);
-                load_list_block(nxt, row, kBlk);
                 float ob[4];
+                if constexpr (FIXED) {
+                    cur = head0;
+                    nxt = head1;
 #pragma unroll
-                for (int it = 0; it < 4; ++it) ob[it] = (RESIDENT_ABL & 32) ? 0.5f * it : obs[((size_t)ib[it] * T + t) * S + jr];
+                    for (int it = 0; it < 4; ++it) ob[it] = obnext[it];
+                } else {
+                    load_list_block(cur, row, 0);
+                    load_list_block(nxt, row, kBlk);
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+                        ob[it] = (RESIDENT_ABL & 32) ? 0.5f * it : obs[((size_t)ib[it] * T + t) * S + jr];
+                }
                 float seedt[4][kR];
 #pragma unroll
                 for (int it = 0; it < 4; ++it)
@@ -444,23 +535,125 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, co
                     pend[p][it] = o;
                     if (jv && live[it] && !(RESIDENT_ABL & 8)) hist[((size_t)ib[it] * T + t) * S + jr] = o;
                     const u64 key = top_key(o, jr);
-                    if (jv && key > last4[it] && !(RESIDENT_ABL & 16)) top_insert(top + (4 * g + it) * kTop, key);
+                    if (jv && key > last4[it] && !(RESIDENT_ABL & 16)) top_insert<kTop>(top + (4 * g + it) * kTop, key);
+                }
+                // CLUSTER: this row's 16 outputs go to the other members as one write-through 64-byte row (16 bytes per
+                // lane of the quad), in the layout of the LDS tile
+                if constexpr (CLUSTER) {
+                    if (jv && t + 1 < fmax)
+                        store_through(buffer_of(reinterpret_cast<const char *>(clu.xchg) + (size_t)(2 * cid + (t & 1)) * xbytes, xrow),
+                                      (jj * kNI + 4 * g) * 4, make_float4(pend[p][0], pend[p][1], pend[p][2], pend[p][3]));
                 }
                 RSTAMP(4);
             }
+        }
+        // CLUSTER: a wave's slice stores must have left before its workgroup raises the flag (every storing wave drains)
+        if constexpr (CLUSTER) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            RSTAMP(8);
         }
         __syncthreads();      // every wave is done reading the tile and mtop, every output is in `top`
         RSTAMP(5);
 #pragma unroll
         for (int p = 0; p < MAXP; ++p) {
-            const int rg = wave + KW * p + opaque;
+            const int rg = rg_lo + wave + KW * p + opaque;
             const int jj = kRowGroup * rg + jl;
-            if (rg < nrg && jj < S)
+            if (rg < rg_hi && jj < S)
                 *reinterpret_cast<float4 *>(lds + (size_t)jj * kNI + 4 * g) =
                     make_float4(pend[p][0], pend[p][1], pend[p][2], pend[p][3]);
         }
+        if constexpr (FIXED) {
+            if (t + 1 < fmax) {
+                const int jj = kRowGroup * (rg_lo + wave) + jl;
+                const int jr = (rg_lo + wave < rg_hi && jj < S) ? jj : S - 1;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) obnext[it] = obs[((size_t)ib[it] * T + t + 1) * S + jr];
+            }
+        }
+        if constexpr (CLUSTER) {
+            if (t + 1 < fmax) {
+                const int par = t & 1;
+                unsigned *const cflags = clu.flags + (size_t)cid * kMaxR;
+                // (1) this member's partial top lists behind the posterior row of its slot, then its flag (wave 0; the
+                // slices were drained before the barrier above)
+                const __amdgpu_buffer_rsrc_t xsrc =
+                    buffer_of(reinterpret_cast<const char *>(clu.xchg) + (size_t)(2 * cid + par) * xbytes, xbytes);
+                if (wave == 0) {
+                    if (lane < kNI * kTop / 2) {
+                        const u64 k0 = top[2 * lane], k1 = top[2 * lane + 1];
+                        v4u x = {(unsigned)k0, (unsigned)(k0 >> 32), (unsigned)k1, (unsigned)(k1 >> 32)};
+                        __builtin_amdgcn_raw_buffer_store_b128(x, xsrc, (int)xrow + (member * kNI * kMaxTop + 2 * lane) * 8, 0, 16);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(cflags + member, (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                RSTAMP(6);
+                // (2) every wave waits until the other members have published timestep t (one relaxed poll per member
+                // and round, lanes 0..R-1; bounded: a cluster that cannot complete gives up and reports it)
+                {
+                    unsigned spins = 0;
+                    for (;;) {
+                        unsigned seen = 0xffffffffu;
+                        if (lane < R && lane != member)
+                            seen = __hip_atomic_load(cflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__all(seen >= (unsigned)t)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1u << 22)) {
+                            if (lane == 0) smisc[1] = 1;
+                            break;
+                        }
+                    }
+                }
+                RSTAMP(9);
+                // (3) their slices of row t -> the tile (every 16-byte piece except this member's own rows) and their
+                // partial top lists -> this workgroup's lists; all loads of a thread in flight together (eight slice pieces
+                // per round: one round up to 1536 states)
+                {
+                    const int own_lo = kRowGroup * rg_lo, own_hi = kRowGroup * rg_hi < S ? kRowGroup * rg_hi : S;
+                    const int pieces = (S - (own_hi - own_lo)) * 4;
+                    auto place = [&](int c) {          // byte offset of piece c (tile and slot alike)
+                        int row = c >> 2;
+                        row = row < own_lo ? row : row + (own_hi - own_lo);
+                        return (row * kNI + 4 * (c & 3)) * 4;
+                    };
+                    // keys: two per thread (R * 16 * kTop / 2 <= 512 threads)
+                    const int kpair = kNI * kTop / 2;
+                    const int km = tid / kpair, ks = tid - km * kpair;
+                    const bool keyed = km < R && km != member;
+                    v4u keys = {0u, 0u, 0u, 0u};
+                    if (keyed) keys = __builtin_amdgcn_raw_buffer_load_b128(xsrc, (int)xrow + (km * kNI * kMaxTop + 2 * ks) * 8, 0, 16);
+                    constexpr int kRound = 8;
+                    for (int first = 0; first < pieces; first += kRound * 64 * KW) {
+                        float4 got[kRound];
+#pragma unroll
+                        for (int u = 0; u < kRound; ++u) {
+                            const int c = first + tid + u * 64 * KW;
+                            if (c < pieces) got[u] = load_through(xsrc, place(c));
+                        }
+#pragma unroll
+                        for (int u = 0; u < kRound; ++u) {
+                            const int c = first + tid + u * 64 * KW;
+                            if (c < pieces) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(lds) + place(c)) = got[u];
+                        }
+                    }
+                    if (keyed) {
+                        const u64 k0 = ((u64)keys.y << 32) | keys.x, k1 = ((u64)keys.w << 32) | keys.z;
+                        u64 *list = top + (2 * ks / kTop) * kTop;
+                        if (k0) top_insert<kTop>(list, k0);
+                        if (k1) top_insert<kTop>(top + ((2 * ks + 1) / kTop) * kTop, k1);
+                    }
+                }
+                RSTAMP(10);
+                __syncthreads();      // the tile holds row t, `top` its largest entries
+                RSTAMP(11);
+                if (smisc[1]) break;  // (uniform: read behind the barrier)
+            }
+        }
         publish_top();
         RSTAMP(6);
+    }
+    if constexpr (CLUSTER) {
+        if (tid == 0 && smisc[1]) atomicAdd(&grp.stats[127], 1u);     // workgroups that gave up waiting (0 on any sane run)
     }
     if (lane == 0 && stat_passes) {
         atomicAdd(&grp.stats[0], stat_blocks);

@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
+#include <mutex>
+#include <vector>
 #include <stdint.h>
 #include <stddef.h>
 #include <math.h>
@@ -427,9 +429,30 @@ inline int cu_count(int device) {
     return n;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is per (kernel, device): set once, and again only for a larger request
+struct LdsGrant { const void *fn; int device; size_t bytes; };
+std::mutex g_lds_mutex;
+std::vector<LdsGrant> g_lds_grants;
+inline hipError_t ensure_dynamic_lds(const void *fn, size_t bytes) {
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> hold(g_lds_mutex);
+    for (auto &g : g_lds_grants)
+        if (g.fn == fn && g.device == device) {
+            if (g.bytes >= bytes) return hipSuccess;
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e == hipSuccess) g.bytes = bytes;
+            return e;
+        }
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) g_lds_grants.push_back(LdsGrant{fn, device, bytes});
+    return e;
+}
+
 // Which forward recurrence runs.  GENERIC materialises the int32 trellis like the reference does; the other three
 // keep the posterior history and recompute backpointers along the decoded path (lazy_backtrace.hpp).
-enum Route { ROUTE_GENERIC = 0, ROUTE_DENSE = 1, ROUTE_PRUNED = 2, ROUTE_RESIDENT = 3, ROUTE_ROWS = 4 };
+enum Route { ROUTE_GENERIC = 0, ROUTE_DENSE = 1, ROUTE_PRUNED = 2, ROUTE_RESIDENT = 3, ROUTE_ROWS = 4, ROUTE_CLUSTER = 5 };
 
 inline bool use_dense(int B, int S) { return B >= 32 && S >= 64; }
 
@@ -443,7 +466,8 @@ inline int default_path() {
         v = !e ? TORBI_HIP_FORWARD_AUTO
                : e[0] == 'd' ? TORBI_HIP_FORWARD_DENSE
                : e[0] == 'p' ? TORBI_HIP_FORWARD_PRUNED
-               : e[0] == 'r' ? TORBI_HIP_FORWARD_RESIDENT : TORBI_HIP_FORWARD_AUTO;
+               : e[0] == 'r' ? TORBI_HIP_FORWARD_RESIDENT
+               : e[0] == 'c' ? TORBI_HIP_FORWARD_CLUSTER : TORBI_HIP_FORWARD_AUTO;
         g_forward_path.store(v, std::memory_order_relaxed);
     }
     return v;
@@ -455,18 +479,35 @@ inline int requested_path(unsigned flags) {
 }
 constexpr unsigned kKnownFlags = TORBI_HIP_REUSE_TRANSITION | TORBI_HIP_COLLECT_STATS | (7u << 4) | TORBI_HIP_SHORTEST_FIRST;
 inline bool flags_ok(unsigned flags) {
-    return !(flags & ~kKnownFlags) && ((flags >> 4) & 7u) <= (unsigned)TORBI_HIP_FORWARD_RESIDENT + 1u;
+    return !(flags & ~kKnownFlags) && ((flags >> 4) & 7u) <= (unsigned)TORBI_HIP_FORWARD_CLUSTER + 1u;
 }
 
 constexpr int kMaxGroupTiles = 16384;     // 16-item tiles one launch group may hold (262 144 items)
 inline int tiles_of(int B) { return (B + resident::kNI - 1) / resident::kNI; }
 inline bool resident_fits(int S, int tiles) { return resident::supported(S) && tiles <= kMaxGroupTiles; }
 
-// route of ONE batch.  AUTO: the time-resident kernel when the batch alone gives at least half the CUs a
-// workgroup, else the per-timestep pruned pass where supported, else the dense (max,+) GEMM, else generic.
+// members per cluster for a launch of `tiles` 16-item tiles: 1 (every workgroup owns a whole tile) once the tiles give
+// at least half the compute units a workgroup, else as many as the compute units allow (<= kMaxR, <= one row group each)
+inline int cluster_members(int tiles, int S, int cus) {
+    if (tiles < 1 || 2 * tiles > cus) return 1;
+    int R = cus / tiles;
+    const int nrg = (S + resident::kRowGroup - 1) / resident::kRowGroup;
+    R = std::min(R, std::min(resident::kMaxR, nrg));
+    return R < 2 ? 1 : R;
+}
+
+// route of ONE batch.  AUTO: the time-resident kernel -- whole tiles per workgroup when the batch alone gives at least
+// half the compute units a workgroup, tiles split over clusters of workgroups for smaller batches of >= 17 items --
+// else the per-timestep pruned pass where supported, else the dense (max,+) GEMM, else generic.
 inline Route route_for(int path, int B, int S, int cus) {
-    if (path == TORBI_HIP_FORWARD_RESIDENT && resident_fits(S, tiles_of(B))) return ROUTE_RESIDENT;
-    if (path == TORBI_HIP_FORWARD_AUTO && resident_fits(S, tiles_of(B)) && 2 * tiles_of(B) >= cus) return ROUTE_RESIDENT;
+    const bool fits = resident_fits(S, tiles_of(B));
+    if (path == TORBI_HIP_FORWARD_RESIDENT && fits) return ROUTE_RESIDENT;
+    if (path == TORBI_HIP_FORWARD_CLUSTER && fits) return cluster_members(tiles_of(B), S, cus) > 1 ? ROUTE_CLUSTER : ROUTE_RESIDENT;
+    if (path == TORBI_HIP_FORWARD_AUTO && fits && 2 * tiles_of(B) > cus) return ROUTE_RESIDENT;
+    // (one batch, AUTO: clusters where the per-timestep pruned pass would need a second round of workgroups -- more
+    // than cus / 8 tiles, 512 items on an MI355X: 27.8 against 34.8 us per timestep at 768 items, equal at 512)
+    if (path == TORBI_HIP_FORWARD_AUTO && fits && 8 * tiles_of(B) > cus && cluster_members(tiles_of(B), S, cus) > 1)
+        return ROUTE_CLUSTER;
     if (path != TORBI_HIP_FORWARD_DENSE && pruned::supported(B, S)) return ROUTE_PRUNED;
     if ((path == TORBI_HIP_FORWARD_PRUNED && rowscan::supported(B, S)) ||
         (path != TORBI_HIP_FORWARD_DENSE && rowscan::profitable(B, S)))
@@ -543,11 +584,15 @@ struct ResidentWorkspace {
     int32_t *order;       // [B] this batch's items by descending length
     int32_t *tile_map;    // [kMaxGroupTiles] workgroup -> tile of the launch group (first batch's workspace)
     unsigned *stats;      // [128] scan statistics of the last launch group (first batch's workspace)
+    // cluster form (first batch's workspace): exchange buffers of up to cus / 2 tiles
+    float *xchg;          // [tiles][2][S4][16]
+    unsigned *flags;      // [tiles][kMaxR] + 16 control words
+    size_t flag_bytes;
     int SpP, NPOW;
     size_t bytes;
 };
 
-inline ResidentWorkspace carve_resident(void *base, int B, int T, int S) {
+inline ResidentWorkspace carve_resident(void *base, int B, int T, int S, int cus) {
     ResidentWorkspace w;
     char *p = static_cast<char *>(base);
     const int Sp = (S + 15) / 16 * 16;
@@ -559,6 +604,9 @@ inline ResidentWorkspace carve_resident(void *base, int B, int T, int S) {
     const size_t tt_bytes = align_up(sizeof(float) * (size_t)S * S, 256);
     const size_t range_bytes = align_up(sizeof(int32_t) * 2 * (size_t)S, 256);
     const size_t order_bytes = align_up(sizeof(int32_t) * (size_t)B, 256) + sizeof(int32_t) * (kMaxGroupTiles + 128);
+    const size_t ctiles = (size_t)std::max(cus / 2, 1);                 // a cluster launch holds at most this many tiles
+    const size_t xchg_bytes = align_up(ctiles * 2 * resident::cluster_slot_bytes(S), 256);
+    w.flag_bytes = align_up(sizeof(unsigned) * (ctiles * resident::kMaxR + 16), 256);
     w.hist = reinterpret_cast<float *>(p);
     p += hist_bytes;
     w.tile_map = reinterpret_cast<int32_t *>(p);   // ahead of the preparation: offsets depend on B and T only
@@ -568,7 +616,10 @@ inline ResidentWorkspace carve_resident(void *base, int B, int T, int S) {
     w.sorted = reinterpret_cast<float2 *>(p);
     w.tt = reinterpret_cast<float *>(p + sorted_bytes);
     w.row_range = reinterpret_cast<int32_t *>(p + sorted_bytes + tt_bytes);
-    w.bytes = hist_bytes + order_bytes + sorted_bytes + tt_bytes + range_bytes;
+    p += sorted_bytes + tt_bytes + range_bytes;
+    w.xchg = reinterpret_cast<float *>(p);
+    w.flags = reinterpret_cast<unsigned *>(p + xchg_bytes);
+    w.bytes = hist_bytes + order_bytes + sorted_bytes + tt_bytes + range_bytes + xchg_bytes + w.flag_bytes;
     return w;
 }
 
@@ -648,7 +699,7 @@ inline size_t need_bytes(int B, int T, int S, int cus) {
     size_t need = carve(nullptr, B, T, S).bytes;
     if (use_dense(B, S)) need = std::max(need, carve_dense(nullptr, B, T, S, cus).bytes);
     if (pruned::supported(B, S)) need = std::max(need, carve_pruned(nullptr, B, T, S, cus).bytes);
-    if (resident::supported(S)) need = std::max(need, carve_resident(nullptr, B, T, S).bytes);
+    if (resident::supported(S)) need = std::max(need, carve_resident(nullptr, B, T, S, cus).bytes);
     if (rowscan::supported(B, S)) need = std::max(need, carve_rows(nullptr, B, T, S).bytes);
     return need;
 }
@@ -726,8 +777,7 @@ hipError_t launch_dense_steps(const float *obs, const int32_t *frames, const Den
                               int B, int T, int S, hipStream_t stream, int *launches) {
     const dense::Plan &pl = w.plan;
     const size_t lds = dense::lds_bytes<BL, JL, NW, KC, MSL>();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense::step_dense_kernel<BL, JL, NW, KC, MSL>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&dense::step_dense_kernel<BL, JL, NW, KC, MSL>), lds);
     if (e != hipSuccess) return e;
     const int ntiles = pl.n_bt * pl.n_jt;
     const int grid = 8 * ((ntiles + 7) / 8);
@@ -829,8 +879,7 @@ hipError_t launch_pruned_forward(const float *obs, const int32_t *frames, const 
     else
         fn = collect ? &pruned::step_pruned_kernel<pruned::kNB / 2, true>
                      : &pruned::step_pruned_kernel<pruned::kNB / 2, false>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), lds);
     if (e != hipSuccess) return e;
     int n = 0;
     for (int t = 1; t < T; ++t) {
@@ -909,37 +958,38 @@ struct HostBatch {
     int B, T;
 };
 
-// TORBI_HIP_RESIDENT_PIPE=0 selects the variant without software-pipelined posterior reads (experiments)
-inline bool resident_pipe() {
-    static const bool v = [] {
-        const char *e = getenv("TORBI_HIP_RESIDENT_PIPE");
-        return !(e && e[0] == '0');
+// TORBI_HIP_RESIDENT_KR=1|3: seeds per item of the time-resident kernel (experiments; default 3)
+inline int resident_seeds() {
+    static const int v = [] {
+        const char *e = getenv("TORBI_HIP_RESIDENT_KR");
+        const int x = e ? atoi(e) : 0;
+        return x == 1 ? 1 : 3;
     }();
     return v;
 }
 
-template <int KW, int MAXP, bool PIPE>
-hipError_t launch_resident_variant(const resident::Group &grp, int tiles, const ResidentWorkspace &w, const float *init,
-                                   int S, hipStream_t stream) {
-    const size_t lds = resident::lds_bytes(S);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resident::resident_forward_kernel<KW, MAXP, PIPE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+template <int KW, int MAXP, int KR, bool CLUSTER>
+hipError_t launch_resident_variant(const resident::Group &grp, const resident::Cluster &clu, int workgroups,
+                                   const ResidentWorkspace &w, const float *init, int S, hipStream_t stream) {
+    const size_t lds = resident::lds_bytes(S, KR + 1);
+    const void *fn = reinterpret_cast<const void *>(&resident::resident_forward_kernel<KW, MAXP, true, KR, CLUSTER>);
+    hipError_t e = ensure_dynamic_lds(fn, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((resident::resident_forward_kernel<KW, MAXP, PIPE>), dim3(tiles), dim3(64 * KW), lds, stream, grp,
-                       w.tt, w.sorted, init, S, w.SpP);
+    hipLaunchKernelGGL((resident::resident_forward_kernel<KW, MAXP, true, KR, CLUSTER>), dim3(workgroups), dim3(64 * KW), lds,
+                       stream, grp, clu, w.tt, w.sorted, init, S, w.SpP);
     return hipGetLastError();
 }
 
-template <int KW, int MAXP>
-hipError_t launch_resident_kernel(const resident::Group &grp, int tiles, const ResidentWorkspace &w, const float *init,
-                                  int S, hipStream_t stream) {
-    return resident_pipe() ? launch_resident_variant<KW, MAXP, true>(grp, tiles, w, init, S, stream)
-                           : launch_resident_variant<KW, MAXP, false>(grp, tiles, w, init, S, stream);
+template <int KW, int MAXP, bool CLUSTER>
+hipError_t launch_resident_kernel(const resident::Group &grp, const resident::Cluster &clu, int workgroups,
+                                  const ResidentWorkspace &w, const float *init, int S, hipStream_t stream) {
+    return resident_seeds() == 1 ? launch_resident_variant<KW, MAXP, 1, CLUSTER>(grp, clu, workgroups, w, init, S, stream)
+                                 : launch_resident_variant<KW, MAXP, 3, CLUSTER>(grp, clu, workgroups, w, init, S, stream);
 }
 
 // batches with B > 0 only; the preparation lives in the first batch's workspace
-hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const float *init, int S, hipStream_t s,
-                        hipEvent_t *ev, int *launches, bool reuse, bool ascending = false) {
+hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const float *init, int S, int cus, hipStream_t s,
+                        hipEvent_t *ev, int *launches, bool reuse, bool ascending = false, bool clusters = false) {
     resident::Group grp{};
     resident::OrderJobs jobs{};
     jobs.ascending = ascending ? 1 : 0;
@@ -947,7 +997,7 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
     int tiles = 0, items = 0, widest = 0;
     for (int k = 0; k < n; ++k) {
         resident::Batch &b = grp.batch[k];
-        const ResidentWorkspace wk = carve_resident(hb[k].workspace, hb[k].B, hb[k].T, S);
+        const ResidentWorkspace wk = carve_resident(hb[k].workspace, hb[k].B, hb[k].T, S, cus);
         b.obs = hb[k].obs;
         b.frames = hb[k].frames;
         b.out = hb[k].out;
@@ -962,7 +1012,7 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
         tiles += tiles_of(hb[k].B);
         items += hb[k].B;
     }
-    const ResidentWorkspace w = carve_resident(hb[0].workspace, hb[0].B, hb[0].T, S);
+    const ResidentWorkspace w = carve_resident(hb[0].workspace, hb[0].B, hb[0].T, S, cus);
     if (tiles > kMaxGroupTiles) return hipErrorInvalidValue;
     grp.tile_map = w.tile_map;
     grp.stats = w.stats;
@@ -970,16 +1020,29 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
     jobs.n = n;
     jobs.tiles = tiles;
     jobs.tile_map = w.tile_map;
+    // cluster form: R workgroups per tile (exchange buffers in the first batch's workspace, flags and tickets zeroed)
+    const int R = clusters ? cluster_members(tiles, S, cus) : 1;
+    resident::Cluster clu{w.xchg, w.flags, w.flags + (size_t)std::max(cus / 2, 1) * resident::kMaxR, R};
     if (ev) (void)hipEventRecord(ev[0], s);
     if (!reuse) launch_list_preparation(trans, w.sorted, w.row_range, w.tt, S, w.SpP, w.NPOW, resident::kNI, s);
     hipLaunchKernelGGL(resident::order_items_kernel, dim3((widest + 255) / 256, n), dim3(256), 0, s, jobs);
     hipLaunchKernelGGL(resident::order_tiles_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, jobs);
-    if (ev) (void)hipEventRecord(ev[3], s);
     hipError_t e;
+    if (R > 1) {
+        e = hipMemsetAsync(w.flags, 0, w.flag_bytes, s);
+        if (e != hipSuccess) return e;
+    }
+    if (ev) (void)hipEventRecord(ev[3], s);
     const int nrg = (S + resident::kRowGroup - 1) / resident::kRowGroup;
-    if (nrg <= 72) e = launch_resident_kernel<12, 6>(grp, tiles, w, init, S, s);
-    else if (nrg <= 96) e = launch_resident_kernel<12, 8>(grp, tiles, w, init, S, s);
-    else e = launch_resident_kernel<12, 11>(grp, tiles, w, init, S, s);
+    if (R > 1) {
+        const int passes = ((nrg + R - 1) / R + 11) / 12;       // row groups of the largest share over 12 waves
+        if (passes <= 1) e = launch_resident_kernel<12, 1, true>(grp, clu, tiles * R, w, init, S, s);
+        else if (passes <= 2) e = launch_resident_kernel<12, 2, true>(grp, clu, tiles * R, w, init, S, s);
+        else if (passes <= 4) e = launch_resident_kernel<12, 4, true>(grp, clu, tiles * R, w, init, S, s);
+        else e = launch_resident_kernel<12, 6, true>(grp, clu, tiles * R, w, init, S, s);
+    } else if (nrg <= 72) e = launch_resident_kernel<12, 6, false>(grp, clu, tiles, w, init, S, s);
+    else if (nrg <= 96) e = launch_resident_kernel<12, 8, false>(grp, clu, tiles, w, init, S, s);
+    else e = launch_resident_kernel<12, 11, false>(grp, clu, tiles, w, init, S, s);
     if (launches) *launches = 1;
     if (ev) (void)hipEventRecord(ev[1], s);
     if (e != hipSuccess) return e;
@@ -1014,9 +1077,9 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
     hipError_t e;
     const int cus = cu_count(device);
     const Route route = route_for(path, B, S, cus);
-    if (route == ROUTE_RESIDENT) {
+    if (route == ROUTE_RESIDENT || route == ROUTE_CLUSTER) {
         const HostBatch hb{obs, frames, out, workspace, B, T};
-        return run_resident(&hb, 1, trans, init, S, s, ev, launches, reuse);
+        return run_resident(&hb, 1, trans, init, S, cus, s, ev, launches, reuse, false, route == ROUTE_CLUSTER);
     }
     if (ev) (void)hipEventRecord(ev[0], s);
     if (ev) (void)hipEventRecord(ev[3], s);
@@ -1125,7 +1188,7 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S) {
 }
 
 int torbi_hip_set_forward_path(int path) {
-    if (path < TORBI_HIP_FORWARD_AUTO || path > TORBI_HIP_FORWARD_RESIDENT) return TORBI_HIP_EINVAL;
+    if (path < TORBI_HIP_FORWARD_AUTO || path > TORBI_HIP_FORWARD_CLUSTER) return TORBI_HIP_EINVAL;
     g_forward_path.store(path, std::memory_order_relaxed);
     return TORBI_HIP_OK;
 }
@@ -1187,22 +1250,31 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int path = requested_path(flags);
     const bool reuse = (flags & TORBI_HIP_REUSE_TRANSITION) != 0;
+    // ONE time-resident launch for the whole group: named (whole tiles per workgroup, or clusters), or AUTO with enough
+    // items -- half the compute units' worth of tiles, or fewer tiles split over clusters (batches of >= 17 items)
+    int largest = 0;
+    for (int k = 0; k < n; ++k) largest = std::max(largest, hb[k].B);
+    const bool split = cluster_members(tiles, S, cus) > 1;
     const bool together = resident_fits(S, tiles) &&
-                          (path == TORBI_HIP_FORWARD_RESIDENT || (path == TORBI_HIP_FORWARD_AUTO && 2 * tiles >= cus));
+                          (path == TORBI_HIP_FORWARD_RESIDENT || path == TORBI_HIP_FORWARD_CLUSTER ||
+                           (path == TORBI_HIP_FORWARD_AUTO && (2 * tiles > cus || (split && largest > 16))));
+    const bool clusters = together && split && path != TORBI_HIP_FORWARD_RESIDENT;
+    const bool ascending = (flags & TORBI_HIP_SHORTEST_FIRST) != 0;
     if (phase_ms) {
         PhaseEvents pe;
         if (pe.err != hipSuccess) return (int)pe.err;
         int launches = 0;
         hipError_t e;
         if (together) {
-            e = run_resident(hb, n, transition, initial, S, s, pe.ev, &launches, reuse, (flags & TORBI_HIP_SHORTEST_FIRST) != 0);
-            phase_ms[3] = (float)ROUTE_RESIDENT;
+            e = run_resident(hb, n, transition, initial, S, cus, s, pe.ev, &launches, reuse, ascending, clusters);
+            phase_ms[3] = (float)(clusters ? ROUTE_CLUSTER : ROUTE_RESIDENT);
         } else {
             // one batch after the other, each on the path it would take alone; phases of the LAST batch only
             e = hipSuccess;
+            // (the reuse promise covers the first batch's workspace only)
             for (int k = 0; k < n && e == hipSuccess; ++k)
                 e = run_decode(hb[k].obs, hb[k].frames, transition, initial, hb[k].out, hb[k].workspace, hb[k].B,
-                               hb[k].T, S, device, s, k == n - 1 ? pe.ev : nullptr, &launches, reuse, false, path);
+                               hb[k].T, S, device, s, k == n - 1 ? pe.ev : nullptr, &launches, reuse && k == 0, false, path);
             phase_ms[3] = (float)route_for(path, hb[n - 1].B, S, cus);
         }
         if (e == hipSuccess) e = pe.read(phase_ms);
@@ -1211,11 +1283,10 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
         return (int)e;
     }
     if (together)
-        return (int)run_resident(hb, n, transition, initial, S, s, nullptr, nullptr, reuse,
-                                 (flags & TORBI_HIP_SHORTEST_FIRST) != 0);
+        return (int)run_resident(hb, n, transition, initial, S, cus, s, nullptr, nullptr, reuse, ascending, clusters);
     for (int k = 0; k < n; ++k) {
         const hipError_t e = run_decode(hb[k].obs, hb[k].frames, transition, initial, hb[k].out, hb[k].workspace,
-                                        hb[k].B, hb[k].T, S, device, s, nullptr, nullptr, reuse,
+                                        hb[k].B, hb[k].T, S, device, s, nullptr, nullptr, reuse && k == 0,
                                         (flags & TORBI_HIP_COLLECT_STATS) != 0, path);
         if (e != hipSuccess) return (int)e;
     }
@@ -1229,8 +1300,9 @@ int torbi_hip_scan_stats(const void *workspace, size_t workspace_bytes, int B, i
     if (guard.err != hipSuccess) return (int)guard.err;
     if (workspace_bytes < need_bytes(B, T, S, cu_count(device))) return TORBI_HIP_EWORKSPACE;
     const unsigned *stats;
-    if (requested_path(flags) == TORBI_HIP_FORWARD_RESIDENT && resident::supported(S))
-        stats = carve_resident(const_cast<void *>(workspace), B, T, S).stats;
+    const int asked = requested_path(flags);
+    if ((asked == TORBI_HIP_FORWARD_RESIDENT || asked == TORBI_HIP_FORWARD_CLUSTER) && resident::supported(S))
+        stats = carve_resident(const_cast<void *>(workspace), B, T, S, cu_count(device)).stats;
     else if (pruned::supported(B, S))
         stats = carve_pruned(const_cast<void *>(workspace), B, T, S, cu_count(device)).stats;
     else

@@ -66,7 +66,7 @@ def _path_flag(path: str) -> int:
     return (FORWARD_PATHS[path] + 1) << 4
 
 
-def _resolve_path(trans, transition, B, S, device, path, tiles, measure):
+def _resolve_path(trans, transition, B, S, device, path, tiles, measure, count=1):
     """The path name this call passes to the library, and the tuner that wants its timing (or None)."""
     forced = _forced_path if path is None else path
     if forced not in FORWARD_PATHS:
@@ -81,17 +81,23 @@ def _resolve_path(trans, transition, B, S, device, path, tiles, measure):
         tuner = _tuner_for(transition, S, device)
         if tuner is not None:
             chosen = tuner.choose()
-    if 64 <= S <= 2048 and tiles <= 16384 and 2 * tiles >= compute_units(device):
-        # enough items to give the compute units a workgroup of 16 each: the time-resident kernel -- also for a
-        # narrow band (its lists end at the band edge, so the scan is short whatever the posteriors look like:
-        # 58 M against 32 M timesteps/s for eight batches of peaked rows with the pitch transition) -- unless
-        # measurements on this matrix have shown that pruning does not work on the caller's data
-        # the scan statistics of an earlier time-resident launch with this matrix say that hardly anything is pruned
-        # (see _watch_resident).  Whether the per-timestep pruned kernel beats the dense one is NOT the question here:
-        # on peaked rows with a dense matrix it does not, and the time-resident kernel still runs at twice the dense
-        # kernel's rate (tools/peaked_group_probe.py: 17.6-27.6 M against 12.6 M timesteps/s).
+    cus = compute_units(device)
+    if 64 <= S <= 2048 and tiles <= 16384 and (2 * tiles > cus or (count > 1 and B > 16) or 8 * tiles > cus):
+        # The time-resident kernel (csrc/resident_forward.hpp), whatever the single-batch choice would be:
+        #  * enough items to give half the compute units a workgroup of 16 each: whole tiles per workgroup -- also for
+        #    a narrow band (its lists end at the band edge, so the scan is short whatever the posteriors look like:
+        #    58 M against 32 M timesteps/s for eight batches of peaked rows with the pitch transition);
+        #  * a launch group that fills less (the tail of a job, a small job): tiles split over clusters of workgroups
+        #    (2 x 512 items: 31.7 us per timestep against 62.7 with whole tiles and 2 x 20.4 one batch after the other);
+        #  * ONE batch too large for one round of the per-timestep kernel (more than cus / 8 tiles): clusters
+        #    (768 items: 27.8 against 34.8 us per timestep);
+        # unless the scan statistics of an earlier time-resident launch with this matrix say that hardly anything is
+        # pruned (see _watch_resident).  Whether the per-timestep pruned kernel beats the dense one is NOT the question
+        # here: on peaked rows with a dense matrix it does not, and the time-resident kernel still runs at twice the
+        # dense kernel's rate (tools/peaked_group_probe.py: 17.6-27.6 M against 12.6 M timesteps/s).
+        # 'cluster' lets the library pick the form (whole tiles once 2 * tiles > compute units).
         if banded or chosen in ('pruned', 'dense'):
-            chosen = 'dense' if (not banded and _resident_is_losing(transition, S)) else 'resident'
+            chosen = 'dense' if (not banded and _resident_is_losing(transition, S)) else 'cluster'
     return chosen, tuner
 
 
@@ -185,7 +191,7 @@ def decode(
             TORBI_HIP_REUSE_TRANSITION)
         workspace: optional uint8 scratch tensor on the compute device with at least
             `workspace_bytes(N, T, S)` bytes; allocated from torch's caching allocator if None
-        path: forward recurrence for THIS call ('auto', 'dense', 'pruned', 'resident'; None = the
+        path: forward recurrence for THIS call ('auto', 'dense', 'pruned', 'resident', 'cluster'; None = the
             process default of `set_forward_path`).  Every path returns the same indices.
 
     Return:
@@ -219,7 +225,7 @@ def decode(
     index = device.index if device.index is not None else torch.cuda.current_device()
     stream = torch.cuda.current_stream(device).cuda_stream
     chosen, tuner = _resolve_path(trans, transition, B, S, device, path, (B + 15) // 16, _profile is None)
-    if chosen == 'resident':
+    if chosen in TIME_RESIDENT:
         tuner = None                     # the per-timestep tuner has nothing to learn from a time-resident launch
     begin = None
     if tuner is not None and not tuner.settled():
@@ -243,13 +249,13 @@ def decode(
                 stats.copy_(scan_stats(workspace, B, T, S), non_blocking=True)
             end = torch.cuda.Event(enable_timing=True)
             end.record(torch.cuda.current_stream(device))
-            tuner.launched('pruned' if chosen == 'resident' else chosen, begin, end, stats, B * T)
+            tuner.launched('pruned' if chosen in TIME_RESIDENT else chosen, begin, end, stats, B * T)
     else:
         phases = (ctypes.c_float * 6)()
         _lib.check(lib.torbi_hip_viterbi_decode_profiled(*args, flags, phases),
                    'torbi_hip_viterbi_decode_profiled')
         _profile[:] = list(phases)
-    if chosen == 'resident' and (_forced_path if path is None else path) == 'auto':
+    if chosen in TIME_RESIDENT and (_forced_path if path is None else path) == 'auto':
         _watch_resident(transition, workspace, B, T, S)
     return indices if home == device else indices.to(home)
 
@@ -380,11 +386,11 @@ def decode_batches(
     stream = torch.cuda.current_stream(device).cuda_stream
     largest = max(B for B, _, _ in shapes)
     tiles = sum((B + 15) // 16 for B, _, _ in shapes)
-    chosen, _ = _resolve_path(trans, transition, largest, S, device, path, tiles, False)
+    chosen, _ = _resolve_path(trans, transition, largest, S, device, path, tiles, False, count=count)
     flags = _path_flag(chosen)
     first = next((k for k, (B, _, _) in enumerate(shapes) if B > 0), 0)
     if _reusable(workspaces[first], transition, (tuple(shapes), chosen, stream), reuse_preparation) \
-            and (chosen == 'resident' or count == 1):
+            and (chosen in TIME_RESIDENT or count == 1):
         flags |= 1
     if shortest_first:
         flags |= 256                               # TORBI_HIP_SHORTEST_FIRST
@@ -394,13 +400,14 @@ def decode_batches(
                'torbi_hip_viterbi_decode_batches')
     if _profile is not None:
         _profile[:] = list(phases)
-    if chosen == 'resident' and (_forced_path if path is None else path) == 'auto':
+    if chosen in TIME_RESIDENT and (_forced_path if path is None else path) == 'auto':
         B0, T0, _ = shapes[first]
         _watch_resident(transition, workspaces[first], B0, T0, S)
     return indices
 
 
-FORWARD_PATHS = {'auto': 0, 'dense': 1, 'pruned': 2, 'resident': 3}
+TIME_RESIDENT = ('resident', 'cluster')       # the two forms of the time-resident kernel (include/torbi_hip.h)
+FORWARD_PATHS = {'auto': 0, 'dense': 1, 'pruned': 2, 'resident': 3, 'cluster': 4}
 
 
 class _Tuner:
@@ -480,7 +487,7 @@ def _tuner_for(transition: torch.Tensor, states: int, device) -> Optional[_Tuner
         known = (weakref.ref(transition), version, states, _Tuner(states))
         _tuners[id(transition)] = known
     return known[3]
-_forced_path = {'d': 'dense', 'p': 'pruned', 'r': 'resident'}.get(os.environ.get('TORBI_HIP_FORWARD', 'a')[:1], 'auto')
+_forced_path = {'d': 'dense', 'p': 'pruned', 'r': 'resident', 'c': 'cluster'}.get(os.environ.get('TORBI_HIP_FORWARD', 'a')[:1], 'auto')
 _prepared = {}                   # id(workspace) -> (weakref, state): see decode(reuse_preparation=True)
 _structure_cache = {}            # id(transition) -> (weakref, (version, states), mean finite range of a row / S)
 BANDED_RANGE = 0.25              # rows reaching less than this fraction of the states: dense + -inf skipping
@@ -554,7 +561,7 @@ def _choose_path(trans: torch.Tensor, original: torch.Tensor, batch: int, states
     return 'dense' if 0.0 < reach < BANDED_RANGE else 'pruned'
 
 
-ROUTES = {0: 'generic', 1: 'dense', 2: 'pruned', 3: 'resident', 4: 'rows'}
+ROUTES = {0: 'generic', 1: 'dense', 2: 'pruned', 3: 'resident', 4: 'rows', 5: 'cluster'}
 
 
 def forward_path(batch: int, states: int, path: Optional[str] = None, device: int = 0) -> str:
