@@ -28,6 +28,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec
+PCIE_PEAK_GBS = 63.0                  # MI355X_MICROARCH.md: host link, PCIe Gen5 x16 (spec)
 VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz lane-instructions/s
 METRIC = 'timesteps decoded/sec, 1440 states batch=512'
 KERNELS = {'resident': 'resident::resident_forward_kernel', 'cluster': 'resident::resident_forward_kernel',
@@ -481,8 +482,8 @@ class Bench:
         except (OSError, RuntimeError) as exc:
             out['cpu_twin'] = {'value': None, 'note': f'not measured: {exc}'}
         try:
-            # configs[3] from files to files (2 048 sequences: torch.save()d inputs in /dev/shm -> one output file each)
-            out['c4_files_end_to_end'] = self.c4_end_to_end(2048)
+            # configs[3] from files to files (4 096 sequences: torch.save()d inputs in /dev/shm -> one output file each)
+            out['c4_files_end_to_end'] = self.c4_end_to_end(4096)
         except (OSError, RuntimeError) as exc:
             out['c4_files_end_to_end'] = {'value': None, 'note': f'not measured: {exc}'}
         return out
@@ -631,6 +632,10 @@ class Bench:
                     'host_path': 'direct reader (payloads pread into pinned batch rows by native threads, outputs from '
                                  'a prebuilt container image)' if direct else 'torch.load + collate in DataLoader workers, torch.save',
                     'gb_per_s_from_files': sum(lengths) * S * 4 / elapsed / 1e9,
+                    'roofline': {'bound': 'pcie', 'achieved': sum(lengths) * S * 4 / elapsed / 1e9, 'peak': PCIE_PEAK_GBS,
+                                 'unit': 'GB/s', 'frac': sum(lengths) * S * 4 / elapsed / 1e9 / PCIE_PEAK_GBS,
+                                 'note': 'every frame crosses the host link once as 4 * S bytes of fp32 log-probabilities '
+                                         '(MI355X_MICROARCH.md: PCIe Gen5 x16, 63 GB/s spec; 57 GB/s measured for pinned H2D)'},
                     'note': 'files -> pinned batches -> H2D -> epsilon clamp -> decode -> D2H -> one output file per input, '
                             f'length-bucketed batches, files in {folder.rsplit("/", 1)[0]}; value = the second call '
                             '(steady state of a long job), first_call_seconds = the same job cold'}

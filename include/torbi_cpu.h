@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TORBI_CPU_ABI_VERSION 2
+#define TORBI_CPU_ABI_VERSION 3
 #define TORBI_CPU_OK 0
 #define TORBI_CPU_EINVAL (-1)   /* null pointer / non-positive dimension */
 #define TORBI_CPU_ENOMEM (-6)   /* the posterior history could not be allocated */
@@ -58,6 +58,9 @@ int torbi_cpu_read_rows(const int *fds, const int64_t *offsets, const int64_t *b
                         const int64_t *zero_bytes, int count, int threads, int *error_out);
 int torbi_cpu_write_files(const char *const *paths, const void *const *data, const int64_t *bytes, int count,
                           int threads, int *error_out);
+/* (torbi_hip_open_heads: the files' descriptors and first bytes, on native threads) */
+int torbi_cpu_open_heads(const char *const *paths, int count, int threads, int head_bytes, int *fds_out,
+                         unsigned char *heads_out, int *lengths_out, int *error_out);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,7 @@ def twin(obs, frames, trans, init, num_threads=None):
 def test_library_exports_what_the_header_declares():
     header = open(os.path.join(ROOT, 'include', 'torbi_cpu.h')).read()
     declared = set(re.findall(r'\b(torbi_cpu_[a-z_]+)\s*\(', header))
-    assert declared == {'torbi_cpu_abi_version', 'torbi_cpu_viterbi_decode', 'torbi_cpu_read_rows', 'torbi_cpu_write_files'}
+    assert declared == {'torbi_cpu_abi_version', 'torbi_cpu_viterbi_decode', 'torbi_cpu_read_rows', 'torbi_cpu_write_files', 'torbi_cpu_open_heads'}
     lib = ctypes.CDLL(_lib.CPU_LIBRARY)
     for name in declared:
         getattr(lib, name)

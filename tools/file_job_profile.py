@@ -30,6 +30,11 @@ try:
         prof.disable()
         dt = time.perf_counter() - t0
         print(f'run {attempt}: {dt:.2f} s, {sum(lengths) / dt / 1e6:.2f} M frames/s', flush=True)
+        from torbi_amd import slabs, fastio
+        for rec in getattr(fastio, 'LAST_TIMINGS', None) or []:
+            print(f'  batch: open+headers {rec[0] * 1e3:6.1f} ms, slab {rec[1] * 1e3:6.1f} ms, native read {rec[2] * 1e3:6.1f} ms ({rec[3] / rec[2] / 1e9:5.1f} GB/s)')
+        for name, p in slabs._pools.items():
+            print(f'  slab pool {name}: {len(p._free)} free, {len(p._busy)} busy, {p.held_bytes() / 1e9:.1f} GB', flush=True)
         pstats.Stats(prof).sort_stats('cumulative').print_stats(28)
 finally:
     shutil.rmtree(folder, ignore_errors=True)

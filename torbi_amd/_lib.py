@@ -55,6 +55,8 @@ SYMBOLS = {
     'torbi_hip_read_rows': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int,
                                        _c.c_int, _c.POINTER(_c.c_int)]),
     'torbi_hip_write_files': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.POINTER(_c.c_int)]),
+    'torbi_hip_open_heads': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                        _c.POINTER(_c.c_int)]),
     'torbi_hip_fill_synthetic': (_c.c_int, [
         _c.c_void_p, _c.c_uint64, _c.c_uint64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
 }
@@ -73,7 +75,7 @@ _LIB = None
 # the host twin (include/torbi_cpu.h): a separate library, g++ -fopenmp, no HIP dependency
 CPU_SOURCE = os.path.join(_HERE, 'csrc', 'torbi_cpu.cpp')
 CPU_LIBRARY = os.path.join(_HERE, 'libtorbi_cpu.so')
-CPU_ABI_VERSION = 2
+CPU_ABI_VERSION = 3
 _CPU_LIB = None
 
 
@@ -170,6 +172,8 @@ def load_cpu():
     lib.torbi_cpu_read_rows.argtypes = SYMBOLS['torbi_hip_read_rows'][1]
     lib.torbi_cpu_write_files.restype = _c.c_int
     lib.torbi_cpu_write_files.argtypes = SYMBOLS['torbi_hip_write_files'][1]
+    lib.torbi_cpu_open_heads.restype = _c.c_int
+    lib.torbi_cpu_open_heads.argtypes = SYMBOLS['torbi_hip_open_heads'][1]
     if lib.torbi_cpu_abi_version() != CPU_ABI_VERSION:
         raise RuntimeError('libtorbi_cpu.so ABI mismatch: rebuild')
     _CPU_LIB = lib
@@ -185,6 +189,11 @@ def host_io(gpu: bool):
         return lib.torbi_hip_read_rows, lib.torbi_hip_write_files
     lib = load_cpu()
     return lib.torbi_cpu_read_rows, lib.torbi_cpu_write_files
+
+
+def host_open_heads(gpu: bool):
+    """`open_heads` of the library `host_io(gpu)` takes its entry points from."""
+    return load().torbi_hip_open_heads if gpu else load_cpu().torbi_cpu_open_heads
 
 
 def check_io(code, what):

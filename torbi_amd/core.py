@@ -308,7 +308,7 @@ def from_dataloader(
     from .pipeline import DecodePipeline
     import collections
     from concurrent.futures import ThreadPoolExecutor
-    pipe = None
+    pipe, give_back = None, None
     savers = ThreadPoolExecutor(max_workers=SAVE_THREADS) if SAVE_THREADS > 0 else None
     written = collections.deque()
 
@@ -332,8 +332,18 @@ def from_dataloader(
         def store(tensor, file, length):
             save(tensor, file) if length is None else save_masked(tensor, file, length)
 
+    stage = None
     if gpu is not None and torch.cuda.is_available():
-        pipe = DecodePipeline(torch.device('cuda', gpu), depth=2, group=GROUP_SIZE)
+        pipe, give_back = _job_pipeline(torch.device('cuda', gpu))
+        stage = _Staging(torch.device('cuda', gpu))
+        if log_probs and hasattr(dataloader, 'stage') and getattr(dataloader, 'pin_memory', False):
+            dataloader.stage = stage.upload           # (fastio.FileBatches: copies start in the assembling threads)
+        if transition is not None:
+            # the one look at the transition matrix that costs a host sync (torbi_amd.viterbi._choose_path) happens now,
+            # while the device is idle, not at the first launch group with several batches' copies queued behind it
+            from .viterbi import _choose_path
+            prepared = _prepared_transition(transition, log_probs, torch.device('cuda', gpu))
+            _choose_path(prepared, prepared, BATCH_SIZE, prepared.shape[-1])
 
     def finish(item):
         indices, input_filenames, batch_frames, batch_chunks = item
@@ -359,16 +369,21 @@ def from_dataloader(
     starved = getattr(dataloader, 'more_ready', None)
     try:
         for observation, batch_frames, batch_chunks, input_filenames in dataloader:
-            indices = from_probabilities(
-                observation=observation,
-                batch_frames=batch_frames,
-                transition=transition,
-                initial=initial,
-                log_probs=log_probs,
-                gpu=gpu,
-                num_threads=num_threads,
-                _pipeline=pipe,
-                _model=model)
+            if stage is not None and stage.takes(observation, log_probs):
+                # log-probabilities in pinned memory: copy on the copy stream into a pooled device slab, epsilon round
+                # trip (core.py:193-197) on the preparation stream, decode on the pipeline's streams
+                indices = stage.decode(observation, batch_frames, transition, initial, gpu, num_threads, pipe, model)
+            else:
+                indices = from_probabilities(
+                    observation=observation,
+                    batch_frames=batch_frames,
+                    transition=transition,
+                    initial=initial,
+                    log_probs=log_probs,
+                    gpu=gpu,
+                    num_threads=num_threads,
+                    _pipeline=pipe,
+                    _model=model)
             outstanding.append((indices, input_filenames, batch_frames, batch_chunks))
             if pipe is not None and starved is not None and not starved():
                 pipe.flush()      # the reader is the slower side: decode what has arrived instead of waiting for a full group
@@ -381,6 +396,102 @@ def from_dataloader(
     finally:
         if savers is not None:
             savers.shutdown(wait=True)
+        if give_back is not None:
+            if pipe is not None:
+                pipe.synchronize()         # (an exception above may have left batches collected or in flight)
+            give_back()
+
+
+_job_pipelines = {}           # device -> [DecodePipeline kept between many-file jobs, lock held by the job using it]
+
+
+def _job_pipeline(device):
+    """The launch-group pipeline of the many-file jobs on `device` and what gives it back: created once per process, so
+    that a second job finds its scratch (16 x 1.5-2.7 GB at 1440 states) allocated; a job that finds it taken (another
+    host thread is decoding files on the same device) works with one of its own.  `release_job_memory()` drops it."""
+    import threading
+    from .pipeline import DecodePipeline
+    key = str(device)
+    kept = _job_pipelines.get(key)
+    from ._lib import MAX_BATCHES
+    if kept is None or kept[0].group != max(1, min(int(GROUP_SIZE), MAX_BATCHES)):     # (GROUP_SIZE changed)
+        kept = _job_pipelines[key] = [DecodePipeline(device, depth=2, group=GROUP_SIZE), threading.Lock()]
+    if kept[1].acquire(blocking=False):
+        return kept[0], kept[1].release
+    return DecodePipeline(device, depth=2, group=GROUP_SIZE), lambda: None
+
+
+def release_job_memory() -> None:
+    """Free what the many-file jobs keep between calls: the pipelines' scratch and the staging slabs."""
+    from . import slabs
+    _job_pipelines.clear()
+    slabs.release()
+
+
+class _Staging:
+    """Host-to-device staging of the many-file job's batches: a COPY stream that carries nothing but the H2D copies (so a
+    copy never waits behind a kernel that waits for a compute unit -- a launch group's forward kernel holds every one
+    of them for tens of milliseconds), a PREPARATION stream for the epsilon round trip, pooled buffers on both sides
+    (torbi_amd/slabs.py).  Same operations on the same values as from_probabilities (core.py:189-197)."""
+
+    def __init__(self, device):
+        from . import slabs
+        self.device = device
+        self.pool = slabs.pool(device)
+        self.host_pool = slabs.pool(None)
+        streams = _staging_streams.get(str(device))
+        if streams is None:
+            streams = _staging_streams[str(device)] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        self.copy, self.prep = streams
+
+    @staticmethod
+    def takes(observation, log_probs) -> bool:
+        return log_probs and (hasattr(observation, 'torbi_copied') or (
+            observation.device.type == 'cpu' and observation.dtype == torch.float32 and observation.is_contiguous()
+            and observation.is_pinned()))
+
+    def upload(self, observation, batch_frames):
+        """Start the host-to-device copy of a pinned batch (any thread: the reader's assembling threads call this as soon
+        as a batch exists): the batch on a pooled device slab, its lengths as int32, the event behind both."""
+        nbytes = observation.numel() * 4
+        slab = self.pool.take(nbytes)
+        staged = slab[:nbytes].view(torch.float32).view(observation.shape)
+        # (the lengths go first and from pinned memory: a pageable source would make the copy synchronous, and issued
+        # behind the batch it would hold the calling thread until the whole batch has crossed the link)
+        lengths = batch_frames.to(torch.int32).pin_memory()
+        with torch.cuda.stream(self.copy):
+            staged.torbi_lengths = lengths.to(self.device, non_blocking=True)
+            staged.copy_(observation, non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(self.copy)
+        host_slab = getattr(observation, 'torbi_slab', None)
+        if host_slab is not None:
+            self.host_pool.give(host_slab, copied)       # the reader may refill it once the copy has left
+        staged.torbi_copied = copied
+        staged.torbi_device_slab = slab
+        staged.torbi_keep = (observation, lengths)       # (pinned sources stay alive until the copy has been issued)
+        return staged
+
+    def decode(self, observation, batch_frames, transition, initial, gpu, num_threads, pipe, model):
+        staged = observation if hasattr(observation, 'torbi_copied') else self.upload(observation, batch_frames)
+        slab, copied = staged.torbi_device_slab, staged.torbi_copied
+        self.prep.wait_event(copied)
+        with torch.cuda.stream(self.prep):
+            # (from_probabilities: already on the device, float32, log_probs -> epsilon round trip in place, then the
+            # pipeline, whose side stream waits for the readiness event recorded on the stream that is current here)
+            indices = from_probabilities(observation=staged, batch_frames=staged.torbi_lengths, transition=transition,
+                                         initial=initial, log_probs=True, gpu=gpu, num_threads=num_threads,
+                                         _pipeline=pipe, _model=model)
+        if pipe is not None and model.get('uniform') is None:
+            pipe.when_done(indices, lambda event, slab=slab: self.pool.give(slab, event))
+        else:
+            done = torch.cuda.Event()
+            done.record(self.prep)
+            self.pool.give(slab, done)
+        return indices
+
+
+_staging_streams = {}
 
 
 def save(tensor, file):

@@ -261,4 +261,15 @@ int torbi_cpu_write_files(const char *const *paths, const void *const *data, con
     return rc == 0 ? TORBI_CPU_OK : TORBI_CPU_EIO_BASE + rc + 1;      // -(100 + index)
 }
 
+int torbi_cpu_open_heads(const char *const *paths, int count, int threads, int head_bytes, int *fds_out,
+                         unsigned char *heads_out, int *lengths_out, int *error_out) {
+    if (count < 0 || threads < 1 || head_bytes < 1) return TORBI_CPU_EINVAL;
+    if (count == 0) return TORBI_CPU_OK;
+    if (!paths || !fds_out || !heads_out || !lengths_out) return TORBI_CPU_EINVAL;
+    for (int k = 0; k < count; ++k)
+        if (!paths[k]) return TORBI_CPU_EINVAL;
+    const int rc = filerows::open_heads(paths, count, threads, head_bytes, fds_out, heads_out, lengths_out, error_out);
+    return rc == 0 ? TORBI_CPU_OK : TORBI_CPU_EIO_BASE + rc + 1;      // -(100 + index)
+}
+
 }  // extern "C"

@@ -31,6 +31,9 @@ import torch
 from . import _lib
 
 
+LAST_TIMINGS = None        # TORBI_FILE_TIMINGS=1: per-batch reader timings of the last FileBatches that ran (tools/)
+
+
 class UnsupportedFile(Exception):
     """The file is not a plain float32 tensor in torch.save's zip container."""
 
@@ -115,11 +118,12 @@ def _scan_head(head):
     return None
 
 
-def payload_of_open_file(fd):
+def payload_of_open_file(fd, head=None):
     """(frames, states, byte offset of the float32 payload) of the torch.save()d tensor behind `fd`: one 4 KB read
-    and a walk over the local headers.  LookupError when that does not get there (`payload` then goes through the
-    central directory)."""
-    head = os.pread(fd, 4096, 0)
+    (unless the caller has it: `head`) and a walk over the local headers.  LookupError when that does not get there
+    (`payload` then goes through the central directory)."""
+    if head is None:
+        head = os.pread(fd, 4096, 0)
     members = _scan_head(head)
     if members is None or b'data.pkl' not in members:
         raise LookupError
@@ -169,6 +173,43 @@ def payload(path):
         raise UnsupportedFile(str(exc)) from exc
 
 
+HEAD_BYTES = 4096
+
+
+def _open_payloads(paths, gpu, threads):
+    """`_open_payload` for a batch: the files are opened and their heads read by native threads in one call
+    (torbi_hip_open_heads); the interpreter only walks the headers it is handed.  [(fd, frames, states, offset)];
+    on any failure every descriptor is closed again."""
+    count = len(paths)
+    names = [os.fsencode(os.fspath(p)) for p in paths]
+    table = (ctypes.c_char_p * count)(*names)
+    fds = np.full(count, -1, dtype=np.int32)
+    heads = np.empty(count * HEAD_BYTES, dtype=np.uint8)
+    lengths = np.zeros(count, dtype=np.int32)
+    error = ctypes.c_int(0)
+    code = _lib.host_open_heads(gpu)(table, count, max(1, min(int(threads), count)), HEAD_BYTES, fds.ctypes.data,
+                                     heads.ctypes.data, lengths.ctypes.data, ctypes.byref(error))
+    opened = []
+    try:
+        if code <= -100:
+            raise OSError(error.value, os.strerror(error.value) if error.value else 'could not read', os.fsdecode(names[-(code + 100)]))
+        _lib.check_io(code, 'open_heads')
+        view = memoryview(heads)
+        for k in range(count):
+            fd = int(fds[k])
+            head = bytes(view[k * HEAD_BYTES:k * HEAD_BYTES + int(lengths[k])])
+            try:
+                opened.append((fd,) + payload_of_open_file(fd, head))
+            except (LookupError, struct.error, pickle.UnpicklingError):
+                opened.append((fd,) + payload(paths[k]))
+        return opened
+    except BaseException:
+        for fd in fds.tolist():
+            if fd >= 0:
+                os.close(fd)
+        raise
+
+
 def _open_payload(path):
     """(fd, frames, states, payload offset); the caller closes the descriptor."""
     fd = os.open(path, os.O_RDONLY)
@@ -192,26 +233,35 @@ class FileBatches:
         self.gpu = torch.cuda.is_available() if gpu is None else bool(gpu)
         self.input_files = list(input_files)
         self.batch_size = int(batch_size)
-        self.threads = max(1, int(threads if threads else min(32, (os.cpu_count() or 4))))
+        # (more reader threads are not better: 16-32 copy 85-97 GB/s from the page cache into pinned memory on the GPU
+        # box's EPYC, 64 drop to 33 GB/s, 128 to 25 -- tools/host_bw_probe.py)
+        self.threads = max(1, min(32, int(threads if threads else min(32, (os.cpu_count() or 4)))))
         self.pin_memory = torch.cuda.is_available() if pin_memory is None else bool(pin_memory)
         self.ahead = max(1, int(ahead))
-        self._ready = None
+        self.producers = 2
+        # optional: called by the assembling thread with the finished (pinned) observation, returns what is yielded in its
+        # place -- the many-file driver starts the host-to-device copy here, so that copies are queued as soon as batches
+        # exist, not when the consuming thread next comes round (torbi_amd/core.py::_Staging.upload)
+        self.stage = None
+        self._window = None
+        self.timings = [] if os.environ.get('TORBI_FILE_TIMINGS') else None     # (open + headers, slab, native read, bytes)
 
     def more_ready(self):
         """True while the batch after the one just yielded is already assembled (or the job is over).  The many-file
         driver launches a partial group instead of waiting for a full one when the reader is the slower side."""
-        ready = self._ready
-        return ready is None or not ready.empty()
+        window = self._window
+        return window is None or not window or window[0].done()
 
     def __len__(self):
         return (len(self.input_files) + self.batch_size - 1) // self.batch_size
 
     def _assemble(self, files):
+        import time
         opened = []
+        t0 = time.perf_counter()
         try:
             try:
-                for file in files:
-                    opened.append(_open_payload(file))
+                opened = _open_payloads(files, self.gpu, self.threads // self.producers)
                 if any(entry[2] != opened[0][2] for entry in opened):
                     raise UnsupportedFile('files of one batch differ in their number of states')
             except UnsupportedFile:
@@ -222,8 +272,17 @@ class FileBatches:
                 return (observation.pin_memory() if self.pin_memory else observation), batch_frames, batch_chunks, names
             count, states = len(files), opened[0][2]
             longest = max(entry[1] for entry in opened)
-            observation = torch.empty((count, longest, states), dtype=torch.float32, pin_memory=self.pin_memory)
             row_bytes = 4 * longest * states
+            t1 = time.perf_counter()
+            if self.pin_memory:
+                # a pinned slab of the process-wide pool (torbi_amd/slabs.py): the consumer hands it back with the event of
+                # its host-to-device copy (`observation.torbi_slab`); one that never does just lets it be collected
+                from . import slabs
+                slab = slabs.pool(None).take(count * row_bytes, limit=4)     # two being read, one ready, one being copied
+                observation = slab[:count * row_bytes].view(torch.float32).view(count, longest, states)
+                observation.torbi_slab = slab
+            else:
+                observation = torch.empty((count, longest, states), dtype=torch.float32)
             fds = np.array([entry[0] for entry in opened], dtype=np.int32)
             frames = np.array([entry[1] for entry in opened], dtype=np.int64)
             offsets = np.array([entry[3] for entry in opened], dtype=np.int64)
@@ -232,53 +291,50 @@ class FileBatches:
             zeros = row_bytes - sizes                                      # collate's zero padding (collate.py:24-31)
             error = ctypes.c_int(0)
             read_rows, _ = _lib.host_io(self.gpu)
+            t2 = time.perf_counter()
             code = read_rows(fds.ctypes.data, offsets.ctypes.data, sizes.ctypes.data, rows.ctypes.data, zeros.ctypes.data,
-                             count, min(self.threads, count), ctypes.byref(error))
+                             count, max(1, min(self.threads // self.producers, count)), ctypes.byref(error))
             if code <= -100:
                 raise OSError(error.value, f'could not read {files[-(code + 100)]} in full')
             _lib.check_io(code, 'read_rows')
-            return observation, torch.from_numpy(frames.copy()), [1] * count, tuple(files)
+            if self.timings is not None:
+                self.timings.append((t1 - t0, t2 - t1, time.perf_counter() - t2, count * row_bytes))
+            batch_frames = torch.from_numpy(frames.copy())
+            if self.stage is not None:
+                observation = self.stage(observation, batch_frames)
+            return observation, batch_frames, [1] * count, tuple(files)
         finally:
             for entry in opened:
                 os.close(entry[0])
 
     def __iter__(self):
-        groups = [self.input_files[k:k + self.batch_size] for k in range(0, len(self.input_files), self.batch_size)]
-        ready = self._ready = queue.Queue(maxsize=self.ahead)
-        stop = threading.Event()
-
-        def hand_over(item):
-            # never blocks past `stop`: a consumer that left early (an exception in its loop, a break) is not waited for
-            while not stop.is_set():
-                try:
-                    ready.put(item, timeout=0.1)
-                    return
-                except queue.Full:
-                    continue
-
-        def produce():
-            try:
-                for files in groups:
-                    if stop.is_set():
-                        return
-                    hand_over(self._assemble(files))
-                hand_over(None)
-            except BaseException as exc:      # surfaces in the consumer
-                hand_over(exc)
-
-        worker = threading.Thread(target=produce, name='torbi-file-batches', daemon=True)
-        worker.start()
+        """Batches in order, assembled by `producers` threads that take alternate batches (a batch's Python side -- 512
+        opens, header reads and closes under the interpreter lock, 10-15 ms -- then hides behind the native copy of the
+        other one), at most `ahead` + `producers` batches ahead of the consumer."""
+        import collections
+        from concurrent.futures import ThreadPoolExecutor
+        groups = iter([self.input_files[k:k + self.batch_size] for k in range(0, len(self.input_files), self.batch_size)])
+        workers = ThreadPoolExecutor(max_workers=self.producers, thread_name_prefix='torbi-file-batches')
+        window = self._window = collections.deque()
         try:
-            while True:
-                item = ready.get()
-                if item is None:
-                    return
-                if isinstance(item, BaseException):
-                    raise item
+            def submit():
+                files = next(groups, None)
+                if files is not None:
+                    window.append(workers.submit(self._assemble, files))
+            for _ in range(self.ahead + self.producers - 1):
+                submit()
+            while window:
+                item = window.popleft().result()         # (an exception of the worker surfaces here)
+                submit()
                 yield item
         finally:
-            stop.set()
-            worker.join(timeout=5.0)
+            if self.timings is not None:
+                global LAST_TIMINGS
+                LAST_TIMINGS = list(self.timings)
+            for future in window:
+                future.cancel()
+            window.clear()
+            workers.shutdown(wait=True)                  # (a batch being assembled finishes: bounded, no consumer needed)
 
 
 def open_batches(input_files, batch_size, threads=None, pin_memory=None, gpu=None):

@@ -58,6 +58,7 @@ class DecodePipeline:
         self.pending: List[tuple] = []           # (indices, completion event, inputs kept alive until then)
         self.last_done: List[Optional[torch.cuda.Event]] = [None] * self.depth    # completion of a slot's latest launch
         self.retired: List[tuple] = []           # (outgrown scratch buffer, the event it may still be in use until)
+        self.releases: List[tuple] = []          # (indices, callback) waiting for their decode's launch (when_done)
         self.waiting: List[tuple] = []          # batches collected for the next group
         self.turn = 0
 
@@ -83,6 +84,15 @@ class DecodePipeline:
             for k in range(self.group):
                 self._scratch(slot, k, need)
 
+    def when_done(self, indices: torch.Tensor, release: Callable) -> None:
+        """Call `release(event)` once the decode that produces `indices` has been LAUNCHED, with its completion event
+        (the many-file driver returns a batch's staging buffer to its pool this way: torbi_amd/slabs.py)."""
+        for entry in self.pending:
+            if entry[0] is indices:           # launched already (group == 1, or a group that has just been flushed)
+                release(entry[1])
+                return
+        self.releases.append((indices, release))
+
     def decode(self, observation, batch_frames, transition, initial, after: Optional[Callable] = None) -> torch.Tensor:
         """Enqueue one decode; arguments as `torbi_amd.decode` (tensors on `self.device`).
 
@@ -90,15 +100,19 @@ class DecodePipeline:
         RCCL gather of a sharded batch or an asynchronous copy to pinned host memory; its return value
         replaces the indices handed back here only for `group` == 1.
         """
+        # the inputs are ready where the caller's current stream is NOW (a launch group is launched later, possibly
+        # from another stream context: it waits for this event, not for whatever is current then)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
         if self.group == 1:
-            return self._launch([(observation, batch_frames, transition, initial, after, None)])[0]
+            return self._launch([(observation, batch_frames, transition, initial, after, None, ready)])[0]
         B, T, _ = observation.shape
         indices = torch.empty((B, T), dtype=torch.int32, device=self.device)
         # a group shares one transition / initial: a different model flushes what has been collected
         if self.waiting and (self.waiting[0][2] is not transition or self.waiting[0][3] is not initial
                              or self.waiting[0][0].shape[-1] != observation.shape[-1]):
             self.flush()
-        self.waiting.append((observation, batch_frames, transition, initial, after, indices))
+        self.waiting.append((observation, batch_frames, transition, initial, after, indices, ready))
         if len(self.waiting) >= self.group:
             self.flush()
         return indices
@@ -114,12 +128,13 @@ class DecodePipeline:
         self.turn += 1
         stream = self.streams[slot]
         transition, initial = batches[0][2], batches[0][3]
-        # the inputs may have been produced on the caller's stream
-        stream.wait_stream(torch.cuda.current_stream(self.device))
+        # the inputs may have been produced on other streams: wait for each batch's readiness event
+        for batch in batches:
+            stream.wait_event(batch[6])
         results = []
         with torch.cuda.stream(stream):
             if len(batches) == 1 and batches[0][5] is None:
-                observation, batch_frames, _, _, after, _ = batches[0]
+                observation, batch_frames, _, _, after, _, _ = batches[0]
                 B, T, S = observation.shape
                 scratch = self._scratch(slot, 0, viterbi.workspace_bytes(B, T, S))
                 indices = viterbi.decode(observation, batch_frames, transition, initial, workspace=scratch,
@@ -137,7 +152,7 @@ class DecodePipeline:
                                                  reuse_preparation=self.reuse_preparation, path=self.path,
                                                  out=[b[5] for b in batches],
                                                  shortest_first=self.depth > 1 and self.turn % 2 == 1)
-                for (_, _, _, _, after, _), indices in zip(batches, decoded):
+                for (_, _, _, _, after, _, _), indices in zip(batches, decoded):
                     if after is not None:
                         after(indices)
                     results.append(indices)
@@ -152,6 +167,11 @@ class DecodePipeline:
         keep = [(b[0], b[1]) for b in batches] + [(transition, initial)]
         for indices in results:
             self.pending.append((indices, done, keep))
+        if self.releases:
+            launched = {id(indices) for indices in results}
+            for indices, release in [entry for entry in self.releases if id(entry[0]) in launched]:
+                release(done)
+            self.releases = [entry for entry in self.releases if id(entry[0]) not in launched]
         return results
 
     def _prune(self) -> None:
