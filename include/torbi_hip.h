@@ -174,7 +174,10 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
 
 /*
  * Scan statistics for adaptive path selection (torbi_amd/viterbi.py uses them): copies 128 uint32 to `stats_out`
- * (DEVICE pointer) on `stream`.  `flags` = the path flag of the decode in question:
+ * (DEVICE pointer) on `stream`.  Which of the two records below is copied is decided ON THE DEVICE by the route the last
+ * decode with `workspace` actually took (every decode stamps it behind its scratch layout: a batch decoded inside a
+ * launch group takes the group's route, whatever its own shape and flags would have chosen); `flags` is accepted for
+ * compatibility and ignored.  Zeros for a decode on another route.
  *   PRUNED (a decode run with TORBI_HIP_COLLECT_STATS on `workspace`; zeros otherwise):
  *     stats_out[0..63]   sum over (sampled timestep, tile) of the deepest scan among the tile's waves, in 16-entry
  *                        list blocks (a launch lasts as long as its deepest wave)
@@ -217,8 +220,9 @@ int torbi_hip_viterbi_decode_profiled(const float *observation, const int32_t *b
 /*
  * Test/diagnostic access to the final posterior rows the forward pass produced by the last
  * decode that used `workspace` (reference: the `posterior` tensor, viterbi.cu:334-336).
- * Copies (B,S) fp32 into `posterior_out` (device pointer) on `stream`.  `flags`: the flags of that
- * decode (its path decides where the rows live).
+ * Copies (B,S) fp32 into `posterior_out` (device pointer) on `stream`.  Where the rows live depends on the route that
+ * decode took; it is read on the device from the route record the decode left in the workspace (`flags` is accepted for
+ * compatibility and ignored).
  */
 int torbi_hip_read_posterior(const void *workspace, size_t workspace_bytes,
                              const int32_t *batch_frames, float *posterior_out,

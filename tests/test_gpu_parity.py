@@ -404,6 +404,38 @@ def test_posterior_rows_match_oracle_bitwise():
     assert np.array_equal(got.view(np.uint32), post.view(np.uint32))
 
 
+def test_posterior_and_statistics_follow_the_route_the_decode_took(forward):
+    """torbi_hip_read_posterior / torbi_hip_scan_stats look at the route RECORD the last decode left in the workspace,
+    not at what the batch's own shape and flags would choose: a 5-item batch decoded inside a time-resident launch
+    group (its own route would be the generic kernels, whose posterior rows live elsewhere) reads back the oracle's
+    posterior rows bit for bit, and the group's scan statistics are found without naming a path."""
+    if forward != 'auto':
+        pytest.skip('names its paths itself')
+    dev = torch.device('cuda:0')
+    S = 300
+    _, trans, init = synth.problem(1, 1, S, seed=78)
+    d_trans, d_init = torch.tensor(trans, device=dev), torch.tensor(init, device=dev)
+    shapes = [(300, 11), (5, 23)]
+    batches, spaces, wanted = [], [], []
+    for k, (B, T) in enumerate(shapes):
+        obs = synth.scores(synth.STREAM_OBSERVATION, (B, T, S), seed=200 + k)
+        frames = np.clip(synth.lengths(B, 1, T, seed=k), 1, T).astype(np.int32)
+        frames[0] = T
+        batches.append((torch.tensor(obs, device=dev), torch.tensor(frames, device=dev)))
+        spaces.append(torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev))
+        wanted.append(oracle.decode(obs, frames, trans, init, return_posterior=True, num_threads=oracle.max_threads()))
+    for path in ('resident', 'cluster', 'pruned'):
+        got = viterbi.decode_batches([b[0] for b in batches], [b[1] for b in batches], d_trans, d_init, workspaces=spaces,
+                                     path=path)
+        for k, (B, T) in enumerate(shapes):
+            np.testing.assert_array_equal(got[k].cpu().numpy(), wanted[k][0])
+            post = viterbi.read_posterior(spaces[k], batches[k][1], B, T, S).cpu().numpy()      # no path named
+            assert np.array_equal(post.view(np.uint32), wanted[k][1].view(np.uint32)), (path, k)
+        stats = viterbi.scan_stats(spaces[0], shapes[0][0], shapes[0][1], S).cpu()
+        if path != 'pruned':
+            assert int(stats[64]) > 0 and int(stats[127]) == 0       # wave passes counted, no cluster gave up waiting
+
+
 def test_fill_synthetic_matches_numpy_definition():
     for stream, seed, n, start in [(1, 0, 100003, 0), (2, 5, 4099, 17), (3, 1, 7, 1 << 33)]:
         got = viterbi.fill_synthetic((n,), stream, seed=seed, start=start).cpu().numpy()

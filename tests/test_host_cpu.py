@@ -159,13 +159,13 @@ def test_auto_path_choice_reads_the_transition_structure_once_per_version():
     """torbi_amd/viterbi.py::_choose_path: narrow bands -> dense kernel (-inf block skipping), everything else ->
     pruned; forced paths and unsupported shapes pass through; the look is cached per tensor version."""
     import torch
-    from torbi_amd import synth, viterbi
+    from torbi_amd import state, synth, viterbi
     S = 256
     dense = torch.as_tensor(synth.problem(1, 1, S, seed=1)[1])
     band = torch.as_tensor(synth.banded_transition(S, 12.0))
     assert viterbi._choose_path(dense, dense, 64, S) == 'pruned'
     assert viterbi._choose_path(band, band, 64, S) == 'dense'
-    assert 0.0 < viterbi._structure_cache[id(band)][2] < viterbi.BANDED_RANGE
+    assert 0.0 < state.notes(band)[('reach', S)] < viterbi.BANDED_RANGE
     band.fill_(-1.0)                                  # new version of the same storage: looked at again
     assert viterbi._choose_path(band, band, 64, S) == 'pruned'
     dead = torch.full((S, S), float('-inf'))
@@ -197,7 +197,7 @@ def test_auto_path_choice_reads_the_transition_structure_once_per_version():
         inf = torch.as_tensor(synth.banded_transition(S, 12.0)) * 1
         assert viterbi._version_of(inf) is None
         assert viterbi._choose_path(inf, inf, 64, S) == 'dense'
-        assert id(inf) not in viterbi._structure_cache
+        assert state.peek(inf) is None and state.notes(inf) is None
         assert viterbi._tuner_for(inf, S, 'cpu') is None
 
 
@@ -599,3 +599,44 @@ def test_head_route_rejects_a_header_that_promises_more_than_the_file_holds(tmp_
             fastio.payload_of_open_file(fd)
     finally:
         os.close(fd)
+
+
+def test_one_store_keeps_what_is_known_about_tensors_for_as_long_as_they_live():
+    """torbi_amd/state.py: path tuners, structure looks, prepared transitions and workspace contents hang off the tensor
+    object and its version in ONE store; entries die with their tensors and are never evicted by count -- a hundred other
+    matrices do not take a live matrix's tuner with them; a write to the tensor starts afresh; reset_path_state() forgets."""
+    import gc
+    import torch
+    import torbi_amd
+    from torbi_amd import state, viterbi
+    torbi_amd.reset_path_state()
+    S = 64
+    mine = torch.rand(S, S)
+    tuner = viterbi._tuner_for(mine, S, 'cpu')
+    assert tuner is not None and viterbi._tuner_for(mine, S, 'cpu') is tuner
+    viterbi._choose_path(mine, mine, 64, S)
+    prepared = torbi_amd.core._prepared_transition(mine, True, 'cpu')
+    assert torbi_amd.core._prepared_transition(mine, True, 'cpu') is prepared
+    others = []
+    for k in range(100):                       # a hundred distinct matrices, half of them kept alive
+        other = torch.rand(S, S)
+        viterbi._tuner_for(other, S, 'cpu')
+        viterbi._choose_path(other, other, 64, S)
+        if k % 2:
+            others.append(other)
+    del other
+    gc.collect()
+    assert viterbi._tuner_for(mine, S, 'cpu') is tuner            # still there
+    assert state.size() == 1 + len(others)                        # the dead ones left with their tensors
+    assert tuner in state.every('tuner')
+    mine.add_(1.0)                                                # a new version: nothing carries over
+    assert viterbi._tuner_for(mine, S, 'cpu') is not tuner and ('reach', S) not in state.notes(mine)
+    # a workspace remembers which preparation it holds, for its transition's object and version
+    ws = torch.empty(16, dtype=torch.uint8)
+    assert not viterbi._reusable(ws, mine, (1, 2, 3, 'pruned', 0), True)
+    assert viterbi._reusable(ws, mine, (1, 2, 3, 'pruned', 0), True)
+    assert not viterbi._reusable(ws, mine, (1, 2, 4, 'pruned', 0), True)
+    mine.mul_(2.0)
+    assert not viterbi._reusable(ws, mine, (1, 2, 4, 'pruned', 0), True)
+    torbi_amd.reset_path_state()
+    assert state.size() == 0 and state.peek(mine) is None

@@ -6,7 +6,6 @@ Differences that follow from "GPU only" are stated in each docstring and in INTE
 """
 import math
 import os
-import weakref
 from typing import Dict, List, Optional, Union
 
 import torch
@@ -71,23 +70,18 @@ def _from_probabilities_cpu(observation, batch_frames, transition, initial, log_
     return decode_cpu(observation, batch_frames, transition, initial, num_threads=num_threads)
 
 
-_transition_cache = {}        # id(caller's tensor) -> (weakref, version, log_probs, device, prepared tensor)
-
-
 def _prepared_transition(transition: torch.Tensor, log_probs: bool, device) -> torch.Tensor:
-    """log() (unless `log_probs`) and device move of the transition matrix (core.py:181-187), remembered per
-    caller tensor and version: repeated calls with one matrix then hand torbi_amd.decode the SAME device
-    tensor, which is what its per-tensor structure look and path measurements are keyed on."""
-    version = _version_of(transition)          # None under torch.inference_mode(): nothing to key a cache on
-    known = _transition_cache.get(id(transition)) if version is not None else None
-    state = (version, bool(log_probs), str(device))
-    if known is not None and known[0]() is transition and known[1] == state:
-        return known[2]
+    """log() (unless `log_probs`) and device move of the transition matrix (core.py:181-187), remembered with the
+    caller's tensor (object and version, torbi_amd/state.py): repeated calls with one matrix then hand torbi_amd.decode
+    the SAME device tensor, which is what its structure look and path measurements hang off."""
+    from . import state
+    kept = state.notes(transition)             # None under torch.inference_mode(): nothing to remember it by
+    key = ('prepared', bool(log_probs), str(device))
+    if kept is not None and key in kept:
+        return kept[key]
     prepared = (transition if log_probs else torch.log(transition)).to(device)
-    if version is not None:
-        if len(_transition_cache) >= 16:
-            _transition_cache.clear()
-        _transition_cache[id(transition)] = (weakref.ref(transition), state, prepared)
+    if kept is not None:
+        kept[key] = prepared
     return prepared
 
 

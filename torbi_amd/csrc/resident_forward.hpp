@@ -96,9 +96,11 @@ __host__ __device__ inline int cluster_first_group(int m, int nrg, int R) { retu
 // 16 consecutive ranks then loops to the longest of 16 items of SIMILAR length -- a ragged batch costs recurrence
 // steps for its valid frames only (collate pads every item of a 512-batch to the batch maximum: reference
 // torbi/data/collate.py:24-31) -- and the longest tiles are dispatched first.  Results do not depend on the order.
-// grid = (ceil(max B / 256), batches), block = 256; O(B^2) compares, batches above kMaxOrdered items keep their order.
+// grid = (ceil(max B / 256), batches), block = 256; O(B^2) compares up to kMaxOrdered items; larger batches are ranked by
+// a counting sort over the lengths (order_large_* below: items of equal length in arrival order of their atomics --
+// which of two equally long items lands in which tile changes nothing, neither results nor work).
 constexpr int kMaxOrdered = 8192;
-struct OrderJob { const int32_t *frames; int32_t *order; int B, T, tile0; };
+struct OrderJob { const int32_t *frames; int32_t *order; int B, T, tile0; int32_t *hist; };
 struct OrderJobs { OrderJob job[kMaxBatches]; int ascending; int n; int tiles; int32_t *tile_map; unsigned *stats; };
 
 __global__ __launch_bounds__(256) void order_items_kernel(OrderJobs jobs) {
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void order_items_kernel(OrderJobs jobs) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     const int B = jb.B, T = jb.T;
     if (b >= B) return;
-    if (B > kMaxOrdered) { jb.order[b] = b; return; }
+    if (B > kMaxOrdered) return;                     // order_large_* rank this batch
     int f = jb.frames[b];
     f = f < 1 ? 1 : (f > T ? T : f);
     int rank = 0;
@@ -116,6 +118,47 @@ __global__ __launch_bounds__(256) void order_items_kernel(OrderJobs jobs) {
         rank += (g > f) || (g == f && o < b);
     }
     jb.order[jobs.ascending ? B - 1 - rank : rank] = b;
+}
+
+// Batches above kMaxOrdered items: hist[f] = items of (clamped) length f (zeroed by the host), turned into the first rank
+// of every length by one block, then every item takes the next rank of its length.
+__global__ __launch_bounds__(256) void order_large_count_kernel(OrderJob jb) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= jb.B) return;
+    int f = jb.frames[b];
+    f = f < 1 ? 1 : (f > jb.T ? jb.T : f);
+    atomicAdd(&jb.hist[f], 1);
+}
+
+__global__ __launch_bounds__(1024) void order_large_scan_kernel(OrderJob jb, int ascending) {
+    // hist[f] <- number of items that rank before the items of length f (longer ones; shorter ones when ascending)
+    __shared__ int part[1024];
+    const int T = jb.T, tid = threadIdx.x;
+    const int per = (T + 1024) / 1024;                       // lengths 1..T in 1024 contiguous chunks, in rank order
+    auto length_at = [&](int k) { return ascending ? 1 + k : T - k; };      // k-th length in rank order
+    int sum = 0;
+    for (int k = tid * per; k < (tid + 1) * per && k < T; ++k) sum += jb.hist[length_at(k)];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 1024; ++i) { const int v = part[i]; part[i] = run; run += v; }
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int k = tid * per; k < (tid + 1) * per && k < T; ++k) {
+        const int f = length_at(k), v = jb.hist[f];
+        jb.hist[f] = run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(256) void order_large_place_kernel(OrderJob jb) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= jb.B) return;
+    int f = jb.frames[b];
+    f = f < 1 ? 1 : (f > jb.T ? jb.T : f);
+    jb.order[atomicAdd(&jb.hist[f], 1)] = b;
 }
 
 // ... and the group's TILES by descending length of their longest item: workgroup w decodes tile_map[w].  The GPU hands

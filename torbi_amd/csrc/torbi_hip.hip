@@ -315,33 +315,29 @@ __global__ __launch_bounds__(64) void finalize_kernel(
     }
 }
 
-// posterior read-back for tests (each item's last row lives in buffer (frames-1)&1)
-__global__ __launch_bounds__(256) void gather_posterior_kernel(
-    const float *__restrict__ post0, const float *__restrict__ post1,
-    const int32_t *__restrict__ frames, float *__restrict__ dst, int B, int T, int S) {
+// final posterior rows of the last decode, whatever path it took (route record): the generic path keeps them in its
+// ping-pong buffers, every value-only path as row frames-1 of the history at the start of the workspace
+__global__ __launch_bounds__(256) void gather_final_kernel(const int32_t *__restrict__ route, const float *__restrict__ hist,
+                                                           const float *__restrict__ post0, const float *__restrict__ post1,
+                                                           const int32_t *__restrict__ frames, float *__restrict__ dst,
+                                                           int B, int T, int S) {
+    const bool generic = *route == 0;
     const size_t n = (size_t)B * S;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
-         e += (size_t)gridDim.x * blockDim.x) {
-        const int b = (int)(e / S);
-        int f = frames[b];
-        f = f < 1 ? 1 : (f > T ? T : f);
-        dst[e] = (((f - 1) & 1) ? post1 : post0)[e];
-    }
-}
-
-// dense path: each item's last posterior row is history row frames-1
-__global__ __launch_bounds__(256) void gather_history_kernel(const float *__restrict__ hist,
-                                                             const int32_t *__restrict__ frames,
-                                                             float *__restrict__ dst, int B, int T, int S) {
-    const size_t n = (size_t)B * S;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
-         e += (size_t)gridDim.x * blockDim.x) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const int b = (int)(e / S);
         const int i = (int)(e - (size_t)b * S);
         int f = frames[b];
         f = f < 1 ? 1 : (f > T ? T : f);
-        dst[e] = hist[((size_t)b * T + (f - 1)) * S + i];
+        dst[e] = generic ? (((f - 1) & 1) ? post1 : post0)[e] : hist[((size_t)b * T + (f - 1)) * S + i];
     }
+}
+
+// scan statistics of the last decode by its route record: time-resident forms, per-timestep pruned pass, else zeros
+__global__ __launch_bounds__(128) void gather_stats_kernel(const int32_t *__restrict__ route, const unsigned *__restrict__ resident_stats,
+                                                           const unsigned *__restrict__ pruned_stats, unsigned *__restrict__ dst) {
+    const int r = *route;
+    const unsigned *src = (r == 3 || r == 5) ? resident_stats : (r == 2 ? pruned_stats : nullptr);
+    dst[threadIdx.x] = src ? src[threadIdx.x] : 0u;
 }
 
 // x <- log(exp(x) + tiny), the epsilon clamp of from_probabilities (torbi/core.py:193-197)
@@ -582,6 +578,8 @@ struct ResidentWorkspace {
     float *tt;
     int32_t *row_range;
     int32_t *order;       // [B] this batch's items by descending length
+    int32_t *lengths_hist;  // [T + 2] items per length (batches above resident::kMaxOrdered items only, else null)
+    size_t lengths_hist_bytes;
     int32_t *tile_map;    // [kMaxGroupTiles] workgroup -> tile of the launch group (first batch's workspace)
     unsigned *stats;      // [128] scan statistics of the last launch group (first batch's workspace)
     // cluster form (first batch's workspace): exchange buffers of up to cus / 2 tiles
@@ -603,7 +601,8 @@ inline ResidentWorkspace carve_resident(void *base, int B, int T, int S, int cus
     const size_t sorted_bytes = align_up(sizeof(float2) * (size_t)S * w.SpP, 256);
     const size_t tt_bytes = align_up(sizeof(float) * (size_t)S * S, 256);
     const size_t range_bytes = align_up(sizeof(int32_t) * 2 * (size_t)S, 256);
-    const size_t order_bytes = align_up(sizeof(int32_t) * (size_t)B, 256) + sizeof(int32_t) * (kMaxGroupTiles + 128);
+    const size_t hist_len = B > resident::kMaxOrdered ? align_up(sizeof(int32_t) * ((size_t)T + 2), 256) : 0;
+    const size_t order_bytes = align_up(sizeof(int32_t) * (size_t)B, 256) + sizeof(int32_t) * (kMaxGroupTiles + 128) + hist_len;
     const size_t ctiles = (size_t)std::max(cus / 2, 1);                 // a cluster launch holds at most this many tiles
     const size_t xchg_bytes = align_up(ctiles * 2 * resident::cluster_slot_bytes(S), 256);
     w.flag_bytes = align_up(sizeof(unsigned) * (ctiles * resident::kMaxR + 16), 256);
@@ -612,6 +611,8 @@ inline ResidentWorkspace carve_resident(void *base, int B, int T, int S, int cus
     w.tile_map = reinterpret_cast<int32_t *>(p);   // ahead of the preparation: offsets depend on B and T only
     w.stats = reinterpret_cast<unsigned *>(w.tile_map + kMaxGroupTiles);
     w.order = w.tile_map + kMaxGroupTiles + 128;
+    w.lengths_hist_bytes = hist_len;
+    w.lengths_hist = hist_len ? reinterpret_cast<int32_t *>(p + order_bytes - hist_len) : nullptr;
     p += order_bytes;
     w.sorted = reinterpret_cast<float2 *>(p);
     w.tt = reinterpret_cast<float *>(p + sorted_bytes);
@@ -694,14 +695,25 @@ inline DenseWorkspace carve_dense(void *base, int B, int T, int S, int cus) {
     return w;
 }
 
-// scratch a (B,T,S) problem needs on a device with `cus` compute units, whichever path runs
-inline size_t need_bytes(int B, int T, int S, int cus) {
+// scratch a (B,T,S) problem needs on a device with `cus` compute units, whichever path runs ...
+inline size_t layout_bytes(int B, int T, int S, int cus) {
     size_t need = carve(nullptr, B, T, S).bytes;
     if (use_dense(B, S)) need = std::max(need, carve_dense(nullptr, B, T, S, cus).bytes);
     if (pruned::supported(B, S)) need = std::max(need, carve_pruned(nullptr, B, T, S, cus).bytes);
     if (resident::supported(S)) need = std::max(need, carve_resident(nullptr, B, T, S, cus).bytes);
     if (rowscan::supported(B, S)) need = std::max(need, carve_rows(nullptr, B, T, S).bytes);
-    return need;
+    return align_up(need, 256);
+}
+// ... plus the ROUTE RECORD behind every layout: the forward path the last decode with this workspace actually took
+// (a Route), written on the stream by that decode and read ON THE DEVICE by torbi_hip_read_posterior /
+// torbi_hip_scan_stats -- a batch decoded inside a launch group takes the group's route, not the one its own shape
+// and flags would give it.
+inline size_t need_bytes(int B, int T, int S, int cus) { return layout_bytes(B, T, S, cus) + 256; }
+inline int32_t *route_record(const void *workspace, int B, int T, int S, int cus) {
+    return reinterpret_cast<int32_t *>(static_cast<char *>(const_cast<void *>(workspace)) + layout_bytes(B, T, S, cus));
+}
+inline hipError_t stamp_route(void *workspace, int B, int T, int S, int cus, Route route, hipStream_t s) {
+    return hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(route_record(workspace, B, T, S, cus)), (int)route, 1, s);
 }
 
 // ... on the device with the most demanding plan (devices of one node are normally identical)
@@ -1003,7 +1015,7 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
         b.out = hb[k].out;
         b.hist = wk.hist;
         b.order = wk.order;
-        jobs.job[k] = resident::OrderJob{hb[k].frames, wk.order, hb[k].B, hb[k].T, tiles};
+        jobs.job[k] = resident::OrderJob{hb[k].frames, wk.order, hb[k].B, hb[k].T, tiles, wk.lengths_hist};
         widest = std::max(widest, hb[k].B);
         b.B = hb[k].B;
         b.T = hb[k].T;
@@ -1024,8 +1036,22 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
     const int R = clusters ? cluster_members(tiles, S, cus) : 1;
     resident::Cluster clu{w.xchg, w.flags, w.flags + (size_t)std::max(cus / 2, 1) * resident::kMaxR, R};
     if (ev) (void)hipEventRecord(ev[0], s);
+    for (int k = 0; k < n; ++k) {
+        const hipError_t re = stamp_route(hb[k].workspace, hb[k].B, hb[k].T, S, cus, R > 1 ? ROUTE_CLUSTER : ROUTE_RESIDENT, s);
+        if (re != hipSuccess) return re;
+    }
     if (!reuse) launch_list_preparation(trans, w.sorted, w.row_range, w.tt, S, w.SpP, w.NPOW, resident::kNI, s);
     hipLaunchKernelGGL(resident::order_items_kernel, dim3((widest + 255) / 256, n), dim3(256), 0, s, jobs);
+    for (int k = 0; k < n; ++k) {            // batches too large for the all-pairs ranking: counting sort over the lengths
+        const resident::OrderJob &jb = jobs.job[k];
+        if (jb.B <= resident::kMaxOrdered) continue;
+        const ResidentWorkspace wk = carve_resident(hb[k].workspace, hb[k].B, hb[k].T, S, cus);
+        hipError_t me = hipMemsetAsync(wk.lengths_hist, 0, wk.lengths_hist_bytes, s);
+        if (me != hipSuccess) return me;
+        hipLaunchKernelGGL(resident::order_large_count_kernel, dim3((jb.B + 255) / 256), dim3(256), 0, s, jb);
+        hipLaunchKernelGGL(resident::order_large_scan_kernel, dim3(1), dim3(1024), 0, s, jb, jobs.ascending);
+        hipLaunchKernelGGL(resident::order_large_place_kernel, dim3((jb.B + 255) / 256), dim3(256), 0, s, jb);
+    }
     hipLaunchKernelGGL(resident::order_tiles_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, jobs);
     hipError_t e;
     if (R > 1) {
@@ -1083,6 +1109,8 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
     }
     if (ev) (void)hipEventRecord(ev[0], s);
     if (ev) (void)hipEventRecord(ev[3], s);
+    e = stamp_route(workspace, B, T, S, cus, route, s);
+    if (e != hipSuccess) return e;
     if (route == ROUTE_PRUNED) {
         const PrunedWorkspace w = carve_pruned(workspace, B, T, S, cus);
         e = launch_pruned_forward(obs, frames, trans, init, w, B, T, S, s, launches, reuse, collect);
@@ -1299,16 +1327,15 @@ int torbi_hip_scan_stats(const void *workspace, size_t workspace_bytes, int B, i
     DeviceGuard guard(device);
     if (guard.err != hipSuccess) return (int)guard.err;
     if (workspace_bytes < need_bytes(B, T, S, cu_count(device))) return TORBI_HIP_EWORKSPACE;
-    const unsigned *stats;
-    const int asked = requested_path(flags);
-    if ((asked == TORBI_HIP_FORWARD_RESIDENT || asked == TORBI_HIP_FORWARD_CLUSTER) && resident::supported(S))
-        stats = carve_resident(const_cast<void *>(workspace), B, T, S, cu_count(device)).stats;
-    else if (pruned::supported(B, S))
-        stats = carve_pruned(const_cast<void *>(workspace), B, T, S, cu_count(device)).stats;
-    else
-        return TORBI_HIP_EUNSUPPORTED;
-    return (int)hipMemcpyAsync(stats_out, stats, sizeof(unsigned) * 2 * pruned::kStatSlots, hipMemcpyDeviceToDevice,
-                               static_cast<hipStream_t>(stream));
+    // which statistics: decided on the device by the route the last decode with this workspace took
+    const int cus = cu_count(device);
+    const unsigned *resident_stats = resident::supported(S) ? carve_resident(const_cast<void *>(workspace), B, T, S, cus).stats : nullptr;
+    const unsigned *pruned_stats = pruned::supported(B, S) ? carve_pruned(const_cast<void *>(workspace), B, T, S, cus).stats : nullptr;
+    if (!resident_stats && !pruned_stats) return TORBI_HIP_EUNSUPPORTED;
+    hipLaunchKernelGGL(gather_stats_kernel, dim3(1), dim3(2 * pruned::kStatSlots), 0, static_cast<hipStream_t>(stream),
+                       route_record(workspace, B, T, S, cus), resident_stats ? resident_stats : pruned_stats,
+                       pruned_stats ? pruned_stats : resident_stats, stats_out);
+    return (int)hipGetLastError();
 }
 
 int torbi_hip_viterbi_decode_uniform(const float *observation, const int32_t *batch_frames,
@@ -1362,16 +1389,10 @@ int torbi_hip_read_posterior(const void *workspace, size_t workspace_bytes,
     if (workspace_bytes < need_bytes(B, T, S, cu_count(device))) return TORBI_HIP_EWORKSPACE;
     const size_t n = (size_t)B * S;
     const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    if (route_for(requested_path(flags), B, S, cu_count(device)) != ROUTE_GENERIC) {
-        // every value-only path keeps the posterior history at the start of the workspace
-        hipLaunchKernelGGL(gather_history_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
-                           static_cast<const float *>(workspace), batch_frames, posterior_out, B, T, S);
-    } else {
-        const Workspace w = carve(const_cast<void *>(workspace), B, T, S);
-        hipLaunchKernelGGL(gather_posterior_kernel, dim3(grid), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), w.post[0], w.post[1], batch_frames,
-                           posterior_out, B, T, S);
-    }
+    const Workspace w = carve(const_cast<void *>(workspace), B, T, S);
+    hipLaunchKernelGGL(gather_final_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       route_record(workspace, B, T, S, cu_count(device)), static_cast<const float *>(workspace), w.post[0],
+                       w.post[1], batch_frames, posterior_out, B, T, S);
     return (int)hipGetLastError();
 }
 

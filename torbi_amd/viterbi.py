@@ -6,12 +6,12 @@ implementation through the C ABI (include/torbi_hip.h) instead of
 """
 import ctypes
 import os
-import weakref
 from typing import Optional
 
 import torch
 
-from . import _lib
+from . import _lib, state
+from .state import _version_of
 
 
 def _require_gpu():
@@ -50,15 +50,6 @@ def _check_inputs(observation, batch_frames, transition, initial):
 def workspace_bytes(batch: int, frames: int, states: int) -> int:
     """Scratch bytes one decode of this shape needs (trellis + posterior rows)."""
     return int(_lib.load().torbi_hip_workspace_bytes(batch, frames, states))
-
-
-def _version_of(tensor: torch.Tensor):
-    """A tensor's version counter, or None where it has none (tensors created under
-    torch.inference_mode() raise on `_version`): callers then neither cache nor reuse anything keyed on it."""
-    try:
-        return tensor._version
-    except RuntimeError:
-        return None
 
 
 def _path_flag(path: str) -> int:
@@ -104,21 +95,15 @@ def _resolve_path(trans, transition, B, S, device, path, tiles, measure, count=1
 # fraction of a row's S/16 list blocks per scan above which the dense kernel wins (tools/peaked_group_probe.py at 1440
 # states: 11 blocks -> 53 M timesteps/s, 19 -> 36 M, 31 -> 23 M, 44 -> 17 M; the dense kernel 12.7 M whatever the data)
 RESIDENT_GATE = 0.65
-_group_depth = {}        # id(transition) -> [weakref, version, states, blocks or None, pending (pinned stats, event)]
 
 
 def _depth_record(transition: torch.Tensor, states: int):
-    version = _version_of(transition)
-    if version is None:
+    """[blocks per scan of a time-resident launch with this matrix (None until known), pending (pinned stats, event)],
+    kept with the tensor's notes (torbi_amd/state.py)."""
+    kept = state.notes(transition)
+    if kept is None:
         return None
-    known = _group_depth.get(id(transition))
-    if known is None or known[0]() is not transition or known[1:3] != [version, states]:
-        if len(_group_depth) > 64:
-            for key in [k for k, v in list(_group_depth.items()) if v[0]() is None]:
-                _group_depth.pop(key, None)
-        known = [weakref.ref(transition), version, states, None, None]
-        _group_depth[id(transition)] = known
-    return known
+    return kept.setdefault(('depth', states), [None, None])
 
 
 def _resident_is_losing(transition: torch.Tensor, states: int) -> bool:
@@ -127,23 +112,23 @@ def _resident_is_losing(transition: torch.Tensor, states: int) -> bool:
     known = _depth_record(transition, states)
     if known is None:
         return False
-    if known[3] is None and known[4] is not None and known[4][1].query():
-        known[3] = critical_blocks(known[4][0])
-        known[4] = None
-    return known[3] is not None and known[3] > RESIDENT_GATE * states / 16.0
+    if known[0] is None and known[1] is not None and known[1][1].query():
+        known[0] = critical_blocks(known[1][0])
+        known[1] = None
+    return known[0] is not None and known[0] > RESIDENT_GATE * states / 16.0
 
 
 def _watch_resident(transition, workspace, batch, frames, states) -> None:
     """After a time-resident launch chosen by AUTO: once per matrix, copy the scan statistics it leaves in its first
     workspace to pinned host memory (asynchronously; looked at by a later call, never waited for)."""
     known = _depth_record(transition, states)
-    if known is None or known[3] is not None or known[4] is not None:
+    if known is None or known[0] is not None or known[1] is not None:
         return
     stats = torch.empty((128,), dtype=torch.int32, pin_memory=True)
     stats.copy_(scan_stats(workspace, batch, frames, states, path='resident'), non_blocking=True)
     done = torch.cuda.Event()
     done.record(torch.cuda.current_stream(workspace.device))
-    known[4] = (stats, done)
+    known[1] = (stats, done)
 
 
 def compute_units(device) -> int:
@@ -296,16 +281,16 @@ def _reusable(workspace, transition, shape_state, wanted) -> bool:
     """Remember what `workspace` will hold after the call being issued (the per-transition preparation for this
     shape, path and stream) and say whether it already does.  The transition is identified by the tensor OBJECT
     and its version (a new tensor can reuse a freed address); a tensor without a version counter (inference
-    mode) is never reused."""
+    mode) is never reused.  Kept with the workspace tensor's notes (torbi_amd/state.py)."""
+    import weakref
     version = _version_of(transition)
-    state = shape_state + (version,)
-    known = _prepared.get(id(workspace))
-    hit = (wanted and version is not None and known is not None and known[0]() is workspace and known[1] == state
-           and known[2]() is transition)
-    if len(_prepared) > 64:
-        for key in [k for k, v in list(_prepared.items()) if v[0]() is None]:
-            _prepared.pop(key, None)
-    _prepared[id(workspace)] = (weakref.ref(workspace), state, weakref.ref(transition))
+    kept = state.notes(workspace)
+    if kept is None:
+        return False
+    known = kept.get('holds')
+    holds = shape_state + (version,)
+    hit = (wanted and version is not None and known is not None and known[0] == holds and known[1]() is transition)
+    kept['holds'] = (holds, weakref.ref(transition))
     return bool(hit)
 
 
@@ -464,32 +449,27 @@ class _Tuner:
         self.pending.append((path, begin, end, stats, steps))
 
 
-_tuners = {}                     # id(transition) -> (weakref, version, states, _Tuner)
-
-
 def collect_measurements() -> None:
     """Fold completed decodes into the path tuners now (DecodePipeline calls this whenever it has waited for the
     device anyway, so the bookkeeping does not land at the start of the next decode)."""
-    for known in list(_tuners.values()):
-        if not known[3].settled():
-            known[3]._collect()
+    for tuner in state.every('tuner'):
+        if not tuner.settled():
+            tuner._collect()
 
 
 def _tuner_for(transition: torch.Tensor, states: int, device) -> Optional[_Tuner]:
-    version = _version_of(transition)
-    if version is None:
+    """The path tuner of this transition tensor (object and version): it lives as long as the tensor does."""
+    kept = state.notes(transition)
+    if kept is None:
         return None              # no identity to key measurements on (inference tensor): keep the default path
-    known = _tuners.get(id(transition))
-    if known is None or known[0]() is not transition or known[1:3] != (version, states):
-        if len(_tuners) > 64:
-            for key in [k for k, v in list(_tuners.items()) if v[0]() is None]:
-                _tuners.pop(key, None)
-        known = (weakref.ref(transition), version, states, _Tuner(states))
-        _tuners[id(transition)] = known
-    return known[3]
+    tuner = kept.get('tuner')
+    if tuner is None or kept.get('tuner_states') != states:
+        tuner = kept['tuner'] = _Tuner(states)
+        kept['tuner_states'] = states
+    return tuner
+
+
 _forced_path = {'d': 'dense', 'p': 'pruned', 'r': 'resident', 'c': 'cluster'}.get(os.environ.get('TORBI_HIP_FORWARD', 'a')[:1], 'auto')
-_prepared = {}                   # id(workspace) -> (weakref, state): see decode(reuse_preparation=True)
-_structure_cache = {}            # id(transition) -> (weakref, (version, states), mean finite range of a row / S)
 BANDED_RANGE = 0.25              # rows reaching less than this fraction of the states: dense + -inf skipping
 
 
@@ -543,21 +523,16 @@ def _choose_path(trans: torch.Tensor, original: torch.Tensor, batch: int, states
     own fallbacks) for shapes where the value-only paths offer no choice."""
     if batch < 32 or states < 64 or states > 4096:   # dense needs B >= 32
         return 'auto'
-    version = _version_of(original)
-    known = _structure_cache.get(id(original)) if version is not None else None
-    reach = None
-    if known is not None and known[0]() is original and known[1] == (version, states):
-        reach = known[2]
+    kept = state.notes(original)                     # None for tensors without a version counter: looked at, not kept
+    reach = kept.get(('reach', states)) if kept is not None else None
     if reach is None:
         finite = trans != float('-inf')
         index = torch.arange(states, device=trans.device)
         lo = torch.where(finite, index, states).amin(dim=1)
         hi = torch.where(finite, index, -1).amax(dim=1)
         reach = float((hi - lo + 1).clamp(min=0).float().mean().item()) / states
-        if version is not None:
-            if len(_structure_cache) >= 64:
-                _structure_cache.clear()
-            _structure_cache[id(original)] = (weakref.ref(original), (version, states), reach)
+        if kept is not None:
+            kept[('reach', states)] = reach
     return 'dense' if 0.0 < reach < BANDED_RANGE else 'pruned'
 
 
