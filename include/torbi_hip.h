@@ -137,6 +137,12 @@ int torbi_hip_viterbi_decode(const float *observation, const int32_t *batch_fram
 #define TORBI_HIP_REUSE_TRANSITION 1u
 #define TORBI_HIP_COLLECT_STATS 2u     /* a PRUNED decode also leaves scan statistics: torbi_hip_scan_stats */
 #define TORBI_HIP_SHORTEST_FIRST 256u  /* RESIDENT: workgroups in ascending order of their items' lengths (default: longest first) */
+#define TORBI_HIP_FEW_SEEDS 512u       /* RESIDENT / CLUSTER: ONE explicit candidate per item (its largest posterior) instead of
+                                        * three.  Same results.  For callers that have seen shallow scans with this matrix
+                                        * (torbi_hip_scan_stats: ~11 of 90 list blocks per scan on the benchmark): the seed
+                                        * gathers walk whole rows of the transposed matrix through the L2s -- two thirds of the
+                                        * kernel's memory-side read traffic with three seeds -- and buy nothing on flat
+                                        * posterior rows; on peaked rows three seeds scan a fifth fewer list blocks. */
 int torbi_hip_viterbi_decode_ex(const float *observation, const int32_t *batch_frames,
                                 const float *transition, const float *initial,
                                 int32_t *indices_out, void *workspace, size_t workspace_bytes,

@@ -436,6 +436,34 @@ def test_posterior_and_statistics_follow_the_route_the_decode_took(forward):
             assert int(stats[64]) > 0 and int(stats[127]) == 0       # wave passes counted, no cluster gave up waiting
 
 
+def test_one_seed_per_item_after_shallow_scans_gives_the_same_indices(forward):
+    """TORBI_HIP_FEW_SEEDS: once an earlier time-resident launch with a matrix has reported shallow scans, later launches
+    keep ONE explicit candidate per item instead of three (a third of the seed gathers' traffic, same speed on flat rows).
+    The flag must not show in the results: flat and peaked rows, whole tiles and clusters, against the oracle."""
+    if forward != 'auto':
+        pytest.skip('names its paths itself')
+    dev = torch.device('cuda:0')
+    S, T = 360, 14
+    obs, trans, init = synth.problem(300, T, S, seed=31)
+    rng = np.random.default_rng(5)
+    peaked = obs.copy()
+    centre = rng.integers(0, S, size=(300, T, 1))
+    peaked -= ((np.abs(np.arange(S)[None, None, :] - centre) / 6.0) ** 2).astype(np.float32)
+    frames = np.clip(synth.lengths(300, 1, T, seed=2), 1, T).astype(np.int32)
+    frames[0] = T
+    d_trans, d_init = torch.tensor(trans, device=dev), torch.tensor(init, device=dev)
+    for data in (obs, peaked):
+        want = oracle.decode(data, frames, trans, init, num_threads=oracle.max_threads())
+        d_obs, d_frames = torch.tensor(data, device=dev), torch.tensor(frames, device=dev)
+        for path in ('resident', 'cluster'):
+            for blocks in (None, 1.0):                           # unknown depth: three seeds; shallow: one
+                viterbi._depth_record(d_trans, S)[0] = blocks
+                assert viterbi._few_seeds(d_trans, S) == (blocks is not None)
+                got = torbi_amd.decode(d_obs, d_frames, d_trans, d_init, path=path)
+                np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f'{path} few={blocks is not None}')
+    torbi_amd.reset_path_state()
+
+
 def test_fill_synthetic_matches_numpy_definition():
     for stream, seed, n, start in [(1, 0, 100003, 0), (2, 5, 4099, 17), (3, 1, 7, 1 << 33)]:
         got = viterbi.fill_synthetic((n,), stream, seed=seed, start=start).cpu().numpy()

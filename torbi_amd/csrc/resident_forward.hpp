@@ -100,13 +100,15 @@ __host__ __device__ inline int cluster_first_group(int m, int nrg, int R) { retu
 // a counting sort over the lengths (order_large_* below: items of equal length in arrival order of their atomics --
 // which of two equally long items lands in which tile changes nothing, neither results nor work).
 constexpr int kMaxOrdered = 8192;
-struct OrderJob { const int32_t *frames; int32_t *order; int B, T, tile0; int32_t *hist; };
-struct OrderJobs { OrderJob job[kMaxBatches]; int ascending; int n; int tiles; int32_t *tile_map; unsigned *stats; };
+struct OrderJob { const int32_t *frames; int32_t *order; int B, T, tile0; int32_t *hist; int32_t *route_record; int route; };
+struct OrderJobs { OrderJob job[kMaxBatches]; int ascending; int n; int tiles; int32_t *tile_map; unsigned *stats;
+                   unsigned *flags; int nflags; };      // cluster form: the flag / ticket words to zero (else nflags = 0)
 
 __global__ __launch_bounds__(256) void order_items_kernel(OrderJobs jobs) {
     const OrderJob &jb = jobs.job[blockIdx.y];
     const int b = blockIdx.x * 256 + threadIdx.x;
     const int B = jb.B, T = jb.T;
+    if (b == 0 && jb.route_record) *jb.route_record = jb.route;      // the route this batch's decode takes (torbi_hip.hip)
     if (b >= B) return;
     if (B > kMaxOrdered) return;                     // order_large_* rank this batch
     int f = jb.frames[b];
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(256) void order_large_place_kernel(OrderJob jb) {
 __global__ __launch_bounds__(256) void order_tiles_kernel(OrderJobs jobs) {
     const int w = blockIdx.x * 256 + threadIdx.x;
     if (w < 128) jobs.stats[w] = 0u;                 // the forward launch that follows accumulates into them
+    for (int k = w; k < jobs.nflags; k += gridDim.x * 256) jobs.flags[k] = 0u;     // cluster flags and tickets start at zero
     if (w >= jobs.tiles) return;
     auto tile_length = [&](int k, int j) {
         const OrderJob &jb = jobs.job[k];
@@ -404,8 +407,8 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
         // seeds and bound of this lane's four items: the kR largest posteriors are explicit candidates, the
         // (kR+1)-th bounds every other one.  Items that have ended (t >= frames) get thr = -inf: their bound
         // never asks for another list block.
-        float seedv[4][kR], thr[4];
-        int seedo[4][kR];
+        float seedv[4][kR ? kR : 1], thr[4];          // (kR = 0: no seeds at all, thr = the largest posterior)
+        int seedo[4][kR ? kR : 1];
         bool live[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                     for (int it = 0; it < 4; ++it)
                         ob[it] = (RESIDENT_ABL & 32) ? 0.5f * it : obs[((size_t)ib[it] * T + t) * S + jr];
                 }
-                float seedt[4][kR];
+                float seedt[4][kR ? kR : 1];
 #pragma unroll
                 for (int it = 0; it < 4; ++it)
 #pragma unroll

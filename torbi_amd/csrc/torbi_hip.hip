@@ -473,7 +473,8 @@ inline int requested_path(unsigned flags) {
     const unsigned f = (flags >> 4) & 7u;
     return f ? (int)f - 1 : default_path();
 }
-constexpr unsigned kKnownFlags = TORBI_HIP_REUSE_TRANSITION | TORBI_HIP_COLLECT_STATS | (7u << 4) | TORBI_HIP_SHORTEST_FIRST;
+constexpr unsigned kKnownFlags = TORBI_HIP_REUSE_TRANSITION | TORBI_HIP_COLLECT_STATS | (7u << 4) | TORBI_HIP_SHORTEST_FIRST |
+                                 TORBI_HIP_FEW_SEEDS;
 inline bool flags_ok(unsigned flags) {
     return !(flags & ~kKnownFlags) && ((flags >> 4) & 7u) <= (unsigned)TORBI_HIP_FORWARD_CLUSTER + 1u;
 }
@@ -712,8 +713,11 @@ inline size_t need_bytes(int B, int T, int S, int cus) { return layout_bytes(B, 
 inline int32_t *route_record(const void *workspace, int B, int T, int S, int cus) {
     return reinterpret_cast<int32_t *>(static_cast<char *>(const_cast<void *>(workspace)) + layout_bytes(B, T, S, cus));
 }
+__global__ void stamp_route_kernel(int32_t *record, int route) { *record = route; }
 inline hipError_t stamp_route(void *workspace, int B, int T, int S, int cus, Route route, hipStream_t s) {
-    return hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(route_record(workspace, B, T, S, cus)), (int)route, 1, s);
+    // (a one-thread kernel: hipMemsetD32Async costs ~0.17 ms per call on this stack)
+    hipLaunchKernelGGL(stamp_route_kernel, dim3(1), dim3(1), 0, s, route_record(workspace, B, T, S, cus), (int)route);
+    return hipGetLastError();
 }
 
 // ... on the device with the most demanding plan (devices of one node are normally identical)
@@ -970,14 +974,15 @@ struct HostBatch {
     int B, T;
 };
 
-// TORBI_HIP_RESIDENT_KR=1|3: seeds per item of the time-resident kernel (experiments; default 3)
-inline int resident_seeds() {
-    static const int v = [] {
+// seeds per item of the time-resident kernel: 3, or 1 with TORBI_HIP_FEW_SEEDS; TORBI_HIP_RESIDENT_KR=0|1|3 overrides
+// both (experiments)
+inline int resident_seeds(bool few) {
+    static const int forced = [] {
         const char *e = getenv("TORBI_HIP_RESIDENT_KR");
-        const int x = e ? atoi(e) : 0;
-        return x == 1 ? 1 : 3;
+        const int x = e ? atoi(e) : -1;
+        return (x == 0 || x == 1 || x == 3) ? x : -1;
     }();
-    return v;
+    return forced >= 0 ? forced : (few ? 1 : 3);
 }
 
 template <int KW, int MAXP, int KR, bool CLUSTER>
@@ -994,14 +999,17 @@ hipError_t launch_resident_variant(const resident::Group &grp, const resident::C
 
 template <int KW, int MAXP, bool CLUSTER>
 hipError_t launch_resident_kernel(const resident::Group &grp, const resident::Cluster &clu, int workgroups,
-                                  const ResidentWorkspace &w, const float *init, int S, hipStream_t stream) {
-    return resident_seeds() == 1 ? launch_resident_variant<KW, MAXP, 1, CLUSTER>(grp, clu, workgroups, w, init, S, stream)
-                                 : launch_resident_variant<KW, MAXP, 3, CLUSTER>(grp, clu, workgroups, w, init, S, stream);
+                                  const ResidentWorkspace &w, const float *init, int S, hipStream_t stream, bool few) {
+    const int kr = resident_seeds(few);
+    return kr == 0 ? launch_resident_variant<KW, MAXP, 0, CLUSTER>(grp, clu, workgroups, w, init, S, stream)
+         : kr == 1 ? launch_resident_variant<KW, MAXP, 1, CLUSTER>(grp, clu, workgroups, w, init, S, stream)
+                   : launch_resident_variant<KW, MAXP, 3, CLUSTER>(grp, clu, workgroups, w, init, S, stream);
 }
 
 // batches with B > 0 only; the preparation lives in the first batch's workspace
 hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const float *init, int S, int cus, hipStream_t s,
-                        hipEvent_t *ev, int *launches, bool reuse, bool ascending = false, bool clusters = false) {
+                        hipEvent_t *ev, int *launches, bool reuse, bool ascending = false, bool clusters = false,
+                        bool few = false) {
     resident::Group grp{};
     resident::OrderJobs jobs{};
     jobs.ascending = ascending ? 1 : 0;
@@ -1015,7 +1023,7 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
         b.out = hb[k].out;
         b.hist = wk.hist;
         b.order = wk.order;
-        jobs.job[k] = resident::OrderJob{hb[k].frames, wk.order, hb[k].B, hb[k].T, tiles, wk.lengths_hist};
+        jobs.job[k] = resident::OrderJob{hb[k].frames, wk.order, hb[k].B, hb[k].T, tiles, wk.lengths_hist, nullptr, 0};
         widest = std::max(widest, hb[k].B);
         b.B = hb[k].B;
         b.T = hb[k].T;
@@ -1036,9 +1044,9 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
     const int R = clusters ? cluster_members(tiles, S, cus) : 1;
     resident::Cluster clu{w.xchg, w.flags, w.flags + (size_t)std::max(cus / 2, 1) * resident::kMaxR, R};
     if (ev) (void)hipEventRecord(ev[0], s);
-    for (int k = 0; k < n; ++k) {
-        const hipError_t re = stamp_route(hb[k].workspace, hb[k].B, hb[k].T, S, cus, R > 1 ? ROUTE_CLUSTER : ROUTE_RESIDENT, s);
-        if (re != hipSuccess) return re;
+    for (int k = 0; k < n; ++k) {            // (order_items_kernel stamps the batches' route records)
+        jobs.job[k].route_record = route_record(hb[k].workspace, hb[k].B, hb[k].T, S, cus);
+        jobs.job[k].route = (int)(R > 1 ? ROUTE_CLUSTER : ROUTE_RESIDENT);
     }
     if (!reuse) launch_list_preparation(trans, w.sorted, w.row_range, w.tt, S, w.SpP, w.NPOW, resident::kNI, s);
     hipLaunchKernelGGL(resident::order_items_kernel, dim3((widest + 255) / 256, n), dim3(256), 0, s, jobs);
@@ -1052,23 +1060,21 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
         hipLaunchKernelGGL(resident::order_large_scan_kernel, dim3(1), dim3(1024), 0, s, jb, jobs.ascending);
         hipLaunchKernelGGL(resident::order_large_place_kernel, dim3((jb.B + 255) / 256), dim3(256), 0, s, jb);
     }
+    jobs.flags = w.flags;
+    jobs.nflags = R > 1 ? (int)(w.flag_bytes / sizeof(unsigned)) : 0;
     hipLaunchKernelGGL(resident::order_tiles_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, jobs);
     hipError_t e;
-    if (R > 1) {
-        e = hipMemsetAsync(w.flags, 0, w.flag_bytes, s);
-        if (e != hipSuccess) return e;
-    }
     if (ev) (void)hipEventRecord(ev[3], s);
     const int nrg = (S + resident::kRowGroup - 1) / resident::kRowGroup;
     if (R > 1) {
         const int passes = ((nrg + R - 1) / R + 11) / 12;       // row groups of the largest share over 12 waves
-        if (passes <= 1) e = launch_resident_kernel<12, 1, true>(grp, clu, tiles * R, w, init, S, s);
-        else if (passes <= 2) e = launch_resident_kernel<12, 2, true>(grp, clu, tiles * R, w, init, S, s);
-        else if (passes <= 4) e = launch_resident_kernel<12, 4, true>(grp, clu, tiles * R, w, init, S, s);
-        else e = launch_resident_kernel<12, 6, true>(grp, clu, tiles * R, w, init, S, s);
-    } else if (nrg <= 72) e = launch_resident_kernel<12, 6, false>(grp, clu, tiles, w, init, S, s);
-    else if (nrg <= 96) e = launch_resident_kernel<12, 8, false>(grp, clu, tiles, w, init, S, s);
-    else e = launch_resident_kernel<12, 11, false>(grp, clu, tiles, w, init, S, s);
+        if (passes <= 1) e = launch_resident_kernel<12, 1, true>(grp, clu, tiles * R, w, init, S, s, few);
+        else if (passes <= 2) e = launch_resident_kernel<12, 2, true>(grp, clu, tiles * R, w, init, S, s, few);
+        else if (passes <= 4) e = launch_resident_kernel<12, 4, true>(grp, clu, tiles * R, w, init, S, s, few);
+        else e = launch_resident_kernel<12, 6, true>(grp, clu, tiles * R, w, init, S, s, few);
+    } else if (nrg <= 72) e = launch_resident_kernel<12, 6, false>(grp, clu, tiles, w, init, S, s, few);
+    else if (nrg <= 96) e = launch_resident_kernel<12, 8, false>(grp, clu, tiles, w, init, S, s, few);
+    else e = launch_resident_kernel<12, 11, false>(grp, clu, tiles, w, init, S, s, few);
     if (launches) *launches = 1;
     if (ev) (void)hipEventRecord(ev[1], s);
     if (e != hipSuccess) return e;
@@ -1099,13 +1105,13 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
 // one decode on `s`; optional events bracket the forward and backtrace phases (ev[3]: end of the preparation)
 hipError_t run_decode(const float *obs, const int32_t *frames, const float *trans, const float *init,
                       int32_t *out, void *workspace, int B, int T, int S, int device, hipStream_t s,
-                      hipEvent_t *ev, int *launches, bool reuse, bool collect, int path) {
+                      hipEvent_t *ev, int *launches, bool reuse, bool collect, int path, bool few = false) {
     hipError_t e;
     const int cus = cu_count(device);
     const Route route = route_for(path, B, S, cus);
     if (route == ROUTE_RESIDENT || route == ROUTE_CLUSTER) {
         const HostBatch hb{obs, frames, out, workspace, B, T};
-        return run_resident(&hb, 1, trans, init, S, cus, s, ev, launches, reuse, false, route == ROUTE_CLUSTER);
+        return run_resident(&hb, 1, trans, init, S, cus, s, ev, launches, reuse, false, route == ROUTE_CLUSTER, few);
     }
     if (ev) (void)hipEventRecord(ev[0], s);
     if (ev) (void)hipEventRecord(ev[3], s);
@@ -1249,7 +1255,7 @@ int torbi_hip_viterbi_decode_ex(const float *observation, const int32_t *batch_f
     return (int)run_decode(observation, batch_frames, transition, initial, indices_out, workspace,
                            B, T, S, device, static_cast<hipStream_t>(stream), nullptr, nullptr,
                            (flags & TORBI_HIP_REUSE_TRANSITION) != 0, (flags & TORBI_HIP_COLLECT_STATS) != 0,
-                           requested_path(flags));
+                           requested_path(flags), (flags & TORBI_HIP_FEW_SEEDS) != 0);
 }
 
 int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, const float *transition,
@@ -1287,14 +1293,14 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
                           (path == TORBI_HIP_FORWARD_RESIDENT || path == TORBI_HIP_FORWARD_CLUSTER ||
                            (path == TORBI_HIP_FORWARD_AUTO && (2 * tiles > cus || (split && largest > 16))));
     const bool clusters = together && split && path != TORBI_HIP_FORWARD_RESIDENT;
-    const bool ascending = (flags & TORBI_HIP_SHORTEST_FIRST) != 0;
+    const bool ascending = (flags & TORBI_HIP_SHORTEST_FIRST) != 0, few = (flags & TORBI_HIP_FEW_SEEDS) != 0;
     if (phase_ms) {
         PhaseEvents pe;
         if (pe.err != hipSuccess) return (int)pe.err;
         int launches = 0;
         hipError_t e;
         if (together) {
-            e = run_resident(hb, n, transition, initial, S, cus, s, pe.ev, &launches, reuse, ascending, clusters);
+            e = run_resident(hb, n, transition, initial, S, cus, s, pe.ev, &launches, reuse, ascending, clusters, few);
             phase_ms[3] = (float)(clusters ? ROUTE_CLUSTER : ROUTE_RESIDENT);
         } else {
             // one batch after the other, each on the path it would take alone; phases of the LAST batch only
@@ -1302,7 +1308,7 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
             // (the reuse promise covers the first batch's workspace only)
             for (int k = 0; k < n && e == hipSuccess; ++k)
                 e = run_decode(hb[k].obs, hb[k].frames, transition, initial, hb[k].out, hb[k].workspace, hb[k].B,
-                               hb[k].T, S, device, s, k == n - 1 ? pe.ev : nullptr, &launches, reuse && k == 0, false, path);
+                               hb[k].T, S, device, s, k == n - 1 ? pe.ev : nullptr, &launches, reuse && k == 0, false, path, few);
             phase_ms[3] = (float)route_for(path, hb[n - 1].B, S, cus);
         }
         if (e == hipSuccess) e = pe.read(phase_ms);
@@ -1311,11 +1317,11 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
         return (int)e;
     }
     if (together)
-        return (int)run_resident(hb, n, transition, initial, S, cus, s, nullptr, nullptr, reuse, ascending, clusters);
+        return (int)run_resident(hb, n, transition, initial, S, cus, s, nullptr, nullptr, reuse, ascending, clusters, few);
     for (int k = 0; k < n; ++k) {
         const hipError_t e = run_decode(hb[k].obs, hb[k].frames, transition, initial, hb[k].out, hb[k].workspace,
                                         hb[k].B, hb[k].T, S, device, s, nullptr, nullptr, reuse && k == 0,
-                                        (flags & TORBI_HIP_COLLECT_STATS) != 0, path);
+                                        (flags & TORBI_HIP_COLLECT_STATS) != 0, path, few);
         if (e != hipSuccess) return (int)e;
     }
     return TORBI_HIP_OK;

@@ -118,6 +118,24 @@ def _resident_is_losing(transition: torch.Tensor, states: int) -> bool:
     return known[0] is not None and known[0] > RESIDENT_GATE * states / 16.0
 
 
+# scans this shallow (fraction of a row's S/16 list blocks per wave pass; 0.12 on the benchmark, 0.28-0.47 on peaked rows
+# with a dense matrix) gain nothing from three seeds per item: one is as fast and reads a third of the transposed matrix
+FEW_SEEDS_GATE = 0.17
+
+
+def _few_seeds(transition: torch.Tensor, states: int) -> bool:
+    """TORBI_HIP_FEW_SEEDS for time-resident launches with this matrix: an earlier launch's scan statistics are in and
+    say that the scans are shallow (read without blocking; until then, and for tensors without a version counter, three
+    seeds)."""
+    known = _depth_record(transition, states)
+    if known is None:
+        return False
+    if known[0] is None and known[1] is not None and known[1][1].query():
+        known[0] = critical_blocks(known[1][0])
+        known[1] = None
+    return known[0] is not None and known[0] <= FEW_SEEDS_GATE * states / 16.0
+
+
 def _watch_resident(transition, workspace, batch, frames, states) -> None:
     """After a time-resident launch chosen by AUTO: once per matrix, copy the scan statistics it leaves in its first
     workspace to pinned host memory (asynchronously; looked at by a later call, never waited for)."""
@@ -222,6 +240,8 @@ def decode(
     flags = _path_flag(chosen)
     if _reusable(workspace, transition, (B, T, S, chosen, stream), reuse_preparation):
         flags |= 1                                  # TORBI_HIP_REUSE_TRANSITION
+    if chosen in TIME_RESIDENT and _few_seeds(transition, S):
+        flags |= 512                                # TORBI_HIP_FEW_SEEDS
     if _profile is None:
         collect = begin is not None and chosen == 'pruned' and tuner.blocks is None
         _lib.check(lib.torbi_hip_viterbi_decode_ex(*args, flags | (2 if collect else 0)),      # COLLECT_STATS
@@ -379,6 +399,8 @@ def decode_batches(
         flags |= 1
     if shortest_first:
         flags |= 256                               # TORBI_HIP_SHORTEST_FIRST
+    if chosen in TIME_RESIDENT and _few_seeds(transition, S):
+        flags |= 512                               # TORBI_HIP_FEW_SEEDS
     phases = (ctypes.c_float * 6)() if _profile is not None else None
     _lib.check(lib.torbi_hip_viterbi_decode_batches(table, count, trans.data_ptr(), init.data_ptr(), S, index,
                                                     ctypes.c_void_p(stream), flags, phases),
