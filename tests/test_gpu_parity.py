@@ -464,6 +464,26 @@ def test_one_seed_per_item_after_shallow_scans_gives_the_same_indices(forward):
     torbi_amd.reset_path_state()
 
 
+def test_timing_scope_covers_the_decode_on_the_device(forward):
+    """torbi_amd.timer (the stand-in for torchutil.time as torbi/core.py:200 uses it): from_probabilities accumulates
+    under 'torbi'; with `device=` the scope is bracketed by HIP events and reports device time."""
+    if forward != 'auto':
+        pytest.skip('once is enough')
+    dev = torch.device('cuda:0')
+    probs = torch.rand(40, 30, 96, generator=torch.Generator().manual_seed(0)).softmax(-1)
+    trans = torch.rand(96, 96, generator=torch.Generator().manual_seed(1)).softmax(-1)
+    torbi_amd.timer.reset()
+    torbi_amd.from_probabilities(probs.clone(), transition=trans, gpu=0)
+    assert torbi_amd.timer.results()['torbi'] > 0.0
+    obs = torch.log(probs).to(dev)
+    frames = torch.full((40,), 30, dtype=torch.int32, device=dev)
+    with torbi_amd.timer.context('device side', device=dev):
+        torbi_amd.decode(obs, frames, torch.log(trans).to(dev), torch.full((96,), -4.5, device=dev))
+    got = torbi_amd.timer.results()
+    assert 0.0 < got['device side'] < 5.0
+    torbi_amd.timer.reset()
+
+
 def test_fill_synthetic_matches_numpy_definition():
     for stream, seed, n, start in [(1, 0, 100003, 0), (2, 5, 4099, 17), (3, 1, 7, 1 << 33)]:
         got = viterbi.fill_synthetic((n,), stream, seed=seed, start=start).cpu().numpy()

@@ -640,3 +640,23 @@ def test_one_store_keeps_what_is_known_about_tensors_for_as_long_as_they_live():
     assert not viterbi._reusable(ws, mine, (1, 2, 4, 'pruned', 0), True)
     torbi_amd.reset_path_state()
     assert state.size() == 0 and state.peek(mine) is None
+
+
+def test_timing_scope_like_the_reference():
+    """torbi/core.py:200 wraps its operator call in torchutil.time.context('torbi'); torbi/evaluate/core.py:40,118 resets and
+    reads the totals.  torbi_amd.timer offers the same three names and from_probabilities opens the same scope."""
+    import torch
+    import torbi_amd
+    torbi_amd.timer.reset()
+    assert torbi_amd.timer.results() == {}
+    probs = torch.rand(2, 9, 12, generator=torch.Generator().manual_seed(0)).softmax(-1)
+    torbi_amd.from_probabilities(probs, gpu=None)
+    first = torbi_amd.timer.results()
+    assert set(first) == {'torbi'} and first['torbi'] > 0.0
+    torbi_amd.from_probabilities(probs, gpu=None)
+    with torbi_amd.timer.context('mine'):
+        pass
+    second = torbi_amd.timer.results()
+    assert second['torbi'] > first['torbi'] and 'mine' in second
+    torbi_amd.timer.reset()
+    assert torbi_amd.timer.results() == {}

@@ -13,10 +13,11 @@ from . import data
 from .chunk import chunk
 from . import synth
 from . import distributed
+from . import timer
 from .pipeline import DecodePipeline
 from .state import reset as reset_path_state
 from .core import release_job_memory
 
 __all__ = ['decode', 'decode_batches', 'decode_cpu', 'chunk', 'decode_uniform', 'workspace_bytes', 'set_forward_path', 'forward_path', 'from_probabilities', 'from_file', 'from_file_to_file',
            'from_files_to_files', 'from_dataloader', 'save', 'save_masked', 'data', 'synth',
-           'distributed', 'DecodePipeline', 'BATCH_SIZE', 'NUM_WORKERS', 'reset_path_state', 'release_job_memory']
+           'distributed', 'DecodePipeline', 'BATCH_SIZE', 'NUM_WORKERS', 'reset_path_state', 'release_job_memory', 'timer']

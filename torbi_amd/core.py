@@ -11,6 +11,7 @@ from typing import Dict, List, Optional, Union
 import torch
 
 from . import data as _data
+from . import timer
 from .viterbi import decode, decode_uniform, epsilon_clamp_, log_epsilon_clamp, _version_of
 
 # reference torbi/config/defaults.py:80,83
@@ -67,7 +68,8 @@ def _from_probabilities_cpu(observation, batch_frames, transition, initial, log_
     torch.exp_(observation)
     observation += tiny
     torch.log_(observation)
-    return decode_cpu(observation, batch_frames, transition, initial, num_threads=num_threads)
+    with timer.context('torbi'):
+        return decode_cpu(observation, batch_frames, transition, initial, num_threads=num_threads)
 
 
 def _prepared_transition(transition: torch.Tensor, log_probs: bool, device) -> torch.Tensor:
@@ -173,13 +175,15 @@ def from_probabilities(
     else:
         epsilon_clamp_(observation)
 
-    if uniform is not None:
-        indices = decode_uniform(observation, batch_frames, uniform, initial)
-    elif _pipeline is not None:
-        # asynchronous: valid after _pipeline.wait(indices); the caller owns the host copy
-        return _pipeline.decode(observation, batch_frames, transition, initial)
-    else:
-        indices = decode(observation, batch_frames, transition, initial, num_threads=num_threads)
+    # Decode, inside the same timing scope as upstream's (core.py:200-206; torbi_amd/timer.py)
+    with timer.context('torbi'):
+        if uniform is not None:
+            indices = decode_uniform(observation, batch_frames, uniform, initial)
+        elif _pipeline is not None:
+            # asynchronous: valid after _pipeline.wait(indices); the caller owns the host copy
+            return _pipeline.decode(observation, batch_frames, transition, initial)
+        else:
+            indices = decode(observation, batch_frames, transition, initial, num_threads=num_threads)
     return indices
 
 
