@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 def forward(request):
     """Every test runs five times: with the automatic path choice (pruned, or dense for narrow-band
     matrices), with the dense (max,+) GEMM forced, with the exact pruned pass forced wherever it is
-    supported, with the time-resident kernel forced wherever it is supported (64 <= S <= 2048, ANY
+    supported, with the time-resident kernel forced wherever it is supported (64 <= S <= 4096, ANY
     batch size) -- whole 16-item tiles per workgroup -- and with its cluster form (the next-states of a tile
     split over up to 16 workgroups that exchange their slices of every posterior row inside the launch).
     Small batches take the generic kernels on the first three."""
@@ -141,10 +141,10 @@ def test_dense_path_edge_shapes(shape):
 def test_forward_path_selection(forward):
     assert viterbi.forward_path(4, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'pruned': 'rows'}.get(forward, 'generic')
     assert viterbi.forward_path(16, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'dense': 'generic'}.get(forward, 'rows')
-    assert viterbi.forward_path(2, 4096) == ('generic' if forward == 'dense' else 'rows')
+    assert viterbi.forward_path(2, 4096) == {'dense': 'generic', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'rows')
     assert viterbi.forward_path(4, 40) == 'generic'                # S < 64: no value-only path
     assert viterbi.forward_path(4, 4100) == 'generic'
-    assert viterbi.forward_path(128, 4096) == ('dense' if forward == 'dense' else 'pruned')   # 8-item tiles
+    assert viterbi.forward_path(128, 4096) == {'dense': 'dense', 'resident': 'resident', 'pruned': 'pruned'}.get(forward, 'cluster')   # 8-item tiles
     assert viterbi.forward_path(128, 4100) == 'dense'              # posterior tile does not fit the LDS
     assert viterbi.forward_path(512, 1440) == {'dense': 'dense', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'pruned')
     assert viterbi.forward_path(64, 130) == {'dense': 'dense', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'pruned')
@@ -154,7 +154,8 @@ def test_forward_path_selection(forward):
     assert viterbi.forward_path(16 * cus, 1440, path='auto') == 'resident'
     assert viterbi.forward_path(16 * cus, 1440, path='cluster') == 'resident'     # nothing to split
     assert viterbi.forward_path(8 * cus, 1440, path='auto') == 'cluster'          # half the chip: two workgroups per tile
-    assert viterbi.forward_path(8 * cus, 2052, path='auto') == 'pruned'
+    assert viterbi.forward_path(8 * cus, 2052, path='auto') == 'resident'         # 8-item tiles above 2048 states
+    assert viterbi.forward_path(8 * cus, 4100, path='auto') == 'dense'            # the posterior tile does not fit the LDS
     assert viterbi.forward_path(3 * cus, 1440, path='auto') == 'cluster'
     assert viterbi.forward_path(2 * cus, 1440, path='auto') == 'pruned'
     # the path travels with the call: naming one never changes the process default
@@ -685,7 +686,7 @@ def _device_problem(B, T, S, seed, dev, ragged=True):
     return obs, frames.astype(np.int32), trans, init
 
 
-@pytest.mark.parametrize('S', [64, 130, 360, 1440, 1442, 2048])
+@pytest.mark.parametrize('S', [64, 130, 360, 1440, 1442, 2048, 2052, 4096])
 def test_decode_batches_equals_oracle_per_batch(S):
     """A group of batches with different sizes and lengths (a many-file job, reference torbi/core.py:417-457)
     through ONE call: every batch equals the oracle decode of that batch alone, whatever path the group takes

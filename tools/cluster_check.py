@@ -19,24 +19,25 @@ def gave_up(ws, B, T, S):
 
 bad = 0
 for (B, T, S) in [(16, 6, 64), (17, 9, 96), (40, 12, 360), (33, 20, 1440), (100, 7, 130), (512, 5, 1440), (64, 9, 2048),
-                  (1, 30, 1440), (3, 12, 1442), (250, 9, 720)]:
+                  (1, 30, 1440), (3, 12, 1442), (250, 9, 720), (40, 6, 4096), (3, 5, 2052), (130, 5, 3000), (9, 7, 4094)]:
     obs, trans, init = synth.problem(B, T, S, seed=B + T)
     frames = np.clip(synth.lengths(B, 1, T, seed=S), 1, T)
     frames[0] = T
     want = oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())
     d = [torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)]
     ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
-    for rep in range(3):
-        got = torbi_amd.decode(*d, workspace=ws, path='cluster')
-        torch.cuda.synchronize()
-        ok = np.array_equal(got.cpu().numpy(), want)
-        g = gave_up(ws, B, T, S)
-        if not ok or g:
-            bad += 1
-            print(f'MISMATCH {(B, T, S)} rep {rep}: equal {ok}, gave up {g}, route {viterbi.forward_path(B, S, "cluster")}', flush=True)
-            break
-    else:
-        print(f'ok {(B, T, S)} route {viterbi.forward_path(B, S, "cluster")}', flush=True)
+    for path in ('cluster', 'resident'):
+        for rep in range(3):
+            got = torbi_amd.decode(*d, workspace=ws, path=path)
+            torch.cuda.synchronize()
+            ok = np.array_equal(got.cpu().numpy(), want)
+            g = gave_up(ws, B, T, S)
+            if not ok or g:
+                bad += 1
+                print(f'MISMATCH {(B, T, S)} {path} rep {rep}: equal {ok}, gave up {g}, route {viterbi.forward_path(B, S, path)}', flush=True)
+                break
+        else:
+            print(f'ok {(B, T, S)} route {viterbi.forward_path(B, S, path)}', flush=True)
 print('small shapes:', 'ALL OK' if not bad else f'{bad} BAD', flush=True)
 if bad or (len(sys.argv) > 1 and sys.argv[1] == 'quick'):
     sys.exit(1 if bad else 0)

@@ -34,9 +34,14 @@ using pruned::ListBlock;
 using pruned::group_bcast;
 using pruned::load_list_block;
 
-constexpr int kNI = 16;            // batch items per workgroup (4 item groups of 4 per next-state: a lane quad)
+constexpr int kNI = 16;            // batch items per tile up to kMaxS16 states (4 item groups of 4 per next-state: a lane
+                                   // quad, 16 next-states per wave pass); 8 above (2 lanes per next-state, 32 per pass):
+                                   // the posterior tile [S][items] fp32 has to fit the 160 KB LDS
 constexpr int kMaxBatches = 16;    // batches one launch can carry
-constexpr int kRowGroup = 16;      // next-states per wave pass (64 lanes / 4 lanes per next-state)
+constexpr int kRowGroup = 16;      // next-states per wave pass of the 16-item form
+// items per tile / next-states per wave pass for S states
+__host__ __device__ inline int tile_items(int S) { return S <= pruned::kMaxS16 ? kNI : kNI / 2; }
+__host__ __device__ inline int pass_rows(int S) { return 64 / (tile_items(S) / 4); }
 
 typedef unsigned long long u64;
 
@@ -79,13 +84,13 @@ struct Cluster {
     int R;
 };
 
-inline bool supported(int S) { return S >= 64 && S <= pruned::kMaxS16; }
+inline bool supported(int S) { return S >= 64 && S <= pruned::kMaxS; }
 
 // dynamic LDS: posterior tile [S4][16] + running top lists (64-bit keys) + decoded top lists + frame counts + items
 // + 4 control words (cluster ticket, gave-up flag)
 inline size_t lds_bytes(int S, int ktop = kTop) {
-    const size_t S4 = ((size_t)S + 3) / 4 * 4;
-    return sizeof(float) * kNI * S4 + sizeof(u64) * kNI * ktop + (sizeof(float) + sizeof(int)) * kNI * ktop +
+    const size_t S4 = ((size_t)S + 3) / 4 * 4, ni = (size_t)tile_items(S);
+    return sizeof(float) * ni * S4 + sizeof(u64) * kNI * ktop + (sizeof(float) + sizeof(int)) * kNI * ktop +
            2 * sizeof(int) * kNI + 4 * sizeof(int);
 }
 
@@ -102,7 +107,8 @@ __host__ __device__ inline int cluster_first_group(int m, int nrg, int R) { retu
 constexpr int kMaxOrdered = 8192;
 struct OrderJob { const int32_t *frames; int32_t *order; int B, T, tile0; int32_t *hist; int32_t *route_record; int route; };
 struct OrderJobs { OrderJob job[kMaxBatches]; int ascending; int n; int tiles; int32_t *tile_map; unsigned *stats;
-                   unsigned *flags; int nflags; };      // cluster form: the flag / ticket words to zero (else nflags = 0)
+                   unsigned *flags; int nflags;         // cluster form: the flag / ticket words to zero (else nflags = 0)
+                   int ni; };                           // items per tile (16, or 8 above kMaxS16 states)
 
 __global__ __launch_bounds__(256) void order_items_kernel(OrderJobs jobs) {
     const OrderJob &jb = jobs.job[blockIdx.y];
@@ -178,8 +184,8 @@ __global__ __launch_bounds__(256) void order_tiles_kernel(OrderJobs jobs) {
     auto tile_length = [&](int k, int j) {
         const OrderJob &jb = jobs.job[k];
         // the longest item of tile j: its first in descending order, its last (within the batch) in ascending order
-        const int last = 16 * j + 15 < jb.B ? 16 * j + 15 : jb.B - 1;
-        int f = jb.frames[jb.order[jobs.ascending ? last : 16 * j]];
+        const int last = jobs.ni * j + jobs.ni - 1 < jb.B ? jobs.ni * j + jobs.ni - 1 : jb.B - 1;
+        int f = jb.frames[jb.order[jobs.ascending ? last : jobs.ni * j]];
         return f < 1 ? 1 : (f > jb.T ? jb.T : f);
     };
     int k = 0;
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(256) void order_tiles_kernel(OrderJobs jobs) {
     const int mine = tile_length(k, j);
     int rank = 0;
     for (int q = 0; q < jobs.n; ++q) {
-        const int nt = (jobs.job[q].B + 15) / 16;
+        const int nt = (jobs.job[q].B + jobs.ni - 1) / jobs.ni;
         for (int t = 0; t < nt; ++t) {
             const int other = tile_length(q, t);
             const int ow = jobs.job[q].tile0 + t;
@@ -268,12 +274,14 @@ __device__ unsigned long long g_wgtime[1024 * 4];        // per workgroup: start
 // termination test decides whether it is needed) -- with one timestep per launch the scan was a third of the
 // kernel and this bought nothing (tools/prune_proto5.hip); here the scan IS the kernel.
 // KR: seeds per item (explicit candidates; thr = the (KR+1)-th largest posterior).  CLUSTER: see struct Cluster.
-template <int KW, int MAXP, bool PIPE, int KR = kR, bool CLUSTER = false>
+// NI: items per tile (16; 8 for kMaxS16 < S <= kMaxS: G = NI / 4 lanes per next-state, 64 / G next-states per wave pass).
+template <int KW, int MAXP, bool PIPE, int KR = kR, bool CLUSTER = false, int NI = 16>
 __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cluster clu, const float *__restrict__ tt,
                                                                    const float2 *__restrict__ sorted,
                                                                    const float *__restrict__ initial, int S, int SpP) {
-    constexpr int G = 4, EPL = kBlk / G;
-    constexpr int kR = KR, kTop = KR + 1;                             // (shadow the namespace-wide defaults)
+    constexpr int kNI = NI, G = NI / 4, EPL = kBlk / G, kRowGroup = 64 / G;     // (shadow the namespace-wide 16-item values)
+    constexpr int kR = KR, kTop = KR + 1;
+    static_assert(NI == 16 || NI == 8, "tiles of 16 or 8 items");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int S4 = (S + 3) / 4 * 4;
     u64 *top = reinterpret_cast<u64 *>(lds + (size_t)kNI * S4);       // [16][kTop] this timestep's largest outputs
@@ -342,8 +350,10 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
 
     // lane = next-state jl of the wave's 16 x item group g; quads of lanes -> next-states so that every
     // ds_read_b128 lane group holds an aligned row quad (as in pruned::step_pruned_kernel)
-    const int g = lane & 3;
-    const int jl = (int)((0xFBAE9DC873261540ull >> (4 * (lane >> 2))) & 15);
+    // (8-item tiles: lane pairs -> next-states, aligned groups of eight rows per lane group, as in step_pruned_kernel)
+    const int g = lane & (G - 1);
+    const int jl = G == 4 ? (int)((0xFBAE9DC873261540ull >> (4 * (lane >> 2))) & 15)
+                          : (int)((0xFE7654DC32BA9810ull >> (4 * ((lane >> 1) & 15))) & 15) + (lane & 32) / 2;
     const char *ptile = reinterpret_cast<const char *>(lds) + 16 * g;
     const int nrg = (S + kRowGroup - 1) / kRowGroup;
     // this workgroup's row groups: all of them, or its share as member of a cluster
@@ -656,11 +666,11 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                 // per round: one round up to 1536 states)
                 {
                     const int own_lo = kRowGroup * rg_lo, own_hi = kRowGroup * rg_hi < S ? kRowGroup * rg_hi : S;
-                    const int pieces = (S - (own_hi - own_lo)) * 4;
+                    const int pieces = (S - (own_hi - own_lo)) * G;
                     auto place = [&](int c) {          // byte offset of piece c (tile and slot alike)
-                        int row = c >> 2;
+                        int row = c / G;
                         row = row < own_lo ? row : row + (own_hi - own_lo);
-                        return (row * kNI + 4 * (c & 3)) * 4;
+                        return (row * kNI + 4 * (c % G)) * 4;
                     };
                     // keys: two per thread (R * 16 * kTop / 2 <= 512 threads)
                     const int kpair = kNI * kTop / 2;
@@ -742,7 +752,8 @@ __global__ __launch_bounds__(64) void group_backtrace_sorted_kernel(Group grp, c
     extern __shared__ __attribute__((aligned(16))) float hrow_lds[];
     const Batch &bat = grp.batch[batch_of_item(grp, blockIdx.x)];
     const int b = (int)blockIdx.x - bat.item0;
-    lazy::backtrace_sorted_item<NQ>(bat.hist + (size_t)b * bat.T * S, sorted, SpP, 6 /* offsets = state * 64 */,
+    // (list offsets = state * bytes of a tile row: 64 with 16-item tiles, 32 with 8-item tiles)
+    lazy::backtrace_sorted_item<NQ>(bat.hist + (size_t)b * bat.T * S, sorted, SpP, tile_items(S) == kNI ? 6 : 5,
                                     bat.frames[b], bat.out + (size_t)b * bat.T, bat.T, S, threadIdx.x, hrow_lds);
 }
 

@@ -480,7 +480,8 @@ inline bool flags_ok(unsigned flags) {
 }
 
 constexpr int kMaxGroupTiles = 16384;     // 16-item tiles one launch group may hold (262 144 items)
-inline int tiles_of(int B) { return (B + resident::kNI - 1) / resident::kNI; }
+// tiles of a batch in the time-resident kernel: 16 items each, 8 above 2048 states
+inline int tiles_of(int B, int S) { const int ni = resident::tile_items(S); return (B + ni - 1) / ni; }
 inline bool resident_fits(int S, int tiles) { return resident::supported(S) && tiles <= kMaxGroupTiles; }
 
 // members per cluster for a launch of `tiles` 16-item tiles: 1 (every workgroup owns a whole tile) once the tiles give
@@ -488,7 +489,7 @@ inline bool resident_fits(int S, int tiles) { return resident::supported(S) && t
 inline int cluster_members(int tiles, int S, int cus) {
     if (tiles < 1 || 2 * tiles > cus) return 1;
     int R = cus / tiles;
-    const int nrg = (S + resident::kRowGroup - 1) / resident::kRowGroup;
+    const int nrg = (S + resident::pass_rows(S) - 1) / resident::pass_rows(S);
     R = std::min(R, std::min(resident::kMaxR, nrg));
     return R < 2 ? 1 : R;
 }
@@ -497,13 +498,16 @@ inline int cluster_members(int tiles, int S, int cus) {
 // half the compute units a workgroup, tiles split over clusters of workgroups for smaller batches of >= 17 items --
 // else the per-timestep pruned pass where supported, else the dense (max,+) GEMM, else generic.
 inline Route route_for(int path, int B, int S, int cus) {
-    const bool fits = resident_fits(S, tiles_of(B));
+    const bool fits = resident_fits(S, tiles_of(B, S));
     if (path == TORBI_HIP_FORWARD_RESIDENT && fits) return ROUTE_RESIDENT;
-    if (path == TORBI_HIP_FORWARD_CLUSTER && fits) return cluster_members(tiles_of(B), S, cus) > 1 ? ROUTE_CLUSTER : ROUTE_RESIDENT;
-    if (path == TORBI_HIP_FORWARD_AUTO && fits && 2 * tiles_of(B) > cus) return ROUTE_RESIDENT;
+    if (path == TORBI_HIP_FORWARD_CLUSTER && fits) return cluster_members(tiles_of(B, S), S, cus) > 1 ? ROUTE_CLUSTER : ROUTE_RESIDENT;
+    if (path == TORBI_HIP_FORWARD_AUTO && fits && 2 * tiles_of(B, S) > cus) return ROUTE_RESIDENT;
     // (one batch, AUTO: clusters where the per-timestep pruned pass would need a second round of workgroups -- more
     // than cus / 8 tiles, 512 items on an MI355X: 27.8 against 34.8 us per timestep at 768 items, equal at 512)
-    if (path == TORBI_HIP_FORWARD_AUTO && fits && 8 * tiles_of(B) > cus && cluster_members(tiles_of(B), S, cus) > 1)
+    // ... and, above 2048 states (8-item tiles), for any batch of more than 16 items: the per-timestep kernel restages a
+    // 131 KB tile per workgroup and timestep there (128 x 4096: 28.4 against 32.6 us per timestep, 512 x 4096: 74 against 83)
+    if (path == TORBI_HIP_FORWARD_AUTO && fits && B > 16 && (8 * tiles_of(B, S) > cus || S > pruned::kMaxS16) &&
+        cluster_members(tiles_of(B, S), S, cus) > 1)
         return ROUTE_CLUSTER;
     if (path != TORBI_HIP_FORWARD_DENSE && pruned::supported(B, S)) return ROUTE_PRUNED;
     if ((path == TORBI_HIP_FORWARD_PRUNED && rowscan::supported(B, S)) ||
@@ -985,25 +989,24 @@ inline int resident_seeds(bool few) {
     return forced >= 0 ? forced : (few ? 1 : 3);
 }
 
-template <int KW, int MAXP, int KR, bool CLUSTER>
+template <int KW, int MAXP, int KR, bool CLUSTER, int NI>
 hipError_t launch_resident_variant(const resident::Group &grp, const resident::Cluster &clu, int workgroups,
                                    const ResidentWorkspace &w, const float *init, int S, hipStream_t stream) {
     const size_t lds = resident::lds_bytes(S, KR + 1);
-    const void *fn = reinterpret_cast<const void *>(&resident::resident_forward_kernel<KW, MAXP, true, KR, CLUSTER>);
+    const void *fn = reinterpret_cast<const void *>(&resident::resident_forward_kernel<KW, MAXP, true, KR, CLUSTER, NI>);
     hipError_t e = ensure_dynamic_lds(fn, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((resident::resident_forward_kernel<KW, MAXP, true, KR, CLUSTER>), dim3(workgroups), dim3(64 * KW), lds,
+    hipLaunchKernelGGL((resident::resident_forward_kernel<KW, MAXP, true, KR, CLUSTER, NI>), dim3(workgroups), dim3(64 * KW), lds,
                        stream, grp, clu, w.tt, w.sorted, init, S, w.SpP);
     return hipGetLastError();
 }
 
-template <int KW, int MAXP, bool CLUSTER>
+// (seeds: 3, or 1 with TORBI_HIP_FEW_SEEDS; the experiment value 0 of TORBI_HIP_RESIDENT_KR runs as 1)
+template <int KW, int MAXP, bool CLUSTER, int NI = 16>
 hipError_t launch_resident_kernel(const resident::Group &grp, const resident::Cluster &clu, int workgroups,
                                   const ResidentWorkspace &w, const float *init, int S, hipStream_t stream, bool few) {
-    const int kr = resident_seeds(few);
-    return kr == 0 ? launch_resident_variant<KW, MAXP, 0, CLUSTER>(grp, clu, workgroups, w, init, S, stream)
-         : kr == 1 ? launch_resident_variant<KW, MAXP, 1, CLUSTER>(grp, clu, workgroups, w, init, S, stream)
-                   : launch_resident_variant<KW, MAXP, 3, CLUSTER>(grp, clu, workgroups, w, init, S, stream);
+    return resident_seeds(few) == 3 ? launch_resident_variant<KW, MAXP, 3, CLUSTER, NI>(grp, clu, workgroups, w, init, S, stream)
+                                    : launch_resident_variant<KW, MAXP, 1, CLUSTER, NI>(grp, clu, workgroups, w, init, S, stream);
 }
 
 // batches with B > 0 only; the preparation lives in the first batch's workspace
@@ -1029,7 +1032,7 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
         b.T = hb[k].T;
         b.tile0 = tiles;
         b.item0 = items;
-        tiles += tiles_of(hb[k].B);
+        tiles += tiles_of(hb[k].B, S);
         items += hb[k].B;
     }
     const ResidentWorkspace w = carve_resident(hb[0].workspace, hb[0].B, hb[0].T, S, cus);
@@ -1048,7 +1051,7 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
         jobs.job[k].route_record = route_record(hb[k].workspace, hb[k].B, hb[k].T, S, cus);
         jobs.job[k].route = (int)(R > 1 ? ROUTE_CLUSTER : ROUTE_RESIDENT);
     }
-    if (!reuse) launch_list_preparation(trans, w.sorted, w.row_range, w.tt, S, w.SpP, w.NPOW, resident::kNI, s);
+    if (!reuse) launch_list_preparation(trans, w.sorted, w.row_range, w.tt, S, w.SpP, w.NPOW, resident::tile_items(S), s);
     hipLaunchKernelGGL(resident::order_items_kernel, dim3((widest + 255) / 256, n), dim3(256), 0, s, jobs);
     for (int k = 0; k < n; ++k) {            // batches too large for the all-pairs ranking: counting sort over the lengths
         const resident::OrderJob &jb = jobs.job[k];
@@ -1060,18 +1063,28 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
         hipLaunchKernelGGL(resident::order_large_scan_kernel, dim3(1), dim3(1024), 0, s, jb, jobs.ascending);
         hipLaunchKernelGGL(resident::order_large_place_kernel, dim3((jb.B + 255) / 256), dim3(256), 0, s, jb);
     }
+    jobs.ni = resident::tile_items(S);
     jobs.flags = w.flags;
     jobs.nflags = R > 1 ? (int)(w.flag_bytes / sizeof(unsigned)) : 0;
     hipLaunchKernelGGL(resident::order_tiles_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, jobs);
     hipError_t e;
     if (ev) (void)hipEventRecord(ev[3], s);
-    const int nrg = (S + resident::kRowGroup - 1) / resident::kRowGroup;
+    const int nrg = (S + resident::pass_rows(S) - 1) / resident::pass_rows(S);
+    const bool small = resident::tile_items(S) != resident::kNI;       // 8-item tiles (2048 < S <= 4096)
     if (R > 1) {
         const int passes = ((nrg + R - 1) / R + 11) / 12;       // row groups of the largest share over 12 waves
-        if (passes <= 1) e = launch_resident_kernel<12, 1, true>(grp, clu, tiles * R, w, init, S, s, few);
+        if (small) {
+            if (passes <= 1) e = launch_resident_kernel<12, 1, true, 8>(grp, clu, tiles * R, w, init, S, s, few);
+            else if (passes <= 2) e = launch_resident_kernel<12, 2, true, 8>(grp, clu, tiles * R, w, init, S, s, few);
+            else if (passes <= 4) e = launch_resident_kernel<12, 4, true, 8>(grp, clu, tiles * R, w, init, S, s, few);
+            else e = launch_resident_kernel<12, 6, true, 8>(grp, clu, tiles * R, w, init, S, s, few);
+        } else if (passes <= 1) e = launch_resident_kernel<12, 1, true>(grp, clu, tiles * R, w, init, S, s, few);
         else if (passes <= 2) e = launch_resident_kernel<12, 2, true>(grp, clu, tiles * R, w, init, S, s, few);
         else if (passes <= 4) e = launch_resident_kernel<12, 4, true>(grp, clu, tiles * R, w, init, S, s, few);
         else e = launch_resident_kernel<12, 6, true>(grp, clu, tiles * R, w, init, S, s, few);
+    } else if (small) {
+        if (nrg <= 96) e = launch_resident_kernel<12, 8, false, 8>(grp, clu, tiles, w, init, S, s, few);
+        else e = launch_resident_kernel<12, 11, false, 8>(grp, clu, tiles, w, init, S, s, few);
     } else if (nrg <= 72) e = launch_resident_kernel<12, 6, false>(grp, clu, tiles, w, init, S, s, few);
     else if (nrg <= 96) e = launch_resident_kernel<12, 8, false>(grp, clu, tiles, w, init, S, s, few);
     else e = launch_resident_kernel<12, 11, false>(grp, clu, tiles, w, init, S, s, few);
@@ -1087,15 +1100,20 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
         else if (S <= 1536)
             hipLaunchKernelGGL(resident::group_backtrace_sorted_kernel<6>, dim3(items), dim3(64), row_lds, s, grp,
                                w.sorted, w.SpP, S);
-        else
+        else if (S <= 2048)
             hipLaunchKernelGGL(resident::group_backtrace_sorted_kernel<8>, dim3(items), dim3(64), row_lds, s, grp,
+                               w.sorted, w.SpP, S);
+        else
+            hipLaunchKernelGGL(resident::group_backtrace_sorted_kernel<16>, dim3(items), dim3(64), row_lds, s, grp,
                                w.sorted, w.SpP, S);
     } else if (vec && S <= 512)
         hipLaunchKernelGGL(resident::group_backtrace_prefetch_kernel<2>, dim3(items), dim3(64), 0, s, grp, trans, S);
     else if (vec && S <= 1536)
         hipLaunchKernelGGL(resident::group_backtrace_prefetch_kernel<6>, dim3(items), dim3(64), 0, s, grp, trans, S);
-    else if (vec)
+    else if (vec && S <= 2048)
         hipLaunchKernelGGL(resident::group_backtrace_prefetch_kernel<8>, dim3(items), dim3(64), 0, s, grp, trans, S);
+    else if (vec)
+        hipLaunchKernelGGL(resident::group_backtrace_prefetch_kernel<16>, dim3(items), dim3(64), 0, s, grp, trans, S);
     else
         hipLaunchKernelGGL(resident::group_backtrace_kernel<1>, dim3(items), dim3(64), 0, s, grp, trans, S);
     if (ev) (void)hipEventRecord(ev[2], s);
@@ -1276,7 +1294,7 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
         if (rc != TORBI_HIP_OK) return rc;
         if (b.B == 0) continue;
         hb[n++] = HostBatch{b.observation, b.batch_frames, b.indices_out, b.workspace, b.B, b.T};
-        tiles += tiles_of(b.B);
+        tiles += tiles_of(b.B, S);
     }
     if (n == 0) return TORBI_HIP_OK;
     DeviceGuard guard(device);

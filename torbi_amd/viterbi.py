@@ -73,7 +73,8 @@ def _resolve_path(trans, transition, B, S, device, path, tiles, measure, count=1
         if tuner is not None:
             chosen = tuner.choose()
     cus = compute_units(device)
-    if 64 <= S <= 2048 and tiles <= 16384 and (2 * tiles > cus or (count > 1 and B > 16) or 8 * tiles > cus):
+    if 64 <= S <= 4096 and tiles <= 16384 and (2 * tiles > cus or (count > 1 and B > 16) or 8 * tiles > cus
+                                             or (S > 2048 and B > 16)):
         # The time-resident kernel (csrc/resident_forward.hpp), whatever the single-batch choice would be:
         #  * enough items to give half the compute units a workgroup of 16 each: whole tiles per workgroup -- also for
         #    a narrow band (its lists end at the band edge, so the scan is short whatever the posteriors look like:
@@ -81,7 +82,8 @@ def _resolve_path(trans, transition, B, S, device, path, tiles, measure, count=1
         #  * a launch group that fills less (the tail of a job, a small job): tiles split over clusters of workgroups
         #    (2 x 512 items: 31.7 us per timestep against 62.7 with whole tiles and 2 x 20.4 one batch after the other);
         #  * ONE batch too large for one round of the per-timestep kernel (more than cus / 8 tiles): clusters
-        #    (768 items: 27.8 against 34.8 us per timestep);
+        #    (768 items: 27.8 against 34.8 us per timestep); above 2048 states (8-item tiles) any batch of more than 16
+        #    items (128 x 4096: 28.4 against 32.6 us per timestep; 16 x 128 x 4096 as a launch group: 238 against 506);
         # unless the scan statistics of an earlier time-resident launch with this matrix say that hardly anything is
         # pruned (see _watch_resident).  Whether the per-timestep pruned kernel beats the dense one is NOT the question
         # here: on peaked rows with a dense matrix it does not, and the time-resident kernel still runs at twice the
@@ -147,6 +149,13 @@ def _watch_resident(transition, workspace, batch, frames, states) -> None:
     done = torch.cuda.Event()
     done.record(torch.cuda.current_stream(workspace.device))
     known[1] = (stats, done)
+
+
+def tiles_of(batch: int, states: int) -> int:
+    """Tiles of a batch in the time-resident kernel: 16 items each up to 2048 states, 8 above (the posterior tile has to
+    fit the 160 KB LDS; csrc/resident_forward.hpp)."""
+    items = 16 if states <= 2048 else 8
+    return (batch + items - 1) // items
 
 
 def compute_units(device) -> int:
@@ -227,7 +236,7 @@ def decode(
 
     index = device.index if device.index is not None else torch.cuda.current_device()
     stream = torch.cuda.current_stream(device).cuda_stream
-    chosen, tuner = _resolve_path(trans, transition, B, S, device, path, (B + 15) // 16, _profile is None)
+    chosen, tuner = _resolve_path(trans, transition, B, S, device, path, tiles_of(B, S), _profile is None)
     if chosen in TIME_RESIDENT:
         tuner = None                     # the per-timestep tuner has nothing to learn from a time-resident launch
     begin = None
@@ -390,7 +399,7 @@ def decode_batches(
     index = device.index if device.index is not None else torch.cuda.current_device()
     stream = torch.cuda.current_stream(device).cuda_stream
     largest = max(B for B, _, _ in shapes)
-    tiles = sum((B + 15) // 16 for B, _, _ in shapes)
+    tiles = sum(tiles_of(B, S) for B, _, _ in shapes)
     chosen, _ = _resolve_path(trans, transition, largest, S, device, path, tiles, False, count=count)
     flags = _path_flag(chosen)
     first = next((k for k, (B, _, _) in enumerate(shapes) if B > 0), 0)
