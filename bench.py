@@ -467,8 +467,21 @@ class Bench:
             f5 = torch.full((B5,), T5, dtype=torch.int32, device=dev)
             w5 = torch.empty(v.workspace_bytes(B5, T5, S5), dtype=torch.uint8, device=dev)
             sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(o5, f5, t5, i5, workspace=w5), 2)
-            record('c5', sec, B5 * T5, S5, 'BASELINE configs[4]: 4096 states, 2000 frames, batch=128')
-            del o5, t5, i5, f5, w5
+            record('c5', sec, B5 * T5, S5, 'BASELINE configs[4]: 4096 states, 2000 frames, batch=128 (AUTO: the cluster form '
+                                           'of the time-resident kernel on 8-item tiles)')
+            sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(o5, f5, t5, i5, workspace=w5, path='pruned'), 2)
+            record('c5_per_timestep_kernel', sec, B5 * T5, S5, 'the same batch on the per-timestep pruned kernel (round 2\'s path)')
+            # the same shape as a launch group (a many-file job at 4096 states): four batches in one time-resident launch
+            T5g, n5 = 500, 4
+            spaces5 = [torch.empty(v.workspace_bytes(B5, T5g, S5), dtype=torch.uint8, device=dev) for _ in range(n5)]
+            obs5 = [o5[:, k * T5g:(k + 1) * T5g].contiguous() for k in range(n5)]
+            fr5 = [torch.full((B5,), T5g, dtype=torch.int32, device=dev)] * n5
+            prof = []
+            v.decode_batches(obs5, fr5, t5, i5, workspaces=spaces5, _profile=prof)
+            sec, _ = self.timed_decodes(lambda: v.decode_batches(obs5, fr5, t5, i5, workspaces=spaces5), 2)
+            record('c5_shape_launch_group', sec, n5 * B5 * T5g, S5,
+                   f'{n5} batches of 128 x {T5g} x 4096 in one call (launch group)', {'forward_path': ROUTES[int(prof[3])]})
+            del o5, t5, i5, f5, w5, spaces5, obs5
         except RuntimeError as exc:     # out of memory next to the headline buffers: say so instead of dying
             out['c5'] = {'value': None, 'note': f'not measured: {exc}'}
         out['chunked_long_sequence'] = self.chunked_long_sequence(trans, init)

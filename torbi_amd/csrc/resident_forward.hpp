@@ -372,7 +372,10 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
     // A cluster member whose waves scan ONE row group per timestep (MAXP == 1) meets the same sorted rows every
     // timestep: their first two list blocks stay in registers, and the next timestep's observations are requested
     // before the wait for the other members (everything a pass needs that does not depend on the exchange).
-    constexpr bool FIXED = CLUSTER && MAXP == 1;
+#ifndef RESIDENT_FIXED8
+#define RESIDENT_FIXED8 1
+#endif
+    constexpr bool FIXED = CLUSTER && MAXP == 1 && (NI == 16 || RESIDENT_FIXED8);
     ListBlock<EPL> head0, head1;
     float obnext[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (FIXED) {
