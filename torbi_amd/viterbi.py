@@ -546,7 +546,8 @@ def scan_stats(workspace: torch.Tensor, batch: int, frames: int, states: int,
 def critical_blocks(stats: torch.Tensor) -> float:
     """Mean number of 16-entry list blocks on the critical path of a launch (host sync)."""
     host = (stats if not stats.is_cuda else stats.cpu()).to(torch.int64)
-    return float(host[:64].sum()) / max(1.0, float(host[64:].sum()))
+    # ([127] is not a count of passes: workgroups of the cluster form that gave up waiting -- 0 on any sane run)
+    return float(host[:64].sum()) / max(1.0, float(host[64:127].sum()))
 
 
 def _choose_path(trans: torch.Tensor, original: torch.Tensor, batch: int, states: int) -> str:
