@@ -40,7 +40,10 @@ constexpr int kNI = 16;            // batch items per tile up to kMaxS16 states 
 constexpr int kMaxBatches = 16;    // batches one launch can carry
 constexpr int kRowGroup = 16;      // next-states per wave pass of the 16-item form
 // items per tile / next-states per wave pass for S states
-__host__ __device__ inline int tile_items(int S) { return S <= pruned::kMaxS16 ? kNI : kNI / 2; }
+#ifndef TORBI_TILE16_MAX_S
+#define TORBI_TILE16_MAX_S pruned::kMaxS16      // (experiments: -DTORBI_TILE16_MAX_S=0 runs every shape on 8-item tiles)
+#endif
+__host__ __device__ inline int tile_items(int S) { return S <= TORBI_TILE16_MAX_S ? kNI : kNI / 2; }
 __host__ __device__ inline int pass_rows(int S) { return 64 / (tile_items(S) / 4); }
 
 typedef unsigned long long u64;
