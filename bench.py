@@ -467,10 +467,11 @@ class Bench:
             f5 = torch.full((B5,), T5, dtype=torch.int32, device=dev)
             w5 = torch.empty(v.workspace_bytes(B5, T5, S5), dtype=torch.uint8, device=dev)
             sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(o5, f5, t5, i5, workspace=w5), 2)
-            record('c5', sec, B5 * T5, S5, 'BASELINE configs[4]: 4096 states, 2000 frames, batch=128 (AUTO: the cluster form '
-                                           'of the time-resident kernel on 8-item tiles)')
-            sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(o5, f5, t5, i5, workspace=w5, path='pruned'), 2)
-            record('c5_per_timestep_kernel', sec, B5 * T5, S5, 'the same batch on the per-timestep pruned kernel (round 2\'s path)')
+            record('c5', sec, B5 * T5, S5, 'BASELINE configs[4]: 4096 states, 2000 frames, batch=128 (AUTO: the per-timestep '
+                                           'pruned kernel on 8-item tiles)')
+            sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(o5, f5, t5, i5, workspace=w5, path='cluster'), 2)
+            record('c5_cluster_form', sec, B5 * T5, S5, 'the same batch in the cluster form of the time-resident kernel (16 tiles '
+                                                        'of 8 items x 16 workgroups each)')
             # the same shape as a launch group (a many-file job at 4096 states): four batches in one time-resident launch
             T5g, n5 = 500, 4
             spaces5 = [torch.empty(v.workspace_bytes(B5, T5g, S5), dtype=torch.uint8, device=dev) for _ in range(n5)]

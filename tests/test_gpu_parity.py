@@ -144,7 +144,7 @@ def test_forward_path_selection(forward):
     assert viterbi.forward_path(2, 4096) == {'dense': 'generic', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'rows')
     assert viterbi.forward_path(4, 40) == 'generic'                # S < 64: no value-only path
     assert viterbi.forward_path(4, 4100) == 'generic'
-    assert viterbi.forward_path(128, 4096) == {'dense': 'dense', 'resident': 'resident', 'pruned': 'pruned'}.get(forward, 'cluster')   # 8-item tiles
+    assert viterbi.forward_path(128, 4096) == {'dense': 'dense', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'pruned')   # 8-item tiles
     assert viterbi.forward_path(128, 4100) == 'dense'              # posterior tile does not fit the LDS
     assert viterbi.forward_path(512, 1440) == {'dense': 'dense', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'pruned')
     assert viterbi.forward_path(64, 130) == {'dense': 'dense', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'pruned')

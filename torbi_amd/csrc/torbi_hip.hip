@@ -504,10 +504,9 @@ inline Route route_for(int path, int B, int S, int cus) {
     if (path == TORBI_HIP_FORWARD_AUTO && fits && 2 * tiles_of(B, S) > cus) return ROUTE_RESIDENT;
     // (one batch, AUTO: clusters where the per-timestep pruned pass would need a second round of workgroups -- more
     // than cus / 8 tiles, 512 items on an MI355X: 27.8 against 34.8 us per timestep at 768 items, equal at 512)
-    // ... and, above 2048 states (8-item tiles), for any batch of more than 16 items: the per-timestep kernel restages a
-    // 131 KB tile per workgroup and timestep there (128 x 4096: 28.4 against 32.6 us per timestep, 512 x 4096: 74 against 83)
-    if (path == TORBI_HIP_FORWARD_AUTO && fits && B > 16 && (8 * tiles_of(B, S) > cus || S > pruned::kMaxS16) &&
-        cluster_members(tiles_of(B, S), S, cus) > 1)
+    // (a batch that fits one round of the per-timestep kernel stays there: 128 x 2000 x 4096 decodes in 55.6 ms on it
+    // against 60.3 ms in clusters of 16, although short runs of the same shape favoured the clusters by 5-15 %)
+    if (path == TORBI_HIP_FORWARD_AUTO && fits && B > 16 && 8 * tiles_of(B, S) > cus && cluster_members(tiles_of(B, S), S, cus) > 1)
         return ROUTE_CLUSTER;
     if (path != TORBI_HIP_FORWARD_DENSE && pruned::supported(B, S)) return ROUTE_PRUNED;
     if ((path == TORBI_HIP_FORWARD_PRUNED && rowscan::supported(B, S)) ||

@@ -73,8 +73,7 @@ def _resolve_path(trans, transition, B, S, device, path, tiles, measure, count=1
         if tuner is not None:
             chosen = tuner.choose()
     cus = compute_units(device)
-    if 64 <= S <= 4096 and tiles <= 16384 and (2 * tiles > cus or (count > 1 and B > 16) or 8 * tiles > cus
-                                             or (S > 2048 and B > 16)):
+    if 64 <= S <= 4096 and tiles <= 16384 and (2 * tiles > cus or (count > 1 and B > 16) or 8 * tiles > cus):
         # The time-resident kernel (csrc/resident_forward.hpp), whatever the single-batch choice would be:
         #  * enough items to give half the compute units a workgroup of 16 each: whole tiles per workgroup -- also for
         #    a narrow band (its lists end at the band edge, so the scan is short whatever the posteriors look like:
@@ -82,8 +81,8 @@ def _resolve_path(trans, transition, B, S, device, path, tiles, measure, count=1
         #  * a launch group that fills less (the tail of a job, a small job): tiles split over clusters of workgroups
         #    (2 x 512 items: 31.7 us per timestep against 62.7 with whole tiles and 2 x 20.4 one batch after the other);
         #  * ONE batch too large for one round of the per-timestep kernel (more than cus / 8 tiles): clusters
-        #    (768 items: 27.8 against 34.8 us per timestep); above 2048 states (8-item tiles) any batch of more than 16
-        #    items (128 x 4096: 28.4 against 32.6 us per timestep; 16 x 128 x 4096 as a launch group: 238 against 506);
+        #    (768 items: 27.8 against 34.8 us per timestep; above 2048 states the tiles hold 8 items, so 128 x 4096 is 16
+        #    tiles and stays on the per-timestep kernel: 55.6 against 60.3 ms for 2000 frames);
         # unless the scan statistics of an earlier time-resident launch with this matrix say that hardly anything is
         # pruned (see _watch_resident).  Whether the per-timestep pruned kernel beats the dense one is NOT the question
         # here: on peaked rows with a dense matrix it does not, and the time-resident kernel still runs at twice the
