@@ -20,7 +20,7 @@ import threading
 import weakref
 from typing import Optional
 
-_lock = threading.Lock()
+_lock = threading.RLock()        # (re-entrant: a weak-reference callback may run, on this thread, while the lock is held)
 _entries = {}          # id(tensor) -> [weakref, version, notes dict]
 
 
