@@ -152,11 +152,13 @@ int torbi_oracle_viterbi_decode(const float *observation, const int32_t *batch_f
                      post_fin, frames, S, mode, num_threads);
         if (posterior_out) memcpy(posterior_out + (long)b * S, post_fin, sizeof(float) * (size_t)S);
 
-        /* posterior.argmax(1) -> first maximal index; repeat over all T columns (:218-221) */
+        /* posterior.argmax(1) -> first maximal index; repeat over all T columns (:218-221).  ATen's argmax treats
+           NaN as the maximum (the FIRST NaN of a row wins); the forward scan above already behaves like the
+           reference's on NaN by construction (a NaN candidate at index 0 is never replaced, later ones never win) */
         int32_t arg = 0;
         float best = post_fin[0];
         for (int i = 1; i < S; i++)
-            if (post_fin[i] > best) { best = post_fin[i]; arg = i; }
+            if (post_fin[i] > best || (post_fin[i] != post_fin[i] && best == best)) { best = post_fin[i]; arg = i; }
         for (int t = 0; t < T; t++) out[t] = arg;
 
         /* viterbi.cpp:153-157 */

@@ -92,3 +92,32 @@ def test_oracle_equals_reference_operator_on_fresh_inputs(seed):
     want = oracle.ref_decode(obs, frames, trans, init, num_threads=2).numpy()
     for mode in (0, 1):
         assert np.array_equal(oracle.decode(obs, frames, trans, init, 3, mode), want)
+
+
+@pytest.mark.skipif(not oracle.ref_available(), reason='oracle/_ref not built (no /root/reference)')
+@pytest.mark.parametrize('seed', range(4))
+def test_oracle_follows_the_reference_operator_on_nan_inputs(seed):
+    """NaN is outside the contract of the HIP path (include/torbi_hip.h), but the ORACLE restates the reference also
+    there: a NaN candidate at prev-state 0 is never replaced (viterbi.cpp:94-100 starts its running maximum there),
+    later NaN candidates never win, and the final state is ATen's argmax, which takes the first NaN of a row
+    (viterbi.cpp:218).  Checked against the reference operator itself."""
+    if _torbi_namespace_taken():
+        pytest.skip('torbi::viterbi_decode was registered by torbi_amd.torch_op in this process')
+    rng = np.random.default_rng(100 + seed)
+    B, T, S = 3, 12, 40
+    obs, trans, init = synth.problem(B, T, S, seed=2000 + seed)
+    nan = np.float32('nan')
+    if seed == 0:
+        obs[0, 3, 5] = nan                      # a NaN observation in the middle
+    elif seed == 1:
+        trans[7, 0] = nan                       # a NaN transition INTO prev-state 0 position of a row
+        trans[9, 11] = nan
+    elif seed == 2:
+        init[0] = nan                           # the first posterior's first entry
+    else:
+        obs[1, T - 1, 17] = nan                 # NaN in the final row: argmax takes it
+        obs[2, 0, :] = nan
+    frames = np.array([T, T, T - 2], np.int32)
+    want = oracle.ref_decode(obs, frames, trans, init, num_threads=2).numpy()
+    for mode in (0, 1):
+        assert np.array_equal(oracle.decode(obs, frames, trans, init, 2, mode), want), mode
