@@ -385,6 +385,8 @@ def from_dataloader(
             outstanding.append((indices, input_filenames, batch_frames, batch_chunks))
             if pipe is not None and starved is not None and not starved():
                 pipe.flush()      # the reader is the slower side: decode what has arrived instead of waiting for a full group
+            elif pipe is not None and stage is not None:
+                pipe.flush_if_idle()      # ... and so is the host link: an idle device decodes what is ready
             while len(outstanding) > keep:
                 finish(outstanding.popleft())
         while outstanding:

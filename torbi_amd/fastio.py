@@ -31,6 +31,7 @@ import torch
 from . import _lib
 
 
+SERIAL_READS = os.environ.get('TORBI_SERIAL_READS', '1') != '0'
 LAST_TIMINGS = None        # TORBI_FILE_TIMINGS=1: per-batch reader timings of the last FileBatches that ran (tools/)
 
 
@@ -239,6 +240,7 @@ class FileBatches:
         self.pin_memory = torch.cuda.is_available() if pin_memory is None else bool(pin_memory)
         self.ahead = max(1, int(ahead))
         self.producers = 2
+        self._read_lock = threading.Lock()
         # optional: called by the assembling thread with the finished (pinned) observation, returns what is yielded in its
         # place -- the many-file driver starts the host-to-device copy here, so that copies are queued as soon as batches
         # exist, not when the consuming thread next comes round (torbi_amd/core.py::_Staging.upload)
@@ -292,8 +294,16 @@ class FileBatches:
             error = ctypes.c_int(0)
             read_rows, _ = _lib.host_io(self.gpu)
             t2 = time.perf_counter()
-            code = read_rows(fds.ctypes.data, offsets.ctypes.data, sizes.ctypes.data, rows.ctypes.data, zeros.ctypes.data,
-                             count, max(1, min(self.threads // self.producers, count)), ctypes.byref(error))
+            # one native read at a time, with every reader thread: two concurrent reads share the same 85 GB/s (and 64
+            # threads collapse it to 33), so serialising them costs nothing and hands the first batch of a job over in
+            # a third of the time; the other assembling thread does its opens and headers meanwhile
+            if SERIAL_READS:
+                with self._read_lock:
+                    code = read_rows(fds.ctypes.data, offsets.ctypes.data, sizes.ctypes.data, rows.ctypes.data,
+                                     zeros.ctypes.data, count, max(1, min(self.threads, count)), ctypes.byref(error))
+            else:
+                code = read_rows(fds.ctypes.data, offsets.ctypes.data, sizes.ctypes.data, rows.ctypes.data, zeros.ctypes.data,
+                                 count, max(1, min(self.threads // self.producers, count)), ctypes.byref(error))
             if code <= -100:
                 raise OSError(error.value, f'could not read {files[-(code + 100)]} in full')
             _lib.check_io(code, 'read_rows')
