@@ -409,9 +409,16 @@ class Bench:
         # BASELINE configs[3] on this one GPU: 40 000 ragged sequences (79 batches, ten launch groups), decode only
         out['c4_40000_files'] = self.c4_decode_only(40000, steps=0, quiet=True)
         ws = torch.empty(v.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+        prof = []
+        for _ in range(3):
+            self.torbi_amd.decode(obs, frames, trans, init, workspace=ws, _profile=prof)
+        sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(obs, frames, trans, init, workspace=ws), 3)
+        record('serial', sec, B * T, S, 'headline batch, ONE batch at a time on one stream (latency of a single decode): '
+                                       'AUTO = ONE time-resident launch, each 16-item tile split over a cluster of 8 '
+                                       'workgroups', {'forward_path': ROUTES[int(prof[3])]})
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(obs, frames, trans, init, workspace=ws, path='pruned'), 3)
-        record('serial', sec, B * T, S, 'headline batch, ONE batch at a time on one stream: per-timestep launches of '
-                                       'the pruned recurrence (latency of a single decode)')
+        record('serial_per_timestep_kernel', sec, B * T, S, 'the same with per-timestep launches of the pruned recurrence '
+                                                           '(what AUTO took for one batch before round 3)')
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(obs, frames, trans, init, workspace=ws, path='dense'), 2)
         record('every_cell', sec, B * T, S, 'headline batch, dense (max,+) GEMM forced: every (prev, next) cell evaluated',
                {'valu_frac_at_1p5_instr_per_cell': 1.5 * B * T * S * S / sec / VALU_LANE_OPS})
@@ -433,7 +440,9 @@ class Bench:
                'posteriorgram-like rows (log_softmax of peaked logits, clamped at log tiny) with the reference\'s banded '
                'pitch transition; path = what AUTO settled on', {'forward_path': ROUTES[int(prof[3])]})
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(peaked, frames, trans, init, workspace=ws), 3, warmup=4)
-        record('peaked_dense_transition', sec, B * T, S, 'the same peaked rows with the dense random transition (AUTO)')
+        self.torbi_amd.decode(peaked, frames, trans, init, workspace=ws, _profile=prof)
+        record('peaked_dense_transition', sec, B * T, S, 'the same peaked rows with the dense random transition (AUTO)',
+               {'forward_path': ROUTES[int(prof[3])]})
         # the same workload as a launch group of 8 batches (what from_files_to_files sees): AUTO's choice for the group
         spaces = [torch.empty(v.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev) for _ in range(8)]
         prof = []

@@ -143,6 +143,10 @@ int torbi_hip_viterbi_decode(const float *observation, const int32_t *batch_fram
                                         * gathers walk whole rows of the transposed matrix through the L2s -- two thirds of the
                                         * kernel's memory-side read traffic with three seeds -- and buy nothing on flat
                                         * posterior rows; on peaked rows three seeds scan a fifth fewer list blocks. */
+#define TORBI_HIP_MANY_SEEDS 1024u     /* ... and THREE.  Without either flag the whole-tile form keeps three seeds and the
+                                        * cluster form one (its passes run in lock step across the workgroup, so the seed
+                                        * gathers' latency sits on every timestep's critical path: 512 x 1440 18.8 against
+                                        * 20.7 us per timestep; peaked rows with a dense matrix are 10 % faster with three) */
 int torbi_hip_viterbi_decode_ex(const float *observation, const int32_t *batch_frames,
                                 const float *transition, const float *initial,
                                 int32_t *indices_out, void *workspace, size_t workspace_bytes,

@@ -146,10 +146,10 @@ def test_forward_path_selection(forward):
     assert viterbi.forward_path(4, 4100) == 'generic'
     assert viterbi.forward_path(128, 4096) == {'dense': 'dense', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'pruned')   # 8-item tiles
     assert viterbi.forward_path(128, 4100) == 'dense'              # posterior tile does not fit the LDS
-    assert viterbi.forward_path(512, 1440) == {'dense': 'dense', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'pruned')
-    assert viterbi.forward_path(64, 130) == {'dense': 'dense', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'pruned')
-    # AUTO: a batch that gives at least half the compute units a 16-item workgroup is decoded time-resident with whole
-    # tiles per workgroup, one that is too large for one round of the per-timestep kernel in clusters
+    assert viterbi.forward_path(512, 1440) == {'dense': 'dense', 'resident': 'resident', 'pruned': 'pruned'}.get(forward, 'cluster')
+    assert viterbi.forward_path(64, 130) == {'dense': 'dense', 'resident': 'resident', 'pruned': 'pruned'}.get(forward, 'cluster')
+    # AUTO: a batch that gives more than half the compute units a 16-item workgroup is decoded time-resident with whole
+    # tiles per workgroup, a smaller one of more than 16 items (up to 2048 states) in clusters of workgroups per tile
     cus = viterbi.compute_units('cuda:0')
     assert viterbi.forward_path(16 * cus, 1440, path='auto') == 'resident'
     assert viterbi.forward_path(16 * cus, 1440, path='cluster') == 'resident'     # nothing to split
@@ -157,7 +157,11 @@ def test_forward_path_selection(forward):
     assert viterbi.forward_path(8 * cus, 2052, path='auto') == 'resident'         # 8-item tiles above 2048 states
     assert viterbi.forward_path(8 * cus, 4100, path='auto') == 'dense'            # the posterior tile does not fit the LDS
     assert viterbi.forward_path(3 * cus, 1440, path='auto') == 'cluster'
-    assert viterbi.forward_path(2 * cus, 1440, path='auto') == 'pruned'
+    assert viterbi.forward_path(2 * cus, 1440, path='auto') == 'cluster'
+    assert viterbi.forward_path(17, 1440, path='auto') == 'cluster'
+    assert viterbi.forward_path(16, 1440, path='auto') == 'rows'
+    assert viterbi.forward_path(128, 4096, path='auto') == 'pruned'               # 8-item tiles: clusters only beyond one round
+    assert viterbi.forward_path(2 * cus, 1440, path='pruned') == 'pruned'
     # the path travels with the call: naming one never changes the process default
     assert viterbi.forward_path(512, 1440, path='dense') == 'dense'
     assert viterbi.workspace_bytes(512, 500, 1440) >= 512 * 500 * 1440 * 4
@@ -174,13 +178,13 @@ def test_auto_takes_the_dense_kernel_for_narrow_bands_only(forward):
     args = [torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)]
     prof = []
     torbi_amd.decode(*args, _profile=prof)
-    assert int(prof[3]) == 2                                         # dense random matrix: pruned
+    assert int(prof[3]) == 5                                         # dense random matrix: time-resident clusters
     band = torch.as_tensor(synth.banded_transition(S, 20.0)).to(dev)
     torbi_amd.decode(args[0], args[1], band, args[3], _profile=prof)
     assert int(prof[3]) == 1                                         # narrow band: dense + -inf skipping
     band.fill_(-1.0)                                                 # same storage, new version
     torbi_amd.decode(args[0], args[1], band, args[3], _profile=prof)
-    assert int(prof[3]) == 2
+    assert int(prof[3]) == 5
 
 
 @pytest.mark.parametrize('kind', ['flat', 'nearly_flat', 'peaked', 'anti', 'two_level'])
@@ -304,13 +308,14 @@ def test_preparation_reuse_follows_the_transition_and_the_shape(B):
 
 
 def test_auto_tuner_switches_paths_without_changing_results(forward):
-    """Repeated decodes with one transition tensor: the Python layer may move between the pruned and the dense
-    path by measurement (viterbi._Tuner); indices stay those of the oracle, and on data where a few states
-    dominate every posterior row the dense path has been tried by the end."""
+    """Repeated decodes with one transition tensor where AUTO keeps the per-timestep kernels (one batch above 2048
+    states): the Python layer may move between the pruned and the dense path by measurement (viterbi._Tuner); indices
+    stay those of the oracle, and on data where a few states dominate every posterior row the dense path has been tried
+    by the end."""
     if forward != 'auto':
         pytest.skip('path forced')
     dev = torch.device('cuda:0')
-    B, T, S = 64, 30, 720
+    B, T, S = 64, 16, 2064
     obs, trans, init = synth.problem(B, T, S, seed=21)
     obs = (obs + np.float32(40.0) * (obs > np.float32(-0.03))).astype(np.float32)
     frames = np.full(B, T, dtype=np.int32)
@@ -457,11 +462,12 @@ def test_one_seed_per_item_after_shallow_scans_gives_the_same_indices(forward):
         want = oracle.decode(data, frames, trans, init, num_threads=oracle.max_threads())
         d_obs, d_frames = torch.tensor(data, device=dev), torch.tensor(frames, device=dev)
         for path in ('resident', 'cluster'):
-            for blocks in (None, 1.0):                           # unknown depth: three seeds; shallow: one
+            # unknown depth: the library's default (three seeds with whole tiles, one in clusters); shallow: one; deep: three
+            for blocks, flag in ((None, 0), (1.0, 512), (float(S), 1024)):
                 viterbi._depth_record(d_trans, S)[0] = blocks
-                assert viterbi._few_seeds(d_trans, S) == (blocks is not None)
+                assert viterbi._seed_flag(d_trans, S) == flag
                 got = torbi_amd.decode(d_obs, d_frames, d_trans, d_init, path=path)
-                np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f'{path} few={blocks is not None}')
+                np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f'{path} seeds flag {flag}')
     torbi_amd.reset_path_state()
 
 

@@ -174,21 +174,25 @@ def test_auto_path_choice_reads_the_transition_structure_once_per_version():
     assert viterbi._choose_path(dense, dense, 64, 8192) == 'auto'       # outside the pruned path's range
     # a forced path never reaches the look; an explicit per-call 'auto' ignores the process default
     old, units = viterbi._forced_path, dict(viterbi._compute_units)
+    band2 = torch.as_tensor(synth.banded_transition(S, 12.0))     # `band` was overwritten above
     try:
         viterbi._forced_path = 'dense'
         viterbi._compute_units[0] = 256               # what torbi_hip_compute_units(0) reports on an MI355X
         assert viterbi._resolve_path(dense, dense, 64, S, 'cuda:0', None, 4, False) == ('dense', None)
-        assert viterbi._resolve_path(dense, dense, 64, S, 'cuda:0', 'auto', 4, False) == ('pruned', None)
+        assert viterbi._resolve_path(dense, dense, 64, S, 'cuda:0', 'auto', 4, False) == ('cluster', None)
         assert viterbi._resolve_path(dense, dense, 64, S, 'cuda:0', 'resident', 4, False) == ('resident', None)
         # enough 16-item tiles to give half the compute units a workgroup: AUTO decodes time-resident ('cluster' = the
         # library picks the form: whole tiles per workgroup here, clusters of workgroups per tile below half the chip)
         assert viterbi._resolve_path(dense, dense, 2048, S, 'cuda:0', 'auto', 128, False) == ('cluster', None)
         assert viterbi._resolve_path(band, band, 2048, S, 'cuda:0', 'auto', 128, False) == ('cluster', None)
-        # a launch group below half the chip, one batch beyond one round of the per-timestep kernel: clusters; one
-        # 512-item batch: the per-timestep pruned kernel
+        # below half the chip -- a launch group or one batch of more than 16 items -- clusters of workgroups per tile;
+        # one batch with a narrow band: the dense kernel's -inf skipping; 16 items or fewer: the per-timestep kernels
         assert viterbi._resolve_path(dense, dense, 512, S, 'cuda:0', 'auto', 64, False, count=2) == ('cluster', None)
         assert viterbi._resolve_path(dense, dense, 768, S, 'cuda:0', 'auto', 48, False) == ('cluster', None)
-        assert viterbi._resolve_path(dense, dense, 512, S, 'cuda:0', 'auto', 32, False) == ('pruned', None)
+        assert viterbi._resolve_path(dense, dense, 512, S, 'cuda:0', 'auto', 32, False) == ('cluster', None)
+        assert viterbi._resolve_path(band2, band2, 512, S, 'cuda:0', 'auto', 32, False) == ('dense', None)
+        assert viterbi._resolve_path(band2, band2, 512, S, 'cuda:0', 'auto', 32, False, count=2) == ('cluster', None)
+        assert viterbi._resolve_path(dense, dense, 16, S, 'cuda:0', 'auto', 1, False) == ('auto', None)
     finally:
         viterbi._forced_path = old
         viterbi._compute_units.clear()

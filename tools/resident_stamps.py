@@ -6,7 +6,7 @@
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIB = os.path.join(ROOT, 'tools', 'libtorbi_hip_rstamp.so')
+LIB = os.environ.get('STAMP_LIB') or os.path.join(ROOT, 'tools', 'libtorbi_hip_rstamp.so')
 
 if len(sys.argv) > 1 and sys.argv[1] == 'build':
     subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',

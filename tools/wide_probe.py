@@ -1,4 +1,6 @@
-"""Threshold seeds (TORBI_HIP_WIDE_SEEDS) on peaked rows and on the benchmark: launch groups and one batch. (GPU box)"""
+"""Peaked rows and the benchmark on the time-resident forms and the per-timestep paths: launch groups and one batch.
+(GPU box.)  Written for the threshold-seed experiment of round 3 (the TORBI_HIP_WIDE_SEEDS build it compared
+is not in the tree any more; profiles/r03_threshold_seeds_probe.txt holds its output); still useful as a data-dependence probe."""
 import math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -247,7 +247,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void *base, un
 
 // build-time ablations for tools/variants_probe.py (timing only, results are wrong): bit 0 fixed scan depth of 11 blocks
 // (no termination test), 1 no posterior reads from the LDS, 2 no quad broadcasts, 3 no history stores, 4 no top-list
-// inserts, 5 no observation loads, 6 no seeds.  RESIDENT_EXTRA_VALU=n adds n independent v_add_f32 per entry pair (results
+// inserts, 5 no observation loads, 6 no seeds, 7 no exchange stores (cluster form).  RESIDENT_EXTRA_VALU=n adds n independent v_add_f32 per entry pair (results
 // unchanged): how much of the run time is the vector instruction stream
 #ifndef RESIDENT_ABL
 #define RESIDENT_ABL 0
@@ -599,18 +599,26 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                     const u64 key = top_key(o, jr);
                     if (jv && key > last4[it] && !(RESIDENT_ABL & 16)) top_insert<kTop>(top + (4 * g + it) * kTop, key);
                 }
-                // CLUSTER: this row's 16 outputs go to the other members as one write-through 64-byte row (16 bytes per
-                // lane of the quad), in the layout of the LDS tile
-                if constexpr (CLUSTER) {
-                    if (jv && t + 1 < fmax)
-                        store_through(buffer_of(reinterpret_cast<const char *>(clu.xchg) + (size_t)(2 * cid + (t & 1)) * xbytes, xrow),
-                                      (jj * kNI + 4 * g) * 4, make_float4(pend[p][0], pend[p][1], pend[p][2], pend[p][3]));
-                }
                 RSTAMP(4);
             }
         }
-        // CLUSTER: a wave's slice stores must have left before its workgroup raises the flag (every storing wave drains)
+        // CLUSTER: every row's 16 outputs go to the other members as one write-through (sc1) 64-byte row, 16 bytes per lane
+        // of the quad, in the layout of the LDS tile.  All of a wave's rows are stored HERE, behind its last pass, not pass
+        // by pass: a write-through store stays in the wave's memory queue until memory has acknowledged it, and the history
+        // stores and list loads of the next pass queued up behind it (14 of 50 us per timestep with two passes per wave).
+        // The slice stores must have left before the workgroup raises its flag: every storing wave drains.
         if constexpr (CLUSTER) {
+            if (t + 1 < fmax && !(RESIDENT_ABL & 128)) {
+                const __amdgpu_buffer_rsrc_t xdst =
+                    buffer_of(reinterpret_cast<const char *>(clu.xchg) + (size_t)(2 * cid + (t & 1)) * xbytes, xrow);
+#pragma unroll
+                for (int p = 0; p < MAXP; ++p) {
+                    const int rg = rg_lo + wave + KW * p + opaque;
+                    const int jj = kRowGroup * rg + jl;
+                    if (rg < rg_hi && jj < S)
+                        store_through(xdst, (jj * kNI + 4 * g) * 4, make_float4(pend[p][0], pend[p][1], pend[p][2], pend[p][3]));
+                }
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             RSTAMP(8);
         }

@@ -474,7 +474,7 @@ inline int requested_path(unsigned flags) {
     return f ? (int)f - 1 : default_path();
 }
 constexpr unsigned kKnownFlags = TORBI_HIP_REUSE_TRANSITION | TORBI_HIP_COLLECT_STATS | (7u << 4) | TORBI_HIP_SHORTEST_FIRST |
-                                 TORBI_HIP_FEW_SEEDS;
+                                 TORBI_HIP_FEW_SEEDS | TORBI_HIP_MANY_SEEDS;
 inline bool flags_ok(unsigned flags) {
     return !(flags & ~kKnownFlags) && ((flags >> 4) & 7u) <= (unsigned)TORBI_HIP_FORWARD_CLUSTER + 1u;
 }
@@ -504,9 +504,12 @@ inline Route route_for(int path, int B, int S, int cus) {
     if (path == TORBI_HIP_FORWARD_AUTO && fits && 2 * tiles_of(B, S) > cus) return ROUTE_RESIDENT;
     // (one batch, AUTO: clusters where the per-timestep pruned pass would need a second round of workgroups -- more
     // than cus / 8 tiles, 512 items on an MI355X: 27.8 against 34.8 us per timestep at 768 items, equal at 512)
-    // (a batch that fits one round of the per-timestep kernel stays there: 128 x 2000 x 4096 decodes in 55.6 ms on it
-    // against 60.3 ms in clusters of 16, although short runs of the same shape favoured the clusters by 5-15 %)
-    if (path == TORBI_HIP_FORWARD_AUTO && fits && B > 16 && 8 * tiles_of(B, S) > cus && cluster_members(tiles_of(B, S), S, cus) > 1)
+    // ... and, up to 2048 states, for every batch of more than 16 items: with one seed per item the cluster form is at
+    // least as fast as the per-timestep kernel from 17 items on (13.1 against 14.5 us per timestep at 17 items, 18.8 against
+    // 20.1 at 512; profiles/r03_cluster_sweep_1440_kr1.txt).  (Above 2048 states -- 8-item tiles -- a batch that fits one
+    // round of the per-timestep kernel stays there: 128 x 2000 x 4096 decodes in 55.6 ms on it, 60.3 ms in clusters of 16.)
+    if (path == TORBI_HIP_FORWARD_AUTO && fits && B > 16 && (S <= pruned::kMaxS16 || 8 * tiles_of(B, S) > cus) &&
+        cluster_members(tiles_of(B, S), S, cus) > 1)
         return ROUTE_CLUSTER;
     if (path != TORBI_HIP_FORWARD_DENSE && pruned::supported(B, S)) return ROUTE_PRUNED;
     if ((path == TORBI_HIP_FORWARD_PRUNED && rowscan::supported(B, S)) ||
@@ -987,6 +990,12 @@ inline int resident_seeds(bool few) {
     }();
     return forced >= 0 ? forced : (few ? 1 : 3);
 }
+// seeds of a launch from the call's flags: FEW -> one, MANY -> three, neither -> one in the cluster form, three with whole tiles
+inline bool few_seeds(unsigned flags, bool clusters) {
+    if (flags & TORBI_HIP_FEW_SEEDS) return true;
+    if (flags & TORBI_HIP_MANY_SEEDS) return false;
+    return clusters;
+}
 
 template <int KW, int MAXP, int KR, bool CLUSTER, int NI>
 hipError_t launch_resident_variant(const resident::Group &grp, const resident::Cluster &clu, int workgroups,
@@ -1122,13 +1131,14 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
 // one decode on `s`; optional events bracket the forward and backtrace phases (ev[3]: end of the preparation)
 hipError_t run_decode(const float *obs, const int32_t *frames, const float *trans, const float *init,
                       int32_t *out, void *workspace, int B, int T, int S, int device, hipStream_t s,
-                      hipEvent_t *ev, int *launches, bool reuse, bool collect, int path, bool few = false) {
+                      hipEvent_t *ev, int *launches, bool reuse, bool collect, int path, unsigned seed_flags = 0u) {
     hipError_t e;
     const int cus = cu_count(device);
     const Route route = route_for(path, B, S, cus);
     if (route == ROUTE_RESIDENT || route == ROUTE_CLUSTER) {
         const HostBatch hb{obs, frames, out, workspace, B, T};
-        return run_resident(&hb, 1, trans, init, S, cus, s, ev, launches, reuse, false, route == ROUTE_CLUSTER, few);
+        return run_resident(&hb, 1, trans, init, S, cus, s, ev, launches, reuse, false, route == ROUTE_CLUSTER,
+                            few_seeds(seed_flags, route == ROUTE_CLUSTER));
     }
     if (ev) (void)hipEventRecord(ev[0], s);
     if (ev) (void)hipEventRecord(ev[3], s);
@@ -1272,7 +1282,7 @@ int torbi_hip_viterbi_decode_ex(const float *observation, const int32_t *batch_f
     return (int)run_decode(observation, batch_frames, transition, initial, indices_out, workspace,
                            B, T, S, device, static_cast<hipStream_t>(stream), nullptr, nullptr,
                            (flags & TORBI_HIP_REUSE_TRANSITION) != 0, (flags & TORBI_HIP_COLLECT_STATS) != 0,
-                           requested_path(flags), (flags & TORBI_HIP_FEW_SEEDS) != 0);
+                           requested_path(flags), flags);
 }
 
 int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, const float *transition,
@@ -1310,14 +1320,15 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
                           (path == TORBI_HIP_FORWARD_RESIDENT || path == TORBI_HIP_FORWARD_CLUSTER ||
                            (path == TORBI_HIP_FORWARD_AUTO && (2 * tiles > cus || (split && largest > 16))));
     const bool clusters = together && split && path != TORBI_HIP_FORWARD_RESIDENT;
-    const bool ascending = (flags & TORBI_HIP_SHORTEST_FIRST) != 0, few = (flags & TORBI_HIP_FEW_SEEDS) != 0;
+    const bool ascending = (flags & TORBI_HIP_SHORTEST_FIRST) != 0;
     if (phase_ms) {
         PhaseEvents pe;
         if (pe.err != hipSuccess) return (int)pe.err;
         int launches = 0;
         hipError_t e;
         if (together) {
-            e = run_resident(hb, n, transition, initial, S, cus, s, pe.ev, &launches, reuse, ascending, clusters, few);
+            e = run_resident(hb, n, transition, initial, S, cus, s, pe.ev, &launches, reuse, ascending, clusters,
+                             few_seeds(flags, clusters));
             phase_ms[3] = (float)(clusters ? ROUTE_CLUSTER : ROUTE_RESIDENT);
         } else {
             // one batch after the other, each on the path it would take alone; phases of the LAST batch only
@@ -1325,7 +1336,7 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
             // (the reuse promise covers the first batch's workspace only)
             for (int k = 0; k < n && e == hipSuccess; ++k)
                 e = run_decode(hb[k].obs, hb[k].frames, transition, initial, hb[k].out, hb[k].workspace, hb[k].B,
-                               hb[k].T, S, device, s, k == n - 1 ? pe.ev : nullptr, &launches, reuse && k == 0, false, path, few);
+                               hb[k].T, S, device, s, k == n - 1 ? pe.ev : nullptr, &launches, reuse && k == 0, false, path, flags);
             phase_ms[3] = (float)route_for(path, hb[n - 1].B, S, cus);
         }
         if (e == hipSuccess) e = pe.read(phase_ms);
@@ -1334,11 +1345,12 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
         return (int)e;
     }
     if (together)
-        return (int)run_resident(hb, n, transition, initial, S, cus, s, nullptr, nullptr, reuse, ascending, clusters, few);
+        return (int)run_resident(hb, n, transition, initial, S, cus, s, nullptr, nullptr, reuse, ascending, clusters,
+                                 few_seeds(flags, clusters));
     for (int k = 0; k < n; ++k) {
         const hipError_t e = run_decode(hb[k].obs, hb[k].frames, transition, initial, hb[k].out, hb[k].workspace,
                                         hb[k].B, hb[k].T, S, device, s, nullptr, nullptr, reuse && k == 0,
-                                        (flags & TORBI_HIP_COLLECT_STATS) != 0, path, few);
+                                        (flags & TORBI_HIP_COLLECT_STATS) != 0, path, flags);
         if (e != hipSuccess) return (int)e;
     }
     return TORBI_HIP_OK;

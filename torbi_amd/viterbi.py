@@ -73,23 +73,27 @@ def _resolve_path(trans, transition, B, S, device, path, tiles, measure, count=1
         if tuner is not None:
             chosen = tuner.choose()
     cus = compute_units(device)
-    if 64 <= S <= 4096 and tiles <= 16384 and (2 * tiles > cus or (count > 1 and B > 16) or 8 * tiles > cus):
-        # The time-resident kernel (csrc/resident_forward.hpp), whatever the single-batch choice would be:
-        #  * enough items to give half the compute units a workgroup of 16 each: whole tiles per workgroup -- also for
-        #    a narrow band (its lists end at the band edge, so the scan is short whatever the posteriors look like:
-        #    58 M against 32 M timesteps/s for eight batches of peaked rows with the pitch transition);
+    group_like = 2 * tiles > cus or (count > 1 and B > 16)
+    single = count == 1 and B > 16 and not banded and (S <= 2048 or 8 * tiles > cus)
+    if 64 <= S <= 4096 and tiles <= 16384 and (group_like or single):
+        # The time-resident kernel (csrc/resident_forward.hpp), whatever the per-timestep choice would be:
+        #  * enough items to give more than half the compute units a workgroup of 16 each: whole tiles per workgroup --
+        #    also for a narrow band (its lists end at the band edge, so the scan is short whatever the posteriors look
+        #    like: 58 M against 32 M timesteps/s for eight batches of peaked rows with the pitch transition);
         #  * a launch group that fills less (the tail of a job, a small job): tiles split over clusters of workgroups
-        #    (2 x 512 items: 31.7 us per timestep against 62.7 with whole tiles and 2 x 20.4 one batch after the other);
-        #  * ONE batch too large for one round of the per-timestep kernel (more than cus / 8 tiles): clusters
-        #    (768 items: 27.8 against 34.8 us per timestep; above 2048 states the tiles hold 8 items, so 128 x 4096 is 16
-        #    tiles and stays on the per-timestep kernel: 55.6 against 60.3 ms for 2000 frames);
+        #    (2 x 512 items: 25.4 us per timestep against 62.7 with whole tiles and 2 x 20.4 one batch after the other);
+        #  * ONE batch of more than 16 items (up to 2048 states; above, only batches beyond one round of the
+        #    per-timestep kernel): clusters -- 13.1 against 14.5 us per timestep at 17 items, 18.8 against 20.1 at 512,
+        #    20.9 against 34.9 at 768 -- except for a narrow band, which the dense kernel's -inf skipping decodes faster
+        #    one batch at a time (8.0 against 9.5 ms per 512 x 500 batch);
         # unless the scan statistics of an earlier time-resident launch with this matrix say that hardly anything is
         # pruned (see _watch_resident).  Whether the per-timestep pruned kernel beats the dense one is NOT the question
-        # here: on peaked rows with a dense matrix it does not, and the time-resident kernel still runs at twice the
-        # dense kernel's rate (tools/peaked_group_probe.py: 17.6-27.6 M against 12.6 M timesteps/s).
+        # here: on peaked rows with a dense matrix it does not, and the time-resident kernel still runs at the dense
+        # kernel's rate or better (35-38 against 38-40 us per timestep for one batch, twice its rate in launch groups).
         # 'cluster' lets the library pick the form (whole tiles once 2 * tiles > compute units).
         if banded or chosen in ('pruned', 'dense'):
-            chosen = 'dense' if (not banded and _resident_is_losing(transition, S)) else 'cluster'
+            losing = not banded and _resident_is_losing(transition, S, single=not group_like)
+            chosen = 'dense' if losing else 'cluster'
     return chosen, tuner
 
 
@@ -98,25 +102,43 @@ def _resolve_path(trans, transition, B, S, device, path, tiles, measure, count=1
 RESIDENT_GATE = 0.65
 
 
+# one batch in clusters against the dense kernel (tools/depth_probe.py, 512 x 500 x 1440: 20.7 us per timestep at 0.12 of
+# a row's blocks, 43.9 at 0.46; the dense kernel 40.4 whatever the data): the crossing is near 0.40
+SINGLE_BATCH_GATE = 0.40
+# a launch that kept ONE seed per item walks further than one with three before the bound bites (0.60 against 0.46 of a
+# row on peaked rows, 0.130 against 0.119 on the benchmark's): depths measured that way are compared with gates this
+# much higher
+ONE_SEED_DEPTH = 1.25
+
+
 def _depth_record(transition: torch.Tensor, states: int):
-    """[blocks per scan of a time-resident launch with this matrix (None until known), pending (pinned stats, event)],
-    kept with the tensor's notes (torbi_amd/state.py)."""
+    """[blocks per scan of a time-resident launch with this matrix (None until known), pending (pinned stats, event),
+    seeds per item of the launch that was measured], kept with the tensor's notes (torbi_amd/state.py)."""
     kept = state.notes(transition)
     if kept is None:
         return None
-    return kept.setdefault(('depth', states), [None, None])
+    return kept.setdefault(('depth', states), [None, None, 3])
 
 
-def _resident_is_losing(transition: torch.Tensor, states: int) -> bool:
-    """Time-resident launches with this matrix walk so many list blocks per scan that the dense kernel is faster
-    (flat or nearly flat matrices: nothing to prune).  Read without blocking from the statistics the kernel leaves."""
+def _known_depth(transition: torch.Tensor, states: int):
+    """Blocks per scan on the scale of a three-seed launch, or None while no statistics have come back (never waits)."""
     known = _depth_record(transition, states)
     if known is None:
-        return False
+        return None
     if known[0] is None and known[1] is not None and known[1][1].query():
         known[0] = critical_blocks(known[1][0])
         known[1] = None
-    return known[0] is not None and known[0] > RESIDENT_GATE * states / 16.0
+    if known[0] is None:
+        return None
+    return known[0] / (ONE_SEED_DEPTH if known[2] == 1 else 1.0)
+
+
+def _resident_is_losing(transition: torch.Tensor, states: int, single: bool = False) -> bool:
+    """Time-resident launches with this matrix walk so many list blocks per scan that the dense kernel is faster
+    (flat or nearly flat matrices: nothing to prune).  Read without blocking from the statistics the kernel leaves.
+    `single`: the question is asked for ONE batch below half the chip (clusters against one dense batch)."""
+    depth = _known_depth(transition, states)
+    return depth is not None and depth > (SINGLE_BATCH_GATE if single else RESIDENT_GATE) * states / 16.0
 
 
 # scans this shallow (fraction of a row's S/16 list blocks per wave pass; 0.12 on the benchmark, 0.28-0.47 on peaked rows
@@ -124,25 +146,37 @@ def _resident_is_losing(transition: torch.Tensor, states: int) -> bool:
 FEW_SEEDS_GATE = 0.17
 
 
+def _seed_flag(transition: torch.Tensor, states: int) -> int:
+    """TORBI_HIP_FEW_SEEDS (512) / TORBI_HIP_MANY_SEEDS (1024) for a time-resident launch with this matrix, or 0 (the
+    library's default: three seeds per item with whole tiles, one in the cluster form) while nothing is known: once an
+    earlier launch's scan statistics are in (read without blocking) shallow scans select one seed, deep ones three."""
+    depth = _known_depth(transition, states)
+    if depth is None:
+        return 0
+    return 512 if depth <= FEW_SEEDS_GATE * states / 16.0 else 1024
+
+
+def _seeds_kept(flags: int, chosen: str, tiles: int, device) -> int:
+    """Seeds per item of a time-resident launch with these flags (csrc/torbi_hip.hip few_seeds())."""
+    if flags & 512:
+        return 1
+    if flags & 1024:
+        return 3
+    return 1 if chosen != 'resident' and 2 * tiles <= compute_units(device) else 3
+
+
 def _few_seeds(transition: torch.Tensor, states: int) -> bool:
-    """TORBI_HIP_FEW_SEEDS for time-resident launches with this matrix: an earlier launch's scan statistics are in and
-    say that the scans are shallow (read without blocking; until then, and for tensors without a version counter, three
-    seeds)."""
-    known = _depth_record(transition, states)
-    if known is None:
-        return False
-    if known[0] is None and known[1] is not None and known[1][1].query():
-        known[0] = critical_blocks(known[1][0])
-        known[1] = None
-    return known[0] is not None and known[0] <= FEW_SEEDS_GATE * states / 16.0
+    return _seed_flag(transition, states) == 512
 
 
-def _watch_resident(transition, workspace, batch, frames, states) -> None:
+def _watch_resident(transition, workspace, batch, frames, states, seeds=3) -> None:
     """After a time-resident launch chosen by AUTO: once per matrix, copy the scan statistics it leaves in its first
-    workspace to pinned host memory (asynchronously; looked at by a later call, never waited for)."""
+    workspace to pinned host memory (asynchronously; looked at by a later call, never waited for).  `seeds`: what the
+    launch kept per item."""
     known = _depth_record(transition, states)
     if known is None or known[0] is not None or known[1] is not None:
         return
+    known[2] = seeds
     stats = torch.empty((128,), dtype=torch.int32, pin_memory=True)
     stats.copy_(scan_stats(workspace, batch, frames, states, path='resident'), non_blocking=True)
     done = torch.cuda.Event()
@@ -248,8 +282,8 @@ def decode(
     flags = _path_flag(chosen)
     if _reusable(workspace, transition, (B, T, S, chosen, stream), reuse_preparation):
         flags |= 1                                  # TORBI_HIP_REUSE_TRANSITION
-    if chosen in TIME_RESIDENT and _few_seeds(transition, S):
-        flags |= 512                                # TORBI_HIP_FEW_SEEDS
+    if chosen in TIME_RESIDENT:
+        flags |= _seed_flag(transition, S)          # TORBI_HIP_FEW_SEEDS / _MANY_SEEDS once the scan depth is known
     if _profile is None:
         collect = begin is not None and chosen == 'pruned' and tuner.blocks is None
         _lib.check(lib.torbi_hip_viterbi_decode_ex(*args, flags | (2 if collect else 0)),      # COLLECT_STATS
@@ -269,7 +303,7 @@ def decode(
                    'torbi_hip_viterbi_decode_profiled')
         _profile[:] = list(phases)
     if chosen in TIME_RESIDENT and (_forced_path if path is None else path) == 'auto':
-        _watch_resident(transition, workspace, B, T, S)
+        _watch_resident(transition, workspace, B, T, S, _seeds_kept(flags, chosen, tiles_of(B, S), device))
     return indices if home == device else indices.to(home)
 
 
@@ -407,8 +441,8 @@ def decode_batches(
         flags |= 1
     if shortest_first:
         flags |= 256                               # TORBI_HIP_SHORTEST_FIRST
-    if chosen in TIME_RESIDENT and _few_seeds(transition, S):
-        flags |= 512                               # TORBI_HIP_FEW_SEEDS
+    if chosen in TIME_RESIDENT:
+        flags |= _seed_flag(transition, S)         # TORBI_HIP_FEW_SEEDS / _MANY_SEEDS once the scan depth is known
     phases = (ctypes.c_float * 6)() if _profile is not None else None
     _lib.check(lib.torbi_hip_viterbi_decode_batches(table, count, trans.data_ptr(), init.data_ptr(), S, index,
                                                     ctypes.c_void_p(stream), flags, phases),
@@ -417,7 +451,7 @@ def decode_batches(
         _profile[:] = list(phases)
     if chosen in TIME_RESIDENT and (_forced_path if path is None else path) == 'auto':
         B0, T0, _ = shapes[first]
-        _watch_resident(transition, workspaces[first], B0, T0, S)
+        _watch_resident(transition, workspaces[first], B0, T0, S, _seeds_kept(flags, chosen, tiles, device))
     return indices
 
 
