@@ -34,7 +34,7 @@ METRIC = 'timesteps decoded/sec, 1440 states batch=512'
 KERNELS = {'resident': 'resident::resident_forward_kernel', 'cluster': 'resident::resident_forward_kernel',
            'pruned': 'pruned::step_pruned_kernel',
            'dense': 'dense::step_dense_kernel', 'generic': 'step_rows', 'rows': 'rowscan::step_rows_sorted_kernel'}
-ROUTES = {0: 'generic', 1: 'dense', 2: 'pruned', 3: 'resident', 4: 'rows', 5: 'cluster'}
+ROUTES = {0: 'generic', 1: 'dense', 2: 'pruned', 3: 'resident', 4: 'rows', 5: 'cluster', 6: 'held'}
 
 
 def parse_args(argv=None):
@@ -465,7 +465,13 @@ class Bench:
         o1 = obs[:1].contiguous()
         f1 = frames[:1].contiguous()
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(o1, f1, trans, init), 3)
-        record('c2', sec, T, S, f'BASELINE configs[1]: {S} states, {T} frames, batch=1 (latency bound)',
+        self.torbi_amd.decode(o1, f1, trans, init, _profile=prof)
+        record('c2', sec, T, S, f'BASELINE configs[1]: {S} states, {T} frames, batch=1 (latency bound): ONE launch, the '
+                                'matrix held in registers across the chip, posterior rows handed from workgroup to '
+                                'workgroup as {value, timestep} words',
+               {'us_per_timestep': sec / max(T - 1, 1) * 1e6, 'forward_path': ROUTES[int(prof[3])]})
+        sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(o1, f1, trans, init, path='dense'), 3)
+        record('c2_per_timestep_kernels', sec, T, S, 'the same with one launch per timestep (what AUTO took before round 3)',
                {'us_per_timestep': sec / max(T - 1, 1) * 1e6})
         # BASELINE configs[4]: 4096 states, 2000 frames, batch 128
         try:

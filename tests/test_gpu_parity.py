@@ -140,9 +140,14 @@ def test_dense_path_edge_shapes(shape):
 
 def test_forward_path_selection(forward):
     assert viterbi.forward_path(4, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'pruned': 'rows'}.get(forward, 'generic')
+    assert viterbi.forward_path(2, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'pruned': 'rows',
+                                             'auto': 'held'}.get(forward, 'generic')   # AUTO: held matrix for 1-2 items
+    assert viterbi.forward_path(16, 1440, path='held') == 'held' and viterbi.forward_path(17, 1440, path='held') == 'pruned'
+    assert viterbi.forward_path(1, 2048, path='auto') == 'held' and viterbi.forward_path(1, 2052, path='auto') == 'rows'
     assert viterbi.forward_path(16, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'dense': 'generic'}.get(forward, 'rows')
     assert viterbi.forward_path(2, 4096) == {'dense': 'generic', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'rows')
     assert viterbi.forward_path(4, 40) == 'generic'                # S < 64: no value-only path
+    assert viterbi.forward_path(1, 40) == ('held' if forward == 'auto' else 'generic')
     assert viterbi.forward_path(4, 4100) == 'generic'
     assert viterbi.forward_path(128, 4096) == {'dense': 'dense', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'pruned')   # 8-item tiles
     assert viterbi.forward_path(128, 4100) == 'dense'              # posterior tile does not fit the LDS
@@ -165,6 +170,45 @@ def test_forward_path_selection(forward):
     # the path travels with the call: naming one never changes the process default
     assert viterbi.forward_path(512, 1440, path='dense') == 'dense'
     assert viterbi.workspace_bytes(512, 500, 1440) >= 512 * 500 * 1440 * 4
+
+
+@pytest.mark.parametrize('shape', [(1, 50, 1440), (1, 2, 3), (2, 1, 64), (3, 17, 100), (4, 9, 511), (2, 12, 512), (5, 8, 513),
+                                   (16, 6, 1440), (3, 5, 2048), (7, 11, 1027), (1, 300, 360)])
+@pytest.mark.parametrize('kind', ['random', 'ties', 'minus_inf'])
+def test_held_matrix_kernel_equals_the_oracle(shape, kind, forward):
+    """The one-launch forward pass for a handful of sequences (csrc/held_matrix_forward.hpp: the matrix in registers
+    across the chip, posterior rows exchanged as {value, timestep} words): ragged lengths, heavy ties (the first
+    maximum must win through the (value, index) folds), -inf transitions and whole -inf observation rows, every
+    prev-states-per-thread variant (S <= 512, 1024, 1536, 2048) and state counts that leave threads and rows idle."""
+    if forward != 'auto':
+        pytest.skip('names its path itself')
+    B, T, S = shape
+    obs, trans, init = synth.problem(B, T, S, seed=S + B)
+    rng = np.random.default_rng(B * 1000 + S)
+    if kind == 'ties':
+        obs = np.round(obs / 4).astype(np.float32)
+        trans = np.round(trans / 4).astype(np.float32)
+        init = np.round(init / 4).astype(np.float32)
+    elif kind == 'minus_inf':
+        trans = trans.copy()
+        trans[rng.random((S, S)) < 0.6] = -np.inf
+        trans[rng.integers(0, S)] = -np.inf                       # a next-state nothing leads to
+        obs = obs.copy()
+        if T > 2:
+            obs[0, T // 2] = -np.inf                              # a whole frame without support
+    frames = np.clip(synth.lengths(B, 1, T, seed=3), 1, T).astype(np.int32)
+    frames[0] = T
+    dev = torch.device('cuda:0')
+    args = [torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)]
+    space = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+    want, want_post = oracle.decode(obs, frames, trans, init, return_posterior=True)
+    prof = []
+    for _ in range(2):                                            # the second decode finds the first one's words in place
+        got = torbi_amd.decode(*args, workspace=space, path='held', _profile=prof)
+        assert int(prof[3]) == 6 and int(prof[2]) == 1            # route 'held', ONE forward launch
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+    post = viterbi.read_posterior(space, args[1], B, T, S).cpu().numpy()
+    assert np.array_equal(post.view(np.uint32), want_post.view(np.uint32))
 
 
 def test_auto_takes_the_dense_kernel_for_narrow_bands_only(forward):

@@ -1,0 +1,227 @@
+// held_matrix_forward.hpp -- the forward recurrence for a HANDFUL of sequences (B <= 16, S <= 2048) in ONE launch with
+// the transition matrix held in registers across the whole chip.
+//
+// The reference decodes a batch of one with one block that walks the S x S matrix once per timestep
+// (viterbi.cu:217-232); the per-timestep kernels here (step_rows*_kernel, small_batch_forward.hpp) spread a timestep over
+// the chip but pay the gap between dependent launches -- 4.4 us at B = 1, S = 1440, where the arithmetic of a timestep is
+// 2 M cells, a quarter of a microsecond of the chip's vector rate.  An 8.3 MB matrix does not fit a compute unit, but it
+// fits the CHIP: ceil(S / 8) workgroups of 512 threads each hold 8 next-state rows of it in registers for the whole launch
+// (8 x ceil(S / 512) values per thread; 24 at 1440 states) and the time loop runs inside the kernel.  Per timestep a
+// workgroup needs the S posteriors of the step before, produced 8 apiece by all the others: they travel through a
+// [2][B][S] buffer of 8-byte {value, timestep} words written and read with relaxed agent-scope 64-bit atomics (the "LL"
+// hand-off of collective libraries: the tag arrives with the value in one store, so there is no flag round, no fence and
+// no acknowledgement to wait for).  A consumer polls the S words it needs until every tag names the step it is waiting
+// for; two parities suffice because a workgroup can only write step t + 2 after all others have published t + 1, i.e.
+// consumed t.  Everything else is the reference's scan (viterbi.cpp:78-108): candidates fl(post[i] + trans[j][i]) in
+// ascending i per thread, strict '>' (the first maximum wins), (value, index) pairs combined with the lower index on
+// ties, posterior = fl(obs[t][j] + max), backpointer -> trellis; the final argmax and the chase stay in finalize_kernel.
+//
+// All ceil(S / 8) <= 256 workgroups must be resident at once (512 threads, < 64 registers: two fit a compute unit); the
+// polls are bounded and a workgroup that gives up says so in `control[1]` (0 on any sane run).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+namespace held {
+
+constexpr int kThreads = 512;
+constexpr int kWaves = kThreads / 64;
+constexpr int kRows = 8;              // next-states per workgroup
+constexpr int kMaxK = 4;              // prev-states per thread: S <= kThreads * kMaxK
+constexpr int kMaxB = 16;
+constexpr int kMaxS = kThreads * kMaxK;
+
+inline int workgroups(int S) { return (S + kRows - 1) / kRows; }
+inline bool supported(int B, int S, int cus) {
+    return B >= 1 && B <= kMaxB && S >= 1 && S <= kMaxS && workgroups(S) <= 2 * cus;
+}
+inline size_t exchange_bytes(int B, int S) { return sizeof(unsigned long long) * 2 * (size_t)B * S; }
+
+typedef unsigned long long u64;
+
+// (selects, not branches: hipcc otherwise emits an exec-mask branch per comparison -- 47 in the time loop, 2.5 us per item)
+__device__ __forceinline__ void better(float &v, int &i, float ov, int oi) {
+    const bool take = (ov > v) | ((ov == v) & (oi < i));
+    v = take ? ov : v;
+    i = take ? oi : i;
+}
+
+// the other lane's value: DPP for partners inside a 16-lane row (W = 1, 2: quad permutes; 8: rotate the row by 8), the
+// LDS crossbar (ds_bpermute) across rows
+template <int W>
+__device__ __forceinline__ int partner(int x) {
+    if constexpr (W == 1) return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);
+    else if constexpr (W == 2) return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);
+    else if constexpr (W == 8) return __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, true);
+    else return __shfl_xor(x, W, 64);
+}
+
+// lanes l and l ^ W hold N rows each; afterwards each holds the N / 2 rows of its half (upper lanes the upper rows),
+// combined over the pair
+template <int W, int N>
+__device__ __forceinline__ void fold_pairs(float (&v)[kRows], int (&a)[kRows], bool upper) {
+#pragma unroll
+    for (int r = 0; r < N / 2; ++r) {
+        const float sv = upper ? v[r] : v[r + N / 2];
+        const int sa = upper ? a[r] : a[r + N / 2];
+        const float ov = __int_as_float(partner<W>(__float_as_int(sv)));
+        const int oa = partner<W>(sa);
+        float kv = upper ? v[r + N / 2] : v[r];
+        int ka = upper ? a[r + N / 2] : a[r];
+        better(kv, ka, ov, oa);
+        v[r] = kv;
+        a[r] = ka;
+    }
+}
+
+// (value, index) of the best over the 8 lanes that share bits 3..5 of the lane number, in all of them
+__device__ __forceinline__ void reduce_eight(float &v, int &a) {
+    better(v, a, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true)),
+           __builtin_amdgcn_update_dpp(0, a, 0xB1, 0xf, 0xf, true));                       // quad_perm [1,0,3,2]
+    better(v, a, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true)),
+           __builtin_amdgcn_update_dpp(0, a, 0x4E, 0xf, 0xf, true));                       // quad_perm [2,3,0,1]
+    better(v, a, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true)),
+           __builtin_amdgcn_update_dpp(0, a, 0x141, 0xf, 0xf, true));                      // row_half_mirror
+}
+
+__global__ __launch_bounds__(256) void clear_kernel(uint4 *__restrict__ dst, size_t count) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x)
+        dst[e] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// grid = workgroups(S), block = 512.  post0 holds row 0 of every item (init_posterior_kernel); `xchg` is zeroed.
+template <int K>
+__global__ __launch_bounds__(kThreads) void held_forward_kernel(
+    const float *__restrict__ obs, const int32_t *__restrict__ frames, const float *__restrict__ trans,
+    float *__restrict__ post0, float *__restrict__ post1, int32_t *__restrict__ trellis, u64 *__restrict__ xchg,
+    unsigned *__restrict__ control, int B, int T, int S) {
+    __shared__ float sv[2][kWaves][kRows];
+    __shared__ int sa[2][kWaves][kRows];
+    __shared__ int sframes[kMaxB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j0 = blockIdx.x * kRows;
+    const bool last_valid = tid + kThreads * (K - 1) < S;       // only the last of a thread's prev-states can lie beyond S
+
+    // this workgroup's 8 rows of the matrix, for the whole launch
+    float tr[kRows][K];
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+        const int j = j0 + r < S ? j0 + r : S - 1;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int i = tid + kThreads * k;
+            tr[r][k] = (k < K - 1 || last_valid) ? trans[(size_t)j * S + i] : 0.0f;
+        }
+    }
+    if (tid < kMaxB) {
+        int f = tid < B ? frames[tid] : 1;
+        sframes[tid] = f < 1 ? 1 : (f > T ? T : f);
+    }
+    __syncthreads();
+    int longest = 1;
+    for (int b = 0; b < B; ++b) longest = max(longest, sframes[b]);
+    bool gave_up = false;
+    int round = 0;
+    const int jmine = j0 + tid;
+    const bool writer = tid < kRows && jmine < S;
+
+    // the words of posterior row t-1 of item b this thread scans: requested here, looked at by the caller
+    auto request = [&](int t, int b, u64 (&w)[K]) {
+        const u64 *src = xchg + ((size_t)((t - 1) & 1) * B + b) * S;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            w[k] = (k < K - 1 || last_valid)
+                       ? __hip_atomic_load(src + tid + kThreads * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                       : (u64)(unsigned)(t - 1) << 32;
+    };
+    // work items in order: every sequence that has not ended, timestep by timestep (uniform over the whole grid)
+    auto advance = [&](int &t, int &b) {
+        do {
+            if (++b == B) { b = 0; ++t; }
+        } while (t < longest && t >= sframes[b]);
+    };
+    int t = 1, b = -1;
+    advance(t, b);
+    u64 ahead[K];
+    bool requested = false;
+    while (t < longest) {
+        int nt = t, nb = b;
+        advance(nt, nb);
+        // the output row's observation does not depend on the exchange: ask for it first
+        float ob = 0.0f;
+        if (writer) ob = obs[((size_t)b * T + t) * S + jmine];
+        float p[K];
+        if (t == 1) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) p[k] = (k < K - 1 || last_valid) ? post0[(size_t)b * S + tid + kThreads * k] : 0.0f;
+        } else {
+            const unsigned want = (unsigned)(t - 1);
+            unsigned spins = 0;
+            for (;;) {
+                if (!requested) request(t, b, ahead);
+                requested = false;
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < K; ++k) ok = ok && (unsigned)(ahead[k] >> 32) == want;
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                if (++spins > (1u << 22)) { gave_up = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) p[k] = __uint_as_float((unsigned)ahead[k]);
+        }
+        // the next item's words, if another sequence's (they were published an item ago): in flight during this item's scan
+        if (nt < longest && nt > 1 && !(nb == b)) {
+            request(nt, nb, ahead);
+            requested = true;
+        }
+        // the reference's scan over this thread's prev-states, for each of the 8 rows
+        float v[kRows];
+        int a[kRows];
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            v[r] = p[0] + tr[r][0];                              // (K == 1: a thread beyond S holds no candidate)
+            a[r] = tid;
+            if (K == 1 && !last_valid) { v[r] = -INFINITY; a[r] = 0x7fffffff; }
+#pragma unroll
+            for (int k = 1; k < K; ++k) {
+                const float c = p[k] + tr[r][k];
+                const bool take = (c > v[r]) & (k < K - 1 || last_valid);
+                v[r] = take ? c : v[r];
+                a[r] = take ? tid + kThreads * k : a[r];
+            }
+        }
+        // 8 rows x 64 lanes -> one row per lane (3 halving folds), then over the 8 lanes that share a row
+        fold_pairs<32, 8>(v, a, (lane & 32) != 0);
+        fold_pairs<16, 4>(v, a, (lane & 16) != 0);
+        fold_pairs<8, 2>(v, a, (lane & 8) != 0);
+        reduce_eight(v[0], a[0]);
+        const int slot = round & 1;
+        ++round;
+        if ((lane & 7) == 0) {
+            const int row = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+            sv[slot][wave][row] = v[0];
+            sa[slot][wave][row] = a[0];
+        }
+        __syncthreads();
+        if (writer) {
+            float bv = sv[slot][0][tid];
+            int ba = sa[slot][0][tid];
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) better(bv, ba, sv[slot][w][tid], sa[slot][w][tid]);
+            const float out = ob + bv;
+            const u64 word = ((u64)(unsigned)t << 32) | __float_as_uint(out);
+            __hip_atomic_store(xchg + ((size_t)(t & 1) * B + b) * S + jmine, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            trellis[((size_t)b * T + t) * S + jmine] = ba;
+            if (t == sframes[b] - 1) ((t & 1) ? post1 : post0)[(size_t)b * S + jmine] = out;
+        }
+        t = nt;
+        b = nb;
+    }
+    if (gave_up && lane == 0) atomicAdd(control + 1, 1u);
+}
+
+}  // namespace held

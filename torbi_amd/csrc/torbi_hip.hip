@@ -32,6 +32,7 @@
 #include "pruned_forward.hpp"
 #include "resident_forward.hpp"
 #include "small_batch_forward.hpp"
+#include "held_matrix_forward.hpp"
 #include "file_rows.hpp"
 
 #ifndef TORBI_UNIFORM_DEPTH
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(256) void gather_final_kernel(const int32_t *__rest
                                                            const float *__restrict__ post0, const float *__restrict__ post1,
                                                            const int32_t *__restrict__ frames, float *__restrict__ dst,
                                                            int B, int T, int S) {
-    const bool generic = *route == 0;
+    const bool generic = *route == 0 || *route == 6;       // trellis kernels: per-timestep or held-matrix
     const size_t n = (size_t)B * S;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const int b = (int)(e / S);
@@ -448,7 +449,8 @@ inline hipError_t ensure_dynamic_lds(const void *fn, size_t bytes) {
 
 // Which forward recurrence runs.  GENERIC materialises the int32 trellis like the reference does; the other three
 // keep the posterior history and recompute backpointers along the decoded path (lazy_backtrace.hpp).
-enum Route { ROUTE_GENERIC = 0, ROUTE_DENSE = 1, ROUTE_PRUNED = 2, ROUTE_RESIDENT = 3, ROUTE_ROWS = 4, ROUTE_CLUSTER = 5 };
+enum Route { ROUTE_GENERIC = 0, ROUTE_DENSE = 1, ROUTE_PRUNED = 2, ROUTE_RESIDENT = 3, ROUTE_ROWS = 4, ROUTE_CLUSTER = 5,
+             ROUTE_HELD = 6 };
 
 inline bool use_dense(int B, int S) { return B >= 32 && S >= 64; }
 
@@ -463,7 +465,8 @@ inline int default_path() {
                : e[0] == 'd' ? TORBI_HIP_FORWARD_DENSE
                : e[0] == 'p' ? TORBI_HIP_FORWARD_PRUNED
                : e[0] == 'r' ? TORBI_HIP_FORWARD_RESIDENT
-               : e[0] == 'c' ? TORBI_HIP_FORWARD_CLUSTER : TORBI_HIP_FORWARD_AUTO;
+               : e[0] == 'c' ? TORBI_HIP_FORWARD_CLUSTER
+               : e[0] == 'h' ? TORBI_HIP_FORWARD_HELD : TORBI_HIP_FORWARD_AUTO;
         g_forward_path.store(v, std::memory_order_relaxed);
     }
     return v;
@@ -476,7 +479,7 @@ inline int requested_path(unsigned flags) {
 constexpr unsigned kKnownFlags = TORBI_HIP_REUSE_TRANSITION | TORBI_HIP_COLLECT_STATS | (7u << 4) | TORBI_HIP_SHORTEST_FIRST |
                                  TORBI_HIP_FEW_SEEDS | TORBI_HIP_MANY_SEEDS;
 inline bool flags_ok(unsigned flags) {
-    return !(flags & ~kKnownFlags) && ((flags >> 4) & 7u) <= (unsigned)TORBI_HIP_FORWARD_CLUSTER + 1u;
+    return !(flags & ~kKnownFlags) && ((flags >> 4) & 7u) <= (unsigned)TORBI_HIP_FORWARD_HELD + 1u;
 }
 
 constexpr int kMaxGroupTiles = 16384;     // 16-item tiles one launch group may hold (262 144 items)
@@ -492,6 +495,19 @@ inline int cluster_members(int tiles, int S, int cus) {
     const int nrg = (S + resident::pass_rows(S) - 1) / resident::pass_rows(S);
     R = std::min(R, std::min(resident::kMaxR, nrg));
     return R < 2 ? 1 : R;
+}
+
+// AUTO takes the held-matrix kernel up to this many items (TORBI_HIP_HELD_ITEMS overrides; 0 = never).  tools/held_probe.py,
+// 500 frames x 1440 states, ms per decode against the per-timestep trellis kernels: 1 item 1.40 / 2.41, 2 items 2.20 / 2.53,
+// 3 items 2.83 / 2.70 -- a timestep of the kernel costs one hand-off (~2 us) for the first item and ~1.7 us of
+// instruction issue for every further one, a launch of the per-timestep kernels 4.4 us plus ~0.3 us per item
+inline bool held_auto(int B, int S) {
+    static const int limit = [] {
+        const char *e = getenv("TORBI_HIP_HELD_ITEMS");
+        return e ? atoi(e) : 2;
+    }();
+    (void)S;
+    return B <= limit;
 }
 
 // route of ONE batch.  AUTO: the time-resident kernel -- whole tiles per workgroup when the batch alone gives at least
@@ -512,6 +528,10 @@ inline Route route_for(int path, int B, int S, int cus) {
         cluster_members(tiles_of(B, S), S, cus) > 1)
         return ROUTE_CLUSTER;
     if (path != TORBI_HIP_FORWARD_DENSE && pruned::supported(B, S)) return ROUTE_PRUNED;
+    // a handful of sequences: the whole time loop in one launch, the matrix held in registers across the chip
+    // (held_matrix_forward.hpp) -- AUTO up to two items (held_auto), any B <= 16 when named
+    if (held::supported(B, S, cus) && (path == TORBI_HIP_FORWARD_HELD || (path == TORBI_HIP_FORWARD_AUTO && held_auto(B, S))))
+        return ROUTE_HELD;
     if ((path == TORBI_HIP_FORWARD_PRUNED && rowscan::supported(B, S)) ||
         (path != TORBI_HIP_FORWARD_DENSE && rowscan::profitable(B, S)))
         return ROUTE_ROWS;
@@ -524,6 +544,8 @@ inline size_t history_bytes(int B, int T, int S) { return align_up(sizeof(float)
 struct Workspace {
     float *post[2];     // (B,S) ping-pong posterior rows
     int32_t *trellis;   // (B,T,S) backpointers; rows t >= 1 of valid frames are written
+    held::u64 *xchg;    // [2][B][S] {posterior, timestep} words of the held-matrix kernel (B <= 16, S <= 2048), else null
+    unsigned *control;  // [64] its control words ([1]: workgroups that gave up waiting)
     size_t bytes;
 };
 
@@ -535,6 +557,13 @@ inline Workspace carve(void *base, int B, int T, int S) {
     w.post[0] = reinterpret_cast<float *>(p + history_bytes(B, T, S));
     w.post[1] = reinterpret_cast<float *>(p + history_bytes(B, T, S) + post_bytes);
     w.bytes = history_bytes(B, T, S) + 2 * post_bytes;
+    w.xchg = nullptr;
+    w.control = nullptr;
+    if (B <= held::kMaxB && S <= held::kMaxS) {
+        w.control = reinterpret_cast<unsigned *>(p + w.bytes);
+        w.xchg = reinterpret_cast<held::u64 *>(p + w.bytes + 256);
+        w.bytes += 256 + align_up(held::exchange_bytes(B, S), 256);
+    }
     return w;
 }
 
@@ -783,6 +812,38 @@ hipError_t launch_forward(const float *obs, const int32_t *frames, const float *
         ++n;
     }
     if (launches) *launches = n;
+    return hipGetLastError();
+}
+
+// the same outputs from ONE launch: the time loop inside the kernel, the matrix in registers (held_matrix_forward.hpp)
+hipError_t launch_held_forward(const float *obs, const int32_t *frames, const float *trans, const float *init,
+                               const Workspace &w, int B, int T, int S, hipStream_t stream, int *launches) {
+    {
+        const size_t n = (size_t)B * S;
+        const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+        hipLaunchKernelGGL(init_posterior_kernel, dim3(grid), dim3(256), 0, stream, obs, init, w.post[0], B, T, S);
+    }
+    if (launches) *launches = 1;
+    if (T < 2) return hipGetLastError();
+    {   // control words and exchange buffer are adjacent: one fill (a kernel: hipMemsetAsync costs ~0.17 ms per call here)
+        const size_t words = (256 + held::exchange_bytes(B, S)) / 16;
+        const int grid = (int)((words + 255) / 256 < 1024 ? (words + 255) / 256 : 1024);
+        hipLaunchKernelGGL(held::clear_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<uint4 *>(w.control), words);
+    }
+    const dim3 grid(held::workgroups(S)), block(held::kThreads);
+    const int K = (S + held::kThreads - 1) / held::kThreads;
+    if (K == 1)
+        hipLaunchKernelGGL(held::held_forward_kernel<1>, grid, block, 0, stream, obs, frames, trans, w.post[0], w.post[1],
+                           w.trellis, w.xchg, w.control, B, T, S);
+    else if (K == 2)
+        hipLaunchKernelGGL(held::held_forward_kernel<2>, grid, block, 0, stream, obs, frames, trans, w.post[0], w.post[1],
+                           w.trellis, w.xchg, w.control, B, T, S);
+    else if (K == 3)
+        hipLaunchKernelGGL(held::held_forward_kernel<3>, grid, block, 0, stream, obs, frames, trans, w.post[0], w.post[1],
+                           w.trellis, w.xchg, w.control, B, T, S);
+    else
+        hipLaunchKernelGGL(held::held_forward_kernel<4>, grid, block, 0, stream, obs, frames, trans, w.post[0], w.post[1],
+                           w.trellis, w.xchg, w.control, B, T, S);
     return hipGetLastError();
 }
 
@@ -1177,7 +1238,8 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
             e = launch_backtrace_sorted(w.hist, w.sorted, w.SpP, pruned::kNB, trans, frames, out, B, T, S, s);
     } else {
         const Workspace w = carve(workspace, B, T, S);
-        e = launch_forward(obs, frames, trans, init, w, B, T, S, s, launches);
+        e = route == ROUTE_HELD ? launch_held_forward(obs, frames, trans, init, w, B, T, S, s, launches)
+                                : launch_forward(obs, frames, trans, init, w, B, T, S, s, launches);
         if (ev) (void)hipEventRecord(ev[1], s);
         if (e == hipSuccess) e = launch_finalize(frames, w, out, B, T, S, s);
     }

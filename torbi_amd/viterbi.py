@@ -456,7 +456,7 @@ def decode_batches(
 
 
 TIME_RESIDENT = ('resident', 'cluster')       # the two forms of the time-resident kernel (include/torbi_hip.h)
-FORWARD_PATHS = {'auto': 0, 'dense': 1, 'pruned': 2, 'resident': 3, 'cluster': 4}
+FORWARD_PATHS = {'auto': 0, 'dense': 1, 'pruned': 2, 'resident': 3, 'cluster': 4, 'held': 5}
 
 
 class _Tuner:
@@ -601,7 +601,7 @@ def _choose_path(trans: torch.Tensor, original: torch.Tensor, batch: int, states
     return 'dense' if 0.0 < reach < BANDED_RANGE else 'pruned'
 
 
-ROUTES = {0: 'generic', 1: 'dense', 2: 'pruned', 3: 'resident', 4: 'rows', 5: 'cluster'}
+ROUTES = {0: 'generic', 1: 'dense', 2: 'pruned', 3: 'resident', 4: 'rows', 5: 'cluster', 6: 'held'}
 
 
 def forward_path(batch: int, states: int, path: Optional[str] = None, device: int = 0) -> str:
