@@ -89,9 +89,9 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
  *             all states for every timestep, the posterior rows never leave its LDS (64 <= S <= 2048).
  *             16 items per compute unit: the path for many items in flight -- several batches through
  *             torbi_hip_viterbi_decode_batches, or one batch of >= 8 * compute-units items.
- *   HELD      B <= 16, S <= 2048: the reference's scan with the time loop inside ONE launch: ceil(S / 8) workgroups
+ *   HELD      B <= 16, S <= 4096: the reference's scan with the time loop inside ONE launch: ceil(S / 8) workgroups
  *             hold 8 rows of the matrix each in registers for the whole launch and pass the posterior rows to each
- *             other through 8-byte {value, timestep} words (held_matrix_forward.hpp).  AUTO takes it for one or two items.
+ *             other through 8-byte {value, timestep} words (held_matrix_forward.hpp).  AUTO takes it for one or two items (up to four above 2048 states).
  * AUTO takes RESIDENT when the call's items fill at least half the compute units with workgroups of
  * 16, else PRUNED / ROWS where supported, else DENSE, else GENERIC.
  *
@@ -108,7 +108,7 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
 #define TORBI_HIP_FORWARD_PRUNED 2
 #define TORBI_HIP_FORWARD_RESIDENT 3
 #define TORBI_HIP_FORWARD_CLUSTER 4
-#define TORBI_HIP_FORWARD_HELD 5       /* B <= 16, S <= 2048: ONE launch, the matrix held in registers across the chip */
+#define TORBI_HIP_FORWARD_HELD 5       /* B <= 16, S <= 4096: ONE launch, the matrix held in registers across the chip */
 #define TORBI_HIP_PATH_FLAG(path) (((unsigned)(path) + 1u) << 4)   /* bits 4..6 of `flags`; 0 = process default */
 int torbi_hip_set_forward_path(int path);
 int torbi_hip_forward_path(int B, int S);

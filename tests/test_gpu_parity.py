@@ -143,9 +143,11 @@ def test_forward_path_selection(forward):
     assert viterbi.forward_path(2, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'pruned': 'rows',
                                              'auto': 'held'}.get(forward, 'generic')   # AUTO: held matrix for 1-2 items
     assert viterbi.forward_path(16, 1440, path='held') == 'held' and viterbi.forward_path(17, 1440, path='held') == 'pruned'
-    assert viterbi.forward_path(1, 2048, path='auto') == 'held' and viterbi.forward_path(1, 2052, path='auto') == 'rows'
+    assert viterbi.forward_path(1, 4096, path='auto') == 'held' and viterbi.forward_path(1, 4100, path='auto') == 'generic'
     assert viterbi.forward_path(16, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'dense': 'generic'}.get(forward, 'rows')
-    assert viterbi.forward_path(2, 4096) == {'dense': 'generic', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'rows')
+    assert viterbi.forward_path(2, 4096) == {'dense': 'generic', 'resident': 'resident', 'cluster': 'cluster',
+                                             'auto': 'held'}.get(forward, 'rows')
+    assert viterbi.forward_path(5, 4096) == {'dense': 'generic', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'rows')
     assert viterbi.forward_path(4, 40) == 'generic'                # S < 64: no value-only path
     assert viterbi.forward_path(1, 40) == ('held' if forward == 'auto' else 'generic')
     assert viterbi.forward_path(4, 4100) == 'generic'
@@ -173,13 +175,15 @@ def test_forward_path_selection(forward):
 
 
 @pytest.mark.parametrize('shape', [(1, 50, 1440), (1, 2, 3), (2, 1, 64), (3, 17, 100), (4, 9, 511), (2, 12, 512), (5, 8, 513),
-                                   (16, 6, 1440), (3, 5, 2048), (7, 11, 1027), (1, 300, 360)])
+                                   (16, 6, 1440), (3, 5, 2048), (7, 11, 1027), (1, 300, 360), (2, 5, 2052), (3, 4, 3072),
+                                   (2, 7, 3100), (1, 6, 4096), (16, 3, 4096)])
 @pytest.mark.parametrize('kind', ['random', 'ties', 'minus_inf'])
 def test_held_matrix_kernel_equals_the_oracle(shape, kind, forward):
     """The one-launch forward pass for a handful of sequences (csrc/held_matrix_forward.hpp: the matrix in registers
     across the chip, posterior rows exchanged as {value, timestep} words): ragged lengths, heavy ties (the first
     maximum must win through the (value, index) folds), -inf transitions and whole -inf observation rows, every
-    prev-states-per-thread variant (S <= 512, 1024, 1536, 2048) and state counts that leave threads and rows idle."""
+    prev-states-per-thread variant (S <= 512, 1024, 1536, 2048 with 8 rows per workgroup; <= 3072, 4096 with 16) and state
+    counts that leave threads and rows idle."""
     if forward != 'auto':
         pytest.skip('names its path itself')
     B, T, S = shape

@@ -1,7 +1,7 @@
 """A handful of sequences: the held-matrix kernel (ONE launch, csrc/held_matrix_forward.hpp) against the per-timestep
 kernels (generic trellis kernels = path 'dense' for B < 32; sorted-row scan = path 'pruned' for B <= 16).
 
-    python tools/held_probe.py [S] [T]
+    python tools/held_probe.py [S] [T]          # HELD_PROBE_ITEMS=1,2 HELD_PROBE_ONLY=1 TORBI_HIP_LIBRARY=... for A/B builds
 """
 import os
 import sys
@@ -18,13 +18,13 @@ def main():
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 500
     dev = torch.device('cuda:0')
     print(f'S = {S}, T = {T}: ms per decode (forward ms, backtrace ms) [us per timestep]')
-    for B in (1, 2, 3, 4, 6, 8, 12, 16):
+    for B in [int(x) for x in os.environ.get('HELD_PROBE_ITEMS', '1,2,3,4,6,8,12,16').split(',')]:
         obs, trans, init = synth.problem(B, T, S, seed=B)
         args = [torch.tensor(obs, device=dev), torch.full((B,), T, dtype=torch.int32, device=dev),
                 torch.tensor(trans, device=dev), torch.tensor(init, device=dev)]
         space = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
         row, ref = [f'B = {B:2d}'], None
-        for name, path in (('generic', 'dense'), ('rows', 'pruned'), ('held', 'held')):
+        for name, path in (('held', 'held'),) if os.environ.get('HELD_PROBE_ONLY') else (('generic', 'dense'), ('rows', 'pruned'), ('held', 'held')):
             for _ in range(2):
                 got = viterbi.decode(*args, workspace=space, path=path)
             torch.cuda.synchronize()

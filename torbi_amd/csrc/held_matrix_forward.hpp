@@ -1,4 +1,4 @@
-// held_matrix_forward.hpp -- the forward recurrence for a HANDFUL of sequences (B <= 16, S <= 2048) in ONE launch with
+// held_matrix_forward.hpp -- the forward recurrence for a HANDFUL of sequences (B <= 16, S <= 4096) in ONE launch with
 // the transition matrix held in registers across the whole chip.
 //
 // The reference decodes a batch of one with one block that walks the S x S matrix once per timestep
@@ -6,7 +6,9 @@
 // the chip but pay the gap between dependent launches -- 4.4 us at B = 1, S = 1440, where the arithmetic of a timestep is
 // 2 M cells, a quarter of a microsecond of the chip's vector rate.  An 8.3 MB matrix does not fit a compute unit, but it
 // fits the CHIP: ceil(S / 8) workgroups of 512 threads each hold 8 next-state rows of it in registers for the whole launch
-// (8 x ceil(S / 512) values per thread; 24 at 1440 states) and the time loop runs inside the kernel.  Per timestep a
+// (8 x ceil(S / 512) values per thread; 24 at 1440 states; above 2048 states 16 rows per workgroup of 1024 threads, 64
+// values per thread at 4096 states = the 64 MB matrix in the registers of 256 compute units) and the time loop runs
+// inside the kernel.  Per timestep a
 // workgroup needs the S posteriors of the step before, produced 8 apiece by all the others: they travel through a
 // [2][B][S] buffer of 8-byte {value, timestep} words written and read with relaxed agent-scope 64-bit atomics (the "LL"
 // hand-off of collective libraries: the tag arrives with the value in one store, so there is no flag round, no fence and
@@ -16,26 +18,38 @@
 // ascending i per thread, strict '>' (the first maximum wins), (value, index) pairs combined with the lower index on
 // ties, posterior = fl(obs[t][j] + max), backpointer -> trellis; the final argmax and the chase stay in finalize_kernel.
 //
-// All ceil(S / 8) <= 256 workgroups must be resident at once (512 threads, < 64 registers: two fit a compute unit); the
-// polls are bounded and a workgroup that gives up says so in `control[1]` (0 on any sane run).
+// All workgroups (<= 256) must be resident at once -- one per compute unit of an MI355X; the polls are bounded and a
+// workgroup that gives up says so in `control[1]` (0 on any sane run).
 #pragma once
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
 
+#ifndef HELD_FIRST_SLEEP
+#define HELD_FIRST_SLEEP 16     // x 64 cycles before the first poll of a timestep (tools/held_probe.py, 1 x 500 x 1440,
+                                // us per timestep: 0 -> 2.79, 8 -> 2.41, 12 -> 2.32, 16 -> 2.26, 20 -> 2.34, 32 -> 2.67)
+#endif
+#ifndef HELD_POLL_SLEEP
+#define HELD_POLL_SLEEP 1       // x 64 cycles between polls
+#endif
+
 namespace held {
 
-constexpr int kThreads = 512;
-constexpr int kWaves = kThreads / 64;
-constexpr int kRows = 8;              // next-states per workgroup
-constexpr int kMaxK = 4;              // prev-states per thread: S <= kThreads * kMaxK
+// Two shapes: up to 2048 states 8 next-states per workgroup of 512 threads (<= 256 workgroups, 4 prev-states per thread);
+// up to 4096 states 16 next-states per workgroup of 1024 threads (<= 256 workgroups, 4 prev-states per thread, 64 matrix
+// registers).  Either way one workgroup per compute unit of an MI355X, all resident at once.
+constexpr int kMaxK = 4;              // prev-states per thread
 constexpr int kMaxB = 16;
-constexpr int kMaxS = kThreads * kMaxK;
+constexpr int kSmallS = 2048;
+constexpr int kMaxS = 4096;
+constexpr int kMaxRows = 16;
 
-inline int workgroups(int S) { return (S + kRows - 1) / kRows; }
+inline int rows_per_workgroup(int S) { return S <= kSmallS ? 8 : 16; }
+inline int threads(int S) { return S <= kSmallS ? 512 : 1024; }
+inline int workgroups(int S) { return (S + rows_per_workgroup(S) - 1) / rows_per_workgroup(S); }
 inline bool supported(int B, int S, int cus) {
-    return B >= 1 && B <= kMaxB && S >= 1 && S <= kMaxS && workgroups(S) <= 2 * cus;
+    return B >= 1 && B <= kMaxB && S >= 1 && S <= kMaxS && workgroups(S) <= (S <= kSmallS ? 2 * cus : cus);
 }
 inline size_t exchange_bytes(int B, int S) { return sizeof(unsigned long long) * 2 * (size_t)B * S; }
 
@@ -48,20 +62,22 @@ __device__ __forceinline__ void better(float &v, int &i, float ov, int oi) {
     i = take ? oi : i;
 }
 
-// the other lane's value: DPP for partners inside a 16-lane row (W = 1, 2: quad permutes; 8: rotate the row by 8), the
-// LDS crossbar (ds_bpermute) across rows
+// the other lane's value: DPP for partners inside a 16-lane row (W = 1, 2: quad permutes; 4: mirror the half row -- a
+// matching between the lanes with bit 2 clear and set, all a fold needs; 8: rotate the row by 8), the LDS crossbar
+// (ds_bpermute) across rows
 template <int W>
 __device__ __forceinline__ int partner(int x) {
     if constexpr (W == 1) return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);
     else if constexpr (W == 2) return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);
+    else if constexpr (W == 4) return __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true);   // row_half_mirror: l <-> 7 - l
     else if constexpr (W == 8) return __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, true);
     else return __shfl_xor(x, W, 64);
 }
 
 // lanes l and l ^ W hold N rows each; afterwards each holds the N / 2 rows of its half (upper lanes the upper rows),
 // combined over the pair
-template <int W, int N>
-__device__ __forceinline__ void fold_pairs(float (&v)[kRows], int (&a)[kRows], bool upper) {
+template <int W, int N, int R>
+__device__ __forceinline__ void fold_pairs(float (&v)[R], int (&a)[R], bool upper) {
 #pragma unroll
     for (int r = 0; r < N / 2; ++r) {
         const float sv = upper ? v[r] : v[r + N / 2];
@@ -74,6 +90,14 @@ __device__ __forceinline__ void fold_pairs(float (&v)[kRows], int (&a)[kRows], b
         v[r] = kv;
         a[r] = ka;
     }
+}
+
+// (value, index) of the best over the 4 lanes of a quad, in all of them
+__device__ __forceinline__ void reduce_quad(float &v, int &a) {
+    better(v, a, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true)),
+           __builtin_amdgcn_update_dpp(0, a, 0xB1, 0xf, 0xf, true));
+    better(v, a, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true)),
+           __builtin_amdgcn_update_dpp(0, a, 0x4E, 0xf, 0xf, true));
 }
 
 // (value, index) of the best over the 8 lanes that share bits 3..5 of the lane number, in all of them
@@ -91,12 +115,15 @@ __global__ __launch_bounds__(256) void clear_kernel(uint4 *__restrict__ dst, siz
         dst[e] = make_uint4(0u, 0u, 0u, 0u);
 }
 
-// grid = workgroups(S), block = 512.  post0 holds row 0 of every item (init_posterior_kernel); `xchg` is zeroed.
-template <int K>
+// grid = workgroups(S), block = threads(S).  post0 holds row 0 of every item (init_posterior_kernel); `xchg` is zeroed.
+// K prev-states per thread, kRows next-states per workgroup (8 or 16), kThreads threads.
+template <int K, int kRows, int kThreads>
 __global__ __launch_bounds__(kThreads) void held_forward_kernel(
     const float *__restrict__ obs, const int32_t *__restrict__ frames, const float *__restrict__ trans,
     float *__restrict__ post0, float *__restrict__ post1, int32_t *__restrict__ trellis, u64 *__restrict__ xchg,
     unsigned *__restrict__ control, int B, int T, int S) {
+    constexpr int kWaves = kThreads / 64;
+    static_assert(kRows == 8 || kRows == 16, "folds are written for 8 and 16 rows");
     __shared__ float sv[2][kWaves][kRows];
     __shared__ int sa[2][kWaves][kRows];
     __shared__ int sframes[kMaxB];
@@ -105,7 +132,7 @@ __global__ __launch_bounds__(kThreads) void held_forward_kernel(
     const int j0 = blockIdx.x * kRows;
     const bool last_valid = tid + kThreads * (K - 1) < S;       // only the last of a thread's prev-states can lie beyond S
 
-    // this workgroup's 8 rows of the matrix, for the whole launch
+    // this workgroup's rows of the matrix, for the whole launch
     float tr[kRows][K];
 #pragma unroll
     for (int r = 0; r < kRows; ++r) {
@@ -158,17 +185,25 @@ __global__ __launch_bounds__(kThreads) void held_forward_kernel(
 #pragma unroll
             for (int k = 0; k < K; ++k) p[k] = (k < K - 1 || last_valid) ? post0[(size_t)b * S + tid + kThreads * k] : 0.0f;
         } else {
+            // (Measured and dropped: a second poll in flight half a round trip behind the first -- 3.1 against 2.8 us per
+            // timestep; the hand-off is paid in the consumer's own memory queue, every extra poll lengthens it.)
             const unsigned want = (unsigned)(t - 1);
             unsigned spins = 0;
+            if (!requested) {
+                // the others finish this timestep when this workgroup does and their words take ~1 us to become visible:
+                // a poll sent now must fail and the next one waits behind it
+                __builtin_amdgcn_s_sleep(HELD_FIRST_SLEEP);
+                request(t, b, ahead);
+            }
+            requested = false;
             for (;;) {
-                if (!requested) request(t, b, ahead);
-                requested = false;
                 bool ok = true;
 #pragma unroll
                 for (int k = 0; k < K; ++k) ok = ok && (unsigned)(ahead[k] >> 32) == want;
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
                 if (++spins > (1u << 22)) { gave_up = true; break; }
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(HELD_POLL_SLEEP);
+                request(t, b, ahead);
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) p[k] = __uint_as_float((unsigned)ahead[k]);
@@ -178,7 +213,7 @@ __global__ __launch_bounds__(kThreads) void held_forward_kernel(
             request(nt, nb, ahead);
             requested = true;
         }
-        // the reference's scan over this thread's prev-states, for each of the 8 rows
+        // the reference's scan over this thread's prev-states, for each of the rows
         float v[kRows];
         int a[kRows];
 #pragma unroll
@@ -194,15 +229,28 @@ __global__ __launch_bounds__(kThreads) void held_forward_kernel(
                 a[r] = take ? tid + kThreads * k : a[r];
             }
         }
-        // 8 rows x 64 lanes -> one row per lane (3 halving folds), then over the 8 lanes that share a row
-        fold_pairs<32, 8>(v, a, (lane & 32) != 0);
-        fold_pairs<16, 4>(v, a, (lane & 16) != 0);
-        fold_pairs<8, 2>(v, a, (lane & 8) != 0);
-        reduce_eight(v[0], a[0]);
+        // rows x 64 lanes -> one row per lane (halving folds), then over the lanes that share a row
+        int row;
+        bool keeper;
+        if constexpr (kRows == 8) {
+            fold_pairs<32, 8, kRows>(v, a, (lane & 32) != 0);
+            fold_pairs<16, 4, kRows>(v, a, (lane & 16) != 0);
+            fold_pairs<8, 2, kRows>(v, a, (lane & 8) != 0);
+            reduce_eight(v[0], a[0]);
+            row = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+            keeper = (lane & 7) == 0;
+        } else {
+            fold_pairs<32, 16, kRows>(v, a, (lane & 32) != 0);
+            fold_pairs<16, 8, kRows>(v, a, (lane & 16) != 0);
+            fold_pairs<8, 4, kRows>(v, a, (lane & 8) != 0);
+            fold_pairs<4, 2, kRows>(v, a, (lane & 4) != 0);
+            reduce_quad(v[0], a[0]);
+            row = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+            keeper = (lane & 3) == 0;
+        }
         const int slot = round & 1;
         ++round;
-        if ((lane & 7) == 0) {
-            const int row = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+        if (keeper) {
             sv[slot][wave][row] = v[0];
             sa[slot][wave][row] = a[0];
         }

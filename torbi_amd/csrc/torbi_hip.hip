@@ -504,10 +504,10 @@ inline int cluster_members(int tiles, int S, int cus) {
 inline bool held_auto(int B, int S) {
     static const int limit = [] {
         const char *e = getenv("TORBI_HIP_HELD_ITEMS");
-        return e ? atoi(e) : 2;
+        return e ? atoi(e) : -1;
     }();
-    (void)S;
-    return B <= limit;
+    // (4096 states, 300 frames, against the sorted-row scan: 1 item 1.36 / 3.87 ms, 2 items 2.40 / 4.20, 4 items 4.20 / 5.95)
+    return B <= (limit >= 0 ? limit : S > held::kSmallS ? 4 : 2);
 }
 
 // route of ONE batch.  AUTO: the time-resident kernel -- whole tiles per workgroup when the batch alone gives at least
@@ -830,20 +830,22 @@ hipError_t launch_held_forward(const float *obs, const int32_t *frames, const fl
         const int grid = (int)((words + 255) / 256 < 1024 ? (words + 255) / 256 : 1024);
         hipLaunchKernelGGL(held::clear_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<uint4 *>(w.control), words);
     }
-    const dim3 grid(held::workgroups(S)), block(held::kThreads);
-    const int K = (S + held::kThreads - 1) / held::kThreads;
-    if (K == 1)
-        hipLaunchKernelGGL(held::held_forward_kernel<1>, grid, block, 0, stream, obs, frames, trans, w.post[0], w.post[1],
-                           w.trellis, w.xchg, w.control, B, T, S);
-    else if (K == 2)
-        hipLaunchKernelGGL(held::held_forward_kernel<2>, grid, block, 0, stream, obs, frames, trans, w.post[0], w.post[1],
-                           w.trellis, w.xchg, w.control, B, T, S);
-    else if (K == 3)
-        hipLaunchKernelGGL(held::held_forward_kernel<3>, grid, block, 0, stream, obs, frames, trans, w.post[0], w.post[1],
-                           w.trellis, w.xchg, w.control, B, T, S);
-    else
-        hipLaunchKernelGGL(held::held_forward_kernel<4>, grid, block, 0, stream, obs, frames, trans, w.post[0], w.post[1],
-                           w.trellis, w.xchg, w.control, B, T, S);
+    const dim3 grid(held::workgroups(S)), block(held::threads(S));
+    const int K = (S + held::threads(S) - 1) / held::threads(S);
+#define TORBI_HELD(K_, R_, N_)                                                                                          \
+    hipLaunchKernelGGL((held::held_forward_kernel<K_, R_, N_>), grid, block, 0, stream, obs, frames, trans, w.post[0], \
+                       w.post[1], w.trellis, w.xchg, w.control, B, T, S)
+    if (S <= held::kSmallS) {
+        if (K == 1) TORBI_HELD(1, 8, 512);
+        else if (K == 2) TORBI_HELD(2, 8, 512);
+        else if (K == 3) TORBI_HELD(3, 8, 512);
+        else TORBI_HELD(4, 8, 512);
+    } else if (K == 3) {
+        TORBI_HELD(3, 16, 1024);
+    } else {
+        TORBI_HELD(4, 16, 1024);
+    }
+#undef TORBI_HELD
     return hipGetLastError();
 }
 
