@@ -91,7 +91,7 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
  *             torbi_hip_viterbi_decode_batches, or one batch of >= 8 * compute-units items.
  *   HELD      B <= 16, S <= 4096: the reference's scan with the time loop inside ONE launch: ceil(S / 8) workgroups
  *             hold 8 rows of the matrix each in registers for the whole launch and pass the posterior rows to each
- *             other through 8-byte {value, timestep} words (held_matrix_forward.hpp).  AUTO takes it for one or two items (up to four above 2048 states).
+ *             other through 8-byte {value, timestep} words (held_matrix_forward.hpp).  AUTO takes it up to three items (eight above 2048 states).
  * AUTO takes RESIDENT when the call's items fill at least half the compute units with workgroups of
  * 16, else PRUNED / ROWS where supported, else DENSE, else GENERIC.
  *

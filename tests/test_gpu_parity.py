@@ -140,14 +140,14 @@ def test_dense_path_edge_shapes(shape):
 
 def test_forward_path_selection(forward):
     assert viterbi.forward_path(4, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'pruned': 'rows'}.get(forward, 'generic')
-    assert viterbi.forward_path(2, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'pruned': 'rows',
-                                             'auto': 'held'}.get(forward, 'generic')   # AUTO: held matrix for 1-2 items
+    assert viterbi.forward_path(3, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'pruned': 'rows',
+                                             'auto': 'held'}.get(forward, 'generic')   # AUTO: held matrix up to 3 items
     assert viterbi.forward_path(16, 1440, path='held') == 'held' and viterbi.forward_path(17, 1440, path='held') == 'pruned'
     assert viterbi.forward_path(1, 4096, path='auto') == 'held' and viterbi.forward_path(1, 4100, path='auto') == 'generic'
     assert viterbi.forward_path(16, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'dense': 'generic'}.get(forward, 'rows')
     assert viterbi.forward_path(2, 4096) == {'dense': 'generic', 'resident': 'resident', 'cluster': 'cluster',
                                              'auto': 'held'}.get(forward, 'rows')
-    assert viterbi.forward_path(5, 4096) == {'dense': 'generic', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'rows')
+    assert viterbi.forward_path(9, 4096) == {'dense': 'generic', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'rows')
     assert viterbi.forward_path(4, 40) == 'generic'                # S < 64: no value-only path
     assert viterbi.forward_path(1, 40) == ('held' if forward == 'auto' else 'generic')
     assert viterbi.forward_path(4, 4100) == 'generic'

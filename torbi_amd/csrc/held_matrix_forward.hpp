@@ -30,6 +30,9 @@
 #define HELD_FIRST_SLEEP 16     // x 64 cycles before the first poll of a timestep (tools/held_probe.py, 1 x 500 x 1440,
                                 // us per timestep: 0 -> 2.79, 8 -> 2.41, 12 -> 2.32, 16 -> 2.26, 20 -> 2.34, 32 -> 2.67)
 #endif
+#ifndef HELD_TWO_POINT
+#define HELD_TWO_POINT 1        // two sequences in flight: the next one's words are asked for after the folds (1) / the scan (0)
+#endif
 #ifndef HELD_POLL_SLEEP
 #define HELD_POLL_SLEEP 1       // x 64 cycles between polls
 #endif
@@ -46,7 +49,8 @@ constexpr int kMaxS = 4096;
 constexpr int kMaxRows = 16;
 
 inline int rows_per_workgroup(int S) { return S <= kSmallS ? 8 : 16; }
-inline int threads(int S) { return S <= kSmallS ? 512 : 1024; }
+inline int threads(int S) { return S <= kSmallS ? 512 : 1024; }                  // scanning threads
+inline int block_threads(int S) { return S <= kSmallS ? 512 + 64 : 1024; }      // + the store wave where there is room
 inline int workgroups(int S) { return (S + rows_per_workgroup(S) - 1) / rows_per_workgroup(S); }
 inline bool supported(int B, int S, int cus) {
     return B >= 1 && B <= kMaxB && S >= 1 && S <= kMaxS && workgroups(S) <= (S <= kSmallS ? 2 * cus : cus);
@@ -92,6 +96,28 @@ __device__ __forceinline__ void fold_pairs(float (&v)[R], int (&a)[R], bool uppe
     }
 }
 
+// The same fold for partners 32 or 16 lanes apart with gfx950's v_permlane32_swap / v_permlane16_swap: the instruction
+// exchanges the upper half (odd 16-lane rows) of its first operand with the lower half (even rows) of its second, so with
+// (lower row, upper row) as operands every lane ends with its own and its partner's value of the row it keeps -- no
+// selects, no trip through the LDS crossbar.
+template <int W, int N, int R>
+__device__ __forceinline__ void fold_swap(float (&v)[R], int (&a)[R]) {
+    static_assert(W == 32 || W == 16, "swap instructions exist for halves and 16-lane rows");
+#pragma unroll
+    for (int r = 0; r < N / 2; ++r) {
+        const unsigned lo = __float_as_uint(v[r]), hi = __float_as_uint(v[r + N / 2]);
+        const auto sv = W == 32 ? __builtin_amdgcn_permlane32_swap(lo, hi, false, false)
+                                : __builtin_amdgcn_permlane16_swap(lo, hi, false, false);
+        const auto sa = W == 32 ? __builtin_amdgcn_permlane32_swap((unsigned)a[r], (unsigned)a[r + N / 2], false, false)
+                                : __builtin_amdgcn_permlane16_swap((unsigned)a[r], (unsigned)a[r + N / 2], false, false);
+        float x = __uint_as_float(sv[0]);
+        int ax = (int)sa[0];
+        better(x, ax, __uint_as_float(sv[1]), (int)sa[1]);
+        v[r] = x;
+        a[r] = ax;
+    }
+}
+
 // (value, index) of the best over the 4 lanes of a quad, in all of them
 __device__ __forceinline__ void reduce_quad(float &v, int &a) {
     better(v, a, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true)),
@@ -110,26 +136,49 @@ __device__ __forceinline__ void reduce_eight(float &v, int &a) {
            __builtin_amdgcn_update_dpp(0, a, 0x141, 0xf, 0xf, true));                      // row_half_mirror
 }
 
-__global__ __launch_bounds__(256) void clear_kernel(uint4 *__restrict__ dst, size_t count) {
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x)
-        dst[e] = make_uint4(0u, 0u, 0u, 0u);
+// Before the launch: row 0 of every sequence (viterbi.cpp:72-76) into post0 AND into parity 0 of the exchange as
+// {value, timestep 0} words -- timestep 1 then reads its input like every other timestep --, parity 1 and the control
+// words cleared (tags of an earlier decode with this workspace must not be taken for this one's).
+__global__ __launch_bounds__(256) void prepare_kernel(const float *__restrict__ obs, const float *__restrict__ initial,
+                                                      float *__restrict__ post0, u64 *__restrict__ xchg,
+                                                      unsigned *__restrict__ control, int B, int T, int S) {
+    const size_t n = (size_t)B * S;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(e / S);
+        const int i = (int)(e - (size_t)b * S);
+        const float v = obs[(size_t)b * T * S + i] + initial[i];
+        post0[e] = v;
+        xchg[e] = (u64)__float_as_uint(v);
+        xchg[n + e] = 0ull;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) control[threadIdx.x] = 0u;
 }
 
-// grid = workgroups(S), block = threads(S).  post0 holds row 0 of every item (init_posterior_kernel); `xchg` is zeroed.
-// K prev-states per thread, kRows next-states per workgroup (8 or 16), kThreads threads.
-template <int K, int kRows, int kThreads>
-__global__ __launch_bounds__(kThreads) void held_forward_kernel(
+// grid = workgroups(S), block = block_threads(S), after prepare_kernel.
+// K prev-states per thread, kRows next-states per workgroup (8 or 16), kThreads scanning threads.  With STORE_WAVE the
+// block carries one more wave that does nothing but combine the scanning waves' results and store them: on gfx9 stores
+// count on the same per-wave counter as loads and a wave with both outstanding can only wait for everything, so a
+// scanning wave that had stored would sit out the acknowledgement of a write-through store (~0.5 us) at its next poll.
+// The store wave never waits for memory: its observations reach it through the LDS from wave 0, which asks for them
+// together with its words.  (1024 scanning threads leave no room for a further wave: there wave 0 stores.)
+template <int K, int kRows, int kThreads, bool STORE_WAVE>
+__global__ __launch_bounds__(kThreads + (STORE_WAVE ? 64 : 0)) void held_forward_kernel(
     const float *__restrict__ obs, const int32_t *__restrict__ frames, const float *__restrict__ trans,
     float *__restrict__ post0, float *__restrict__ post1, int32_t *__restrict__ trellis, u64 *__restrict__ xchg,
     unsigned *__restrict__ control, int B, int T, int S) {
-    constexpr int kWaves = kThreads / 64;
+    constexpr int kWaves = kThreads / 64;                       // scanning waves
     static_assert(kRows == 8 || kRows == 16, "folds are written for 8 and 16 rows");
     __shared__ float sv[2][kWaves][kRows];
     __shared__ int sa[2][kWaves][kRows];
+    __shared__ float sob[2][kRows];
     __shared__ int sframes[kMaxB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool scans = wave < kWaves;
+    const bool stores = (STORE_WAVE ? wave == kWaves : wave == 0) && lane < kRows && blockIdx.x * kRows + lane < S;
+    const bool observes = wave == 0 && lane < kRows && blockIdx.x * kRows + lane < S;     // asks for the observations
     const int j0 = blockIdx.x * kRows;
+    const int jmine = j0 + lane;
     const bool last_valid = tid + kThreads * (K - 1) < S;       // only the last of a thread's prev-states can lie beyond S
 
     // this workgroup's rows of the matrix, for the whole launch
@@ -140,7 +189,7 @@ __global__ __launch_bounds__(kThreads) void held_forward_kernel(
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int i = tid + kThreads * k;
-            tr[r][k] = (k < K - 1 || last_valid) ? trans[(size_t)j * S + i] : 0.0f;
+            tr[r][k] = (scans && (k < K - 1 || last_valid)) ? trans[(size_t)j * S + i] : 0.0f;
         }
     }
     if (tid < kMaxB) {
@@ -151,125 +200,176 @@ __global__ __launch_bounds__(kThreads) void held_forward_kernel(
     int longest = 1;
     for (int b = 0; b < B; ++b) longest = max(longest, sframes[b]);
     bool gave_up = false;
-    int round = 0;
-    const int jmine = j0 + tid;
-    const bool writer = tid < kRows && jmine < S;
+    int round = 0;                                              // work items done so far
 
-    // the words of posterior row t-1 of item b this thread scans: requested here, looked at by the caller
-    auto request = [&](int t, int b, u64 (&w)[K]) {
+    // What a work item (timestep t of sequence b) reads: the words of posterior row t-1 this thread scans and, in wave 0,
+    // the observations of the output rows -- requested together, so that whoever waits for the words has the observation
+    // too and nothing later in the item waits on the vector-memory counter (loads return in order; a wait the compiler
+    // places behind a conditional request is a wait for that request: 1 us).
+    struct Inputs { u64 w[K]; float ob; };
+    auto request = [&](int t, int b, Inputs &in) {
         const u64 *src = xchg + ((size_t)((t - 1) & 1) * B + b) * S;
+        in.ob = observes ? obs[((size_t)b * T + t) * S + jmine] : 0.0f;
 #pragma unroll
         for (int k = 0; k < K; ++k)
-            w[k] = (k < K - 1 || last_valid)
-                       ? __hip_atomic_load(src + tid + kThreads * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                       : (u64)(unsigned)(t - 1) << 32;
+            in.w[k] = (k < K - 1 || last_valid)
+                          ? __hip_atomic_load(src + tid + kThreads * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                          : (u64)(unsigned)(t - 1) << 32;
     };
-    // work items in order: every sequence that has not ended, timestep by timestep (uniform over the whole grid)
+    auto complete = [&](const Inputs &in, int t) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < K; ++k) ok = ok && (unsigned)(in.w[k] >> 32) == (unsigned)(t - 1);
+        return __builtin_amdgcn_ballot_w64(!ok) == 0;
+    };
+    // work items in order: every sequence that has not ended, timestep by timestep (uniform over the whole grid); lanes
+    // 0..B-1 of every wave keep the lengths, so "which sequences are alive at t" is one ballot
+    const int my_frames = sframes[lane & (kMaxB - 1)];
+    auto alive = [&](int t) -> unsigned {
+        return (unsigned)__builtin_amdgcn_ballot_w64(lane < B && my_frames > t);
+    };
     auto advance = [&](int &t, int &b) {
-        do {
-            if (++b == B) { b = 0; ++t; }
-        } while (t < longest && t >= sframes[b]);
+        unsigned m = alive(t);
+        if (b >= 0) m &= ~((2u << b) - 1u);                      // the alive sequences behind b
+        while (m == 0u && t < longest) m = alive(++t);
+        b = m ? __builtin_ctz(m) : 0;
     };
     int t = 1, b = -1;
     advance(t, b);
-    u64 ahead[K];
-    bool requested = false;
-    while (t < longest) {
-        int nt = t, nb = b;
-        advance(nt, nb);
-        // the output row's observation does not depend on the exchange: ask for it first
-        float ob = 0.0f;
-        if (writer) ob = obs[((size_t)b * T + t) * S + jmine];
-        float p[K];
-        if (t == 1) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) p[k] = (k < K - 1 || last_valid) ? post0[(size_t)b * S + tid + kThreads * k] : 0.0f;
-        } else {
-            // (Measured and dropped: a second poll in flight half a round trip behind the first -- 3.1 against 2.8 us per
-            // timestep; the hand-off is paid in the consumer's own memory queue, every extra poll lengthens it.)
-            const unsigned want = (unsigned)(t - 1);
-            unsigned spins = 0;
-            if (!requested) {
-                // the others finish this timestep when this workgroup does and their words take ~1 us to become visible:
-                // a poll sent now must fail and the next one waits behind it
-                __builtin_amdgcn_s_sleep(HELD_FIRST_SLEEP);
-                request(t, b, ahead);
-            }
-            requested = false;
-            for (;;) {
-                bool ok = true;
-#pragma unroll
-                for (int k = 0; k < K; ++k) ok = ok && (unsigned)(ahead[k] >> 32) == want;
-                if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
-                if (++spins > (1u << 22)) { gave_up = true; break; }
-                __builtin_amdgcn_s_sleep(HELD_POLL_SLEEP);
-                request(t, b, ahead);
-            }
-#pragma unroll
-            for (int k = 0; k < K; ++k) p[k] = __uint_as_float((unsigned)ahead[k]);
-        }
-        // the next item's words, if another sequence's (they were published an item ago): in flight during this item's scan
-        if (nt < longest && nt > 1 && !(nb == b)) {
-            request(nt, nb, ahead);
+
+    if (scans) {
+        Inputs ahead = {};        // the NEXT item's inputs while they are in flight
+        bool requested = false;
+        if (t < longest) {        // (row 0 is in place: the first item's inputs can be asked for at once)
+            request(t, b, ahead);
             requested = true;
         }
-        // the reference's scan over this thread's prev-states, for each of the rows
-        float v[kRows];
-        int a[kRows];
-#pragma unroll
-        for (int r = 0; r < kRows; ++r) {
-            v[r] = p[0] + tr[r][0];                              // (K == 1: a thread beyond S holds no candidate)
-            a[r] = tid;
-            if (K == 1 && !last_valid) { v[r] = -INFINITY; a[r] = 0x7fffffff; }
-#pragma unroll
-            for (int k = 1; k < K; ++k) {
-                const float c = p[k] + tr[r][k];
-                const bool take = (c > v[r]) & (k < K - 1 || last_valid);
-                v[r] = take ? c : v[r];
-                a[r] = take ? tid + kThreads * k : a[r];
+        while (t < longest) {
+            int nt = t, nb = b;
+            advance(nt, nb);
+            const int others = __builtin_popcount(alive(t)) - 1;
+            // The next item's inputs can be asked for once its previous row has had time to become visible (~1 us after
+            // that grid-wide store; asked for earlier, the poll fails and the next one waits behind it):
+            //   three or more sequences in flight -- it was stored at least one item ago: ask at the top of this item;
+            //   two -- it was stored as this item began: ask after this item's scan / folds (HELD_TWO_POINT);
+            //   one -- the next item is this sequence again: sleep, then ask (below).
+            // (Measured and dropped: a second poll in flight half a round trip behind the first -- 3.1 against 2.8 us
+            // per timestep; the hand-off is paid in the consumer's own memory queue, every extra poll lengthens it.)
+            const bool prefetch = nt < longest && nb != b;
+            Inputs mine = {};
+            bool ok = false;
+            if (requested) {
+                mine = ahead;                                    // (waits for them)
+                ok = complete(mine, t);
             }
-        }
-        // rows x 64 lanes -> one row per lane (halving folds), then over the lanes that share a row
-        int row;
-        bool keeper;
-        if constexpr (kRows == 8) {
-            fold_pairs<32, 8, kRows>(v, a, (lane & 32) != 0);
-            fold_pairs<16, 4, kRows>(v, a, (lane & 16) != 0);
-            fold_pairs<8, 2, kRows>(v, a, (lane & 8) != 0);
-            reduce_eight(v[0], a[0]);
-            row = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
-            keeper = (lane & 7) == 0;
-        } else {
-            fold_pairs<32, 16, kRows>(v, a, (lane & 32) != 0);
-            fold_pairs<16, 8, kRows>(v, a, (lane & 16) != 0);
-            fold_pairs<8, 4, kRows>(v, a, (lane & 8) != 0);
-            fold_pairs<4, 2, kRows>(v, a, (lane & 4) != 0);
-            reduce_quad(v[0], a[0]);
-            row = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-            keeper = (lane & 3) == 0;
-        }
-        const int slot = round & 1;
-        ++round;
-        if (keeper) {
-            sv[slot][wave][row] = v[0];
-            sa[slot][wave][row] = a[0];
-        }
-        __syncthreads();
-        if (writer) {
-            float bv = sv[slot][0][tid];
-            int ba = sa[slot][0][tid];
+            requested = false;
+            if (prefetch && others >= 2) {
+                request(nt, nb, ahead);
+                requested = true;
+            }
+            if (!ok) {
+                unsigned spins = 0;
+                if (others == 0) __builtin_amdgcn_s_sleep(HELD_FIRST_SLEEP);
+                for (;;) {
+                    request(t, b, mine);
+                    if (complete(mine, t)) break;
+                    if (++spins > (1u << 22)) { gave_up = true; break; }
+                    __builtin_amdgcn_s_sleep(HELD_POLL_SLEEP);
+                }
+            }
+            float p[K];
 #pragma unroll
-            for (int w = 1; w < kWaves; ++w) better(bv, ba, sv[slot][w][tid], sa[slot][w][tid]);
-            const float out = ob + bv;
-            const u64 word = ((u64)(unsigned)t << 32) | __float_as_uint(out);
-            __hip_atomic_store(xchg + ((size_t)(t & 1) * B + b) * S + jmine, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            trellis[((size_t)b * T + t) * S + jmine] = ba;
-            if (t == sframes[b] - 1) ((t & 1) ? post1 : post0)[(size_t)b * S + jmine] = out;
+            for (int k = 0; k < K; ++k) p[k] = __uint_as_float((unsigned)mine.w[k]);
+            // the reference's scan over this thread's prev-states, for each of the rows
+            float v[kRows];
+            int a[kRows];
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) {
+                v[r] = p[0] + tr[r][0];                          // (K == 1: a thread beyond S holds no candidate)
+                a[r] = tid;
+                if (K == 1 && !last_valid) { v[r] = -INFINITY; a[r] = 0x7fffffff; }
+#pragma unroll
+                for (int k = 1; k < K; ++k) {
+                    const float c = p[k] + tr[r][k];
+                    const bool take = (c > v[r]) & (k < K - 1 || last_valid);
+                    v[r] = take ? c : v[r];
+                    a[r] = take ? tid + kThreads * k : a[r];
+                }
+            }
+#if HELD_TWO_POINT == 0
+            if (prefetch && !requested) {
+                request(nt, nb, ahead);
+                requested = true;
+            }
+#endif
+            // rows x 64 lanes -> one row per lane (halving folds), then over the lanes that share a row
+            int row;
+            bool keeper;
+            if constexpr (kRows == 8) {
+                fold_swap<32, 8, kRows>(v, a);
+                fold_swap<16, 4, kRows>(v, a);
+                fold_pairs<8, 2, kRows>(v, a, (lane & 8) != 0);
+                reduce_eight(v[0], a[0]);
+                row = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+                keeper = (lane & 7) == 0;
+            } else {
+                fold_swap<32, 16, kRows>(v, a);
+                fold_swap<16, 8, kRows>(v, a);
+                fold_pairs<8, 4, kRows>(v, a, (lane & 8) != 0);
+                fold_pairs<4, 2, kRows>(v, a, (lane & 4) != 0);
+                reduce_quad(v[0], a[0]);
+                row = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+                keeper = (lane & 3) == 0;
+            }
+#if HELD_TWO_POINT == 1
+            if (prefetch && !requested) {
+                request(nt, nb, ahead);
+                requested = true;
+            }
+#endif
+            const int slot = round & 1;
+            if (keeper) {
+                sv[slot][wave][row] = v[0];
+                sa[slot][wave][row] = a[0];
+            }
+            if (observes) sob[slot][lane] = mine.ob;
+            __syncthreads();
+            if (!STORE_WAVE && stores) {
+                float bv = sv[slot][0][lane];
+                int ba = sa[slot][0][lane];
+#pragma unroll
+                for (int w = 1; w < kWaves; ++w) better(bv, ba, sv[slot][w][lane], sa[slot][w][lane]);
+                const float out = sob[slot][lane] + bv;
+                const u64 word = ((u64)(unsigned)t << 32) | __float_as_uint(out);
+                __hip_atomic_store(xchg + ((size_t)(t & 1) * B + b) * S + jmine, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                trellis[((size_t)b * T + t) * S + jmine] = ba;
+                if (t == sframes[b] - 1) ((t & 1) ? post1 : post0)[(size_t)b * S + jmine] = out;
+            }
+            ++round;
+            t = nt;
+            b = nb;
         }
-        t = nt;
-        b = nb;
+        if (gave_up && lane == 0) atomicAdd(control + 1, 1u);
+    } else {
+        // the store wave: item after item, wait for the scanning waves, combine, store
+        while (t < longest) {
+            const int slot = round & 1;
+            __syncthreads();
+            if (stores) {
+                float bv = sv[slot][0][lane];
+                int ba = sa[slot][0][lane];
+#pragma unroll
+                for (int w = 1; w < kWaves; ++w) better(bv, ba, sv[slot][w][lane], sa[slot][w][lane]);
+                const float out = sob[slot][lane] + bv;
+                const u64 word = ((u64)(unsigned)t << 32) | __float_as_uint(out);
+                __hip_atomic_store(xchg + ((size_t)(t & 1) * B + b) * S + jmine, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                trellis[((size_t)b * T + t) * S + jmine] = ba;
+                if (t == sframes[b] - 1) ((t & 1) ? post1 : post0)[(size_t)b * S + jmine] = out;
+            }
+            ++round;
+            advance(t, b);
+        }
     }
-    if (gave_up && lane == 0) atomicAdd(control + 1, 1u);
 }
 
 }  // namespace held

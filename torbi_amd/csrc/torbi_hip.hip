@@ -498,16 +498,17 @@ inline int cluster_members(int tiles, int S, int cus) {
 }
 
 // AUTO takes the held-matrix kernel up to this many items (TORBI_HIP_HELD_ITEMS overrides; 0 = never).  tools/held_probe.py,
-// 500 frames x 1440 states, ms per decode against the per-timestep trellis kernels: 1 item 1.40 / 2.41, 2 items 2.20 / 2.53,
-// 3 items 2.83 / 2.70 -- a timestep of the kernel costs one hand-off (~2 us) for the first item and ~1.7 us of
-// instruction issue for every further one, a launch of the per-timestep kernels 4.4 us plus ~0.3 us per item
+// ms per decode against the best per-timestep kernel (profiles/r03_held_probe.txt): 500 frames x 1440 states 1 item
+// 1.10 / 2.41, 2 items 1.38 / 2.52, 3 items 2.16 / 2.69, 4 items 2.83 / 2.85, 8 items 5.44 / 4.31; 300 frames x 4096 states
+// 1 item 1.28 / 3.87, 2 items 1.86 / 4.20, 4 items 3.79 / 5.95, 8 items 7.41 / 9.34.  A timestep of the kernel costs one
+// hand-off (~1.5 us) for up to two sequences and ~1.3 us of instruction issue for every further one; a launch of the
+// per-timestep kernels 4.4 us plus ~0.3 us per item.
 inline bool held_auto(int B, int S) {
     static const int limit = [] {
         const char *e = getenv("TORBI_HIP_HELD_ITEMS");
         return e ? atoi(e) : -1;
     }();
-    // (4096 states, 300 frames, against the sorted-row scan: 1 item 1.36 / 3.87 ms, 2 items 2.40 / 4.20, 4 items 4.20 / 5.95)
-    return B <= (limit >= 0 ? limit : S > held::kSmallS ? 4 : 2);
+    return B <= (limit >= 0 ? limit : S > held::kSmallS ? 8 : 3);
 }
 
 // route of ONE batch.  AUTO: the time-resident kernel -- whole tiles per workgroup when the batch alone gives at least
@@ -529,7 +530,7 @@ inline Route route_for(int path, int B, int S, int cus) {
         return ROUTE_CLUSTER;
     if (path != TORBI_HIP_FORWARD_DENSE && pruned::supported(B, S)) return ROUTE_PRUNED;
     // a handful of sequences: the whole time loop in one launch, the matrix held in registers across the chip
-    // (held_matrix_forward.hpp) -- AUTO up to two items (held_auto), any B <= 16 when named
+    // (held_matrix_forward.hpp) -- AUTO up to three items, eight above 2048 states (held_auto); any B <= 16 when named
     if (held::supported(B, S, cus) && (path == TORBI_HIP_FORWARD_HELD || (path == TORBI_HIP_FORWARD_AUTO && held_auto(B, S))))
         return ROUTE_HELD;
     if ((path == TORBI_HIP_FORWARD_PRUNED && rowscan::supported(B, S)) ||
@@ -821,20 +822,16 @@ hipError_t launch_held_forward(const float *obs, const int32_t *frames, const fl
     {
         const size_t n = (size_t)B * S;
         const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-        hipLaunchKernelGGL(init_posterior_kernel, dim3(grid), dim3(256), 0, stream, obs, init, w.post[0], B, T, S);
+        hipLaunchKernelGGL(held::prepare_kernel, dim3(grid), dim3(256), 0, stream, obs, init, w.post[0], w.xchg, w.control,
+                           B, T, S);
     }
     if (launches) *launches = 1;
     if (T < 2) return hipGetLastError();
-    {   // control words and exchange buffer are adjacent: one fill (a kernel: hipMemsetAsync costs ~0.17 ms per call here)
-        const size_t words = (256 + held::exchange_bytes(B, S)) / 16;
-        const int grid = (int)((words + 255) / 256 < 1024 ? (words + 255) / 256 : 1024);
-        hipLaunchKernelGGL(held::clear_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<uint4 *>(w.control), words);
-    }
-    const dim3 grid(held::workgroups(S)), block(held::threads(S));
+    const dim3 grid(held::workgroups(S)), block(held::block_threads(S));
     const int K = (S + held::threads(S) - 1) / held::threads(S);
-#define TORBI_HELD(K_, R_, N_)                                                                                          \
-    hipLaunchKernelGGL((held::held_forward_kernel<K_, R_, N_>), grid, block, 0, stream, obs, frames, trans, w.post[0], \
-                       w.post[1], w.trellis, w.xchg, w.control, B, T, S)
+#define TORBI_HELD(K_, R_, N_)                                                                                       \
+    hipLaunchKernelGGL((held::held_forward_kernel<K_, R_, N_, (N_ < 1024)>), grid, block, 0, stream, obs, frames, trans, \
+                       w.post[0], w.post[1], w.trellis, w.xchg, w.control, B, T, S)
     if (S <= held::kSmallS) {
         if (K == 1) TORBI_HELD(1, 8, 512);
         else if (K == 2) TORBI_HELD(2, 8, 512);
