@@ -215,14 +215,16 @@ def test_held_matrix_kernel_equals_the_oracle(shape, kind, forward):
     assert np.array_equal(post.view(np.uint32), want_post.view(np.uint32))
 
 
-def test_auto_takes_the_dense_kernel_for_narrow_bands_only(forward):
-    """The Python layer looks at the transition once per tensor version (torbi_amd/viterbi.py)."""
+def test_auto_looks_at_the_transition_once_per_tensor_version(forward):
+    """The Python layer's look at the transition decides where ONE batch goes: dense + -inf skipping for a narrow band;
+    otherwise clusters up to 2048 states, the pruned pass above (8-item tiles, a batch that fits one round of the
+    per-timestep kernels) -- once per tensor version."""
     if forward != 'auto':
         pytest.skip('path forced')
+    dev = torch.device('cuda:0')
     B, T, S = 64, 6, 360
     obs, trans, init = synth.problem(B, T, S, seed=3)
     frames = np.full(B, T, dtype=np.int32)
-    dev = torch.device('cuda:0')
     args = [torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)]
     prof = []
     torbi_amd.decode(*args, _profile=prof)
@@ -230,9 +232,18 @@ def test_auto_takes_the_dense_kernel_for_narrow_bands_only(forward):
     band = torch.as_tensor(synth.banded_transition(S, 20.0)).to(dev)
     torbi_amd.decode(args[0], args[1], band, args[3], _profile=prof)
     assert int(prof[3]) == 1                                         # narrow band: dense + -inf skipping
+    B, T, S = 40, 3, 2064
+    obs, trans, init = synth.problem(B, T, S, seed=3)
+    frames = np.full(B, T, dtype=np.int32)
+    args = [torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)]
+    torbi_amd.decode(*args, _profile=prof)
+    assert int(prof[3]) == 2                                         # dense random matrix: pruned
+    band = torch.as_tensor(synth.banded_transition(S, 20.0)).to(dev)
+    torbi_amd.decode(args[0], args[1], band, args[3], _profile=prof)
+    assert int(prof[3]) == 1                                         # narrow band: dense + -inf skipping
     band.fill_(-1.0)                                                 # same storage, new version
     torbi_amd.decode(args[0], args[1], band, args[3], _profile=prof)
-    assert int(prof[3]) == 5
+    assert int(prof[3]) == 2
 
 
 @pytest.mark.parametrize('kind', ['flat', 'nearly_flat', 'peaked', 'anti', 'two_level'])
@@ -784,7 +795,7 @@ def test_decode_batches_auto_goes_resident_when_the_group_fills_the_chip(forward
     assert int(prof[3]) == 5 and int(prof[5]) == 2 and int(prof[2]) == 1
     for k in range(2):
         np.testing.assert_array_equal(got[k].cpu().numpy(), want[k])
-    # a narrow band goes to the dense kernel one batch at a time, to the time-resident kernel as a full group
+    # a narrow band goes to the dense kernel one batch at a time, to the time-resident kernel as a group
     band = synth.banded_transition(S, 12.0)
     d_band = torch.as_tensor(band).to(dev)
     got = viterbi.decode_batches(obs_list, frame_list, d_band, d_init, path='auto', _profile=prof)

@@ -186,11 +186,13 @@ def test_auto_path_choice_reads_the_transition_structure_once_per_version():
         assert viterbi._resolve_path(dense, dense, 2048, S, 'cuda:0', 'auto', 128, False) == ('cluster', None)
         assert viterbi._resolve_path(band, band, 2048, S, 'cuda:0', 'auto', 128, False) == ('cluster', None)
         # below half the chip -- a launch group or one batch of more than 16 items -- clusters of workgroups per tile;
-        # one batch with a narrow band: the dense kernel's -inf skipping; 16 items or fewer: the per-timestep kernels
+        # one batch with a narrow band: the dense kernel's -inf skipping; 16 items or fewer: the library's choice
         assert viterbi._resolve_path(dense, dense, 512, S, 'cuda:0', 'auto', 64, False, count=2) == ('cluster', None)
         assert viterbi._resolve_path(dense, dense, 768, S, 'cuda:0', 'auto', 48, False) == ('cluster', None)
         assert viterbi._resolve_path(dense, dense, 512, S, 'cuda:0', 'auto', 32, False) == ('cluster', None)
         assert viterbi._resolve_path(band2, band2, 512, S, 'cuda:0', 'auto', 32, False) == ('dense', None)
+        wide = torch.as_tensor(synth.banded_transition(2064, 12.0))
+        assert viterbi._resolve_path(wide, wide, 64, 2064, 'cuda:0', 'auto', 8, False) == ('dense', None)    # 8-item tiles, one round
         assert viterbi._resolve_path(band2, band2, 512, S, 'cuda:0', 'auto', 32, False, count=2) == ('cluster', None)
         assert viterbi._resolve_path(dense, dense, 16, S, 'cuda:0', 'auto', 1, False) == ('auto', None)
     finally:

@@ -252,6 +252,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void *base, un
 #ifndef RESIDENT_ABL
 #define RESIDENT_ABL 0
 #endif
+// Cluster form, waiting for the other members' flags: ONE polling wave per workgroup, the others wait at a barrier.  A
+// hand-off is paid in the consumer's own memory queue and every poll lengthens it: with all twelve waves polling, a
+// 512-item batch (R = 8) ran 17.5-18.1 us per timestep, with one 15.3; 256 items 18 -> 14 (tools/cluster_poll_probe.py,
+// profiles/r03_cluster_poll_probe.txt).  The pause between polls (64-cycle units) and a pause before the first poll
+// make no difference once one wave polls.
+#ifndef CLUSTER_POLL_SLEEP
+#define CLUSTER_POLL_SLEEP 1
+#endif
+#ifndef CLUSTER_FIRST_SLEEP
+#define CLUSTER_FIRST_SLEEP 0
+#endif
+#ifndef CLUSTER_ONE_POLLER
+#define CLUSTER_ONE_POLLER 1
+#endif
 #ifndef RESIDENT_EXTRA_VALU
 #define RESIDENT_EXTRA_VALU 0
 #endif
@@ -658,22 +672,26 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                     if (lane == 0) __hip_atomic_store(cflags + member, (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 RSTAMP(6);
-                // (2) every wave waits until the other members have published timestep t (one relaxed poll per member
-                // and round, lanes 0..R-1; bounded: a cluster that cannot complete gives up and reports it)
-                {
+                // (2) wave 0 waits until the other members have published timestep t (one relaxed poll per member and
+                // round, lanes 0..R-1; bounded: a cluster that cannot complete gives up and reports it), the others for wave 0
+                if (!CLUSTER_ONE_POLLER || wave == 0) {
                     unsigned spins = 0;
+#if CLUSTER_FIRST_SLEEP > 0
+                    __builtin_amdgcn_s_sleep(CLUSTER_FIRST_SLEEP);
+#endif
                     for (;;) {
                         unsigned seen = 0xffffffffu;
                         if (lane < R && lane != member)
                             seen = __hip_atomic_load(cflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (__all(seen >= (unsigned)t)) break;
-                        __builtin_amdgcn_s_sleep(1);
+                        __builtin_amdgcn_s_sleep(CLUSTER_POLL_SLEEP);
                         if (++spins > (1u << 22)) {
                             if (lane == 0) smisc[1] = 1;
                             break;
                         }
                     }
                 }
+                if (CLUSTER_ONE_POLLER) __syncthreads();
                 RSTAMP(9);
                 // (3) their slices of row t -> the tile (every 16-byte piece except this member's own rows) and their
                 // partial top lists -> this workgroup's lists; all loads of a thread in flight together (eight slice pieces

@@ -83,9 +83,10 @@ def _resolve_path(trans, transition, B, S, device, path, tiles, measure, count=1
         #  * a launch group that fills less (the tail of a job, a small job): tiles split over clusters of workgroups
         #    (2 x 512 items: 25.4 us per timestep against 62.7 with whole tiles and 2 x 20.4 one batch after the other);
         #  * ONE batch of more than 16 items (up to 2048 states; above, only batches beyond one round of the
-        #    per-timestep kernel): clusters -- 13.1 against 14.5 us per timestep at 17 items, 18.8 against 20.1 at 512,
-        #    20.9 against 34.9 at 768 -- except for a narrow band, which the dense kernel's -inf skipping decodes faster
-        #    one batch at a time (8.0 against 9.5 ms per 512 x 500 batch);
+        #    per-timestep kernel): clusters -- 12.8 against 14.5 us per timestep at 17 items, 15.6 against 20.2 at 512,
+        #    20.4 against 34.9 at 768 (profiles/r03_cluster_sweep_one_poller.txt) -- except for a narrow band: the dense
+        #    kernel's -inf skipping costs by the item (80 pieces of a chunked sequence: 1.9 against 3.0 ms; 512 peaked
+        #    rows 8.0 against 8.3 ms), a cluster timestep has a floor of ~12 us however few items it carries;
         # unless the scan statistics of an earlier time-resident launch with this matrix say that hardly anything is
         # pruned (see _watch_resident).  Whether the per-timestep pruned kernel beats the dense one is NOT the question
         # here: on peaked rows with a dense matrix it does not, and the time-resident kernel still runs at the dense
@@ -102,9 +103,9 @@ def _resolve_path(trans, transition, B, S, device, path, tiles, measure, count=1
 RESIDENT_GATE = 0.65
 
 
-# one batch in clusters against the dense kernel (tools/depth_probe.py, 512 x 500 x 1440: 20.7 us per timestep at 0.12 of
-# a row's blocks, 43.9 at 0.46; the dense kernel 40.4 whatever the data): the crossing is near 0.40
-SINGLE_BATCH_GATE = 0.40
+# one batch in clusters against the dense kernel (tools/depth_probe.py, 512 x 500 x 1440: 18.7 us per timestep at 0.12 of
+# a row's blocks, 42.3 at 0.46; the dense kernel 40.4 whatever the data): the crossing is near 0.43
+SINGLE_BATCH_GATE = 0.43
 # a launch that kept ONE seed per item walks further than one with three before the bound bites (0.60 against 0.46 of a
 # row on peaked rows, 0.130 against 0.119 on the benchmark's): depths measured that way are compared with gates this
 # much higher
