@@ -415,7 +415,7 @@ class Bench:
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(obs, frames, trans, init, workspace=ws), 3)
         record('serial', sec, B * T, S, 'headline batch, ONE batch at a time on one stream (latency of a single decode): '
                                        'AUTO = ONE time-resident launch, each 16-item tile split over a cluster of 8 '
-                                       'workgroups', {'forward_path': ROUTES[int(prof[3])]})
+                                       'workgroups, one seed per item', {'forward_path': ROUTES[int(prof[3])]})
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(obs, frames, trans, init, workspace=ws, path='pruned'), 3)
         record('serial_per_timestep_kernel', sec, B * T, S, 'the same with per-timestep launches of the pruned recurrence '
                                                            '(what AUTO took for one batch before round 3)')

@@ -23,6 +23,26 @@ def test_library_exports_every_declared_symbol():
     assert lib.torbi_hip_abi_version() == _lib.ABI_VERSION
 
 
+def test_every_named_forward_path_is_accepted_by_the_library():
+    """The header's path constants, the Python names and the setter's range agree (no GPU needed: the setter only
+    stores the process default); the path flag of a call has room for every path."""
+    import ctypes
+    from torbi_amd import viterbi
+    header = open(os.path.join(ROOT, 'include', 'torbi_hip.h')).read()
+    constants = {name.lower(): int(value) for name, value in re.findall(r'#define TORBI_HIP_FORWARD_(\w+) (\d+)', header)}
+    assert constants == viterbi.FORWARD_PATHS
+    lib = _lib.load()
+    try:
+        for name, code in viterbi.FORWARD_PATHS.items():
+            assert lib.torbi_hip_set_forward_path(code) == 0, name
+            assert (code + 1) << 4 <= 7 << 4
+        assert lib.torbi_hip_set_forward_path(max(constants.values()) + 1) == -1
+        assert lib.torbi_hip_set_forward_path(-1) == -1
+    finally:
+        lib.torbi_hip_set_forward_path(0)
+    assert set(viterbi.ROUTES.values()) >= set(viterbi.FORWARD_PATHS) - {'auto'}
+
+
 def test_workspace_bytes_and_error_strings():
     lib = _lib.load()
     need = lib.torbi_hip_workspace_bytes(512, 500, 1440)

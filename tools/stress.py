@@ -1,5 +1,5 @@
-"""Randomised parity stress (GPU box): random shapes, lengths, -inf densities and tie levels under the four forward
-paths (and the CPU twin) against the C oracle.   python tools/stress.py [cases] [seed]"""
+"""Randomised parity stress (GPU box): random shapes, lengths, -inf densities, tie levels and peaked rows under the six
+forward paths (and the CPU twin) against the C oracle.   python tools/stress.py [cases] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,13 +13,13 @@ dev = torch.device('cuda:0')
 bad = 0
 t0 = time.time()
 for c in range(cases):
-    S = int(rng.choice([rng.integers(16, 80), rng.integers(16, 560) * 4, rng.integers(64, 2200), rng.integers(513, 1025) * 4]))
+    S = int(rng.choice([rng.integers(1, 80), rng.integers(16, 560) * 4, rng.integers(64, 2200), rng.integers(513, 1025) * 4]))
     B = int(rng.choice([rng.integers(1, 20), rng.integers(17, 70), rng.integers(60, 160), rng.integers(250, 300)]))
-    T = int(rng.integers(1, 10))
+    T = int(rng.integers(1, 10)) if B > 16 else int(rng.integers(1, 60))     # a handful of sequences: many timesteps
     if B * T * S * S > 6e9:
         B = max(1, int(6e9 / (T * S * S)))
     obs, trans, init = synth.problem(B, T, S, seed=int(rng.integers(1 << 30)))
-    kind = rng.integers(6)
+    kind = rng.integers(7)
     if kind == 1:      # heavy ties
         obs = np.round(obs / 4) * 4; trans = np.round(trans / 8) * 8
     elif kind == 2:    # random -inf entries
@@ -31,6 +31,10 @@ for c in range(cases):
         init = np.where(rng.random(S) < 0.5, -np.inf, init).astype(np.float32)
     elif kind == 5:    # tiny spread: nothing prunable
         trans = (trans * np.float32(2.0 ** -int(rng.integers(8, 20)))).astype(np.float32)
+    elif kind == 6:    # peaked rows (posteriorgram-like: a narrow peak per frame over noise), dense matrix
+        centre = rng.integers(0, S, size=(B, T, 1))
+        width = float(rng.choice([3.0, 12.0, 40.0]))
+        obs = (obs / 4 - ((np.abs(np.arange(S)[None, None, :] - centre)) / width) ** 2).astype(np.float32)
     frames = rng.integers(1, T + 1, size=B).astype(np.int32)
     want = oracle.decode(obs.astype(np.float32), frames, trans.astype(np.float32), init.astype(np.float32), num_threads=oracle.max_threads())
     args = [torch.as_tensor(np.ascontiguousarray(x)).to(dev) for x in (obs.astype(np.float32), frames, trans.astype(np.float32), init.astype(np.float32))]
@@ -39,12 +43,12 @@ for c in range(cases):
     if not np.array_equal(twin, want):
         bad += 1
         print('MISMATCH', dict(B=B, T=T, S=S, kind=int(kind), path='cpu twin'), int((twin != want).sum()))
-    for path in ('auto', 'dense', 'pruned', 'resident'):
+    for path in ('auto', 'dense', 'pruned', 'resident', 'cluster', 'held'):
         viterbi.set_forward_path(path)
         got = torbi_amd.decode(*args).cpu().numpy()
         if not np.array_equal(got, want):
             bad += 1
             print('MISMATCH', dict(B=B, T=T, S=S, kind=int(kind), path=path, used=viterbi.forward_path(B, S)), int((got != want).sum()))
 viterbi.set_forward_path('auto')
-print(f'{cases} cases x (4 HIP paths + the CPU twin), {bad} mismatches, {time.time() - t0:.0f} s')
+print(f'{cases} cases x (6 HIP paths + the CPU twin), {bad} mismatches, {time.time() - t0:.0f} s')
 sys.exit(1 if bad else 0)

@@ -1310,7 +1310,7 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S) {
 }
 
 int torbi_hip_set_forward_path(int path) {
-    if (path < TORBI_HIP_FORWARD_AUTO || path > TORBI_HIP_FORWARD_CLUSTER) return TORBI_HIP_EINVAL;
+    if (path < TORBI_HIP_FORWARD_AUTO || path > TORBI_HIP_FORWARD_HELD) return TORBI_HIP_EINVAL;
     g_forward_path.store(path, std::memory_order_relaxed);
     return TORBI_HIP_OK;
 }
