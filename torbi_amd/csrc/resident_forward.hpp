@@ -266,6 +266,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void *base, un
 #ifndef CLUSTER_ONE_POLLER
 #define CLUSTER_ONE_POLLER 1
 #endif
+// the slice stores are drained together with the keys behind the workgroup barrier (1) instead of by every wave before it (0)
+#ifndef CLUSTER_LATE_DRAIN
+#define CLUSTER_LATE_DRAIN 1
+#endif
 #ifndef RESIDENT_EXTRA_VALU
 #define RESIDENT_EXTRA_VALU 0
 #endif
@@ -633,7 +637,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                         store_through(xdst, (jj * kNI + 4 * g) * 4, make_float4(pend[p][0], pend[p][1], pend[p][2], pend[p][3]));
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!CLUSTER_LATE_DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             RSTAMP(8);
         }
         __syncthreads();      // every wave is done reading the tile and mtop, every output is in `top`
@@ -668,8 +672,17 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                         v4u x = {(unsigned)k0, (unsigned)(k0 >> 32), (unsigned)k1, (unsigned)(k1 >> 32)};
                         __builtin_amdgcn_raw_buffer_store_b128(x, xsrc, (int)xrow + (member * kNI * kMaxTop + 2 * lane) * 8, 0, 16);
                     }
+                    if (!CLUSTER_LATE_DRAIN) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0) __hip_atomic_store(cflags + member, (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                if (CLUSTER_LATE_DRAIN) {
+                    // ONE wait for the acknowledgements of the slice stores and of the keys together (the slices were
+                    // stored before the barrier above and have been on their way since), then the flag
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(cflags + member, (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_store(cflags + member, (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 RSTAMP(6);
                 // (2) wave 0 waits until the other members have published timestep t (one relaxed poll per member and
