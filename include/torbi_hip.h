@@ -85,19 +85,25 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
  *   PRUNED    value-only, exact: sorted transition rows + per-item top posteriors bound the cells
  *             that can still win, the rest are never touched (B >= 17, 64 <= S <= 4096); one launch
  *             per timestep over (batch tile x state tile) workgroups
- *   RESIDENT  the PRUNED recurrence with the time loop inside ONE launch: a workgroup owns 16 items x
- *             all states for every timestep, the posterior rows never leave its LDS (64 <= S <= 2048).
- *             16 items per compute unit: the path for many items in flight -- several batches through
- *             torbi_hip_viterbi_decode_batches, or one batch of >= 8 * compute-units items.
+ *   RESIDENT  the PRUNED recurrence with the time loop inside ONE launch: a workgroup owns 16 items (8 above 2048
+ *             states) x all states for every timestep, the posterior rows never leave its LDS (64 <= S <= 4096, any B).
+ *             One tile per compute unit: the path for many items in flight -- several batches through
+ *             torbi_hip_viterbi_decode_batches, or one batch of more than 8 * compute-units items.
+ *   CLUSTER   the same kernel with each tile split over R <= 16 workgroups that scan 1/R of the next-states each and
+ *             exchange their slices of every new posterior row inside the launch (write-through stores, one flag per
+ *             member and timestep): the path for launches that fill at most half the compute units.  Named for a launch
+ *             that fills more, it is RESIDENT.
  *   HELD      B <= 16, S <= 4096: the reference's scan with the time loop inside ONE launch: ceil(S / 8) workgroups
  *             hold 8 rows of the matrix each in registers for the whole launch and pass the posterior rows to each
- *             other through 8-byte {value, timestep} words (held_matrix_forward.hpp).  AUTO takes it up to three items (eight above 2048 states).
- * AUTO takes RESIDENT when the call's items fill at least half the compute units with workgroups of
- * 16, else PRUNED / ROWS where supported, else DENSE, else GENERIC.
+ *             other through 8-byte {value, timestep} words (held_matrix_forward.hpp).
+ * AUTO: RESIDENT when the call's tiles fill more than half the compute units; CLUSTER for any other batch of more than
+ * 16 items up to 2048 states (above: for batches beyond one round of the per-timestep kernel, else PRUNED); HELD up to
+ * three items (eight above 2048 states); ROWS for 8..16 items (and above 2048 states); else GENERIC.  (The Python layer
+ * adds what it knows about the matrix: DENSE for one batch with a narrow band or with scans too deep to prune.)
  *
  * A call selects a path in its `flags` (TORBI_HIP_PATH_FLAG); calls without one use the process-wide
  * default (torbi_hip_set_forward_path, initially the environment variable
- * TORBI_HIP_FORWARD=dense|pruned|resident, else AUTO).  A path that does not cover the shape falls
+ * TORBI_HIP_FORWARD=dense|pruned|resident|cluster|held, else AUTO).  A path that does not cover the shape falls
  * back as AUTO would.  A workspace of torbi_hip_workspace_bytes() fits every path.
  * torbi_hip_forward_path_on reports what a (B, S) batch would run on `device` with `flags`:
  * 0 generic, 1 dense, 2 pruned, 3 resident, 4 rows, 5 cluster, 6 held; torbi_hip_forward_path is the same for device 0, flags 0.

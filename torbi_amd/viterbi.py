@@ -237,7 +237,7 @@ def decode(
             TORBI_HIP_REUSE_TRANSITION)
         workspace: optional uint8 scratch tensor on the compute device with at least
             `workspace_bytes(N, T, S)` bytes; allocated from torch's caching allocator if None
-        path: forward recurrence for THIS call ('auto', 'dense', 'pruned', 'resident', 'cluster'; None = the
+        path: forward recurrence for THIS call ('auto', 'dense', 'pruned', 'resident', 'cluster', 'held'; None = the
             process default of `set_forward_path`).  Every path returns the same indices.
 
     Return:
@@ -534,7 +534,7 @@ def _tuner_for(transition: torch.Tensor, states: int, device) -> Optional[_Tuner
     return tuner
 
 
-_forced_path = {'d': 'dense', 'p': 'pruned', 'r': 'resident', 'c': 'cluster'}.get(os.environ.get('TORBI_HIP_FORWARD', 'a')[:1], 'auto')
+_forced_path = {'d': 'dense', 'p': 'pruned', 'r': 'resident', 'c': 'cluster', 'h': 'held'}.get(os.environ.get('TORBI_HIP_FORWARD', 'a')[:1], 'auto')
 BANDED_RANGE = 0.25              # rows reaching less than this fraction of the states: dense + -inf skipping
 
 
