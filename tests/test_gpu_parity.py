@@ -215,6 +215,77 @@ def test_held_matrix_kernel_equals_the_oracle(shape, kind, forward):
     assert np.array_equal(post.view(np.uint32), want_post.view(np.uint32))
 
 
+@pytest.mark.parametrize('shape', [(1, 40, 1440), (3, 25, 360), (2, 6, 4096), (5, 9, 130)])
+def test_held_launch_that_cannot_complete_is_repaired(shape, forward, monkeypatch):
+    """A held-matrix launch needs all its workgroups resident at once; when they are not (several such launches from
+    different streams on a full device) its polls run out, the workgroups go on without waiting and `repair_kernel` decodes
+    the sequences again.  Forced here with a poll limit of 0: every wait gives up at once (counted in the statistics),
+    the indices and the final posterior rows are still the oracle's; without the limit nothing gives up."""
+    if forward != 'auto':
+        pytest.skip('names its path itself')
+    B, T, S = shape
+    obs, trans, init = synth.problem(B, T, S, seed=77)
+    frames = np.clip(synth.lengths(B, 1, T, seed=5), 1, T).astype(np.int32)
+    frames[0] = T
+    dev = torch.device('cuda:0')
+    args = [torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)]
+    space = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+    want, want_post = oracle.decode(obs, frames, trans, init, return_posterior=True)
+    for limit, gave_up in (('0', True), (None, False), ('0', True)):
+        if limit is None:
+            monkeypatch.delenv('TORBI_HIP_HELD_SPIN_LIMIT', raising=False)
+        else:
+            monkeypatch.setenv('TORBI_HIP_HELD_SPIN_LIMIT', limit)
+        got = torbi_amd.decode(*args, workspace=space, path='held')
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+        post = viterbi.read_posterior(space, args[1], B, T, S).cpu().numpy()
+        assert np.array_equal(post.view(np.uint32), want_post.view(np.uint32))
+        stats = viterbi.scan_stats(space, B, T, S).cpu()
+        assert (int(stats[127]) > 0) == gave_up, (limit, int(stats[127]))
+
+
+def test_concurrent_held_launches_from_several_streams(forward):
+    """Six host threads, six streams, one 4096-state sequence each on the held-matrix kernel -- 256 workgroups of 1024
+    threads per launch, one per compute unit, so the launches cannot all be resident together.  Whatever the dispatcher
+    does (one after the other, or interleaved until polls run out and the repair kernel steps in), every result is the
+    oracle's."""
+    if forward != 'auto':
+        pytest.skip('names its path itself')
+    import threading
+    dev = torch.device('cuda:0')
+    T, S, n = 24, 4096, 6
+    _, trans, init = synth.problem(1, 1, S, seed=9)
+    d_trans, d_init = torch.as_tensor(trans).to(dev), torch.as_tensor(init).to(dev)
+    jobs = []
+    for k in range(n):
+        obs = synth.scores(synth.STREAM_OBSERVATION, (1, T, S), seed=300 + k)
+        frames = np.array([T - k], dtype=np.int32)
+        jobs.append((obs, frames, oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())))
+    results, errors = [None] * n, []
+
+    def work(k):
+        try:
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                d_obs, d_frames = torch.as_tensor(jobs[k][0]).to(dev), torch.as_tensor(jobs[k][1]).to(dev)
+                space = torch.empty(viterbi.workspace_bytes(1, T, S), dtype=torch.uint8, device=dev)
+                for _ in range(3):
+                    got = torbi_amd.decode(d_obs, d_frames, d_trans, d_init, workspace=space, path='held')
+                stream.synchronize()
+                results[k] = got.cpu().numpy()
+        except Exception as exc:                      # surfaced below: a thread must not fail silently
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(n)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for k in range(n):
+        np.testing.assert_array_equal(results[k], jobs[k][2], err_msg=f'stream {k}')
+
+
 def test_auto_looks_at_the_transition_once_per_tensor_version(forward):
     """The Python layer's look at the transition decides where ONE batch goes: dense + -inf skipping for a narrow band;
     otherwise clusters up to 2048 states, the pruned pass above (8-item tiles, a batch that fits one round of the

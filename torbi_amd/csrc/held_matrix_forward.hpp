@@ -18,8 +18,12 @@
 // ascending i per thread, strict '>' (the first maximum wins), (value, index) pairs combined with the lower index on
 // ties, posterior = fl(obs[t][j] + max), backpointer -> trellis; the final argmax and the chase stay in finalize_kernel.
 //
-// All workgroups (<= 256) must be resident at once -- one per compute unit of an MI355X; the polls are bounded and a
-// workgroup that gives up says so in `control[1]` (0 on any sane run).
+// All workgroups (<= 256) must be resident at once -- one per compute unit of an MI355X, up to three at 1440 states.  That
+// holds whenever the launch has the device to itself or shares it with a few of its kind; several such launches from
+// different streams can each end up partly resident and wait for one another.  So every poll is bounded (`spin_limit`, a
+// quarter of a second), a workgroup that gives up says so in `control[1]` and goes on without waiting, and the launch is
+// followed by `repair_kernel`, which does nothing when `control[1]` is 0 and otherwise decodes every sequence again with one
+// workgroup each and no hand-offs (the reference's own kernel shape, viterbi.cu:48-130): slow, never wrong.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -165,7 +169,7 @@ template <int K, int kRows, int kThreads, bool STORE_WAVE>
 __global__ __launch_bounds__(kThreads + (STORE_WAVE ? 64 : 0)) void held_forward_kernel(
     const float *__restrict__ obs, const int32_t *__restrict__ frames, const float *__restrict__ trans,
     float *__restrict__ post0, float *__restrict__ post1, int32_t *__restrict__ trellis, u64 *__restrict__ xchg,
-    unsigned *__restrict__ control, int B, int T, int S) {
+    unsigned *__restrict__ control, int B, int T, int S, unsigned spin_limit) {
     constexpr int kWaves = kThreads / 64;                       // scanning waves
     static_assert(kRows == 8 || kRows == 16, "folds are written for 8 and 16 rows");
     __shared__ float sv[2][kWaves][kRows];
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(kThreads + (STORE_WAVE ? 64 : 0)) void held_forward
                 for (;;) {
                     request(t, b, mine);
                     if (complete(mine, t)) break;
-                    if (++spins > (1u << 22)) { gave_up = true; break; }
+                    if (gave_up || ++spins > spin_limit) { gave_up = true; break; }     // (once given up, never wait again)
                     __builtin_amdgcn_s_sleep(HELD_POLL_SLEEP);
                 }
             }
@@ -369,6 +373,55 @@ __global__ __launch_bounds__(kThreads + (STORE_WAVE ? 64 : 0)) void held_forward
             ++round;
             advance(t, b);
         }
+    }
+}
+
+// The safety net behind a held launch (see the top of the file): one workgroup per sequence, posterior rows ping-pong in
+// the LDS, one wave per next-state and round, lanes over the prev-states in ascending stripes (the reference scan:
+// strict '>', lower index on ties).  grid = B, block = 1024, dynamic LDS = 2 * S floats.
+__global__ __launch_bounds__(1024) void repair_kernel(const float *__restrict__ obs, const int32_t *__restrict__ frames,
+                                                      const float *__restrict__ trans, const float *__restrict__ initial,
+                                                      float *__restrict__ post0, float *__restrict__ post1,
+                                                      int32_t *__restrict__ trellis, const unsigned *__restrict__ control,
+                                                      int B, int T, int S) {
+    if (control[1] == 0u) return;                               // every workgroup of the held launch completed
+    extern __shared__ __attribute__((aligned(16))) float rows[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int f = frames[b];
+    f = f < 1 ? 1 : (f > T ? T : f);
+    for (int i = tid; i < S; i += 1024) {
+        const float v = obs[(size_t)b * T * S + i] + initial[i];
+        rows[i] = v;
+        post0[(size_t)b * S + i] = v;
+    }
+    __syncthreads();
+    for (int t = 1; t < f; ++t) {
+        const float *cur = rows + (size_t)((t - 1) & 1) * S;
+        float *nxt = rows + (size_t)(t & 1) * S;
+        for (int j = wave; j < S; j += 16) {
+            const float *row = trans + (size_t)j * S;
+            float v = -INFINITY;
+            int a = 0x7fffffff;
+            for (int i = lane; i < S; i += 64) {
+                const float c = cur[i] + row[i];
+                const bool take = (c > v) | (a == 0x7fffffff);   // the first candidate is taken whatever it is
+                v = take ? c : v;
+                a = take ? i : a;
+            }
+#pragma unroll
+            for (int w = 32; w > 0; w >>= 1) {
+                const float ov = __shfl_xor(v, w, 64);
+                const int oa = __shfl_xor(a, w, 64);
+                better(v, a, ov, oa);
+            }
+            if (lane == 0) {
+                const float out = obs[((size_t)b * T + t) * S + j] + v;
+                nxt[j] = out;
+                trellis[((size_t)b * T + t) * S + j] = a;
+                if (t == f - 1) ((t & 1) ? post1 : post0)[(size_t)b * S + j] = out;
+            }
+        }
+        __syncthreads();
     }
 }
 

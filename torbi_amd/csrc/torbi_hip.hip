@@ -335,10 +335,14 @@ __global__ __launch_bounds__(256) void gather_final_kernel(const int32_t *__rest
 
 // scan statistics of the last decode by its route record: time-resident forms, per-timestep pruned pass, else zeros
 __global__ __launch_bounds__(128) void gather_stats_kernel(const int32_t *__restrict__ route, const unsigned *__restrict__ resident_stats,
-                                                           const unsigned *__restrict__ pruned_stats, unsigned *__restrict__ dst) {
+                                                           const unsigned *__restrict__ pruned_stats,
+                                                           const unsigned *__restrict__ held_control, unsigned *__restrict__ dst) {
     const int r = *route;
     const unsigned *src = (r == 3 || r == 5) ? resident_stats : (r == 2 ? pruned_stats : nullptr);
-    dst[threadIdx.x] = src ? src[threadIdx.x] : 0u;
+    unsigned v = src ? src[threadIdx.x] : 0u;
+    // held-matrix launch: [127] = workgroups that gave up waiting (the decode was then repaired; 0 on any sane run)
+    if (r == 6 && held_control && threadIdx.x == 127) v = held_control[1];
+    dst[threadIdx.x] = v;
 }
 
 // x <- log(exp(x) + tiny), the epsilon clamp of from_probabilities (torbi/core.py:193-197)
@@ -827,11 +831,15 @@ hipError_t launch_held_forward(const float *obs, const int32_t *frames, const fl
     }
     if (launches) *launches = 1;
     if (T < 2) return hipGetLastError();
+    // polls before a workgroup stops waiting for the others (~1 us each: a quarter of a second; TORBI_HIP_HELD_SPIN_LIMIT for
+    // tests of the repair path)
+    const char *limit_env = getenv("TORBI_HIP_HELD_SPIN_LIMIT");
+    const unsigned spin_limit = limit_env ? (unsigned)strtoul(limit_env, nullptr, 10) : (1u << 18);
     const dim3 grid(held::workgroups(S)), block(held::block_threads(S));
     const int K = (S + held::threads(S) - 1) / held::threads(S);
 #define TORBI_HELD(K_, R_, N_)                                                                                       \
     hipLaunchKernelGGL((held::held_forward_kernel<K_, R_, N_, (N_ < 1024)>), grid, block, 0, stream, obs, frames, trans, \
-                       w.post[0], w.post[1], w.trellis, w.xchg, w.control, B, T, S)
+                       w.post[0], w.post[1], w.trellis, w.xchg, w.control, B, T, S, spin_limit)
     if (S <= held::kSmallS) {
         if (K == 1) TORBI_HELD(1, 8, 512);
         else if (K == 2) TORBI_HELD(2, 8, 512);
@@ -843,6 +851,9 @@ hipError_t launch_held_forward(const float *obs, const int32_t *frames, const fl
         TORBI_HELD(4, 16, 1024);
     }
 #undef TORBI_HELD
+    // does nothing unless a workgroup above gave up waiting (held_matrix_forward.hpp)
+    hipLaunchKernelGGL(held::repair_kernel, dim3(B), dim3(1024), 2 * sizeof(float) * (size_t)S, stream, obs, frames, trans, init,
+                       w.post[0], w.post[1], w.trellis, w.control, B, T, S);
     return hipGetLastError();
 }
 
@@ -1427,10 +1438,12 @@ int torbi_hip_scan_stats(const void *workspace, size_t workspace_bytes, int B, i
     const int cus = cu_count(device);
     const unsigned *resident_stats = resident::supported(S) ? carve_resident(const_cast<void *>(workspace), B, T, S, cus).stats : nullptr;
     const unsigned *pruned_stats = pruned::supported(B, S) ? carve_pruned(const_cast<void *>(workspace), B, T, S, cus).stats : nullptr;
-    if (!resident_stats && !pruned_stats) return TORBI_HIP_EUNSUPPORTED;
+    const unsigned *held_control = carve(const_cast<void *>(workspace), B, T, S).control;
+    if (!resident_stats && !pruned_stats && !held_control) return TORBI_HIP_EUNSUPPORTED;
+    const unsigned *some = resident_stats ? resident_stats : pruned_stats ? pruned_stats : held_control;
     hipLaunchKernelGGL(gather_stats_kernel, dim3(1), dim3(2 * pruned::kStatSlots), 0, static_cast<hipStream_t>(stream),
-                       route_record(workspace, B, T, S, cus), resident_stats ? resident_stats : pruned_stats,
-                       pruned_stats ? pruned_stats : resident_stats, stats_out);
+                       route_record(workspace, B, T, S, cus), resident_stats ? resident_stats : some,
+                       pruned_stats ? pruned_stats : some, held_control, stats_out);
     return (int)hipGetLastError();
 }
 
