@@ -215,6 +215,25 @@ def test_held_matrix_kernel_equals_the_oracle(shape, kind, forward):
     assert np.array_equal(post.view(np.uint32), want_post.view(np.uint32))
 
 
+@pytest.mark.parametrize('shape', [(2, 3000, 360), (1, 1500, 1440), (3, 700, 2050)])
+def test_held_matrix_kernel_over_many_timesteps(shape, forward):
+    """Thousands of hand-offs in one launch (two parities of {value, timestep} words, every workgroup waiting for all the
+    others every timestep): ragged lengths, AUTO's own choice of the path, indices against the oracle."""
+    if forward != 'auto':
+        pytest.skip('once is enough')
+    B, T, S = shape
+    obs, trans, init = synth.problem(B, T, S, seed=T)
+    frames = np.clip(synth.lengths(B, T // 2, T, seed=1), 1, T).astype(np.int32)
+    frames[0] = T
+    dev = torch.device('cuda:0')
+    args = [torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)]
+    prof = []
+    got = torbi_amd.decode(*args, _profile=prof)
+    assert int(prof[3]) == 6 and int(prof[2]) == 1
+    want = oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize('shape', [(1, 40, 1440), (3, 25, 360), (2, 6, 4096), (5, 9, 130)])
 def test_held_launch_that_cannot_complete_is_repaired(shape, forward, monkeypatch):
     """A held-matrix launch needs all its workgroups resident at once; when they are not (several such launches from
