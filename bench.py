@@ -481,12 +481,15 @@ class Bench:
             i5 = v.fill_synthetic((S5,), synth.STREAM_INITIAL, seed=0, device=dev)
             f5 = torch.full((B5,), T5, dtype=torch.int32, device=dev)
             w5 = torch.empty(v.workspace_bytes(B5, T5, S5), dtype=torch.uint8, device=dev)
+            prof = []
+            self.torbi_amd.decode(o5, f5, t5, i5, workspace=w5, _profile=prof)
             sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(o5, f5, t5, i5, workspace=w5), 2)
-            record('c5', sec, B5 * T5, S5, 'BASELINE configs[4]: 4096 states, 2000 frames, batch=128 (AUTO: the per-timestep '
-                                           'pruned kernel on 8-item tiles)')
-            sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(o5, f5, t5, i5, workspace=w5, path='cluster'), 2)
-            record('c5_cluster_form', sec, B5 * T5, S5, 'the same batch in the cluster form of the time-resident kernel (16 tiles '
-                                                        'of 8 items x 16 workgroups each)')
+            record('c5', sec, B5 * T5, S5, 'BASELINE configs[4]: 4096 states, 2000 frames, batch=128 (AUTO: ONE time-resident '
+                                           'launch, 16 tiles of 8 items x 16 workgroups each)',
+                   {'forward_path': ROUTES[int(prof[3])]})
+            sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(o5, f5, t5, i5, workspace=w5, path='pruned'), 2)
+            record('c5_per_timestep_kernel', sec, B5 * T5, S5, 'the same batch with per-timestep launches of the pruned '
+                                                               'recurrence on 8-item tiles (AUTO before round 3)')
             # the same shape as a launch group (a many-file job at 4096 states): four batches in one time-resident launch
             T5g, n5 = 500, 4
             spaces5 = [torch.empty(v.workspace_bytes(B5, T5g, S5), dtype=torch.uint8, device=dev) for _ in range(n5)]

@@ -97,8 +97,8 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
  *             hold 8 rows of the matrix each in registers for the whole launch and pass the posterior rows to each
  *             other through 8-byte {value, timestep} words (held_matrix_forward.hpp).
  * AUTO: RESIDENT when the call's tiles fill more than half the compute units; CLUSTER for any other batch of more than
- * 16 items up to 2048 states (above: for batches beyond one round of the per-timestep kernel, else PRUNED); HELD up to
- * three items (eight above 2048 states); ROWS for 8..16 items (and above 2048 states); else GENERIC.  (The Python layer
+ * 16 items (64 <= S <= 4096: one batch = one forward launch); HELD up to three items (eight above 2048 states); ROWS for
+ * 8..16 items (and above 2048 states); PRUNED / DENSE for large batches outside 64..4096 states; else GENERIC.  (The Python layer
  * adds what it knows about the matrix: DENSE for one batch with a narrow band or with scans too deep to prune.)
  *
  * A call selects a path in its `flags` (TORBI_HIP_PATH_FLAG); calls without one use the process-wide

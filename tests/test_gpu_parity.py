@@ -151,7 +151,7 @@ def test_forward_path_selection(forward):
     assert viterbi.forward_path(4, 40) == 'generic'                # S < 64: no value-only path
     assert viterbi.forward_path(1, 40) == ('held' if forward == 'auto' else 'generic')
     assert viterbi.forward_path(4, 4100) == 'generic'
-    assert viterbi.forward_path(128, 4096) == {'dense': 'dense', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'pruned')   # 8-item tiles
+    assert viterbi.forward_path(128, 4096) == {'dense': 'dense', 'resident': 'resident', 'pruned': 'pruned'}.get(forward, 'cluster')   # 8-item tiles
     assert viterbi.forward_path(128, 4100) == 'dense'              # posterior tile does not fit the LDS
     assert viterbi.forward_path(512, 1440) == {'dense': 'dense', 'resident': 'resident', 'pruned': 'pruned'}.get(forward, 'cluster')
     assert viterbi.forward_path(64, 130) == {'dense': 'dense', 'resident': 'resident', 'pruned': 'pruned'}.get(forward, 'cluster')
@@ -167,7 +167,8 @@ def test_forward_path_selection(forward):
     assert viterbi.forward_path(2 * cus, 1440, path='auto') == 'cluster'
     assert viterbi.forward_path(17, 1440, path='auto') == 'cluster'
     assert viterbi.forward_path(16, 1440, path='auto') == 'rows'
-    assert viterbi.forward_path(128, 4096, path='auto') == 'pruned'               # 8-item tiles: clusters only beyond one round
+    assert viterbi.forward_path(128, 4096, path='auto') == 'cluster'              # 8-item tiles: 16 tiles x 16 members
+    assert viterbi.forward_path(128, 4100, path='auto') == 'dense' and viterbi.forward_path(40, 40, path='auto') == 'generic'
     assert viterbi.forward_path(2 * cus, 1440, path='pruned') == 'pruned'
     # the path travels with the call: naming one never changes the process default
     assert viterbi.forward_path(512, 1440, path='dense') == 'dense'
@@ -306,9 +307,8 @@ def test_concurrent_held_launches_from_several_streams(forward):
 
 
 def test_auto_looks_at_the_transition_once_per_tensor_version(forward):
-    """The Python layer's look at the transition decides where ONE batch goes: dense + -inf skipping for a narrow band;
-    otherwise clusters up to 2048 states, the pruned pass above (8-item tiles, a batch that fits one round of the
-    per-timestep kernels) -- once per tensor version."""
+    """The Python layer's look at the transition decides where ONE batch of more than 16 items goes: dense + -inf
+    skipping for a narrow band, clusters otherwise (16- and 8-item tiles alike) -- once per tensor version."""
     if forward != 'auto':
         pytest.skip('path forced')
     dev = torch.device('cuda:0')
@@ -327,13 +327,13 @@ def test_auto_looks_at_the_transition_once_per_tensor_version(forward):
     frames = np.full(B, T, dtype=np.int32)
     args = [torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)]
     torbi_amd.decode(*args, _profile=prof)
-    assert int(prof[3]) == 2                                         # dense random matrix: pruned
+    assert int(prof[3]) == 5                                         # dense random matrix: clusters on 8-item tiles
     band = torch.as_tensor(synth.banded_transition(S, 20.0)).to(dev)
     torbi_amd.decode(args[0], args[1], band, args[3], _profile=prof)
     assert int(prof[3]) == 1                                         # narrow band: dense + -inf skipping
     band.fill_(-1.0)                                                 # same storage, new version
     torbi_amd.decode(args[0], args[1], band, args[3], _profile=prof)
-    assert int(prof[3]) == 2
+    assert int(prof[3]) == 5
 
 
 @pytest.mark.parametrize('kind', ['flat', 'nearly_flat', 'peaked', 'anti', 'two_level'])
@@ -454,32 +454,6 @@ def test_preparation_reuse_follows_the_transition_and_the_shape(B):
     lib = torbi_amd._lib.load()
     assert lib.torbi_hip_viterbi_decode_ex(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
                                            got.data_ptr(), ws.data_ptr(), ws.numel(), B, T, S, 0, None, 4) == -1
-
-
-def test_auto_tuner_switches_paths_without_changing_results(forward):
-    """Repeated decodes with one transition tensor where AUTO keeps the per-timestep kernels (one batch above 2048
-    states): the Python layer may move between the pruned and the dense path by measurement (viterbi._Tuner); indices
-    stay those of the oracle, and on data where a few states dominate every posterior row the dense path has been tried
-    by the end."""
-    if forward != 'auto':
-        pytest.skip('path forced')
-    dev = torch.device('cuda:0')
-    B, T, S = 64, 16, 2064
-    obs, trans, init = synth.problem(B, T, S, seed=21)
-    obs = (obs + np.float32(40.0) * (obs > np.float32(-0.03))).astype(np.float32)
-    frames = np.full(B, T, dtype=np.int32)
-    want = oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())
-    d = [torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)]
-    ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
-    for _ in range(6):
-        got = torbi_amd.decode(*d, workspace=ws, reuse_preparation=True)
-        torch.cuda.synchronize()
-        np.testing.assert_array_equal(got.cpu().numpy(), want)
-    tuner = viterbi._tuner_for(d[2], S, dev)
-    tuner._collect()
-    assert tuner.blocks is not None
-    if not tuner.settled():
-        assert tuner.time['pruned'] is not None and tuner.time['dense'] is not None
 
 
 def test_decode_pipeline_equals_serial_decodes():

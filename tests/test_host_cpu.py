@@ -198,23 +198,23 @@ def test_auto_path_choice_reads_the_transition_structure_once_per_version():
     try:
         viterbi._forced_path = 'dense'
         viterbi._compute_units[0] = 256               # what torbi_hip_compute_units(0) reports on an MI355X
-        assert viterbi._resolve_path(dense, dense, 64, S, 'cuda:0', None, 4, False) == ('dense', None)
-        assert viterbi._resolve_path(dense, dense, 64, S, 'cuda:0', 'auto', 4, False) == ('cluster', None)
-        assert viterbi._resolve_path(dense, dense, 64, S, 'cuda:0', 'resident', 4, False) == ('resident', None)
+        assert viterbi._resolve_path(dense, dense, 64, S, 'cuda:0', None, 4) == 'dense'
+        assert viterbi._resolve_path(dense, dense, 64, S, 'cuda:0', 'auto', 4) == 'cluster'
+        assert viterbi._resolve_path(dense, dense, 64, S, 'cuda:0', 'resident', 4) == 'resident'
         # enough 16-item tiles to give half the compute units a workgroup: AUTO decodes time-resident ('cluster' = the
         # library picks the form: whole tiles per workgroup here, clusters of workgroups per tile below half the chip)
-        assert viterbi._resolve_path(dense, dense, 2048, S, 'cuda:0', 'auto', 128, False) == ('cluster', None)
-        assert viterbi._resolve_path(band, band, 2048, S, 'cuda:0', 'auto', 128, False) == ('cluster', None)
+        assert viterbi._resolve_path(dense, dense, 2048, S, 'cuda:0', 'auto', 128) == 'cluster'
+        assert viterbi._resolve_path(band, band, 2048, S, 'cuda:0', 'auto', 128) == 'cluster'
         # below half the chip -- a launch group or one batch of more than 16 items -- clusters of workgroups per tile;
         # one batch with a narrow band: the dense kernel's -inf skipping; 16 items or fewer: the library's choice
-        assert viterbi._resolve_path(dense, dense, 512, S, 'cuda:0', 'auto', 64, False, count=2) == ('cluster', None)
-        assert viterbi._resolve_path(dense, dense, 768, S, 'cuda:0', 'auto', 48, False) == ('cluster', None)
-        assert viterbi._resolve_path(dense, dense, 512, S, 'cuda:0', 'auto', 32, False) == ('cluster', None)
-        assert viterbi._resolve_path(band2, band2, 512, S, 'cuda:0', 'auto', 32, False) == ('dense', None)
+        assert viterbi._resolve_path(dense, dense, 512, S, 'cuda:0', 'auto', 64, count=2) == 'cluster'
+        assert viterbi._resolve_path(dense, dense, 768, S, 'cuda:0', 'auto', 48) == 'cluster'
+        assert viterbi._resolve_path(dense, dense, 512, S, 'cuda:0', 'auto', 32) == 'cluster'
+        assert viterbi._resolve_path(band2, band2, 512, S, 'cuda:0', 'auto', 32) == 'dense'
         wide = torch.as_tensor(synth.banded_transition(2064, 12.0))
-        assert viterbi._resolve_path(wide, wide, 64, 2064, 'cuda:0', 'auto', 8, False) == ('dense', None)    # 8-item tiles, one round
-        assert viterbi._resolve_path(band2, band2, 512, S, 'cuda:0', 'auto', 32, False, count=2) == ('cluster', None)
-        assert viterbi._resolve_path(dense, dense, 16, S, 'cuda:0', 'auto', 1, False) == ('auto', None)
+        assert viterbi._resolve_path(wide, wide, 64, 2064, 'cuda:0', 'auto', 8) == 'dense'    # 8-item tiles
+        assert viterbi._resolve_path(band2, band2, 512, S, 'cuda:0', 'auto', 32, count=2) == 'cluster'
+        assert viterbi._resolve_path(dense, dense, 16, S, 'cuda:0', 'auto', 1) == 'auto'
     finally:
         viterbi._forced_path = old
         viterbi._compute_units.clear()
@@ -224,41 +224,6 @@ def test_auto_path_choice_reads_the_transition_structure_once_per_version():
         assert viterbi._version_of(inf) is None
         assert viterbi._choose_path(inf, inf, 64, S) == 'dense'
         assert state.peek(inf) is None and state.notes(inf) is None
-        assert viterbi._tuner_for(inf, S, 'cpu') is None
-
-
-def test_tuner_probes_the_dense_path_only_when_pruning_is_not_clearly_working():
-    """torbi_amd/viterbi.py::_Tuner with stand-in events: the decision logic, no GPU."""
-    from torbi_amd import viterbi
-
-    class Event:
-        def __init__(self, ms, done=True):
-            self.ms, self.done = ms, done
-
-        def query(self):
-            return self.done
-
-        def elapsed_time(self, other):
-            return other.ms
-
-    def run(tuner, ms, blocks, done=True):
-        path = tuner.choose()
-        tuner.launched(path, Event(0.0), Event(ms[path], done), None, 1)
-        if path == 'pruned' and tuner.blocks is None and done:
-            tuner.blocks = blocks
-        return path
-
-    good = viterbi._Tuner()                           # benchmark-like: 12 blocks on the critical path
-    assert [run(good, {'pruned': 1.0, 'dense': 2.0}, 12.0) for _ in range(200)] == ['pruned'] * 200
-    bad = viterbi._Tuner()                            # a few dominant states: pruned slower than dense
-    paths = [run(bad, {'pruned': 1.4, 'dense': 1.0}, 28.0) for _ in range(130)]
-    assert paths[0] == 'pruned' and paths[1] == 'dense'
-    assert paths.count('pruned') == 1 + 2              # the first decode and the re-probes at 64 and 128
-    mild = viterbi._Tuner()                           # wide but prunable: probed once, pruned kept
-    paths = [run(mild, {'pruned': 0.8, 'dense': 1.0}, 25.0) for _ in range(70)]
-    assert paths[:3] == ['pruned', 'dense', 'pruned'] and paths.count('dense') == 2
-    lag = viterbi._Tuner()                            # nothing has completed yet: keep going on the pruned path
-    assert [run(lag, {'pruned': 1.0, 'dense': 1.0}, 30.0, done=False) for _ in range(5)] == ['pruned'] * 5
 
 
 # ---- vectors produced by the reference's own Python (tests/golden/generate_api.py) ---------------------------
@@ -628,9 +593,9 @@ def test_head_route_rejects_a_header_that_promises_more_than_the_file_holds(tmp_
 
 
 def test_one_store_keeps_what_is_known_about_tensors_for_as_long_as_they_live():
-    """torbi_amd/state.py: path tuners, structure looks, prepared transitions and workspace contents hang off the tensor
+    """torbi_amd/state.py: scan depths, structure looks, prepared transitions and workspace contents hang off the tensor
     object and its version in ONE store; entries die with their tensors and are never evicted by count -- a hundred other
-    matrices do not take a live matrix's tuner with them; a write to the tensor starts afresh; reset_path_state() forgets."""
+    matrices do not take a live matrix's notes with them; a write to the tensor starts afresh; reset_path_state() forgets."""
     import gc
     import torch
     import torbi_amd
@@ -638,25 +603,25 @@ def test_one_store_keeps_what_is_known_about_tensors_for_as_long_as_they_live():
     torbi_amd.reset_path_state()
     S = 64
     mine = torch.rand(S, S)
-    tuner = viterbi._tuner_for(mine, S, 'cpu')
-    assert tuner is not None and viterbi._tuner_for(mine, S, 'cpu') is tuner
+    depth = viterbi._depth_record(mine, S)
+    assert depth is not None and viterbi._depth_record(mine, S) is depth
     viterbi._choose_path(mine, mine, 64, S)
     prepared = torbi_amd.core._prepared_transition(mine, True, 'cpu')
     assert torbi_amd.core._prepared_transition(mine, True, 'cpu') is prepared
     others = []
     for k in range(100):                       # a hundred distinct matrices, half of them kept alive
         other = torch.rand(S, S)
-        viterbi._tuner_for(other, S, 'cpu')
+        viterbi._depth_record(other, S)
         viterbi._choose_path(other, other, 64, S)
         if k % 2:
             others.append(other)
     del other
     gc.collect()
-    assert viterbi._tuner_for(mine, S, 'cpu') is tuner            # still there
+    assert viterbi._depth_record(mine, S) is depth                # still there
     assert state.size() == 1 + len(others)                        # the dead ones left with their tensors
-    assert tuner in state.every('tuner')
+    assert any(d is depth for d in state.every(('depth', S)))
     mine.add_(1.0)                                                # a new version: nothing carries over
-    assert viterbi._tuner_for(mine, S, 'cpu') is not tuner and ('reach', S) not in state.notes(mine)
+    assert viterbi._depth_record(mine, S) is not depth and ('reach', S) not in state.notes(mine)
     # a workspace remembers which preparation it holds, for its transition's object and version
     ws = torch.empty(16, dtype=torch.uint8)
     assert not viterbi._reusable(ws, mine, (1, 2, 3, 'pruned', 0), True)

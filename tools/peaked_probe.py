@@ -16,7 +16,7 @@ def estimate_scan_depth(obs: torch.Tensor, trans: torch.Tensor, init: torch.Tens
     95th percentile over a sample of (item, next-state) pairs, computed with torch ops on the exact
     posterior after one timestep (frames 0 and 1 of the first `items` items, `rows` evenly spaced
     next-states).  A cheap predictor that misses heavy tails (a few items with many dominant states) and steady
-    state effects -- which is why the product measures instead (viterbi._Tuner)."""
+    state effects -- which is why the product reads the kernels' own scan statistics instead (viterbi._watch_resident)."""
     B, T, S = obs.shape
     items = max(1, min(items, B, (256 << 20) // (4 * S * S)))
     p = obs[:items, 0, :] + init[None, :]
@@ -60,12 +60,11 @@ viterbi.set_forward_path('auto')
 print('auto (measurement-based choice, 8 decodes each, last three timed):')
 import time
 for name, obs in cases:
-    tr = trans.clone()                      # a fresh tensor: a fresh tuner
+    tr = trans.clone()                      # a fresh tensor: nothing known about it yet
     for i in range(8):
         if i == 5:
             torch.cuda.synchronize(); t0 = time.perf_counter()
         torbi_amd.decode(obs, frames, tr, init, workspace=ws)
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
-    tu = viterbi._tuner_for(tr, S, dev)
-    print(f'{name:26s} {dt * 1e3:6.2f} ms per decode; tuner blocks {tu.blocks}, ms/timestep {tu.time}')
+    print(f'{name:26s} {dt * 1e3:6.2f} ms per decode; scan depth known to the host layer: {viterbi._known_depth(tr, S)}')

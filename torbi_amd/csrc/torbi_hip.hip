@@ -523,14 +523,11 @@ inline Route route_for(int path, int B, int S, int cus) {
     if (path == TORBI_HIP_FORWARD_RESIDENT && fits) return ROUTE_RESIDENT;
     if (path == TORBI_HIP_FORWARD_CLUSTER && fits) return cluster_members(tiles_of(B, S), S, cus) > 1 ? ROUTE_CLUSTER : ROUTE_RESIDENT;
     if (path == TORBI_HIP_FORWARD_AUTO && fits && 2 * tiles_of(B, S) > cus) return ROUTE_RESIDENT;
-    // (one batch, AUTO: clusters where the per-timestep pruned pass would need a second round of workgroups -- more
-    // than cus / 8 tiles, 512 items on an MI355X: 27.8 against 34.8 us per timestep at 768 items, equal at 512)
-    // ... and, up to 2048 states, for every batch of more than 16 items: with one seed per item the cluster form is at
-    // least as fast as the per-timestep kernel from 17 items on (13.1 against 14.5 us per timestep at 17 items, 18.8 against
-    // 20.1 at 512; profiles/r03_cluster_sweep_1440_kr1.txt).  (Above 2048 states -- 8-item tiles -- a batch that fits one
-    // round of the per-timestep kernel stays there: 128 x 2000 x 4096 decodes in 55.6 ms on it, 60.3 ms in clusters of 16.)
-    if (path == TORBI_HIP_FORWARD_AUTO && fits && B > 16 && (S <= pruned::kMaxS16 || 8 * tiles_of(B, S) > cus) &&
-        cluster_members(tiles_of(B, S), S, cus) > 1)
+    // (one batch, AUTO: clusters for every batch of more than 16 items -- with one seed per item and one polling wave per
+    // workgroup the cluster form is at least as fast as the per-timestep kernel from 17 items on: 12.8 against 14.5 us per
+    // timestep at 17 items, 15.6 against 20.2 at 512, 20.4 against 34.9 at 768 (profiles/r03_cluster_sweep_one_poller.txt);
+    // 128 x 2000 x 4096 on 8-item tiles 54.2 against 55.9 ms)
+    if (path == TORBI_HIP_FORWARD_AUTO && fits && B > 16 && cluster_members(tiles_of(B, S), S, cus) > 1)
         return ROUTE_CLUSTER;
     if (path != TORBI_HIP_FORWARD_DENSE && pruned::supported(B, S)) return ROUTE_PRUNED;
     // a handful of sequences: the whole time loop in one launch, the matrix held in registers across the chip

@@ -220,7 +220,6 @@ class DecodePipeline:
                 entry[1].synchronize()
                 break
         self._prune()
-        viterbi.collect_measurements()
         return indices
 
     def synchronize(self) -> None:
@@ -231,4 +230,3 @@ class DecodePipeline:
         self.pending = []
         for stream in self.streams:
             stream.synchronize()
-        viterbi.collect_measurements()

@@ -1,7 +1,7 @@
 """What the host layer remembers about tensors between calls: ONE store, one lifetime rule.
 
 Several pieces of per-tensor knowledge speed up repeated decodes with one model: the look at the transition matrix's
-structure (banded or not), the measured choice between forward paths (`viterbi._Tuner`), the scan depth a time-resident
+structure (banded or not), the scan depth a time-resident
 launch left behind, the log() / device copy of a caller's transition (`core.from_probabilities`), and which
 preparation a workspace holds (`decode(reuse_preparation=True)`).  All of it hangs off the tensor OBJECT and its
 version counter:
@@ -67,7 +67,7 @@ def peek(tensor) -> Optional[dict]:
 
 
 def every(kind: str):
-    """The notes of kind `kind` of every live tensor (e.g. all path tuners)."""
+    """The notes of kind `kind` of every live tensor."""
     with _lock:
         return [entry[2][kind] for entry in _entries.values() if kind in entry[2]]
 

@@ -57,24 +57,18 @@ def _path_flag(path: str) -> int:
     return (FORWARD_PATHS[path] + 1) << 4
 
 
-def _resolve_path(trans, transition, B, S, device, path, tiles, measure, count=1):
-    """The path name this call passes to the library, and the tuner that wants its timing (or None)."""
+def _resolve_path(trans, transition, B, S, device, path, tiles, count=1):
+    """The path name this call passes to the library."""
     forced = _forced_path if path is None else path
     if forced not in FORWARD_PATHS:
         raise ValueError(f'forward path must be one of {sorted(FORWARD_PATHS)}; got {forced!r}')
     if forced != 'auto':
-        return forced, None
+        return forced
     chosen = _choose_path(trans, transition, B, S)
     banded = chosen == 'dense'
-    tuner = None
-    if chosen == 'pruned' and B >= 32 and measure:
-        # both value-only recurrences are available and nothing is forced: pick by measurement (see _Tuner)
-        tuner = _tuner_for(transition, S, device)
-        if tuner is not None:
-            chosen = tuner.choose()
     cus = compute_units(device)
     group_like = 2 * tiles > cus or (count > 1 and B > 16)
-    single = count == 1 and B > 16 and not banded and (S <= 2048 or 8 * tiles > cus)
+    single = count == 1 and B > 16 and not banded
     if 64 <= S <= 4096 and tiles <= 16384 and (group_like or single):
         # The time-resident kernel (csrc/resident_forward.hpp), whatever the per-timestep choice would be:
         #  * enough items to give more than half the compute units a workgroup of 16 each: whole tiles per workgroup --
@@ -82,9 +76,9 @@ def _resolve_path(trans, transition, B, S, device, path, tiles, measure, count=1
         #    like: 58 M against 32 M timesteps/s for eight batches of peaked rows with the pitch transition);
         #  * a launch group that fills less (the tail of a job, a small job): tiles split over clusters of workgroups
         #    (2 x 512 items: 25.4 us per timestep against 62.7 with whole tiles and 2 x 20.4 one batch after the other);
-        #  * ONE batch of more than 16 items (up to 2048 states; above, only batches beyond one round of the
-        #    per-timestep kernel): clusters -- 12.8 against 14.5 us per timestep at 17 items, 15.6 against 20.2 at 512,
-        #    20.4 against 34.9 at 768 (profiles/r03_cluster_sweep_one_poller.txt) -- except for a narrow band: the dense
+        #  * ONE batch of more than 16 items: clusters -- 12.8 against 14.5 us per timestep at 17 items, 15.6 against 20.2
+        #    at 512, 20.4 against 34.9 at 768 (profiles/r03_cluster_sweep_one_poller.txt), 128 x 2000 x 4096 in 54.2
+        #    against 55.9 ms on the per-timestep kernel (profiles/r03_bench.json) -- except for a narrow band: the dense
         #    kernel's -inf skipping costs by the item (80 pieces of a chunked sequence: 1.9 against 3.0 ms; 512 peaked
         #    rows 8.0 against 8.3 ms), a cluster timestep has a floor of ~12 us however few items it carries;
         # unless the scan statistics of an earlier time-resident launch with this matrix say that hardly anything is
@@ -95,7 +89,7 @@ def _resolve_path(trans, transition, B, S, device, path, tiles, measure, count=1
         if banded or chosen in ('pruned', 'dense'):
             losing = not banded and _resident_is_losing(transition, S, single=not group_like)
             chosen = 'dense' if losing else 'cluster'
-    return chosen, tuner
+    return chosen
 
 
 # fraction of a row's S/16 list blocks per scan above which the dense kernel wins (tools/peaked_group_probe.py at 1440
@@ -270,13 +264,7 @@ def decode(
 
     index = device.index if device.index is not None else torch.cuda.current_device()
     stream = torch.cuda.current_stream(device).cuda_stream
-    chosen, tuner = _resolve_path(trans, transition, B, S, device, path, tiles_of(B, S), _profile is None)
-    if chosen in TIME_RESIDENT:
-        tuner = None                     # the per-timestep tuner has nothing to learn from a time-resident launch
-    begin = None
-    if tuner is not None and not tuner.settled():
-        begin = torch.cuda.Event(enable_timing=True)
-        begin.record(torch.cuda.current_stream(device))
+    chosen = _resolve_path(trans, transition, B, S, device, path, tiles_of(B, S))
     args = (obs.data_ptr(), frames.data_ptr(), trans.data_ptr(), init.data_ptr(),
             indices.data_ptr(), workspace.data_ptr(), workspace.numel(), B, T, S, index,
             ctypes.c_void_p(stream))
@@ -286,18 +274,7 @@ def decode(
     if chosen in TIME_RESIDENT:
         flags |= _seed_flag(transition, S)          # TORBI_HIP_FEW_SEEDS / _MANY_SEEDS once the scan depth is known
     if _profile is None:
-        collect = begin is not None and chosen == 'pruned' and tuner.blocks is None
-        _lib.check(lib.torbi_hip_viterbi_decode_ex(*args, flags | (2 if collect else 0)),      # COLLECT_STATS
-                   'torbi_hip_viterbi_decode_ex')
-        if begin is not None:
-            stats = None
-            if collect:
-                # device -> pinned host, enqueued now and read (without any synchronising call) once `end` is done
-                stats = torch.empty((128,), dtype=torch.int32, pin_memory=True)
-                stats.copy_(scan_stats(workspace, B, T, S), non_blocking=True)
-            end = torch.cuda.Event(enable_timing=True)
-            end.record(torch.cuda.current_stream(device))
-            tuner.launched('pruned' if chosen in TIME_RESIDENT else chosen, begin, end, stats, B * T)
+        _lib.check(lib.torbi_hip_viterbi_decode_ex(*args, flags), 'torbi_hip_viterbi_decode_ex')
     else:
         phases = (ctypes.c_float * 6)()
         _lib.check(lib.torbi_hip_viterbi_decode_profiled(*args, flags, phases),
@@ -434,7 +411,7 @@ def decode_batches(
     stream = torch.cuda.current_stream(device).cuda_stream
     largest = max(B for B, _, _ in shapes)
     tiles = sum(tiles_of(B, S) for B, _, _ in shapes)
-    chosen, _ = _resolve_path(trans, transition, largest, S, device, path, tiles, False, count=count)
+    chosen = _resolve_path(trans, transition, largest, S, device, path, tiles, count=count)
     flags = _path_flag(chosen)
     first = next((k for k, (B, _, _) in enumerate(shapes) if B > 0), 0)
     if _reusable(workspaces[first], transition, (tuple(shapes), chosen, stream), reuse_preparation) \
@@ -458,80 +435,6 @@ def decode_batches(
 
 TIME_RESIDENT = ('resident', 'cluster')       # the two forms of the time-resident kernel (include/torbi_hip.h)
 FORWARD_PATHS = {'auto': 0, 'dense': 1, 'pruned': 2, 'resident': 3, 'cluster': 4, 'held': 5}
-
-
-class _Tuner:
-    """Per transition tensor (and state count): which value-only forward path is faster on the caller's data.
-
-    The pruned pass wins when posteriors and transitions have comparable spread (2x on the benchmark) and loses
-    up to 1.4x to the dense kernel when a handful of states dominate every posterior row or the observations
-    spread far wider than the transitions (tools/peaked_probe.py).  The first decode runs pruned and leaves its
-    scan statistics (torbi_hip_scan_stats); if less than `GATE` of a row's list blocks sat on the critical path
-    the matter is settled.  Otherwise one decode runs on the dense path and from then on the path with the
-    smaller GPU time per timestep (events around each decode, read without blocking once they have completed)
-    is used; every `REPROBE`-th decode tries the other one again.  All paths return identical indices."""
-    GATE = 0.2          # fraction of a row's S/16 list blocks on the critical path below which pruned is kept
-    REPROBE = 64
-
-    def __init__(self, states: int = 1440):
-        self.gate = self.GATE * states / 16.0
-        self.time = {'pruned': None, 'dense': None}      # ms per timestep of the latest completed decode
-        self.blocks = None                               # critical-path blocks of a pruned decode
-        self.pending = []
-        self.count = 0
-
-    def _collect(self):
-        done = [entry for entry in self.pending if entry[2].query()]
-        if self.blocks is None:
-            for entry in done:
-                if entry[3] is not None:
-                    self.blocks = critical_blocks(entry[3])
-                    break
-        if self.settled():
-            self.pending = []            # nothing else to learn; in particular no event timing queries
-            return
-        for path, begin, end, stats, steps in done:
-            self.time[path] = begin.elapsed_time(end) / steps
-        self.pending = [entry for entry in self.pending if entry not in done][-8:]
-
-    def settled(self) -> bool:
-        """Pruning clearly works on this data: nothing more to measure (no events, no statistics copies)."""
-        return self.blocks is not None and self.blocks < self.gate
-
-    def choose(self) -> str:
-        if self.settled():
-            return 'pruned'
-        self._collect()
-        self.count += 1
-        if self.time['pruned'] is None or (self.blocks is not None and self.blocks < self.gate):
-            return 'pruned'
-        if self.time['dense'] is None:
-            return 'pruned' if any(p[0] == 'dense' for p in self.pending) else 'dense'
-        fast, slow = ('pruned', 'dense') if self.time['pruned'] <= self.time['dense'] else ('dense', 'pruned')
-        return slow if self.count % self.REPROBE == 0 else fast
-
-    def launched(self, path, begin, end, stats, steps):
-        self.pending.append((path, begin, end, stats, steps))
-
-
-def collect_measurements() -> None:
-    """Fold completed decodes into the path tuners now (DecodePipeline calls this whenever it has waited for the
-    device anyway, so the bookkeeping does not land at the start of the next decode)."""
-    for tuner in state.every('tuner'):
-        if not tuner.settled():
-            tuner._collect()
-
-
-def _tuner_for(transition: torch.Tensor, states: int, device) -> Optional[_Tuner]:
-    """The path tuner of this transition tensor (object and version): it lives as long as the tensor does."""
-    kept = state.notes(transition)
-    if kept is None:
-        return None              # no identity to key measurements on (inference tensor): keep the default path
-    tuner = kept.get('tuner')
-    if tuner is None or kept.get('tuner_states') != states:
-        tuner = kept['tuner'] = _Tuner(states)
-        kept['tuner_states'] = states
-    return tuner
 
 
 _forced_path = {'d': 'dense', 'p': 'pruned', 'r': 'resident', 'c': 'cluster', 'h': 'held'}.get(os.environ.get('TORBI_HIP_FORWARD', 'a')[:1], 'auto')
