@@ -216,6 +216,24 @@ def test_held_matrix_kernel_equals_the_oracle(shape, kind, forward):
     assert np.array_equal(post.view(np.uint32), want_post.view(np.uint32))
 
 
+@pytest.mark.parametrize('path', ['dense', 'held'])
+@pytest.mark.parametrize('T', [129, 160, 161, 257, 500])
+def test_parallel_chase_of_long_sequences(T, path, forward):
+    """The backpointer chase of a handful of long sequences runs as three short launches (chunk maps for every state,
+    boundary states, chunk interiors; torbi_hip.hip chase_*_kernel) from 129 frames on: lengths on and next to every
+    chunk boundary, length 1 and 2, under the per-timestep trellis kernels and the held-matrix kernel."""
+    if forward != 'auto':
+        pytest.skip('names its paths itself')
+    B, S = 12, 96
+    obs, trans, init = synth.problem(B, T, S, seed=T)
+    frames = np.array([T, 1, 2, 31, 32, 33, 64, 65, T - 1, 96, 97, (T // 32) * 32], dtype=np.int32)
+    dev = torch.device('cuda:0')
+    args = [torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)]
+    want = oracle.decode(obs, frames, trans, init)
+    got = torbi_amd.decode(*args, path=path)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize('shape', [(2, 3000, 360), (1, 1500, 1440), (3, 700, 2050)])
 def test_held_matrix_kernel_over_many_timesteps(shape, forward):
     """Thousands of hand-offs in one launch (two parities of {value, timestep} words, every workgroup waiting for all the

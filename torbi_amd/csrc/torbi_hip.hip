@@ -316,6 +316,92 @@ __global__ __launch_bounds__(64) void finalize_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The chase in parallel (a handful of long sequences: one lane following 500 dependent loads at ~265 ns each is 0.13 ms,
+// an eighth of a whole batch-of-one decode).  A backpointer row is a function S -> S and the path is their composition
+// applied to the final state, so the timesteps are cut into chunks of kChaseChunk:
+//   chase_maps_kernel     every chunk at once, every state at once: where does a path that is in state s at the chunk's
+//                         upper end stand at its lower end (kChaseChunk dependent lookups, all rows L1/L2-resident);
+//   chase_entries_kernel  one wave per item: final argmax + tail fill as in finalize_kernel, the top partial chunk
+//                         directly, then chunk map after chunk map: the state at every chunk boundary;
+//   chase_chunks_kernel   every chunk at once: the path inside the chunk from its upper boundary state.
+// Three short launches instead of T dependent loads: 1 x 500 x 1440 in ~40 us instead of 132 us.  Same indices.
+// ---------------------------------------------------------------------------------------
+constexpr int kChaseChunk = 32;
+constexpr int kChaseMinSteps = 128;        // below this the plain chase is as fast
+inline int chase_chunks(int T) { return (T - 1 + kChaseChunk - 1) / kChaseChunk; }
+
+__device__ __forceinline__ int clamped_frames(const int32_t *frames, int b, int T) {
+    const int f = frames[b];
+    return f < 1 ? 1 : (f > T ? T : f);
+}
+
+// grid = (chunks, B, ceil(S / 256)), block = 256: maps[b][k][s] = state at time k * C of the path that is in s at time (k + 1) * C
+__global__ __launch_bounds__(256) void chase_maps_kernel(const int32_t *__restrict__ frames, const int32_t *__restrict__ trellis,
+                                                         int32_t *__restrict__ maps, int B, int T, int S, int chunks) {
+    const int k = blockIdx.x, b = blockIdx.y;
+    const int s = blockIdx.z * 256 + threadIdx.x;
+    const int last = clamped_frames(frames, b, T) - 1;          // the path ends at time `last`
+    const int hi = (k + 1) * kChaseChunk;
+    if (hi > last || s >= S) return;                            // only chunks the path crosses completely
+    const int32_t *tr = trellis + (size_t)b * T * S;
+    int idx = s;
+    for (int t = hi; t > k * kChaseChunk; --t) idx = tr[(size_t)t * S + idx];
+    maps[((size_t)b * chunks + k) * S + s] = idx;
+}
+
+// grid = B, block = 64
+__global__ __launch_bounds__(64) void chase_entries_kernel(const float *__restrict__ post0, const float *__restrict__ post1,
+                                                           const int32_t *__restrict__ frames, const int32_t *__restrict__ trellis,
+                                                           const int32_t *__restrict__ maps, int32_t *__restrict__ entries,
+                                                           int32_t *__restrict__ out, int B, int T, int S, int chunks) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int f = clamped_frames(frames, b, T);
+    const float *post = (((f - 1) & 1) ? post1 : post0) + (size_t)b * S;
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int i = lane; i < S; i += kWave) {
+        const float v = post[i];
+        if (v > best) { best = v; arg = i; }
+        else if (arg == 0x7fffffff) { arg = i; best = v; }
+    }
+    wave_argmax(best, arg);
+    const int fin = __shfl(arg, 0, kWave);
+    int32_t *o = out + (size_t)b * T;
+    for (int tt = f - 1 + lane; tt < T; tt += kWave) o[tt] = fin;
+    if (lane == 0) {
+        const int32_t *tr = trellis + (size_t)b * T * S;
+        const int last = f - 1;
+        const int k0 = last / kChaseChunk;                      // complete chunks below the path's end: 0 .. k0 - 1
+        int idx = fin;
+        for (int tt = last; tt > k0 * kChaseChunk; --tt) {      // the partial chunk at the top, directly
+            idx = tr[(size_t)tt * S + idx];
+            o[tt - 1] = idx;
+        }
+        for (int k = k0 - 1; k >= 0; --k) {                     // idx = state at time (k + 1) * C
+            entries[(size_t)b * chunks + k] = idx;
+            idx = maps[((size_t)b * chunks + k) * S + idx];
+            o[k * kChaseChunk] = idx;
+        }
+    }
+}
+
+// grid = (chunks, B), block = 64: the path inside chunk k from its upper boundary state
+__global__ __launch_bounds__(64) void chase_chunks_kernel(const int32_t *__restrict__ frames, const int32_t *__restrict__ trellis,
+                                                          const int32_t *__restrict__ entries, int32_t *__restrict__ out,
+                                                          int B, int T, int S, int chunks) {
+    const int k = blockIdx.x, b = blockIdx.y;
+    const int last = clamped_frames(frames, b, T) - 1;
+    if ((k + 1) * kChaseChunk > last || threadIdx.x != 0) return;
+    const int32_t *tr = trellis + (size_t)b * T * S;
+    int32_t *o = out + (size_t)b * T;
+    int idx = entries[(size_t)b * chunks + k];
+    for (int t = (k + 1) * kChaseChunk; t > k * kChaseChunk + 1; --t) {
+        idx = tr[(size_t)t * S + idx];
+        o[t - 1] = idx;
+    }
+}
+
 // final posterior rows of the last decode, whatever path it took (route record): the generic path keeps them in its
 // ping-pong buffers, every value-only path as row frames-1 of the history at the start of the workspace
 __global__ __launch_bounds__(256) void gather_final_kernel(const int32_t *__restrict__ route, const float *__restrict__ hist,
@@ -548,6 +634,8 @@ struct Workspace {
     int32_t *trellis;   // (B,T,S) backpointers; rows t >= 1 of valid frames are written
     held::u64 *xchg;    // [2][B][S] {posterior, timestep} words of the held-matrix kernel (B <= 16, S <= 2048), else null
     unsigned *control;  // [64] its control words ([1]: workgroups that gave up waiting)
+    int32_t *maps;      // [B][chunks][S] chunk maps of the parallel chase (B <= 16, S <= 4096, T >= 129), else null
+    int32_t *entries;   // [B][chunks]    the path's state at every chunk boundary
     size_t bytes;
 };
 
@@ -565,6 +653,15 @@ inline Workspace carve(void *base, int B, int T, int S) {
         w.control = reinterpret_cast<unsigned *>(p + w.bytes);
         w.xchg = reinterpret_cast<held::u64 *>(p + w.bytes + 256);
         w.bytes += 256 + align_up(held::exchange_bytes(B, S), 256);
+    }
+    w.maps = nullptr;
+    w.entries = nullptr;
+    if (B <= held::kMaxB && S <= held::kMaxS && T - 1 >= kChaseMinSteps) {
+        const size_t chunks = (size_t)chase_chunks(T);
+        w.maps = reinterpret_cast<int32_t *>(p + w.bytes);
+        w.bytes += align_up(sizeof(int32_t) * (size_t)B * chunks * S, 256);
+        w.entries = reinterpret_cast<int32_t *>(p + w.bytes);
+        w.bytes += align_up(sizeof(int32_t) * (size_t)B * chunks, 256);
     }
     return w;
 }
@@ -856,6 +953,16 @@ hipError_t launch_held_forward(const float *obs, const int32_t *frames, const fl
 
 hipError_t launch_finalize(const int32_t *frames, const Workspace &w, int32_t *out, int B, int T,
                            int S, hipStream_t stream) {
+    if (w.maps) {        // a handful of long sequences: the chase in parallel (chase_*_kernel above)
+        const int chunks = chase_chunks(T);
+        hipLaunchKernelGGL(chase_maps_kernel, dim3(chunks, B, (S + 255) / 256), dim3(256), 0, stream, frames, w.trellis, w.maps,
+                           B, T, S, chunks);
+        hipLaunchKernelGGL(chase_entries_kernel, dim3(B), dim3(64), 0, stream, w.post[0], w.post[1], frames, w.trellis, w.maps,
+                           w.entries, out, B, T, S, chunks);
+        hipLaunchKernelGGL(chase_chunks_kernel, dim3(chunks, B), dim3(64), 0, stream, frames, w.trellis, w.entries, out,
+                           B, T, S, chunks);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(64), 0, stream, w.post[0], w.post[1],
                        frames, w.trellis, out, B, T, S);
     return hipGetLastError();
