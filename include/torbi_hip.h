@@ -204,7 +204,10 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
  *     stats_out[64..127] number of (timestep, tile) pairs counted (every 8th timestep is sampled)
  *   RESIDENT (always collected; `workspace` = the FIRST batch's workspace of the launch group):
  *     stats_out[0]       list blocks walked by the sampled wave passes (every 16th timestep)
- *     stats_out[64]      wave passes counted;            the other entries are zero
+ *     stats_out[64]      wave passes counted
+ *     stats_out[127]     (CLUSTER) workgroups that gave up waiting for their cluster; 0 on any sane run
+ *   HELD: stats_out[127] = workgroups that ran out of polls (the launch could not be resident as a whole); the decode
+ *                        was then redone by the repair kernel and its results are correct.  0 on any sane run.
  * sum(first half) / sum(second half) = list blocks per scan: about 11 of the S/16 = 90 on the 1440-state benchmark;
  * near S/16 nothing is being pruned and the dense path is faster.  TORBI_HIP_EUNSUPPORTED when the shape takes
  * neither path.
