@@ -220,7 +220,7 @@ __device__ __forceinline__ void backtrace_sorted_item(const float *__restrict__ 
                                                       int lane, float *__restrict__ hrow) {
     f = f < 1 ? 1 : (f > T ? T : f);
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 cur[NQ], nxt[NQ];
+    float4 nxt[NQ];
     auto load_row = [&](float4 (&dst)[NQ], int r) {
         const float *row = h + (size_t)r * S;
 #pragma unroll
@@ -229,10 +229,11 @@ __device__ __forceinline__ void backtrace_sorted_item(const float *__restrict__ 
             dst[q] = i < S ? *reinterpret_cast<const float4 *>(row + i) : zero;
         }
     };
-    load_row(cur, f - 1);
-    load_row(nxt, f >= 2 ? f - 2 : 0);
+    load_row(nxt, f - 1);
     // final state = first argmax of the last posterior row (viterbi.cpp:218)
-    int j = wave_first_argmax4<NQ>(cur, lane, S);
+    int j = wave_first_argmax4<NQ>(nxt, lane, S);
+    asm volatile("" : "+v"(j));                              // (the row below is requested behind the argmax: one row live)
+    load_row(nxt, f >= 2 ? f - 2 : 0);
     // every position t >= frames-1 holds the final state (viterbi.cpp:219-221)
     for (int tt = f - 1 + lane; tt < T; tt += 64) o[tt] = j;
     const int Sp = (S + 15) / 16 * 16;
@@ -241,16 +242,16 @@ __device__ __forceinline__ void backtrace_sorted_item(const float *__restrict__ 
         // the list of the state just resolved (depends on j): first chunk on its way ...
         const float2 *row = sorted + (size_t)j * SpP;
         float2 ent = row[lane];
-        // ... while posterior row tt-1 (already in registers) goes to the LDS and row tt-2 is requested
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) cur[q] = nxt[q];
-        load_row(nxt, tt >= 2 ? tt - 2 : 0);
+        // ... while posterior row tt-1 (already in registers) goes to the LDS; row tt-2 is requested behind it, into the
+        // same registers (one row live, not two: 42 registers instead of 61, so the kernel fits beside the three
+        // 152-register forward waves per SIMD of the next launch group; DESIGN.md 4.12 for what that is worth)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int i = 4 * lane + 256 * q;
-            if (i < S) *reinterpret_cast<float4 *>(hrow + i) = cur[q];
+            if (i < S) *reinterpret_cast<float4 *>(hrow + i) = nxt[q];
         }
-        const float hmax = wavered::wave_reduce_f32(lane_max<NQ>(cur, lane, S), wavered::MaxOp());
+        const float hmax = wavered::wave_reduce_f32(lane_max<NQ>(nxt, lane, S), wavered::MaxOp());
+        load_row(nxt, tt >= 2 ? tt - 2 : 0);
         float bv = -INFINITY;
         int bi = kSentinel;
         float best = -INFINITY;
