@@ -276,6 +276,60 @@ __device__ __forceinline__ void backtrace_sorted_item(const float *__restrict__ 
     }
 }
 
+// The same walk without staging posterior rows: the posteriors the list chunk points at are gathered straight from the
+// history (64 four-byte reads touch ~46 of a 1440-state row's 90 sectors; staging reads all of them), and the row maximum
+// the bound needs comes from `rowmax`, which the time-resident forward kernel leaves behind for every row.  A step is two
+// dependent loads (list chunk, then posteriors) instead of one -- and still the faster form from one 512-item batch (0.58
+// against 0.80 ms) to a launch group of eight (1.86 against 3.11 ms: 4096 paths move 11.8 GB through row staging).
+template <int NQ>
+__device__ __forceinline__ void backtrace_gather_item(const float *__restrict__ h, const float *__restrict__ rowmax,
+                                                      const float2 *__restrict__ sorted, int SpP, int shift, int f,
+                                                      int32_t *__restrict__ o, int T, int S, int lane) {
+    f = f < 1 ? 1 : (f > T ? T : f);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    int j;
+    {
+        float4 last[NQ];
+        const float *row = h + (size_t)(f - 1) * S;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = 4 * lane + 256 * q;
+            last[q] = i < S ? *reinterpret_cast<const float4 *>(row + i) : zero;
+        }
+        j = wave_first_argmax4<NQ>(last, lane, S);       // final state = first argmax of the last posterior row
+    }
+    for (int tt = f - 1 + lane; tt < T; tt += 64) o[tt] = j;
+    const int Sp = (S + 15) / 16 * 16;
+    float hmax_next = f >= 2 ? rowmax[f - 2] : 0.0f;
+    for (int tt = f - 1; tt >= 1; --tt) {
+        const float2 *row = sorted + (size_t)j * SpP;
+        float2 ent = row[lane];
+        const float hmax = hmax_next;
+        if (tt >= 2) hmax_next = rowmax[tt - 2];             // (independent of the path: asked for a step ahead)
+        const float *hrow = h + (size_t)(tt - 1) * S;
+        float bv = -INFINITY;
+        int bi = kSentinel;
+        float best = -INFINITY;
+        for (int k0 = 0; k0 < Sp; k0 += 64) {
+            const int kn = k0 + 64 + lane;
+            const float2 ahead = row[kn < SpP ? kn : SpP - 1];
+            if (k0 + lane < Sp) {
+                const int i = __float_as_int(ent.y) >> shift;
+                const float c = hrow[i] + ent.x;
+                if (c > bv || (c == bv && i < bi)) { bv = c; bi = i; }
+            }
+            best = wavered::wave_reduce_f32(bv, wavered::MaxOp());
+            const float tn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__float_as_int(ahead.x)));
+            ent = ahead;
+            if (k0 + 64 >= Sp || tn + hmax < best) break;
+        }
+        const int cand = (bv == best && bi != kSentinel) ? bi : kSentinel;
+        const int win = wavered::wave_min_i32(cand);
+        j = best == -INFINITY ? 0 : win;
+        if (lane == 0) o[tt - 1] = j;
+    }
+}
+
 template <int NQ>
 __global__ __launch_bounds__(64) void backtrace_sorted_kernel(const float *__restrict__ hist,
                                                               const float2 *__restrict__ sorted, int SpP, int shift,

@@ -54,6 +54,7 @@ struct Batch {
     float *hist;             // (B,T,S) posterior history of this batch
     int32_t *out;            // (B,T) decoded indices (backtrace)
     const int32_t *order;    // (B) items by descending length: tile k owns items order[16k .. 16k+15]
+    float *rowmax;           // (B,T) largest entry of every posterior row (the gather form of the backtrace bounds with it)
     int B, T;
     int tile0;               // first workgroup of this batch in the launch
     int item0;               // first item of this batch in the launch-wide item numbering (backtrace grid)
@@ -417,18 +418,23 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
 
     // publish the largest entries of the row the tile holds (decoded; states as offsets into tt) and empty the
     // running lists for the next row's outputs
-    auto publish_top = [&]() {
+    // (`row`: the timestep of the row the tile holds; its maximum goes to bat.rowmax for the backtrace, once per cluster)
+    auto publish_top = [&](int row) {
         if (tid < kNI * kTop) {
             const u64 key = top[tid];
             unsigned u = (unsigned)(key >> 32);
             u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;
-            mtopv[tid] = key ? __uint_as_float(u) : -INFINITY;
+            const float value = key ? __uint_as_float(u) : -INFINITY;
+            mtopv[tid] = value;
             mtopi[tid] = key ? (0x7fffffff - (int)(unsigned)key) * S : 0;
             top[tid] = 0ull;
+            const int item = tid / kTop;
+            if (tid == item * kTop && member == 0 && b0 + item < B && row < sframes[item])
+                bat.rowmax[(size_t)sitem[item] * T + row] = value;
         }
     };
     __syncthreads();
-    publish_top();
+    publish_top(0);
 #ifdef RESIDENT_STAMP
     unsigned long long acc[kPhases] = {};
     unsigned long long last = __builtin_readcyclecounter();
@@ -750,7 +756,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                 if (smisc[1]) break;  // (uniform: read behind the barrier)
             }
         }
-        publish_top();
+        publish_top(t);
         RSTAMP(6);
     }
     if constexpr (CLUSTER) {
@@ -800,6 +806,17 @@ __global__ __launch_bounds__(64) void group_backtrace_sorted_kernel(Group grp, c
     // (list offsets = state * bytes of a tile row: 64 with 16-item tiles, 32 with 8-item tiles)
     lazy::backtrace_sorted_item<NQ>(bat.hist + (size_t)b * bat.T * S, sorted, SpP, tile_items(S) == kNI ? 6 : 5,
                                     bat.frames[b], bat.out + (size_t)b * bat.T, bat.T, S, threadIdx.x, hrow_lds);
+}
+
+// the same with the posteriors gathered from the history where the list points (no row staging): for launches with many
+// waves per compute unit, which are bound by the bytes they move, not by the latency of a step (lazy_backtrace.hpp)
+template <int NQ>
+__global__ __launch_bounds__(64) void group_backtrace_gather_kernel(Group grp, const float2 *__restrict__ sorted, int SpP, int S) {
+    const Batch &bat = grp.batch[batch_of_item(grp, blockIdx.x)];
+    const int b = (int)blockIdx.x - bat.item0;
+    lazy::backtrace_gather_item<NQ>(bat.hist + (size_t)b * bat.T * S, bat.rowmax + (size_t)b * bat.T, sorted, SpP,
+                                    tile_items(S) == kNI ? 6 : 5, bat.frames[b], bat.out + (size_t)b * bat.T, bat.T, S,
+                                    threadIdx.x);
 }
 
 template <int VEC>

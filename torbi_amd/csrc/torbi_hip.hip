@@ -713,6 +713,7 @@ struct ResidentWorkspace {
     float *tt;
     int32_t *row_range;
     int32_t *order;       // [B] this batch's items by descending length
+    float *rowmax;        // [B][T] largest entry of every posterior row (left by the forward kernel for the backtrace)
     int32_t *lengths_hist;  // [T + 2] items per length (batches above resident::kMaxOrdered items only, else null)
     size_t lengths_hist_bytes;
     int32_t *tile_map;    // [kMaxGroupTiles] workgroup -> tile of the launch group (first batch's workspace)
@@ -749,13 +750,16 @@ inline ResidentWorkspace carve_resident(void *base, int B, int T, int S, int cus
     w.lengths_hist_bytes = hist_len;
     w.lengths_hist = hist_len ? reinterpret_cast<int32_t *>(p + order_bytes - hist_len) : nullptr;
     p += order_bytes;
+    const size_t rowmax_bytes = align_up(sizeof(float) * (size_t)B * T, 256);
+    w.rowmax = reinterpret_cast<float *>(p);
+    p += rowmax_bytes;
     w.sorted = reinterpret_cast<float2 *>(p);
     w.tt = reinterpret_cast<float *>(p + sorted_bytes);
     w.row_range = reinterpret_cast<int32_t *>(p + sorted_bytes + tt_bytes);
     p += sorted_bytes + tt_bytes + range_bytes;
     w.xchg = reinterpret_cast<float *>(p);
     w.flags = reinterpret_cast<unsigned *>(p + xchg_bytes);
-    w.bytes = hist_bytes + order_bytes + sorted_bytes + tt_bytes + range_bytes + xchg_bytes + w.flag_bytes;
+    w.bytes = hist_bytes + order_bytes + rowmax_bytes + sorted_bytes + tt_bytes + range_bytes + xchg_bytes + w.flag_bytes;
     return w;
 }
 
@@ -1209,6 +1213,7 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
         b.out = hb[k].out;
         b.hist = wk.hist;
         b.order = wk.order;
+        b.rowmax = wk.rowmax;
         jobs.job[k] = resident::OrderJob{hb[k].frames, wk.order, hb[k].B, hb[k].T, tiles, wk.lengths_hist, nullptr, 0};
         widest = std::max(widest, hb[k].B);
         b.B = hb[k].B;
@@ -1276,7 +1281,23 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
     if (e != hipSuccess) return e;
     const bool vec = (S % 4 == 0) && ((reinterpret_cast<uintptr_t>(trans) & 15) == 0);
     const size_t row_lds = sizeof(float) * (size_t)S;
-    if (S % 4 == 0 && backtrace_sorted_enabled()) {
+    // the backtrace gathers the posteriors the lists point at instead of staging whole rows in the LDS: half the bytes, and
+    // faster from one batch (0.58 against 0.80 ms) to eight (1.86 against 3.11 ms; tools/backtrace_probe.py,
+    // profiles/r03_backtrace_gather.txt).  TORBI_HIP_BACKTRACE_GATHER=0 brings the staging form back.
+    static const bool gather = [] {
+        const char *e = getenv("TORBI_HIP_BACKTRACE_GATHER");
+        return !e || atoi(e) != 0;
+    }();
+    if (S % 4 == 0 && backtrace_sorted_enabled() && gather) {
+        if (S <= 512)
+            hipLaunchKernelGGL(resident::group_backtrace_gather_kernel<2>, dim3(items), dim3(64), 0, s, grp, w.sorted, w.SpP, S);
+        else if (S <= 1536)
+            hipLaunchKernelGGL(resident::group_backtrace_gather_kernel<6>, dim3(items), dim3(64), 0, s, grp, w.sorted, w.SpP, S);
+        else if (S <= 2048)
+            hipLaunchKernelGGL(resident::group_backtrace_gather_kernel<8>, dim3(items), dim3(64), 0, s, grp, w.sorted, w.SpP, S);
+        else
+            hipLaunchKernelGGL(resident::group_backtrace_gather_kernel<16>, dim3(items), dim3(64), 0, s, grp, w.sorted, w.SpP, S);
+    } else if (S % 4 == 0 && backtrace_sorted_enabled()) {
         if (S <= 512)
             hipLaunchKernelGGL(resident::group_backtrace_sorted_kernel<2>, dim3(items), dim3(64), row_lds, s, grp,
                                w.sorted, w.SpP, S);
