@@ -311,17 +311,19 @@ __device__ __forceinline__ void backtrace_gather_item(const float *__restrict__ 
         int bi = kSentinel;
         float best = -INFINITY;
         for (int k0 = 0; k0 < Sp; k0 += 64) {
-            const int kn = k0 + 64 + lane;
-            const float2 ahead = row[kn < SpP ? kn : SpP - 1];
+            // only the FIRST entry of the next chunk is needed to bound the rest of the list (one 8-byte read for the wave
+            // instead of a 512-byte chunk that one step in ten goes on to use)
+            const int kn = k0 + 64 < SpP ? k0 + 64 : SpP - 1;
+            const float tn = row[kn].x;
             if (k0 + lane < Sp) {
                 const int i = __float_as_int(ent.y) >> shift;
                 const float c = hrow[i] + ent.x;
                 if (c > bv || (c == bv && i < bi)) { bv = c; bi = i; }
             }
             best = wavered::wave_reduce_f32(bv, wavered::MaxOp());
-            const float tn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__float_as_int(ahead.x)));
-            ent = ahead;
             if (k0 + 64 >= Sp || tn + hmax < best) break;
+            const int kl = k0 + 64 + lane;
+            ent = row[kl < SpP ? kl : SpP - 1];
         }
         const int cand = (bv == best && bi != kSentinel) ? bi : kSentinel;
         const int win = wavered::wave_min_i32(cand);
