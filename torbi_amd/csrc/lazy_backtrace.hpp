@@ -343,4 +343,14 @@ __global__ __launch_bounds__(64) void backtrace_sorted_kernel(const float *__res
                               threadIdx.x, hrow_lds);
 }
 
+template <int NQ>
+__global__ __launch_bounds__(64) void backtrace_gather_kernel(const float *__restrict__ hist, const float *__restrict__ rowmax,
+                                                              const float2 *__restrict__ sorted, int SpP, int shift,
+                                                              const int32_t *__restrict__ frames, int32_t *__restrict__ out,
+                                                              int B, int T, int S) {
+    const int b = blockIdx.x;
+    backtrace_gather_item<NQ>(hist + (size_t)b * T * S, rowmax + (size_t)b * T, sorted, SpP, shift, frames[b],
+                              out + (size_t)b * T, T, S, threadIdx.x);
+}
+
 }  // namespace lazy

@@ -29,12 +29,14 @@ inline bool supported(int B, int S) { return B >= 1 && B <= 16 && S >= 64 && S <
 // 7.5 ms; B = 8, S = 4096: 14.9 vs 28.1 ms.  AUTO takes the kernel there; TORBI_HIP_FORWARD_PRUNED names it for any B <= 16.
 inline bool profitable(int B, int S) { return supported(B, S) && (S > 2048 || B >= 8); }
 
-// One timestep of every item.  grid = (ceil(S / 4), B), block = 256, dynamic LDS = 4 * S bytes.
+// One timestep of every item.  grid = (ceil(S / 4), B), block = 256, dynamic LDS = 4 * S bytes.  Leaves the maximum of
+// posterior row t-1 in rowmax[b][t-1].
 // List entries are {t, prev-state << shift} (sort_rows_kernel with row_bytes = 1 << shift).
 __global__ __launch_bounds__(256) void step_rows_sorted_kernel(const float *__restrict__ obs,
                                                                const int32_t *__restrict__ frames,
                                                                const float2 *__restrict__ sorted, float *__restrict__ hist,
-                                                               int B, int T, int S, int t, int SpP, int shift) {
+                                                               float *__restrict__ rowmax, int B, int T, int S, int t,
+                                                               int SpP, int shift) {
     extern __shared__ __attribute__((aligned(16))) float prow[];
     __shared__ float xmax[kRowsPerBlock];
     const int b = blockIdx.y;
@@ -62,6 +64,7 @@ __global__ __launch_bounds__(256) void step_rows_sorted_kernel(const float *__re
     if (lane == 0) xmax[wave] = wm;
     __syncthreads();
     const float pmax = __builtin_fmaxf(__builtin_fmaxf(xmax[0], xmax[1]), __builtin_fmaxf(xmax[2], xmax[3]));
+    if (blockIdx.x == 0 && tid == 0) rowmax[(size_t)b * T + t - 1] = pmax;        // for the backtrace's bound (lazy_backtrace.hpp)
 
     const int Sp = (S + 15) / 16 * 16;
     float bv = -INFINITY, best = -INFINITY;

@@ -768,6 +768,7 @@ struct RowsWorkspace {
     float *hist;
     float2 *sorted;
     int32_t *row_range;
+    float *rowmax;     // [B][T] largest entry of every posterior row (step_rows_sorted_kernel leaves it for the backtrace)
     int SpP, NPOW;
     size_t bytes;
 };
@@ -784,7 +785,9 @@ inline RowsWorkspace carve_rows(void *base, int B, int T, int S) {
     p += history_bytes(B, T, S);
     w.sorted = reinterpret_cast<float2 *>(p);
     w.row_range = reinterpret_cast<int32_t *>(p + sorted_bytes);
-    w.bytes = history_bytes(B, T, S) + sorted_bytes + align_up(sizeof(int32_t) * 2 * (size_t)S, 256);
+    const size_t range_bytes = align_up(sizeof(int32_t) * 2 * (size_t)S, 256);
+    w.rowmax = reinterpret_cast<float *>(p + sorted_bytes + range_bytes);
+    w.bytes = history_bytes(B, T, S) + sorted_bytes + range_bytes + align_up(sizeof(float) * (size_t)B * T, 256);
     return w;
 }
 
@@ -1129,13 +1132,31 @@ inline bool backtrace_sorted_enabled() {
     return v;
 }
 
+// (`rowmax`: the row maxima the forward pass left, or null: with them the walk gathers instead of staging rows)
 hipError_t launch_backtrace_sorted(const float *hist, const float2 *sorted, int SpP, int items_per_tile,
                                    const float *trans, const int32_t *frames, int32_t *out, int B, int T, int S,
-                                   hipStream_t stream) {
+                                   hipStream_t stream, const float *rowmax = nullptr) {
     if (!backtrace_sorted_enabled() || S % 4 != 0 || S > 256 * 16)
         return launch_backtrace_on(hist, trans, frames, out, B, T, S, stream);
     const int shift = items_per_tile == pruned::kNB ? 6 : 5;      // list offsets = prev-state * 4 * items per tile
     const size_t lds = sizeof(float) * (size_t)S;
+    static const bool gather = [] {
+        const char *e = getenv("TORBI_HIP_BACKTRACE_GATHER");
+        return !e || atoi(e) != 0;
+    }();
+    if (rowmax && gather) {
+#define TORBI_BTG_CASE(NQ_)                                                                                     \
+        if (S <= 256 * NQ_) {                                                                                   \
+            hipLaunchKernelGGL(lazy::backtrace_gather_kernel<NQ_>, dim3(B), dim3(64), 0, stream, hist, rowmax, sorted, \
+                               SpP, shift, frames, out, B, T, S);                                               \
+            return hipGetLastError();                                                                           \
+        }
+        TORBI_BTG_CASE(2)
+        TORBI_BTG_CASE(6)
+        TORBI_BTG_CASE(8)
+        TORBI_BTG_CASE(16)
+#undef TORBI_BTG_CASE
+    }
 #define TORBI_BTS_CASE(NQ_)                                                                              \
     if (S <= 256 * NQ_) {                                                                                \
         hipLaunchKernelGGL(lazy::backtrace_sorted_kernel<NQ_>, dim3(B), dim3(64), lds, stream, hist, sorted, SpP, \
@@ -1365,12 +1386,12 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
         for (int t = 1; t < T; ++t, ++n)
             hipLaunchKernelGGL(rowscan::step_rows_sorted_kernel,
                                dim3((S + rowscan::kRowsPerBlock - 1) / rowscan::kRowsPerBlock, B), dim3(256),
-                               sizeof(float) * (size_t)S, s, obs, frames, w.sorted, w.hist, B, T, S, t, w.SpP, 6);
+                               sizeof(float) * (size_t)S, s, obs, frames, w.sorted, w.hist, w.rowmax, B, T, S, t, w.SpP, 6);
         if (launches) *launches = n;
         e = hipGetLastError();
         if (ev) (void)hipEventRecord(ev[1], s);
         if (e == hipSuccess)
-            e = launch_backtrace_sorted(w.hist, w.sorted, w.SpP, pruned::kNB, trans, frames, out, B, T, S, s);
+            e = launch_backtrace_sorted(w.hist, w.sorted, w.SpP, pruned::kNB, trans, frames, out, B, T, S, s, w.rowmax);
     } else {
         const Workspace w = carve(workspace, B, T, S);
         e = route == ROUTE_HELD ? launch_held_forward(obs, frames, trans, init, w, B, T, S, s, launches)
