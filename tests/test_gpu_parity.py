@@ -105,6 +105,31 @@ def test_dense_path_skips_minus_inf_blocks_exactly(kind, shape):
     assert np.array_equal(gpu_decode(obs, frames, trans, init), want)
 
 
+@pytest.mark.parametrize('width', [1, 7, 254, 255, 256, 257, 300])
+def test_dense_route_backtrace_reads_the_band_only(width, forward):
+    """On the dense route the backtrace of a banded matrix reads a row's finite range only (a window of up to 512
+    prev-states, lazy::backtrace_ranged_kernel); a matrix with a wider row goes through the whole-row kernel -- decided on
+    the device.  Half widths that put the widest row below, on and above the window, rows cut off by the matrix edge, a
+    row without any finite entry, ties inside the band."""
+    if forward != 'auto':
+        pytest.skip('names its path itself')
+    B, T, S = 40, 7, 1440
+    obs, trans, init = synth.problem(B, T, S, seed=width)
+    obs = np.round(obs * 2) / 2
+    trans = np.round(trans * 2) / 2
+    idx = np.arange(S)
+    trans = np.where(np.abs(idx[:, None] - idx[None, :]) < width, trans, -np.inf).astype(np.float32)
+    trans[S // 3] = -np.inf                                       # a next-state nothing leads to
+    frames = np.clip(synth.lengths(B, 1, T, seed=2), 1, T).astype(np.int32)
+    frames[0] = T
+    dev = torch.device('cuda:0')
+    args = [torch.as_tensor(np.ascontiguousarray(x)).to(dev) for x in (obs.astype(np.float32), frames, trans, init)]
+    want = oracle.decode(obs.astype(np.float32), frames, trans, init)
+    for _ in range(2):                                            # the second call finds the row ranges in the workspace
+        got = torbi_amd.decode(*args, path='dense')
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize('shape', [(3, 40, 1440), (70, 9, 360), (5, 1, 64), (2, 33, 4096), (9, 7, 132),
                                    (4, 6, 63), (130, 5, 256)])
 @pytest.mark.parametrize('ties', [False, True])

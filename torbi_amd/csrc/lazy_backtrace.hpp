@@ -190,11 +190,15 @@ __device__ __forceinline__ void backtrace_prefetch_item(const float *__restrict_
     }
 }
 
+// (`narrow`: null, or the widest row window of the matrix as row_ranges_kernel left it -- at most kRangedWindow means
+// backtrace_ranged_kernel decodes this launch and this kernel has nothing to do)
 template <int NQ>
 __global__ __launch_bounds__(64) void backtrace_prefetch_kernel(const float *__restrict__ hist,
                                                                 const float *__restrict__ trans,
                                                                 const int32_t *__restrict__ frames,
-                                                                int32_t *__restrict__ out, int B, int T, int S) {
+                                                                int32_t *__restrict__ out, int B, int T, int S,
+                                                                const int32_t *__restrict__ narrow) {
+    if (narrow && *narrow <= 512) return;
     const int b = blockIdx.x;
     backtrace_prefetch_item<NQ>(hist + (size_t)b * T * S, trans, frames[b], out + (size_t)b * T, T, S, threadIdx.x);
 }
@@ -351,6 +355,101 @@ __global__ __launch_bounds__(64) void backtrace_gather_kernel(const float *__res
     const int b = blockIdx.x;
     backtrace_gather_item<NQ>(hist + (size_t)b * T * S, rowmax + (size_t)b * T, sorted, SpP, shift, frames[b],
                               out + (size_t)b * T, T, S, threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------
+// Banded matrices (the dense route's usual guest: the reference's pitch model reaches 87 states either way): outside a
+// row's finite range [lo, hi) every candidate is -inf, so the path step reads the range of the transition row and of
+// the posterior row -- 2 x 0.7 KB instead of 2 x 5.76 KB at 1440 states -- and not the rest.  `ranges` holds {lo, hi} per
+// row and `widest` the largest hi - lo4 of the matrix (row_ranges_kernel below); the kernel serves matrices whose widest
+// row fits its window of 512 prev-states and returns at once otherwise (the whole-row kernel, launched next to it, then
+// runs: it returns at once in the opposite case).  All candidates -inf -> prev-state 0, like the reference's scan.
+// ---------------------------------------------------------------------------------------
+constexpr int kRangedWindow = 512;
+
+// grid = S, block = 64: finite range of every transition row; *widest = max over rows of the window its range needs
+// (hi - (lo rounded down to 4)); zeroed by the caller
+__global__ __launch_bounds__(64) void row_ranges_kernel(const float *__restrict__ trans, int32_t *__restrict__ ranges,
+                                                        int32_t *__restrict__ widest, int S) {
+    const int j = blockIdx.x, lane = threadIdx.x;
+    const float *row = trans + (size_t)j * S;
+    int lo = kSentinel, hi = 0;
+    for (int i = lane; i < S; i += 64) {
+        if (row[i] != -INFINITY) {
+            lo = min(lo, i);
+            hi = max(hi, i + 1);
+        }
+    }
+    lo = wavered::wave_min_i32(lo);
+    hi = -wavered::wave_min_i32(-hi);
+    if (lane == 0) {
+        if (hi == 0) lo = 0;                                     // nothing finite: an empty range
+        ranges[2 * j] = lo;
+        ranges[2 * j + 1] = hi;
+        atomicMax(widest, hi - (lo & ~3));
+    }
+}
+
+template <int NQ>
+__global__ __launch_bounds__(64) void backtrace_ranged_kernel(const float *__restrict__ hist, const float *__restrict__ trans,
+                                                              const int32_t *__restrict__ ranges,
+                                                              const int32_t *__restrict__ widest,
+                                                              const int32_t *__restrict__ frames, int32_t *__restrict__ out,
+                                                              int B, int T, int S) {
+    if (*widest > kRangedWindow) return;                         // a wide matrix: the whole-row kernel decodes it
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float *h = hist + (size_t)b * T * S;
+    int32_t *o = out + (size_t)b * T;
+    int f = frames[b];
+    f = f < 1 ? 1 : (f > T ? T : f);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    int j;
+    {
+        float4 last[NQ];
+        const float *row = h + (size_t)(f - 1) * S;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = 4 * lane + 256 * q;
+            last[q] = i < S ? *reinterpret_cast<const float4 *>(row + i) : zero;
+        }
+        j = wave_first_argmax4<NQ>(last, lane, S);
+    }
+    for (int tt = f - 1 + lane; tt < T; tt += 64) o[tt] = j;
+    const float4 none = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int tt = f - 1; tt >= 1; --tt) {
+        const int lo4 = ranges[2 * j] & ~3, hi = ranges[2 * j + 1];
+        const float *tr = trans + (size_t)j * S, *hrow = h + (size_t)(tt - 1) * S;
+        float4 cand[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = lo4 + 4 * lane + 256 * q;
+            if (i < hi) {                                        // (i % 4 == 0 and S % 4 == 0: the four reads stay inside the row)
+                const float4 t4 = *reinterpret_cast<const float4 *>(tr + i);
+                const float4 p4 = *reinterpret_cast<const float4 *>(hrow + i);
+                cand[q] = make_float4(p4.x + t4.x, p4.y + t4.y, p4.z + t4.z, p4.w + t4.w);
+            } else {
+                cand[q] = none;
+            }
+        }
+        // first argmax inside the window (indices relative to lo4), as wave_first_argmax4 finds it over a whole row
+        const float m = wavered::wave_reduce_f32(
+            __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(cand[0].x, cand[0].y), __builtin_fmaxf(cand[0].z, cand[0].w)),
+                            __builtin_fmaxf(__builtin_fmaxf(cand[1].x, cand[1].y), __builtin_fmaxf(cand[1].z, cand[1].w))),
+            wavered::MaxOp());
+        int k = kSentinel;
+#pragma unroll
+        for (int q = 1; q >= 0; --q) {
+            const int i = lo4 + 4 * lane + 256 * q;
+            int kq = cand[q].w == m ? i + 3 : kSentinel;
+            kq = cand[q].z == m ? i + 2 : kq;
+            kq = cand[q].y == m ? i + 1 : kq;
+            kq = cand[q].x == m ? i : kq;
+            k = min(k, kq);
+        }
+        k = wavered::wave_min_i32(k);
+        j = m == -INFINITY ? 0 : k;                             // (every candidate -inf: the reference's scan keeps prev-state 0)
+        if (lane == 0) o[tt - 1] = j;
+    }
 }
 
 }  // namespace lazy

@@ -797,6 +797,7 @@ struct DenseWorkspace {
     float *panel[2];   // [n_bt][Kp][BT] posterior panels (ping-pong)
     float *trp;        // [n_jt][Kp][W]  packed transition panels
     int32_t *chunks;   // [n_jt][NCH+1]  per-tile lists of chunks that are not all -inf
+    int32_t *ranges;   // [S][2] finite range of every transition row + [64] (first word: the widest row window)
     size_t bytes;
 };
 
@@ -833,7 +834,9 @@ inline DenseWorkspace carve_dense(void *base, int B, int T, int S, int cus) {
     w.panel[1] = reinterpret_cast<float *>(p + panel_bytes);
     w.trp = reinterpret_cast<float *>(p + 2 * panel_bytes);
     w.chunks = reinterpret_cast<int32_t *>(p + 2 * panel_bytes + trp_bytes);
-    w.bytes = history_bytes(B, T, S) + 2 * panel_bytes + trp_bytes + list_bytes;
+    w.ranges = reinterpret_cast<int32_t *>(p + 2 * panel_bytes + trp_bytes + list_bytes);
+    w.bytes = history_bytes(B, T, S) + 2 * panel_bytes + trp_bytes + list_bytes +
+              align_up(sizeof(int32_t) * (2 * (size_t)S + 64), 256);
     return w;
 }
 
@@ -1006,6 +1009,9 @@ hipError_t launch_dense_forward(const float *obs, const int32_t *frames, const f
         hipLaunchKernelGGL(dense::build_chunk_lists_kernel, dim3(pl.n_jt), dim3(256),
                            sizeof(int) * (size_t)pl.NCH, stream, w.trp, w.chunks, S, pl.JT, pl.W, pl.Kp, pl.NCH,
                            pl.KC);
+        // for the backtrace: the finite range of every row and the widest of them (lazy_backtrace.hpp)
+        hipLaunchKernelGGL(stamp_route_kernel, dim3(1), dim3(1), 0, stream, w.ranges + 2 * (size_t)S, 0);
+        hipLaunchKernelGGL(lazy::row_ranges_kernel, dim3(S), dim3(64), 0, stream, trans, w.ranges, w.ranges + 2 * (size_t)S, S);
     }
     {
         const size_t n = (size_t)pl.n_bt * pl.BT * pl.Kp;
@@ -1097,14 +1103,21 @@ hipError_t launch_pruned_forward(const float *obs, const int32_t *frames, const 
     return hipGetLastError();
 }
 
+// (`ranges` / `widest`: the finite range of every transition row and the widest window, or null; with them a banded
+// matrix is decoded by backtrace_ranged_kernel and the whole-row kernel returns at once -- decided on the device)
 hipError_t launch_backtrace_on(const float *hist, const float *trans, const int32_t *frames, int32_t *out,
-                               int B, int T, int S, hipStream_t stream) {
+                               int B, int T, int S, hipStream_t stream, const int32_t *ranges = nullptr,
+                               const int32_t *widest = nullptr) {
     const bool vec = (S % 4 == 0) && ((reinterpret_cast<uintptr_t>(trans) & 15) == 0);
     if (vec && S <= 256 * 16) {
+        if (!ranges) widest = nullptr;
 #define TORBI_BT_CASE(NQ_)                                                                          \
     if (S <= 256 * NQ_) {                                                                           \
+        if (ranges)                                                                                 \
+            hipLaunchKernelGGL(lazy::backtrace_ranged_kernel<NQ_>, dim3(B), dim3(64), 0, stream, hist, trans, ranges, \
+                               widest, frames, out, B, T, S);                                       \
         hipLaunchKernelGGL(lazy::backtrace_prefetch_kernel<NQ_>, dim3(B), dim3(64), 0, stream, hist, \
-                           trans, frames, out, B, T, S);                                            \
+                           trans, frames, out, B, T, S, widest);                                    \
         return hipGetLastError();                                                                   \
     }
         TORBI_BT_CASE(2)
@@ -1371,7 +1384,8 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
         const DenseWorkspace w = carve_dense(workspace, B, T, S, cus);
         e = launch_dense_forward(obs, frames, trans, init, w, B, T, S, s, launches, reuse);
         if (ev) (void)hipEventRecord(ev[1], s);
-        if (e == hipSuccess) e = launch_backtrace_on(w.hist, trans, frames, out, B, T, S, s);
+        if (e == hipSuccess)
+            e = launch_backtrace_on(w.hist, trans, frames, out, B, T, S, s, w.ranges, w.ranges + 2 * (size_t)S);
     } else if (route == ROUTE_ROWS) {
         const RowsWorkspace w = carve_rows(workspace, B, T, S);
         if (!reuse)       // per-transition preparation: descending rows, prev-states as byte offsets of a 16-item tile row
