@@ -80,7 +80,7 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
  *             the reference's
  *   ROWS      B <= 16, 64 <= S <= 4096: the pruned recurrence with one wave per (item, next-state), 64 list
  *             entries per wave step (small_batch_forward.hpp); one launch per timestep.  AUTO takes it for
- *             B >= 8 or S > 2048 (below that both it and GENERIC are bound by the gap between launches)
+ *             B >= 6 or S > 2048 (below that both it and GENERIC are bound by the gap between launches)
  *   DENSE     value-only (max,+) GEMM, every (prev, next) cell evaluated, one launch per timestep
  *   PRUNED    value-only, exact: sorted transition rows + per-item top posteriors bound the cells
  *             that can still win, the rest are never touched (B >= 17, 64 <= S <= 4096); one launch
@@ -98,7 +98,7 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
  *             other through 8-byte {value, timestep} words (held_matrix_forward.hpp).
  * AUTO: RESIDENT when the call's tiles fill more than half the compute units; CLUSTER for any other batch of more than
  * 16 items (64 <= S <= 4096: one batch = one forward launch); HELD up to three items (eight above 2048 states); ROWS for
- * 8..16 items (and above 2048 states); PRUNED / DENSE for large batches outside 64..4096 states; else GENERIC.  (The Python layer
+ * 6..16 items (and above 2048 states); PRUNED / DENSE for large batches outside 64..4096 states; else GENERIC.  (The Python layer
  * adds what it knows about the matrix: DENSE for one batch with a narrow band or with scans too deep to prune.)
  *
  * A call selects a path in its `flags` (TORBI_HIP_PATH_FLAG); calls without one use the process-wide

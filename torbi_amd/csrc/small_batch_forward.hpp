@@ -27,7 +27,9 @@ inline bool supported(int B, int S) { return B >= 1 && B <= 16 && S >= 64 && S <
 // dependent launches at B = 1, S = 1440 (rows 2.20 + 0.53 ms backtrace over the sorted rows against 2.30 + 0.13 ms trellis
 // chase); the list walk wins once a launch carries real work: B = 16, S = 1440: 6.0 vs 6.8 ms; B = 1, S = 4096: 5.8 vs
 // 7.5 ms; B = 8, S = 4096: 14.9 vs 28.1 ms.  AUTO takes the kernel there; TORBI_HIP_FORWARD_PRUNED names it for any B <= 16.
-inline bool profitable(int B, int S) { return supported(B, S) && (S > 2048 || B >= 8); }
+// (round 3, with the gather backtrace -- 0.39 instead of 0.61 ms -- and the parallel chase behind the generic kernels:
+// 6 x 500 x 1440 3.55 against 3.99 ms, 4 x 500 x 1440 2.98 against 2.76: profiles/r03_held_probe.txt)
+inline bool profitable(int B, int S) { return supported(B, S) && (S > 2048 || B >= 6); }
 
 // One timestep of every item.  grid = (ceil(S / 4), B), block = 256, dynamic LDS = 4 * S bytes.  Leaves the maximum of
 // posterior row t-1 in rowmax[b][t-1].
