@@ -91,32 +91,37 @@ def algorithmic_bytes_per_timestep(S):
     return 8 * S + 8
 
 
-def profiled_traffic(kernel_prefix, batches):
-    """HBM-side bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
-    (profiles/rNN_pmc.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).  FETCH_SIZE is
-    doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950; both counters are in KiB and
-    include Infinity-Cache hits.  The summary was taken with `_meta.batches_per_forward_launch` batches per launch;
-    the figure is scaled to the `batches` this run puts into one.  (None, None) when no summary names the kernel."""
+def profiled_traffic(kernel_name, batches):
+    """HBM-side bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary that was taken ON
+    THE KERNEL THAT IS RUNNING (profiles/rNN_pmc.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command;
+    `kernel_name` = torbi_hip_last_forward_kernel(), the template instance as rocprofv3 spells it).  FETCH_SIZE is
+    doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950; both counters are in KiB and include
+    Infinity-Cache hits.  The summary was taken with `_meta.batches_per_forward_launch` batches per launch; the figure is
+    scaled to the `batches` this run puts into one.  Returns (bytes or None, provenance): a summary that names another
+    instance of the kernel (other template arguments, i.e. other code) is NOT used -- the line then says so instead of
+    reporting stale traffic."""
     folder = os.path.join(ROOT, 'profiles')
+    squeeze = lambda name: name.replace(' ', '')
     try:
         names = sorted(f for f in os.listdir(folder) if f.endswith('_pmc.json'))
     except OSError:
-        return None, None
+        return None, {'file': None, 'reason': 'no profiles/ folder'}
     for name in reversed(names):
         try:
             pmc = json.load(open(os.path.join(folder, name)))
         except (OSError, ValueError):
             continue
-        taken_with = float(pmc.get('_meta', {}).get('batches_per_forward_launch', batches))
-        # several instances of the kernel may have run (the first launch with a matrix keeps three seeds per item, later
-        # ones one: TORBI_HIP_FEW_SEEDS): the steady-state instance is the one with most dispatches
-        found = [(counters['FETCH_SIZE'].get('dispatches', 1), kernel) for kernel, counters in pmc.items()
-                 if kernel_prefix in kernel and 'FETCH_SIZE' in counters and 'WRITE_SIZE' in counters]
-        if found:
-            counters = pmc[max(found)[1]]
-            return ((2.0 * counters['FETCH_SIZE']['mean_per_dispatch']
-                     + counters['WRITE_SIZE']['mean_per_dispatch']) * 1024.0 * batches / taken_with, name)
-    return None, None
+        meta = pmc.get('_meta', {})
+        taken_with = float(meta.get('batches_per_forward_launch', batches))
+        for kernel, counters in pmc.items():
+            if squeeze(kernel) == squeeze(kernel_name) and 'FETCH_SIZE' in counters and 'WRITE_SIZE' in counters:
+                nbytes = (2.0 * counters['FETCH_SIZE']['mean_per_dispatch']
+                          + counters['WRITE_SIZE']['mean_per_dispatch']) * 1024.0 * batches / taken_with
+                return nbytes, {'file': f'profiles/{name}', 'kernel': kernel, 'taken_at_commit': meta.get('git'),
+                                'batches_per_launch_when_taken': int(taken_with),
+                                'dispatches': counters['FETCH_SIZE'].get('dispatches')}
+    return None, {'file': None, 'running_kernel': kernel_name,
+                  'reason': 'no committed PMC summary was taken on this kernel instance'}
 
 
 def cpu_baseline(obs_dev, trans_dev, init_dev, gpu_indices, budget_s=15.0):
@@ -350,7 +355,36 @@ class Bench:
         bytes_per_launch = timesteps_per_launch * algorithmic_bytes_per_timestep(S)
         achieved = bytes_per_launch / kernel_s / 1e9
         cells_per_launch = timesteps_per_launch * S * S
-        traffic, traffic_file = profiled_traffic(KERNELS[route], covered)
+        running = v.last_forward_kernel()          # the template instance the profiled groups launched
+        traffic, provenance = profiled_traffic(running, covered)
+        # executed work, live: the kernel counts the 16-entry list blocks its sampled wave passes walk (torbi_hip_scan_stats)
+        executed = None
+        if route in ('resident', 'cluster'):
+            stats = v.scan_stats(spaces[0], B, T, S, path='resident').cpu().to(torch.int64)
+            blocks = float(stats[:64].sum()) / max(1.0, float(stats[64:127].sum()))
+            ni = 16 if S <= 2048 else 8
+            rows_per_pass = 64 // (ni // 4)
+            passes = covered * math.ceil(B / ni) * math.ceil(S / rows_per_pass) * (T - 1)
+            cells = passes * blocks * 16.0 * rows_per_pass * ni
+            clock = 2.4e9
+            executed = {
+                'list_blocks_per_wave_pass': blocks, 'row_blocks': math.ceil(S / 16),
+                'cells_per_launch': cells, 'cells_per_s': cells / kernel_s,
+                'fraction_of_all_cells': cells / cells_per_launch if cells_per_launch else None,
+                # issue model of the scan: per entry pair and lane 4 quad broadcasts + 8 adds + 4 max3 = 16 instructions
+                # for 8 cells, ~40 issue cycles (tools/ubench2: v_max3_f32 / DPP moves ~4, v_add_f32 2 cycles per wave
+                # instruction); + bound test, list loads, epilogue: 2.5 instructions per cell measured (SQ_INSTS_VALU of
+                # profiles/r03_pmc.json / executed cells)
+                'valu_instr_per_cell': 2.5,
+                'valu_busy_frac': cells * 2.5 * 2.5 / 64.0 / (256 * 4 * clock * kernel_s),
+                # one ds_read_b128 per 4 cells and lane = 4 LDS cycles per wave instruction x 1.43 (bank conflicts left by
+                # the arrangement pass: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.30)
+                'lds_busy_frac': cells / 256.0 * 4.0 * 1.43 / (256 * clock * kernel_s),
+                'statistics_gave_up': int(stats[127]),
+                'note': 'live: list blocks per wave pass from torbi_hip_scan_stats (every 16th timestep sampled) x 16 '
+                        'entries x 256 (row, item) pairs; the busy fractions price those cells with the per-cell costs '
+                        'stated here at 2.4 GHz -- both pipes are more than half busy and do not overlap fully: that, '
+                        'not HBM, is what binds this kernel'}
         del spaces
         result['config'] = {
             'workload': (f'{S} states, {T} frames, batch={B} per GPU, fp32, dense transition'
@@ -361,35 +395,72 @@ class Bench:
             'parallelism': f'batch-sharded x{size}' if size > 1 else 'single GPU',
             'launch_groups': sizes, 'streams': args.pipeline, 'forward_path': route,
             'throughput_mode': f'{sum(sizes)} batches decoded as {len(sizes)} launch groups over {args.pipeline} '
-                               f'streams; "serial" under "secondary" is one batch at a time',
+                               f'streams; ONE call on ONE batch is "single_call"',
             'transition_preparation': 'reused across launch groups' if args.reuse_preparation
             else 'rebuilt by every launch group'}
         result['roofline'] = {
-            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'bound': 'valu_issue+lds' if route in ('resident', 'cluster', 'pruned') else 'valu_issue',
+            'bound_note': 'achieved / peak / frac are the HBM figures BASELINE.json asks for (algorithmic bytes per launch '
+                          'over the 8 TB/s peak); what binds the kernel is under "executed"',
+            'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic if (B, T, S) == (512, 500, 1440) else None,
-            'traffic_note': f'bytes per launch from profiles/{traffic_file} (2*FETCH_SIZE + WRITE_SIZE of the steady-state '
-                            f'kernel instance, Infinity-Cache hits included, scaled to {covered} batches per launch): the '
-                            f'excess over the algorithmic bytes is the sorted transition lists and the seed rows of the '
-                            f'transposed matrix that miss the 4 MB L2s (served by the Infinity Cache), and partial lines of '
-                            f'the 4-byte history stores'
-            if traffic_file else 'no PMC summary for this kernel committed',
-            'kernel': KERNELS[route] + (f' (ONE launch = the whole forward pass of {covered} batches)'
-                                        if route in ('resident', 'cluster') else ' (one launch = one timestep of one batch)'),
+            'traffic_source': provenance,
+            'traffic_note': '2 * FETCH_SIZE + WRITE_SIZE of that kernel instance, Infinity-Cache hits included, scaled to '
+                            f'{covered} batches per launch; above the algorithmic bytes: the sorted transition lists and seed '
+                            'rows that miss the 4 MB L2s (served by the Infinity Cache)',
+            'kernel': running + (f' (ONE launch = the whole forward pass of {covered} batches)'
+                                 if route in ('resident', 'cluster') else ' (one launch = one timestep of one batch)'),
             'launch_us': kernel_s * 1e6, 'launches_per_group': launches, 'batches_per_launch': covered,
             'algorithmic_bytes_per_launch': bytes_per_launch,
+            'executed': executed,
             'note': 'the (max,+) recurrence holds S/4 = 360 cells per algorithmic byte: kernels that evaluate every cell '
                     'are VALU-bound; the pruned recurrence is bound by LDS gathers + VALU issue (DESIGN.md 4)'}
         result['valu'] = {
             'dense_equivalent_cells_per_s': cells_per_launch / kernel_s, 'lane_instr_peak_per_s': VALU_LANE_OPS,
-            'frac_at_1_instr_per_cell': cells_per_launch / kernel_s / VALU_LANE_OPS}
+            'note': 'dense-equivalent = every (prev, next) cell of the launch, pruned or not, over the kernel time: a '
+                    'speed-up figure against kernels that evaluate every cell, NOT a utilisation (roofline.executed has that)'}
         result['phases_ms'] = {'group_of': g, 'forward_incl_preparation': fwd_ms, 'preparation': prep_ms,
                                'argmax_backtrace': bt_ms}
         result['hbm_roofline_frac_whole_job'] = value / size * algorithmic_bytes_per_timestep(S) / (HBM_PEAK_GBS * 1e9)
+        if rank == 0 and size == 1 and args.transition == 'dense':
+            result['single_call'] = self.single_call(obs[0], frames, trans, init)
         if rank == 0 and size == 1 and not args.no_secondary and args.transition == 'dense':
             result['secondary'] = self.secondary(obs[0], frames, trans, init)
+            result['secondary']['serial'] = dict(result['single_call'], note='= single_call (kept under its old name)')
         if rank == 0 and size == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(last_obs, trans, init, indices)
         return result
+
+    # ---- the literal BASELINE config: ONE decode call on ONE batch -------------------------------------
+    def single_call(self, obs, frames, trans, init):
+        """What the reference times (torbi/core.py:200-206): ONE `decode` of ONE batch, nothing else in flight.  The
+        workspace is the caller's and allocated once; the per-transition preparation is rebuilt by every
+        call unless --reuse-preparation.  Median of 5 after 3 warm-up calls."""
+        torch, v = self.torch, self.viterbi
+        B, T, S = obs.shape
+        ws = torch.empty(v.workspace_bytes(B, T, S), dtype=torch.uint8, device=self.dev)
+        reuse = bool(self.args.reuse_preparation)
+        prof = []
+        for _ in range(3):
+            self.torbi_amd.decode(obs, frames, trans, init, workspace=ws, reuse_preparation=reuse, _profile=prof)
+        kernel = v.last_forward_kernel()
+        times = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            self.torbi_amd.decode(obs, frames, trans, init, workspace=ws, reuse_preparation=reuse)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        sec = sorted(times)[len(times) // 2]
+        rate = B * T / sec
+        return {'value': rate, 'unit': 'timesteps/s', 'ms_per_decode': sec * 1e3,
+                'roofline_frac': rate * algorithmic_bytes_per_timestep(S) / (HBM_PEAK_GBS * 1e9),
+                'forward_path': ROUTES[int(prof[3])], 'kernel': kernel,
+                'phases_ms': {'forward_incl_preparation': prof[0], 'preparation': prof[4], 'argmax_backtrace': prof[1]},
+                'us_per_timestep_forward': (prof[0] - prof[4]) / max(T - 1, 1) * 1e3,
+                'note': f'ONE torbi_amd.decode() of ONE {B} x {T} x {S} batch resident in HBM, host-timed around a '
+                        'synchronised call (median of 5), workspace preallocated, transition preparation '
+                        + ('reused' if reuse else 'rebuilt every call')}
 
     # ---- secondary records: the same run substantiates DESIGN.md's table -------------------------------
     def secondary(self, obs, frames, trans, init):
@@ -412,10 +483,23 @@ class Bench:
         prof = []
         for _ in range(3):
             self.torbi_amd.decode(obs, frames, trans, init, workspace=ws, _profile=prof)
-        sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(obs, frames, trans, init, workspace=ws), 3)
-        record('serial', sec, B * T, S, 'headline batch, ONE batch at a time on one stream (latency of a single decode): '
-                                       'AUTO = ONE time-resident launch, each 16-item tile split over a cluster of 8 '
-                                       'workgroups, one seed per item', {'forward_path': ROUTES[int(prof[3])]})
+        # the call a drop-in user makes (reference torbi/core.py:110-208): device-resident log-probabilities through
+        # from_probabilities -- epsilon round trip (in place, like upstream), workspace allocation and decode included
+        samples = []
+        for k in range(4):
+            x = obs.clone()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            self.torbi_amd.from_probabilities(x, frames, trans, init, log_probs=True, gpu=dev.index or 0)
+            torch.cuda.synchronize()
+            samples.append(time.perf_counter() - t0)
+            del x
+        sec = sorted(samples[1:])[1]
+        record('api_from_probabilities', sec, B * T, S,
+               'torbi_amd.from_probabilities(observation[B,T,S] on the device, batch_frames, transition, initial, '
+               'log_probs=True, gpu=0): epsilon clamp pass over the batch + workspace allocation (caching allocator) + '
+               'decode, host-timed around a synchronised call, median of 3 after one warm-up call',
+               {'first_call_ms': samples[0] * 1e3})
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(obs, frames, trans, init, workspace=ws, path='pruned'), 3)
         record('serial_per_timestep_kernel', sec, B * T, S, 'the same with per-timestep launches of the pruned recurrence '
                                                            '(what AUTO took for one batch before round 3)')

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TORBI_HIP_ABI_VERSION 10
+#define TORBI_HIP_ABI_VERSION 11
 
 #define TORBI_HIP_OK 0
 #define TORBI_HIP_EINVAL (-1)      /* null pointer / non-positive dimension            */
@@ -119,6 +119,14 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
 int torbi_hip_set_forward_path(int path);
 int torbi_hip_forward_path(int B, int S);
 int torbi_hip_forward_path_on(int B, int S, int device, unsigned flags);
+/*
+ * (ABI 11) Name of the forward kernel the CALLING THREAD's most recent decode launched, spelled the way rocprofv3
+ * prints kernels ("streamed::streamed_forward_kernel<15, 6>", "resident::resident_forward_kernel<12, 1, true, 1, true, 16>",
+ * "dense::step_dense_kernel<8, 6, 8, 12, 8>", ...); empty before the first decode.  Measurement plumbing: bench.py
+ * reports counter-derived figures (profiles/ *_pmc.json) only when they were taken on the kernel that is running.
+ * No counterpart in the reference.
+ */
+int torbi_hip_last_forward_kernel(char *name_out, size_t capacity);
 
 /*
  * The operator.  Replaces viterbi_decode_cuda (viterbi.cu:309-362) = forward trellis

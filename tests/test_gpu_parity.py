@@ -307,6 +307,91 @@ def test_held_launch_that_cannot_complete_is_repaired(shape, forward, monkeypatc
         assert (int(stats[127]) > 0) == gave_up, (limit, int(stats[127]))
 
 
+@pytest.mark.parametrize('shape', [(40, 12, 360), (17, 9, 1440), (130, 7, 724), (20, 6, 2052)])
+def test_cluster_that_gives_up_waiting_is_repaired(shape, forward, monkeypatch):
+    """A cluster launch whose members cannot all arrive in time (a device shared with work that holds the compute units)
+    used to return incomplete histories (round-3 advisor).  Now a member that gives up flags its tile and the launch
+    behind the cluster launch decodes the flagged tiles again, whole.  Forced with a wait budget of 0 (every poll that
+    fails gives up): indices and final posterior rows are the oracle's, the give-ups are counted; without the limit
+    nothing gives up."""
+    if forward != 'auto':
+        pytest.skip('names its path itself')
+    B, T, S = shape
+    obs, trans, init = synth.problem(B, T, S, seed=31)
+    frames = np.clip(synth.lengths(B, 1, T, seed=6), 1, T).astype(np.int32)
+    frames[0] = T
+    dev = torch.device('cuda:0')
+    args = [torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)]
+    space = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+    want, want_post = oracle.decode(obs, frames, trans, init, return_posterior=True)
+    for limit, gave_up in (('0', True), (None, False), ('0', True)):
+        if limit is None:
+            monkeypatch.delenv('TORBI_HIP_CLUSTER_WAIT_US', raising=False)
+        else:
+            monkeypatch.setenv('TORBI_HIP_CLUSTER_WAIT_US', limit)
+        got = torbi_amd.decode(*args, workspace=space, path='cluster')
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+        post = viterbi.read_posterior(space, args[1], B, T, S).cpu().numpy()
+        assert np.array_equal(post.view(np.uint32), want_post.view(np.uint32))
+        stats = viterbi.scan_stats(space, B, T, S, path='resident').cpu()
+        assert (int(stats[127]) > 0) == gave_up, (limit, int(stats[127]))
+
+
+def test_a_single_sequence_beside_a_busy_stream_keeps_away_from_the_held_kernel(forward):
+    """Round-3 review item 5: the held-matrix kernel needs all its workgroups resident at once.  A B = 1 AUTO decode
+    issued while a full-chip time-resident launch group occupies ANOTHER stream must not sit out a wait budget and the
+    slow repair: AUTO sees the other stream's work in flight (the library marks the end of every decode with an event)
+    and takes the per-timestep kernels, which queue behind it.  Asserted: oracle equality, no give-ups, wall time of the
+    pair <= the launch group alone + 5 ms; and once the device is idle again the same call is back on the held kernel."""
+    if forward != 'auto':
+        pytest.skip('AUTO routing is the subject')
+    import time
+    dev = torch.device('cuda:0')
+    S, T = 1440, 200
+    trans = viterbi.fill_synthetic((S, S), synth.STREAM_TRANSITION, device=dev)
+    init = viterbi.fill_synthetic((S,), synth.STREAM_INITIAL, device=dev)
+    big = [viterbi.fill_synthetic((512, T, S), synth.STREAM_OBSERVATION, seed=k, device=dev) for k in range(8)]
+    big_frames = [torch.full((512,), T, dtype=torch.int32, device=dev)] * 8
+    spaces = [torch.empty(viterbi.workspace_bytes(512, T, S), dtype=torch.uint8, device=dev) for _ in range(8)]
+    one = viterbi.fill_synthetic((1, T, S), synth.STREAM_OBSERVATION, seed=99, device=dev)
+    one_frames = torch.full((1,), T, dtype=torch.int32, device=dev)
+    one_space = torch.empty(viterbi.workspace_bytes(1, T, S), dtype=torch.uint8, device=dev)
+    want = oracle.decode(one.cpu().numpy(), [T], trans.cpu().numpy(), init.cpu().numpy(), num_threads=oracle.max_threads())
+    side = torch.cuda.Stream(device=dev)
+
+    def group():
+        with torch.cuda.stream(side):
+            viterbi.decode_batches(big, big_frames, trans, init, workspaces=spaces, path='resident')
+
+    # idle device: AUTO takes the held kernel
+    prof = []
+    torbi_amd.decode(one, one_frames, trans, init, workspace=one_space, _profile=prof)
+    assert viterbi.ROUTES[int(prof[3])] == 'held'
+    group()
+    torch.cuda.synchronize()                       # (warm: code objects, LDS grants)
+    t0 = time.perf_counter()
+    group()
+    torch.cuda.synchronize()
+    alone = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    group()
+    got = torbi_amd.decode(one, one_frames, trans, init, workspace=one_space)      # default stream, the group in flight
+    torch.cuda.synchronize()
+    both = time.perf_counter() - t0
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    stats = viterbi.scan_stats(one_space, 1, T, S).cpu()
+    assert int(stats[127]) == 0
+    assert both <= alone + 5e-3, (alone, both)
+    # what ran: the route record in the workspace says per-timestep kernels (0 generic / 4 rows), not held (6)
+    prof = []
+    group()
+    torbi_amd.decode(one, one_frames, trans, init, workspace=one_space, _profile=prof)
+    assert viterbi.ROUTES[int(prof[3])] in ('generic', 'rows'), prof[3]
+    torch.cuda.synchronize()
+    torbi_amd.decode(one, one_frames, trans, init, workspace=one_space, _profile=prof)
+    assert viterbi.ROUTES[int(prof[3])] == 'held'
+
+
 def test_concurrent_held_launches_from_several_streams(forward):
     """Six host threads, six streams, one 4096-state sequence each on the held-matrix kernel -- 256 workgroups of 1024
     threads per launch, one per compute unit, so the launches cannot all be resident together.  Whatever the dispatcher
@@ -1141,6 +1226,34 @@ def test_many_file_job_every_file_equals_the_oracle(tmp_path, forward, monkeypat
     torbi_amd.from_files_to_files(ins, outs3, transition_file=tf, log_probs=True, gpu=0, num_workers=2)
     for a, b in zip(outs, outs3):
         assert torch.equal(torch.load(a), torch.load(b))
+
+
+def test_many_file_job_with_the_default_uniform_transition(tmp_path, forward):
+    """from_files_to_files(log_probs=True, transition_file=None, gpu=0): the reference's default model (core.py:175-180)
+    takes the uniform-transition entry, which decodes on the staging side's preparation stream -- the consumer's copy of
+    the indices has to be ordered behind it (round-3 review: the last batch of a job, drained right behind its
+    host-to-device copy, was saved unwritten).  1 100 ragged files = 3 batches of 512; every output equals the oracle's
+    decode of that file with the materialised matrix."""
+    import math
+    if forward != 'auto':
+        pytest.skip('the uniform entry has one kernel: once is enough')
+    S, count = 256, 1100
+    lengths, ins, outs, _ = _ragged_job(tmp_path, count, S, seed=11, shortest=20, longest=180)
+    tiny = torch.finfo(torch.float32).tiny
+    trans = np.full((S, S), np.float32(math.log(1. / S)), dtype=np.float32)
+    init = np.full((S,), math.log(1. / S + tiny), dtype=np.float32)
+    want = []
+    for k in range(count):
+        x = torch.log(torch.exp(torch.load(ins[k]).to('cuda:0')) + tiny).cpu().numpy()[None]
+        want.append(oracle.decode(x, [x.shape[1]], trans, init, num_threads=8)[0])
+    for rep in range(2):              # (the second job finds the pooled slabs and the kept pipeline of the first)
+        torbi_amd.from_files_to_files(ins, outs, log_probs=True, gpu=0)
+        for k in range(count):
+            got = torch.load(outs[k])
+            assert got.dtype == torch.int32 and got.shape == (lengths[k],)
+            assert np.array_equal(got.numpy(), want[k]), f'file {k} ({lengths[k]} frames), job {rep}'
+        for f in outs:
+            f.unlink()
 
 
 def test_many_file_job_at_1440_states(tmp_path, forward):

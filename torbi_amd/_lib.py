@@ -16,7 +16,7 @@ SOURCE = os.path.join(_HERE, 'csrc', 'torbi_hip.hip')
 INCLUDE = os.path.join(ROOT, 'include')
 # TORBI_HIP_LIBRARY: an alternative build of the library (tools/variants_probe.py: -D experiments)
 LIBRARY = os.environ.get('TORBI_HIP_LIBRARY') or os.path.join(_HERE, 'libtorbi_hip.so')
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # every symbol include/torbi_hip.h declares: name -> (restype, argtypes)
 _c = ctypes
@@ -47,6 +47,7 @@ SYMBOLS = {
     'torbi_hip_set_forward_path': (_c.c_int, [_c.c_int]),
     'torbi_hip_forward_path': (_c.c_int, [_c.c_int, _c.c_int]),
     'torbi_hip_forward_path_on': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_uint]),
+    'torbi_hip_last_forward_kernel': (_c.c_int, [_c.c_char_p, _c.c_size_t]),
     'torbi_hip_read_posterior': (_c.c_int, [
         _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p,
         _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint]),

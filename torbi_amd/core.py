@@ -485,8 +485,11 @@ class _Staging:
         if pipe is not None and model.get('uniform') is None:
             pipe.when_done(indices, lambda event, slab=slab: self.pool.give(slab, event))
         else:
+            # decoded on the preparation stream itself (the uniform-transition entry, or no pipeline): nothing else
+            # orders the consumer's stream -- `indices.cpu()` in from_dataloader runs on the current stream -- behind it
             done = torch.cuda.Event()
             done.record(self.prep)
+            torch.cuda.current_stream(self.device).wait_event(done)
             self.pool.give(slab, done)
         return indices
 

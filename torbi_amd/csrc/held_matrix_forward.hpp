@@ -20,8 +20,10 @@
 //
 // All workgroups (<= 256) must be resident at once -- one per compute unit of an MI355X, up to three at 1440 states.  That
 // holds whenever the launch has the device to itself or shares it with a few of its kind; several such launches from
-// different streams can each end up partly resident and wait for one another.  So every poll is bounded (`spin_limit`, a
-// quarter of a second), a workgroup that gives up says so in `control[1]` and goes on without waiting, and the launch is
+// different streams can each end up partly resident and wait for one another.  So every wait is bounded IN TIME (`wait_ticks`
+// of the 100 MHz wall clock: 20 x T x 2.5 us, at least 2 ms -- a launch that is merely queued behind another kernel gets
+// its compute units within that, a launch that waits for a workgroup that will never be resident does not hang a serving
+// loop for longer), a workgroup that gives up says so in `control[1]` and goes on without waiting, and the launch is
 // followed by `repair_kernel`, which does nothing when `control[1]` is 0 and otherwise decodes every sequence again with one
 // workgroup each and no hand-offs (the reference's own kernel shape, viterbi.cu:48-130): slow, never wrong.
 #pragma once
@@ -169,7 +171,7 @@ template <int K, int kRows, int kThreads, bool STORE_WAVE>
 __global__ __launch_bounds__(kThreads + (STORE_WAVE ? 64 : 0)) void held_forward_kernel(
     const float *__restrict__ obs, const int32_t *__restrict__ frames, const float *__restrict__ trans,
     float *__restrict__ post0, float *__restrict__ post1, int32_t *__restrict__ trellis, u64 *__restrict__ xchg,
-    unsigned *__restrict__ control, int B, int T, int S, unsigned spin_limit) {
+    unsigned *__restrict__ control, int B, int T, int S, unsigned long long wait_ticks) {
     constexpr int kWaves = kThreads / 64;                       // scanning waves
     static_assert(kRows == 8 || kRows == 16, "folds are written for 8 and 16 rows");
     __shared__ float sv[2][kWaves][kRows];
@@ -272,12 +274,13 @@ __global__ __launch_bounds__(kThreads + (STORE_WAVE ? 64 : 0)) void held_forward
                 requested = true;
             }
             if (!ok) {
-                unsigned spins = 0;
+                const unsigned long long waiting_since = wall_clock64();     // (100 MHz, the same on every compute unit)
                 if (others == 0) __builtin_amdgcn_s_sleep(HELD_FIRST_SLEEP);
                 for (;;) {
                     request(t, b, mine);
                     if (complete(mine, t)) break;
-                    if (gave_up || ++spins > spin_limit) { gave_up = true; break; }     // (once given up, never wait again)
+                    // (once given up, never wait again)
+                    if (gave_up || wall_clock64() - waiting_since >= wait_ticks) { gave_up = true; break; }
                     __builtin_amdgcn_s_sleep(HELD_POLL_SLEEP);
                 }
             }

@@ -65,6 +65,8 @@ struct Group {
     int n;
     const int32_t *tile_map;   // [tiles of the group] workgroup -> (batch << 20 | tile of that batch), longest first
     unsigned *stats;           // [128] scan statistics: [0] list blocks walked, [64] wave passes counted (sampled)
+    const unsigned *only;      // null, or [tiles]: workgroup w decodes its tile only where only[w] != 0 -- the repair launch
+                               // behind a cluster launch (Cluster::failed): tiles whose cluster gave up waiting, whole again
 };
 
 // CLUSTER form: R workgroups (a cluster) share one 16-item tile.  Every member keeps the WHOLE posterior tile in its
@@ -85,8 +87,16 @@ struct Cluster {
                            // [S4][16] floats, then their partial top lists [kMaxR][16 * kMaxTop] 64-bit keys
     unsigned *flags;       // [tiles][kMaxR] newest timestep each member has published (zeroed before the launch)
     unsigned *control;     // [0] tickets drawn (zeroed before the launch); give-ups are counted in Group::stats[127]
+    unsigned *failed;      // [tiles] set by a member that gave up waiting for the others (zeroed before the launch): the
+                           // tile's history is incomplete and the launch that follows decodes it again, whole
     int R;
+    unsigned long long wait_ticks;     // how long a member waits for the others' flags (100 MHz ticks; 0: not at all)
 };
+// Cluster::wait_ticks, default (ticks of the 100 MHz wall clock): a quarter of a second -- members that have not been
+// dispatched yet because another stream's launch holds the compute units arrive within tens of milliseconds; a cluster
+// that can never complete (a device shared with a process that never leaves) must not hang the call.
+// TORBI_HIP_CLUSTER_WAIT_US overrides (0 = give up at the first poll that fails: the tests of the repair launch).
+constexpr unsigned long long kClusterWaitTicks = 25000000ull;
 
 inline bool supported(int S) { return S >= 64 && S <= pruned::kMaxS; }
 
@@ -323,6 +333,9 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
     // ticket % R the member
     int cid = blockIdx.x, member = 0;
     const int R = CLUSTER ? clu.R : 1;
+    if constexpr (!CLUSTER) {
+        if (grp.only && grp.only[blockIdx.x] == 0u) return;      // (repair launch: this tile's cluster completed)
+    }
     if constexpr (CLUSTER) {
         if (tid == 0) {
             smisc[0] = (int)__hip_atomic_fetch_add(clu.control, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -695,6 +708,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                 // round, lanes 0..R-1; bounded: a cluster that cannot complete gives up and reports it), the others for wave 0
                 if (!CLUSTER_ONE_POLLER || wave == 0) {
                     unsigned spins = 0;
+                    unsigned long long since = 0ull;
 #if CLUSTER_FIRST_SLEEP > 0
                     __builtin_amdgcn_s_sleep(CLUSTER_FIRST_SLEEP);
 #endif
@@ -704,9 +718,13 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                             seen = __hip_atomic_load(cflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (__all(seen >= (unsigned)t)) break;
                         __builtin_amdgcn_s_sleep(CLUSTER_POLL_SLEEP);
-                        if (++spins > (1u << 22)) {
-                            if (lane == 0) smisc[1] = 1;
-                            break;
+                        if ((spins++ & 255u) == 0u) {           // (the clock is read at the first failed poll, then every 256th)
+                            const unsigned long long now = wall_clock64();
+                            if (since == 0ull) since = now;
+                            if (now - since >= clu.wait_ticks) {
+                                if (lane == 0) smisc[1] = 1;
+                                break;
+                            }
                         }
                     }
                 }
@@ -760,7 +778,10 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
         RSTAMP(6);
     }
     if constexpr (CLUSTER) {
-        if (tid == 0 && smisc[1]) atomicAdd(&grp.stats[127], 1u);     // workgroups that gave up waiting (0 on any sane run)
+        if (tid == 0 && smisc[1]) {
+            atomicAdd(&grp.stats[127], 1u);     // workgroups that gave up waiting (0 on any sane run)
+            clu.failed[cid] = 1u;               // ... and their tile is decoded again by the launch that follows
+        }
     }
     if (lane == 0 && stat_passes) {
         atomicAdd(&grp.stats[0], stat_blocks);

@@ -537,6 +537,58 @@ inline hipError_t ensure_dynamic_lds(const void *fn, size_t bytes) {
     return e;
 }
 
+// Decodes of this library that may still be running on a device, by stream: the end of every decode is marked with an
+// event on its stream.  Read by AUTO before it picks the held-matrix kernel, whose workgroups must all be resident at
+// once (held_matrix_forward.hpp): beside a launch on ANOTHER stream that holds the compute units -- a time-resident
+// launch group takes all of them for tens of milliseconds, a second held launch can leave both partly resident -- its
+// workgroups would spin until their time budget runs out and the slow repair kernel would decode the call.  With another
+// stream busy a handful of sequences take the per-timestep kernels instead, which simply queue behind the other work.
+// (Work this library did not launch is invisible here; the time budget and the repair kernel cover it.)
+struct StreamMark { hipStream_t stream; hipEvent_t done; };
+std::mutex g_marks_mutex;
+std::vector<StreamMark> g_marks[kMaxDevices];
+constexpr size_t kMaxMarks = 64;
+
+inline void mark_decode_end(int device, hipStream_t s) {
+    if (device < 0 || device >= kMaxDevices) return;
+    std::lock_guard<std::mutex> hold(g_marks_mutex);
+    auto &marks = g_marks[device];
+    StreamMark *slot = nullptr;
+    for (auto &m : marks)
+        if (m.stream == s) { slot = &m; break; }
+    if (!slot && marks.size() >= kMaxMarks) {           // full: take over the mark of a stream that has gone quiet
+        for (auto &m : marks)
+            if (hipEventQuery(m.done) == hipSuccess) { slot = &m; break; }
+        if (!slot) return;
+        slot->stream = s;
+    }
+    if (!slot) {
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+        marks.push_back(StreamMark{s, ev});
+        slot = &marks.back();
+    }
+    if (hipEventRecord(slot->done, s) != hipSuccess) (void)hipGetLastError();
+}
+
+inline bool other_streams_busy(int device, hipStream_t s) {
+    if (device < 0 || device >= kMaxDevices) return false;
+    std::lock_guard<std::mutex> hold(g_marks_mutex);
+    for (auto &m : g_marks[device])
+        if (m.stream != s) {
+            const hipError_t q = hipEventQuery(m.done);
+            if (q == hipErrorNotReady) return true;
+            if (q != hipSuccess) (void)hipGetLastError();
+        }
+    return false;
+}
+
+// name of the forward kernel the calling thread's most recent decode launched, spelled as rocprofv3 prints it
+// (torbi_hip_last_forward_kernel: bench.py matches it against the committed counter summaries)
+thread_local char g_last_kernel[160] = "";
+#include <stdio.h>
+#define TORBI_NOTE_KERNEL(...) snprintf(g_last_kernel, sizeof(g_last_kernel), __VA_ARGS__)
+
 // Which forward recurrence runs.  GENERIC materialises the int32 trellis like the reference does; the other three
 // keep the posterior history and recompute backpointers along the decoded path (lazy_backtrace.hpp).
 enum Route { ROUTE_GENERIC = 0, ROUTE_DENSE = 1, ROUTE_PRUNED = 2, ROUTE_RESIDENT = 3, ROUTE_ROWS = 4, ROUTE_CLUSTER = 5,
@@ -604,7 +656,7 @@ inline bool held_auto(int B, int S) {
 // route of ONE batch.  AUTO: the time-resident kernel -- whole tiles per workgroup when the batch alone gives at least
 // half the compute units a workgroup, tiles split over clusters of workgroups for smaller batches of >= 17 items --
 // else the per-timestep pruned pass where supported, else the dense (max,+) GEMM, else generic.
-inline Route route_for(int path, int B, int S, int cus) {
+inline Route route_for(int path, int B, int S, int cus, bool allow_held = true) {
     const bool fits = resident_fits(S, tiles_of(B, S));
     if (path == TORBI_HIP_FORWARD_RESIDENT && fits) return ROUTE_RESIDENT;
     if (path == TORBI_HIP_FORWARD_CLUSTER && fits) return cluster_members(tiles_of(B, S), S, cus) > 1 ? ROUTE_CLUSTER : ROUTE_RESIDENT;
@@ -618,7 +670,8 @@ inline Route route_for(int path, int B, int S, int cus) {
     if (path != TORBI_HIP_FORWARD_DENSE && pruned::supported(B, S)) return ROUTE_PRUNED;
     // a handful of sequences: the whole time loop in one launch, the matrix held in registers across the chip
     // (held_matrix_forward.hpp) -- AUTO up to three items, eight above 2048 states (held_auto); any B <= 16 when named
-    if (held::supported(B, S, cus) && (path == TORBI_HIP_FORWARD_HELD || (path == TORBI_HIP_FORWARD_AUTO && held_auto(B, S))))
+    if (held::supported(B, S, cus) &&
+        (path == TORBI_HIP_FORWARD_HELD || (path == TORBI_HIP_FORWARD_AUTO && allow_held && held_auto(B, S))))
         return ROUTE_HELD;
     if ((path == TORBI_HIP_FORWARD_PRUNED && rowscan::supported(B, S)) ||
         (path != TORBI_HIP_FORWARD_DENSE && rowscan::profitable(B, S)))
@@ -741,7 +794,7 @@ inline ResidentWorkspace carve_resident(void *base, int B, int T, int S, int cus
     const size_t order_bytes = align_up(sizeof(int32_t) * (size_t)B, 256) + sizeof(int32_t) * (kMaxGroupTiles + 128) + hist_len;
     const size_t ctiles = (size_t)std::max(cus / 2, 1);                 // a cluster launch holds at most this many tiles
     const size_t xchg_bytes = align_up(ctiles * 2 * resident::cluster_slot_bytes(S), 256);
-    w.flag_bytes = align_up(sizeof(unsigned) * (ctiles * resident::kMaxR + 16), 256);
+    w.flag_bytes = align_up(sizeof(unsigned) * (ctiles * resident::kMaxR + 16 + ctiles), 256);    // flags, control, failed
     w.hist = reinterpret_cast<float *>(p);
     p += hist_bytes;
     w.tile_map = reinterpret_cast<int32_t *>(p);   // ahead of the preparation: offsets depend on B and T only
@@ -935,15 +988,17 @@ hipError_t launch_held_forward(const float *obs, const int32_t *frames, const fl
     }
     if (launches) *launches = 1;
     if (T < 2) return hipGetLastError();
-    // polls before a workgroup stops waiting for the others (~1 us each: a quarter of a second; TORBI_HIP_HELD_SPIN_LIMIT for
-    // tests of the repair path)
-    const char *limit_env = getenv("TORBI_HIP_HELD_SPIN_LIMIT");
-    const unsigned spin_limit = limit_env ? (unsigned)strtoul(limit_env, nullptr, 10) : (1u << 18);
+    // how long a workgroup waits for the others before it gives up (ticks of the 100 MHz wall clock): 20 x T x 2.5 us, at
+    // least 2 ms -- 25 ms for 500 frames, against the ~1 ms the launch takes when it is resident.  TORBI_HIP_HELD_WAIT_US
+    // overrides; TORBI_HIP_HELD_SPIN_LIMIT (polls of ~1 us, the round-3 knob; 0 forces the repair path in the tests) too.
+    unsigned long long wait_ticks = std::max<unsigned long long>(200000ull, 5000ull * (unsigned long long)T);
+    if (const char *us = getenv("TORBI_HIP_HELD_WAIT_US")) wait_ticks = 100ull * strtoull(us, nullptr, 10);
+    else if (const char *polls = getenv("TORBI_HIP_HELD_SPIN_LIMIT")) wait_ticks = 100ull * strtoull(polls, nullptr, 10);
     const dim3 grid(held::workgroups(S)), block(held::block_threads(S));
     const int K = (S + held::threads(S) - 1) / held::threads(S);
 #define TORBI_HELD(K_, R_, N_)                                                                                       \
     hipLaunchKernelGGL((held::held_forward_kernel<K_, R_, N_, (N_ < 1024)>), grid, block, 0, stream, obs, frames, trans, \
-                       w.post[0], w.post[1], w.trellis, w.xchg, w.control, B, T, S, spin_limit)
+                       w.post[0], w.post[1], w.trellis, w.xchg, w.control, B, T, S, wait_ticks)
     if (S <= held::kSmallS) {
         if (K == 1) TORBI_HELD(1, 8, 512);
         else if (K == 2) TORBI_HELD(2, 8, 512);
@@ -986,6 +1041,7 @@ hipError_t launch_dense_steps(const float *obs, const int32_t *frames, const Den
     const size_t lds = dense::lds_bytes<BL, JL, NW, KC, MSL>();
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&dense::step_dense_kernel<BL, JL, NW, KC, MSL>), lds);
     if (e != hipSuccess) return e;
+    TORBI_NOTE_KERNEL("dense::step_dense_kernel<%d, %d, %d, %d, %d>", BL, JL, NW, KC, MSL);
     const int ntiles = pl.n_bt * pl.n_jt;
     const int grid = 8 * ((ntiles + 7) / 8);
     int n = 0;
@@ -1091,6 +1147,7 @@ hipError_t launch_pruned_forward(const float *obs, const int32_t *frames, const 
                      : &pruned::step_pruned_kernel<pruned::kNB / 2, false>;
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), lds);
     if (e != hipSuccess) return e;
+    TORBI_NOTE_KERNEL("pruned::step_pruned_kernel<%d, %s>", pl.NI, collect ? "true" : "false");
     int n = 0;
     for (int t = 1; t < T; ++t) {
         const size_t in = ((t - 1) & 1) * w.top_stride, out = (t & 1) * w.top_stride;
@@ -1219,6 +1276,8 @@ hipError_t launch_resident_variant(const resident::Group &grp, const resident::C
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((resident::resident_forward_kernel<KW, MAXP, true, KR, CLUSTER, NI>), dim3(workgroups), dim3(64 * KW), lds,
                        stream, grp, clu, w.tt, w.sorted, init, S, w.SpP);
+    if (!grp.only)
+        TORBI_NOTE_KERNEL("resident::resident_forward_kernel<%d, %d, true, %d, %s, %d>", KW, MAXP, KR, CLUSTER ? "true" : "false", NI);
     return hipGetLastError();
 }
 
@@ -1228,6 +1287,19 @@ hipError_t launch_resident_kernel(const resident::Group &grp, const resident::Cl
                                   const ResidentWorkspace &w, const float *init, int S, hipStream_t stream, bool few) {
     return resident_seeds(few) == 3 ? launch_resident_variant<KW, MAXP, 3, CLUSTER, NI>(grp, clu, workgroups, w, init, S, stream)
                                     : launch_resident_variant<KW, MAXP, 1, CLUSTER, NI>(grp, clu, workgroups, w, init, S, stream);
+}
+
+// every workgroup owns a whole tile (resident_forward_kernel without clusters)
+inline hipError_t launch_whole_tiles(const resident::Group &grp, const resident::Cluster &clu, int tiles,
+                                     const ResidentWorkspace &w, const float *init, int S, hipStream_t s, bool few) {
+    const int nrg = (S + resident::pass_rows(S) - 1) / resident::pass_rows(S);
+    if (resident::tile_items(S) != resident::kNI) {       // 8-item tiles (2048 < S <= 4096)
+        if (nrg <= 96) return launch_resident_kernel<12, 8, false, 8>(grp, clu, tiles, w, init, S, s, few);
+        return launch_resident_kernel<12, 11, false, 8>(grp, clu, tiles, w, init, S, s, few);
+    }
+    if (nrg <= 72) return launch_resident_kernel<12, 6, false>(grp, clu, tiles, w, init, S, s, few);
+    if (nrg <= 96) return launch_resident_kernel<12, 8, false>(grp, clu, tiles, w, init, S, s, few);
+    return launch_resident_kernel<12, 11, false>(grp, clu, tiles, w, init, S, s, few);
 }
 
 // batches with B > 0 only; the preparation lives in the first batch's workspace
@@ -1267,7 +1339,10 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
     jobs.tile_map = w.tile_map;
     // cluster form: R workgroups per tile (exchange buffers in the first batch's workspace, flags and tickets zeroed)
     const int R = clusters ? cluster_members(tiles, S, cus) : 1;
-    resident::Cluster clu{w.xchg, w.flags, w.flags + (size_t)std::max(cus / 2, 1) * resident::kMaxR, R};
+    unsigned *const control = w.flags + (size_t)std::max(cus / 2, 1) * resident::kMaxR;
+    const char *wait_env = getenv("TORBI_HIP_CLUSTER_WAIT_US");         // (read per launch: the tests switch it)
+    const unsigned long long wait_ticks = wait_env ? 100ull * strtoull(wait_env, nullptr, 10) : resident::kClusterWaitTicks;
+    resident::Cluster clu{w.xchg, w.flags, control, control + 16, R, wait_ticks};
     if (ev) (void)hipEventRecord(ev[0], s);
     for (int k = 0; k < n; ++k) {            // (order_items_kernel stamps the batches' route records)
         jobs.job[k].route_record = route_record(hb[k].workspace, hb[k].B, hb[k].T, S, cus);
@@ -1304,12 +1379,16 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
         else if (passes <= 2) e = launch_resident_kernel<12, 2, true>(grp, clu, tiles * R, w, init, S, s, few);
         else if (passes <= 4) e = launch_resident_kernel<12, 4, true>(grp, clu, tiles * R, w, init, S, s, few);
         else e = launch_resident_kernel<12, 6, true>(grp, clu, tiles * R, w, init, S, s, few);
-    } else if (small) {
-        if (nrg <= 96) e = launch_resident_kernel<12, 8, false, 8>(grp, clu, tiles, w, init, S, s, few);
-        else e = launch_resident_kernel<12, 11, false, 8>(grp, clu, tiles, w, init, S, s, few);
-    } else if (nrg <= 72) e = launch_resident_kernel<12, 6, false>(grp, clu, tiles, w, init, S, s, few);
-    else if (nrg <= 96) e = launch_resident_kernel<12, 8, false>(grp, clu, tiles, w, init, S, s, few);
-    else e = launch_resident_kernel<12, 11, false>(grp, clu, tiles, w, init, S, s, few);
+        // a cluster that could not complete in time (resident_forward.hpp: CLUSTER_WAIT_TICKS) has flagged its tile: the
+        // launch behind decodes those tiles again, whole -- it returns at once wherever nothing was flagged (every run so far)
+        if (e == hipSuccess) {
+            resident::Group again = grp;
+            again.only = clu.failed;
+            e = launch_whole_tiles(again, clu, tiles, w, init, S, s, few);
+        }
+    } else {
+        e = launch_whole_tiles(grp, clu, tiles, w, init, S, s, few);
+    }
     if (launches) *launches = 1;
     if (ev) (void)hipEventRecord(ev[1], s);
     if (e != hipSuccess) return e;
@@ -1361,10 +1440,15 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
 // one decode on `s`; optional events bracket the forward and backtrace phases (ev[3]: end of the preparation)
 hipError_t run_decode(const float *obs, const int32_t *frames, const float *trans, const float *init,
                       int32_t *out, void *workspace, int B, int T, int S, int device, hipStream_t s,
-                      hipEvent_t *ev, int *launches, bool reuse, bool collect, int path, unsigned seed_flags = 0u) {
+                      hipEvent_t *ev, int *launches, bool reuse, bool collect, int path, unsigned seed_flags = 0u,
+                      Route *taken = nullptr) {
     hipError_t e;
     const int cus = cu_count(device);
-    const Route route = route_for(path, B, S, cus);
+    Route route = route_for(path, B, S, cus);
+    // AUTO keeps away from the held-matrix kernel while another stream of the device is busy (see mark_decode_end)
+    if (route == ROUTE_HELD && path == TORBI_HIP_FORWARD_AUTO && other_streams_busy(device, s))
+        route = route_for(path, B, S, cus, false);
+    if (taken) *taken = route;
     if (route == ROUTE_RESIDENT || route == ROUTE_CLUSTER) {
         const HostBatch hb{obs, frames, out, workspace, B, T};
         return run_resident(&hb, 1, trans, init, S, cus, s, ev, launches, reuse, false, route == ROUTE_CLUSTER,
@@ -1387,6 +1471,7 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
         if (e == hipSuccess)
             e = launch_backtrace_on(w.hist, trans, frames, out, B, T, S, s, w.ranges, w.ranges + 2 * (size_t)S);
     } else if (route == ROUTE_ROWS) {
+        TORBI_NOTE_KERNEL("rowscan::step_rows_sorted_kernel");
         const RowsWorkspace w = carve_rows(workspace, B, T, S);
         if (!reuse)       // per-transition preparation: descending rows, prev-states as byte offsets of a 16-item tile row
             hipLaunchKernelGGL(pruned::sort_rows_kernel, dim3(S), dim3(256), sizeof(float) * 2 * (size_t)w.NPOW, s, trans,
@@ -1408,6 +1493,7 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
             e = launch_backtrace_sorted(w.hist, w.sorted, w.SpP, pruned::kNB, trans, frames, out, B, T, S, s, w.rowmax);
     } else {
         const Workspace w = carve(workspace, B, T, S);
+        TORBI_NOTE_KERNEL(route == ROUTE_HELD ? "held::held_forward_kernel" : "step_rows_kernel / step_tile_kernel");
         e = route == ROUTE_HELD ? launch_held_forward(obs, frames, trans, init, w, B, T, S, s, launches)
                                 : launch_forward(obs, frames, trans, init, w, B, T, S, s, launches);
         if (ev) (void)hipEventRecord(ev[1], s);
@@ -1480,6 +1566,12 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S) {
     return need_bytes_any_device(B, T, S);
 }
 
+int torbi_hip_last_forward_kernel(char *name_out, size_t capacity) {
+    if (!name_out || capacity == 0) return TORBI_HIP_EINVAL;
+    snprintf(name_out, capacity, "%s", g_last_kernel);
+    return TORBI_HIP_OK;
+}
+
 int torbi_hip_set_forward_path(int path) {
     if (path < TORBI_HIP_FORWARD_AUTO || path > TORBI_HIP_FORWARD_HELD) return TORBI_HIP_EINVAL;
     g_forward_path.store(path, std::memory_order_relaxed);
@@ -1511,10 +1603,12 @@ int torbi_hip_viterbi_decode_ex(const float *observation, const int32_t *batch_f
     if (rc != TORBI_HIP_OK || B == 0) return rc;
     DeviceGuard guard(device);
     if (guard.err != hipSuccess) return (int)guard.err;
-    return (int)run_decode(observation, batch_frames, transition, initial, indices_out, workspace,
-                           B, T, S, device, static_cast<hipStream_t>(stream), nullptr, nullptr,
-                           (flags & TORBI_HIP_REUSE_TRANSITION) != 0, (flags & TORBI_HIP_COLLECT_STATS) != 0,
-                           requested_path(flags), flags);
+    const hipError_t e = run_decode(observation, batch_frames, transition, initial, indices_out, workspace,
+                                    B, T, S, device, static_cast<hipStream_t>(stream), nullptr, nullptr,
+                                    (flags & TORBI_HIP_REUSE_TRANSITION) != 0, (flags & TORBI_HIP_COLLECT_STATS) != 0,
+                                    requested_path(flags), flags);
+    mark_decode_end(device, static_cast<hipStream_t>(stream));
+    return (int)e;
 }
 
 int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, const float *transition,
@@ -1566,26 +1660,29 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
             // one batch after the other, each on the path it would take alone; phases of the LAST batch only
             e = hipSuccess;
             // (the reuse promise covers the first batch's workspace only)
+            Route taken = route_for(path, hb[n - 1].B, S, cus);
             for (int k = 0; k < n && e == hipSuccess; ++k)
                 e = run_decode(hb[k].obs, hb[k].frames, transition, initial, hb[k].out, hb[k].workspace, hb[k].B,
-                               hb[k].T, S, device, s, k == n - 1 ? pe.ev : nullptr, &launches, reuse && k == 0, false, path, flags);
-            phase_ms[3] = (float)route_for(path, hb[n - 1].B, S, cus);
+                               hb[k].T, S, device, s, k == n - 1 ? pe.ev : nullptr, &launches, reuse && k == 0, false, path, flags,
+                               &taken);
+            phase_ms[3] = (float)taken;
         }
+        mark_decode_end(device, s);
         if (e == hipSuccess) e = pe.read(phase_ms);
         phase_ms[2] = (float)launches;
         phase_ms[5] = (float)(together ? n : 1);
         return (int)e;
     }
+    hipError_t e = hipSuccess;
     if (together)
-        return (int)run_resident(hb, n, transition, initial, S, cus, s, nullptr, nullptr, reuse, ascending, clusters,
-                                 few_seeds(flags, clusters));
-    for (int k = 0; k < n; ++k) {
-        const hipError_t e = run_decode(hb[k].obs, hb[k].frames, transition, initial, hb[k].out, hb[k].workspace,
-                                        hb[k].B, hb[k].T, S, device, s, nullptr, nullptr, reuse && k == 0,
-                                        (flags & TORBI_HIP_COLLECT_STATS) != 0, path, flags);
-        if (e != hipSuccess) return (int)e;
-    }
-    return TORBI_HIP_OK;
+        e = run_resident(hb, n, transition, initial, S, cus, s, nullptr, nullptr, reuse, ascending, clusters,
+                         few_seeds(flags, clusters));
+    else
+        for (int k = 0; k < n && e == hipSuccess; ++k)
+            e = run_decode(hb[k].obs, hb[k].frames, transition, initial, hb[k].out, hb[k].workspace, hb[k].B, hb[k].T, S,
+                           device, s, nullptr, nullptr, reuse && k == 0, (flags & TORBI_HIP_COLLECT_STATS) != 0, path, flags);
+    mark_decode_end(device, s);
+    return (int)e;
 }
 
 int torbi_hip_scan_stats(const void *workspace, size_t workspace_bytes, int B, int T, int S,
@@ -1624,6 +1721,7 @@ int torbi_hip_viterbi_decode_uniform(const float *observation, const int32_t *ba
     if (S <= 1024 * NQ_) {                                                                          \
         hipLaunchKernelGGL((uniform::uniform_decode_kernel<NQ_, DEPTH_>), dim3(B), dim3(256), 0, s, \
                            observation, batch_frames, initial, log_transition, indices_out, B, T, S); \
+        mark_decode_end(device, s);                                                                 \
         return (int)hipGetLastError();                                                              \
     }
     TORBI_UNIFORM_CASE(1, TORBI_UNIFORM_DEPTH)

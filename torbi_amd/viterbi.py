@@ -518,6 +518,14 @@ def forward_path(batch: int, states: int, path: Optional[str] = None, device: in
     return ROUTES[code]
 
 
+def last_forward_kernel() -> str:
+    """Name of the forward kernel this thread's most recent decode launched, as rocprofv3 spells it
+    (include/torbi_hip.h, torbi_hip_last_forward_kernel); '' before the first decode."""
+    buffer = ctypes.create_string_buffer(192)
+    _lib.check(_lib.load().torbi_hip_last_forward_kernel(buffer, len(buffer)), 'torbi_hip_last_forward_kernel')
+    return buffer.value.decode()
+
+
 def uniform_supported(states: int) -> bool:
     """Shapes the uniform-transition entry point covers (include/torbi_hip.h)."""
     return states % 4 == 0 and states <= 4096
