@@ -237,6 +237,51 @@ class Bench:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def rank_report(self, local_rate, alone, indices, B):
+        """What makes an N > 1 line verifiable from its own output (rates per GPU count, gather time shown
+        separately): the world as the collective saw it, every rank's own rate inside the timed region, the all-gather
+        of one batch's indices timed on its own, and rank 0's rate over the same steps with NO collective (the driver's
+        N = 1 run should agree with it)."""
+        torch, dist = self.torch, self.dist
+        size = self.size
+        ones = int(round(self.sum_over_ranks(1.0)))
+        report = {'ranks_seen': {'world_size': dist.get_world_size(), 'all_reduce_of_ones': ones,
+                                 'backend': dist.get_backend()}}
+        mine = torch.tensor([local_rate if local_rate is not None else float('nan')], dtype=torch.float64,
+                            device=self.dev or 'cpu')
+        every = [torch.zeros_like(mine) for _ in range(size)]
+        dist.all_gather(every, mine)
+        report['per_rank_value'] = [None if math.isnan(float(v)) else float(v) for v in every]
+        # the collective alone: K all-gathers of one batch's (B, T) int32 indices, max over ranks
+        rounds = 20
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(rounds):
+            self.distributed.gather_indices(indices, B * size, force=True)
+        if not self.dry:
+            torch.cuda.synchronize()
+        report['gather_ms_per_batch'] = self.max_over_ranks(time.perf_counter() - t0) / rounds * 1e3
+        report['gather_bytes_per_batch'] = int(indices.numel()) * 4 * size
+        if alone is not None:
+            steps = min(self.args.steps, 8)
+            alone(steps)                         # (warm: the pipeline's streams without the after-hook)
+            self.fence()
+            t0 = time.perf_counter()
+            alone(steps)
+            if not self.dry:
+                torch.cuda.synchronize()
+            rate = float(indices.shape[0]) * indices.shape[1] * steps / (time.perf_counter() - t0)
+            alone_rates = [torch.zeros_like(mine) for _ in range(size)]
+            dist.all_gather(alone_rates, torch.tensor([rate], dtype=torch.float64, device=self.dev or 'cpu'))
+            report['n1_reference_value'] = float(alone_rates[0])
+            report['per_rank_value_without_collective'] = [float(v) for v in alone_rates]
+            report['n1_reference_note'] = (f'rank 0 over {steps} steps with no collective while every other rank does the '
+                                           'same on its own GPU: what `bench.py --gpus 1` measures, up to launch-group shape')
+            self.fence()
+        else:
+            report['n1_reference_value'] = None
+        return report
+
     def model(self, S, transition='dense', half_width=87.2):
         v, synth = self.viterbi, self.synth
         trans = v.fill_synthetic((S, S), synth.STREAM_TRANSITION, seed=0, device=self.dev)
@@ -275,12 +320,15 @@ class Bench:
         rank, size = self.rank, self.size
         if self.dry:
             self.fence()
-            return {'metric': METRIC, 'value': None, 'unit': 'timesteps/s', 'n_gpus': size, 'steps': args.steps,
+            line = {'metric': METRIC, 'value': None, 'unit': 'timesteps/s', 'n_gpus': size, 'steps': args.steps,
                     'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak',
                     'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'dry_run': True,
                     'config': {'workload': f'{S} states, {T} frames, batch={B} per GPU (no HIP device: launch, '
                                            f'rendezvous and planning only)',
                                'launch_groups': self.balanced_groups(args.steps, args.group)}}
+            if self.collective:
+                line['multi_gpu'] = self.rank_report(None, None, torch.zeros((B, T), dtype=torch.int32), B)
+            return line
         dev = self.dev
         trans, init = self.model(S, args.transition, args.half_width)
         frames = torch.full((B,), T, dtype=torch.int32, device=dev)
@@ -315,7 +363,8 @@ class Bench:
         t0 = time.perf_counter()
         indices = run_steps(args.steps)
         self.fence(pipe)
-        elapsed = self.max_over_ranks(time.perf_counter() - t0)
+        local_elapsed = time.perf_counter() - t0
+        elapsed = self.max_over_ranks(local_elapsed)
         value = float(B) * T * args.steps * size / elapsed
         last_obs = obs[(self.balanced_groups(args.steps, group)[-1] - 1) % group]
 
@@ -324,6 +373,18 @@ class Bench:
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         }
+        if self.collective:
+            def alone(count):                  # the same steps WITHOUT the collective: what this rank does on its own
+                pipe.synchronize()
+                for n in self.balanced_groups(count, group):
+                    for j in range(n):
+                        if args.transition == 'uniform':
+                            self.torbi_amd.decode_uniform(obs[0], frames, uniform_c, init)
+                        else:
+                            pipe.decode(obs[j % group], frames, trans, init)
+                    pipe.flush()
+                pipe.synchronize()
+            result['multi_gpu'] = self.rank_report(float(B) * T * args.steps / local_elapsed, alone, indices, B)
         if args.transition == 'uniform':
             per = elapsed / args.steps
             nbytes = float(B) * T * (4 * S + 4)
@@ -736,6 +797,8 @@ class Bench:
                 torch.save(torch.rand(S, S, generator=gen).softmax(-1), tf)
             workers = min(32, max(1, (os.cpu_count() or 2) // (2 * self.size)))
             seconds = []
+            core = self.torbi_amd.core
+            kept_before, core.KEEP_JOB_MEMORY = core.KEEP_JOB_MEMORY, True     # a long-running job server: see the note
             for _ in range(2):      # first call: pinned host blocks, device scratch and code objects are new
                 self.fence()
                 t0 = time.perf_counter()
@@ -744,6 +807,8 @@ class Bench:
                 self.fence()
                 seconds.append(self.max_over_ranks(time.perf_counter() - t0))
             elapsed = seconds[-1]
+            core.KEEP_JOB_MEMORY = kept_before
+            core.release_job_memory()
             ok = all(os.path.exists(f) for f in outs)
             direct = bool(getattr(self.torbi_amd.core, 'DIRECT_FILE_IO', False))
             return {'value': sum(lengths) / elapsed, 'unit': 'timesteps/s', 'seconds': elapsed,
@@ -759,7 +824,9 @@ class Bench:
                                          '(MI355X_MICROARCH.md: PCIe Gen5 x16, 63 GB/s spec; 57 GB/s measured for pinned H2D)'},
                     'note': 'files -> pinned batches -> H2D -> epsilon clamp -> decode -> D2H -> one output file per input, '
                             f'length-bucketed batches, files in {folder.rsplit("/", 1)[0]}; value = the second call '
-                            '(steady state of a long job), first_call_seconds = the same job cold'}
+                            '(steady state of a process that runs job after job with torbi_amd.core.KEEP_JOB_MEMORY = True: '
+                            'pipeline scratch and staging slabs kept between jobs), first_call_seconds = the same job cold '
+                            '(what a single job sees; by default the scratch is freed with the job)'}
         finally:
             if self.rank == 0:
                 shutil.rmtree(folder, ignore_errors=True)

@@ -142,4 +142,15 @@ def test_bench_with_the_collective_forced_prints_the_same_rate():
             line = json.loads([text for text in run.stdout.splitlines() if text.startswith('{')][-1])
             assert line['n_gpus'] == 1 and line['steps'] == 16 and line['value'] > 0
             rates[force] = max(rates.get(force, 0.0), line['value'])
+            assert line['single_call']['value'] > 0 and line['single_call']['forward_path'] == 'cluster'
+            if force == '1':
+                # the line verifies itself (round-3 review item 6c): the world as the collective saw it, every rank's own
+                # rate, the gather on its own, and the no-collective rate an N = 1 run should reproduce
+                report = line['multi_gpu']
+                assert report['ranks_seen'] == {'world_size': 1, 'all_reduce_of_ones': 1, 'backend': 'nccl'}
+                assert len(report['per_rank_value']) == 1 and report['per_rank_value'][0] > 0
+                assert 0.0 < report['gather_ms_per_batch'] < 5.0 and report['gather_bytes_per_batch'] == 512 * 500 * 4
+                assert abs(report['n1_reference_value'] - line['value']) / line['value'] < 0.25, report
+            else:
+                assert 'multi_gpu' not in line
     assert abs(rates['1'] - rates['0']) / rates['0'] < 0.10, rates

@@ -508,6 +508,11 @@ def test_bench_starts_its_own_ranks_and_dry_runs_without_a_gpu():
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['dry_run'] is True and line['value'] is None
     assert line['steps'] == 20 and line['warmup'] == 5 and line['config']['launch_groups'] == [8, 8, 4]
+    # the N > 1 line verifies itself: ranks as the collective saw them, per-rank rates, the gather timed on its own
+    report = line['multi_gpu']
+    assert report['ranks_seen'] == {'world_size': 2, 'all_reduce_of_ones': 2, 'backend': 'gloo'}
+    assert report['per_rank_value'] == [None, None] and report['n1_reference_value'] is None
+    assert report['gather_ms_per_batch'] > 0 and report['gather_bytes_per_batch'] == 2 * 512 * 500 * 4
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', 'c4', '--files', '3000'],
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -977,6 +977,41 @@ hipError_t launch_forward(const float *obs, const int32_t *frames, const float *
     return hipGetLastError();
 }
 
+// The held-matrix kernel's instantiation for S states: kernel, grid, block.
+struct HeldLaunch { const void *fn; int grid, block; };
+inline HeldLaunch held_launch(int S) {
+    const int K = (S + held::threads(S) - 1) / held::threads(S);
+    const void *fn;
+    if (S <= held::kSmallS)
+        fn = K == 1 ? (const void *)&held::held_forward_kernel<1, 8, 512, true>
+           : K == 2 ? (const void *)&held::held_forward_kernel<2, 8, 512, true>
+           : K == 3 ? (const void *)&held::held_forward_kernel<3, 8, 512, true>
+                    : (const void *)&held::held_forward_kernel<4, 8, 512, true>;
+    else
+        fn = K == 3 ? (const void *)&held::held_forward_kernel<3, 16, 1024, false>
+                    : (const void *)&held::held_forward_kernel<4, 16, 1024, false>;
+    return HeldLaunch{fn, held::workgroups(S), held::block_threads(S)};
+}
+// Can every workgroup of that launch be resident at once on `device`?  The runtime's occupancy answer for the very
+// kernel (registers, LDS, waves), queried once per (kernel, device) -- held::supported()'s "two workgroups per compute
+// unit up to 2048 states" is an assumption about this build on an MI355X, this is the check.
+inline bool held_resident(int S, int device, int cus) {
+    struct Known { const void *fn; int device; int per_cu; };
+    static std::mutex mu;
+    static std::vector<Known> known;
+    const HeldLaunch h = held_launch(S);
+    std::lock_guard<std::mutex> hold(mu);
+    for (auto &k : known)
+        if (k.fn == h.fn && k.device == device) return h.grid <= k.per_cu * cus;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, h.fn, h.block, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        per_cu = 0;
+    }
+    known.push_back(Known{h.fn, device, per_cu});
+    return h.grid <= per_cu * cus;
+}
+
 // the same outputs from ONE launch: the time loop inside the kernel, the matrix in registers (held_matrix_forward.hpp)
 hipError_t launch_held_forward(const float *obs, const int32_t *frames, const float *trans, const float *init,
                                const Workspace &w, int B, int T, int S, hipStream_t stream, int *launches) {
@@ -1448,6 +1483,9 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
     // AUTO keeps away from the held-matrix kernel while another stream of the device is busy (see mark_decode_end)
     if (route == ROUTE_HELD && path == TORBI_HIP_FORWARD_AUTO && other_streams_busy(device, s))
         route = route_for(path, B, S, cus, false);
+    // ... and, named or not, from a launch the device cannot hold as a whole (occupancy of this very kernel)
+    if (route == ROUTE_HELD && !held_resident(S, device, cus))
+        route = route_for(path == TORBI_HIP_FORWARD_HELD ? TORBI_HIP_FORWARD_AUTO : path, B, S, cus, false);
     if (taken) *taken = route;
     if (route == ROUTE_RESIDENT || route == ROUTE_CLUSTER) {
         const HostBatch hb{obs, frames, out, workspace, B, T};

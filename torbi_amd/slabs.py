@@ -11,6 +11,7 @@ which they may be reused; a returned slab that is large enough serves any later 
 (`release()` empties them): the second job of a process allocates nothing.
 """
 import threading
+import weakref
 from typing import List, Optional, Tuple
 
 import torch
@@ -25,6 +26,7 @@ class SlabPool:
         self._free: List[torch.Tensor] = []
         self._busy: List[Tuple[torch.Tensor, Optional[torch.cuda.Event]]] = []
         self._out = 0            # slabs handed out and not given back yet
+        self._lent = {}          # id(slab) -> finalizer: a slab that dies without being given back stops counting as out
 
     def _collect(self) -> None:
         still = []
@@ -47,8 +49,7 @@ class SlabPool:
                 fitting = [k for k, slab in enumerate(self._free) if slab.numel() >= nbytes]
                 if fitting:
                     best = min(fitting, key=lambda k: self._free[k].numel())
-                    self._out += 1
-                    return self._free.pop(best)
+                    return self._lend(self._free.pop(best))
                 held = len(self._free) + len(self._busy) + self._out
                 waiting_for = None
                 if limit is not None and held >= limit:
@@ -62,17 +63,35 @@ class SlabPool:
             if waiting_for is None:
                 break
             waiting_for.synchronize()
-        with self._lock:
-            self._out += 1
         size = (nbytes + nbytes // 8 + (1 << 20) - 1) >> 20 << 20
         if self.device is None:
-            return torch.empty((size,), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
-        return torch.empty((size,), dtype=torch.uint8, device=self.device)
+            slab = torch.empty((size,), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+        else:
+            slab = torch.empty((size,), dtype=torch.uint8, device=self.device)
+        with self._lock:
+            return self._lend(slab)
+
+    def _lend(self, slab: torch.Tensor) -> torch.Tensor:
+        """(lock held) Count `slab` as out until it is given back -- or dropped: a batch that takes a path which never
+        returns its slabs (log_probs=False, the CPU route, an exception) must not make the pool believe for ever that it
+        is at its limit and allocate a fresh multi-GB pinned buffer for every batch after."""
+        self._out += 1
+        key = id(slab)
+        self._lent[key] = weakref.finalize(slab, self._lost, key)
+        return slab
+
+    def _lost(self, key: int) -> None:
+        with self._lock:
+            if self._lent.pop(key, None) is not None:
+                self._out = max(0, self._out - 1)
 
     def give(self, slab: torch.Tensor, event: Optional[torch.cuda.Event] = None) -> None:
         """Return a slab; it is handed out again once `event` (recorded behind its last use) has completed."""
         with self._lock:
-            self._out = max(0, self._out - 1)
+            finalizer = self._lent.pop(id(slab), None)
+            if finalizer is not None:
+                finalizer.detach()
+                self._out = max(0, self._out - 1)
             self._busy.append((slab, event))
 
     def release(self) -> None:
