@@ -13,6 +13,45 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'slow: repeats coverage the default GPU run already has (a forced forward path that '
+                                       'routes the case exactly as AUTO does, a second pass through a host path); run with '
+                                       '--runslow or TORBI_RUN_SLOW=1')
+
+
+def pytest_addoption(parser):
+    parser.addoption('--runslow', action='store_true', default=False, help='also run the tests marked slow')
+
+
+# tests/test_gpu_parity.py runs every test under five forward paths (autouse fixture `forward`).  Where a forced path
+# launches exactly the kernels AUTO launches for every shape of the test, the repetition adds run time and no coverage:
+#   PATH_BLIND     tests that never reach a forward kernel choice (elementwise kernels, synthetic fill, library load):
+#                  only the 'auto' instance stays in the default run
+#   SAME_AS_AUTO   test -> forced paths that route every one of its shapes as AUTO does (fresh tensors, 256 compute units:
+#                  batches of 17..2047 items over 64..4096 states with a matrix that is not a narrow band are 'cluster'
+#                  under AUTO)
+# Every route keeps oracle-comparing tests in the default run: cluster / held / rows / generic through 'auto', resident,
+# dense and pruned through their forced instances.
+PATH_BLIND = {'test_extension_is_loaded_and_sees_the_gpu', 'test_fused_epsilon_clamp_is_bit_identical_to_the_torch_ops',
+              'test_fused_log_and_epsilon_clamp_is_bit_identical_to_the_torch_ops',
+              'test_fill_synthetic_matches_numpy_definition'}
+SAME_AS_AUTO = {'test_minus_inf_observations_on_the_large_batch_paths': {'cluster'},
+                'test_pruned_path_adversarial_inputs': {'cluster'},
+                'test_headline_shape_properties': {'cluster'},
+                'test_large_state_shape_properties': {'cluster'},
+                'test_inference_mode_is_supported': {'cluster'}}
+
+
+def pytest_collection_modifyitems(config, items):
+    run_slow = config.getoption('--runslow') or os.environ.get('TORBI_RUN_SLOW') == '1'
+    skip = pytest.mark.skip(reason='slow: repeats default-run coverage (--runslow / TORBI_RUN_SLOW=1 runs it)')
+    for item in items:
+        callspec = getattr(item, 'callspec', None)
+        forward = callspec.params.get('forward') if callspec is not None else None
+        name = getattr(item, 'originalname', None) or item.name.split('[')[0]
+        if forward is not None and ((name in PATH_BLIND and forward != 'auto') or forward in SAME_AS_AUTO.get(name, ())):
+            item.add_marker(pytest.mark.slow)
+        if not run_slow and item.get_closest_marker('slow') is not None:
+            item.add_marker(skip)
 
 
 class Golden:

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import torbi_amd
-from torbi_amd import _lib, synth, distributed
+from torbi_amd import _lib, synth, distributed, viterbi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -656,3 +656,19 @@ def test_timing_scope_like_the_reference():
     assert second['torbi'] > first['torbi'] and 'mine' in second
     torbi_amd.timer.reset()
     assert torbi_amd.timer.results() == {}
+
+
+def test_design_routing_table_is_what_the_library_answers():
+    """DESIGN.md section 4 carries ONE routing table; it is the output of tools/routing_table.py, i.e. of
+    torbi_hip_forward_path_on for every (batch, states, requested path) it lists (round-3 review item 7)."""
+    import re
+    import runpy
+    text = open(os.path.join(ROOT, 'DESIGN.md')).read()
+    found = re.search(r'<!-- routing-table:begin -->\n(.*?)\n<!-- routing-table:end -->', text, flags=re.S)
+    assert found, 'DESIGN.md lost its routing-table markers'
+    table = runpy.run_path(os.path.join(ROOT, 'tools', 'routing_table.py'))['table']()
+    assert found.group(1).strip() == table.strip()
+    # spot checks of the prose rules under it (256 compute units)
+    assert viterbi.forward_path(512, 1440) == 'cluster' and viterbi.forward_path(2049, 1440) == 'resident'
+    assert viterbi.forward_path(1, 1440) == 'held' and viterbi.forward_path(8, 1440) == 'rows'
+    assert os.path.getsize(os.path.join(ROOT, 'DESIGN.md')) <= 25 * 1024 + 512

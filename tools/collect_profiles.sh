@@ -1,6 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (gpurun -- 'bash tools/collect_profiles.sh'): rocprofv3 kernel trace + separate PMC passes of the
 # default bench command; summaries land in gpurun_out/profiles_new/ (copy the ones to keep into profiles/).
+# The box has no .git: pass the commit as  gpurun -- "GIT_HASH=$(git rev-parse --short HEAD) bash tools/collect_profiles.sh"
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
