@@ -32,9 +32,8 @@ PCIE_PEAK_GBS = 63.0                  # MI355X_MICROARCH.md: host link, PCIe Gen
 VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz lane-instructions/s
 METRIC = 'timesteps decoded/sec, 1440 states batch=512'
 KERNELS = {'resident': 'resident::resident_forward_kernel', 'cluster': 'resident::resident_forward_kernel',
-           'pruned': 'pruned::step_pruned_kernel',
            'dense': 'dense::step_dense_kernel', 'generic': 'step_rows', 'rows': 'rowscan::step_rows_sorted_kernel'}
-ROUTES = {0: 'generic', 1: 'dense', 2: 'pruned', 3: 'resident', 4: 'rows', 5: 'cluster', 6: 'held'}
+ROUTES = {0: 'generic', 1: 'dense', 3: 'resident', 4: 'rows', 5: 'cluster', 6: 'held'}
 
 
 def parse_args(argv=None):
@@ -58,7 +57,7 @@ def parse_args(argv=None):
     ap.add_argument('--reuse-preparation', action='store_true',
                     help='let consecutive decodes share the per-transition preparation (sorted rows / packed panels) '
                          'as a serving loop would; off by default: every timed launch group does all of its work')
-    ap.add_argument('--forward', choices=['auto', 'dense', 'pruned', 'resident', 'cluster'], default='auto',
+    ap.add_argument('--forward', choices=['auto', 'dense', 'resident', 'cluster'], default='auto',
                     help='forward-recurrence path (include/torbi_hip.h); every path gives identical indices')
     ap.add_argument('--pipeline', type=int, default=2, help='HIP streams the launch groups alternate between')
     ap.add_argument('--groups', choices=['balanced', 'full'], default='full',
@@ -460,7 +459,7 @@ class Bench:
             'transition_preparation': 'reused across launch groups' if args.reuse_preparation
             else 'rebuilt by every launch group'}
         result['roofline'] = {
-            'bound': 'valu_issue+lds' if route in ('resident', 'cluster', 'pruned') else 'valu_issue',
+            'bound': 'valu_issue+lds' if route in ('resident', 'cluster') else 'valu_issue',
             'bound_note': 'achieved / peak / frac are the HBM figures BASELINE.json asks for (algorithmic bytes per launch '
                           'over the 8 TB/s peak); what binds the kernel is under "executed"',
             'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -561,9 +560,6 @@ class Bench:
                'log_probs=True, gpu=0): epsilon clamp pass over the batch + workspace allocation (caching allocator) + '
                'decode, host-timed around a synchronised call, median of 3 after one warm-up call',
                {'first_call_ms': samples[0] * 1e3})
-        sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(obs, frames, trans, init, workspace=ws, path='pruned'), 3)
-        record('serial_per_timestep_kernel', sec, B * T, S, 'the same with per-timestep launches of the pruned recurrence '
-                                                           '(what AUTO took for one batch before round 3)')
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(obs, frames, trans, init, workspace=ws, path='dense'), 2)
         record('every_cell', sec, B * T, S, 'headline batch, dense (max,+) GEMM forced: every (prev, next) cell evaluated',
                {'valu_frac_at_1p5_instr_per_cell': 1.5 * B * T * S * S / sec / VALU_LANE_OPS})
@@ -632,9 +628,6 @@ class Bench:
             record('c5', sec, B5 * T5, S5, 'BASELINE configs[4]: 4096 states, 2000 frames, batch=128 (AUTO: ONE time-resident '
                                            'launch, 16 tiles of 8 items x 16 workgroups each)',
                    {'forward_path': ROUTES[int(prof[3])]})
-            sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(o5, f5, t5, i5, workspace=w5, path='pruned'), 2)
-            record('c5_per_timestep_kernel', sec, B5 * T5, S5, 'the same batch with per-timestep launches of the pruned '
-                                                               'recurrence on 8-item tiles (AUTO before round 3)')
             # the same shape as a launch group (a many-file job at 4096 states): four batches in one time-resident launch
             T5g, n5 = 500, 4
             spaces5 = [torch.empty(v.workspace_bytes(B5, T5g, S5), dtype=torch.uint8, device=dev) for _ in range(n5)]

@@ -82,10 +82,11 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
  *             entries per wave step (small_batch_forward.hpp); one launch per timestep.  AUTO takes it for
  *             B >= 6 or S > 2048 (below that both it and GENERIC are bound by the gap between launches)
  *   DENSE     value-only (max,+) GEMM, every (prev, next) cell evaluated, one launch per timestep
- *   PRUNED    value-only, exact: sorted transition rows + per-item top posteriors bound the cells
- *             that can still win, the rest are never touched (B >= 17, 64 <= S <= 4096); one launch
- *             per timestep over (batch tile x state tile) workgroups
- *   RESIDENT  the PRUNED recurrence with the time loop inside ONE launch: a workgroup owns 16 items (8 above 2048
+ *   (PRUNED)  the exact pruned recurrence -- sorted transition rows + per-item top posteriors bound the cells that can
+ *             still win, the rest are never touched -- is what ROWS, RESIDENT and CLUSTER run.  Its one-launch-per-timestep
+ *             tile form (rounds 1-3, route number 2) was removed in round 4: TORBI_HIP_FORWARD_PRUNED now names ROWS up to
+ *             16 items and the time-resident forms above.
+ *   RESIDENT  the pruned recurrence with the time loop inside ONE launch: a workgroup owns 16 items (8 above 2048
  *             states) x all states for every timestep, the posterior rows never leave its LDS (64 <= S <= 4096, any B).
  *             One tile per compute unit: the path for many items in flight -- several batches through
  *             torbi_hip_viterbi_decode_batches, or one batch of more than 8 * compute-units items.
@@ -98,7 +99,7 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
  *             other through 8-byte {value, timestep} words (held_matrix_forward.hpp).
  * AUTO: RESIDENT when the call's tiles fill more than half the compute units; CLUSTER for any other batch of more than
  * 16 items (64 <= S <= 4096: one batch = one forward launch); HELD up to three items (eight above 2048 states); ROWS for
- * 6..16 items (and above 2048 states); PRUNED / DENSE for large batches outside 64..4096 states; else GENERIC.  (The Python layer
+ * 6..16 items (and above 2048 states); DENSE for large batches outside 64..4096 states; else GENERIC.  (The Python layer
  * adds what it knows about the matrix: DENSE for one batch with a narrow band or with scans too deep to prune.)
  *
  * A call selects a path in its `flags` (TORBI_HIP_PATH_FLAG); calls without one use the process-wide
@@ -106,8 +107,8 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
  * TORBI_HIP_FORWARD=dense|pruned|resident|cluster|held, else AUTO).  A path that does not cover the shape falls
  * back as AUTO would.  A workspace of torbi_hip_workspace_bytes() fits every path.
  * torbi_hip_forward_path_on reports what a (B, S) batch would run on `device` with `flags`:
- * 0 generic, 1 dense, 2 pruned, 3 resident, 4 rows, 5 cluster, 6 held; torbi_hip_forward_path is the same for device 0, flags 0.
- * (TORBI_HIP_FORWARD_PRUNED names the pruned recurrence in its per-timestep form: tiles for B >= 17, rows below.)
+ * 0 generic, 1 dense, 3 resident, 4 rows, 5 cluster, 6 held (2 is retired); torbi_hip_forward_path is the same for device 0,
+ * flags 0.
  */
 #define TORBI_HIP_FORWARD_AUTO 0
 #define TORBI_HIP_FORWARD_DENSE 1
@@ -153,7 +154,7 @@ int torbi_hip_viterbi_decode(const float *observation, const int32_t *batch_fram
  * streams/devices are independent).  flags = 0 is torbi_hip_viterbi_decode.  Unknown bits: EINVAL.
  */
 #define TORBI_HIP_REUSE_TRANSITION 1u
-#define TORBI_HIP_COLLECT_STATS 2u     /* a PRUNED decode also leaves scan statistics: torbi_hip_scan_stats */
+#define TORBI_HIP_COLLECT_STATS 2u     /* accepted and ignored since round 4 (the time-resident forms always leave statistics) */
 #define TORBI_HIP_SHORTEST_FIRST 256u  /* RESIDENT: workgroups in ascending order of their items' lengths (default: longest first) */
 #define TORBI_HIP_FEW_SEEDS 512u       /* RESIDENT / CLUSTER: ONE explicit candidate per item (its largest posterior) instead of
                                         * three.  Same results.  For callers that have seen shallow scans with this matrix
@@ -206,10 +207,6 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
  * decode with `workspace` actually took (every decode stamps it behind its scratch layout: a batch decoded inside a
  * launch group takes the group's route, whatever its own shape and flags would have chosen); `flags` is accepted for
  * compatibility and ignored.  Zeros for a decode on another route.
- *   PRUNED (a decode run with TORBI_HIP_COLLECT_STATS on `workspace`; zeros otherwise):
- *     stats_out[0..63]   sum over (sampled timestep, tile) of the deepest scan among the tile's waves, in 16-entry
- *                        list blocks (a launch lasts as long as its deepest wave)
- *     stats_out[64..127] number of (timestep, tile) pairs counted (every 8th timestep is sampled)
  *   RESIDENT (always collected; `workspace` = the FIRST batch's workspace of the launch group):
  *     stats_out[0]       list blocks walked by the sampled wave passes (every 16th timestep)
  *     stats_out[64]      wave passes counted

@@ -28,17 +28,20 @@ def pytest_addoption(parser):
 #                  only the 'auto' instance stays in the default run
 #   SAME_AS_AUTO   test -> forced paths that route every one of its shapes as AUTO does (fresh tensors, 256 compute units:
 #                  batches of 17..2047 items over 64..4096 states with a matrix that is not a narrow band are 'cluster'
-#                  under AUTO)
-# Every route keeps oracle-comparing tests in the default run: cluster / held / rows / generic through 'auto', resident,
-# dense and pruned through their forced instances.
+#                  under AUTO, and 'pruned' names the same form for them since its per-timestep tile kernel was removed;
+#                  DESIGN.md section 4)
+# Every route keeps oracle-comparing tests in the default run: cluster / held / rows / generic through 'auto' (and through
+# 'cluster' / 'pruned' wherever a test has small batches), resident and dense through their forced instances.
 PATH_BLIND = {'test_extension_is_loaded_and_sees_the_gpu', 'test_fused_epsilon_clamp_is_bit_identical_to_the_torch_ops',
               'test_fused_log_and_epsilon_clamp_is_bit_identical_to_the_torch_ops',
               'test_fill_synthetic_matches_numpy_definition'}
-SAME_AS_AUTO = {'test_minus_inf_observations_on_the_large_batch_paths': {'cluster'},
-                'test_pruned_path_adversarial_inputs': {'cluster'},
-                'test_headline_shape_properties': {'cluster'},
-                'test_large_state_shape_properties': {'cluster'},
-                'test_inference_mode_is_supported': {'cluster'}}
+LARGE_BATCHES_ONLY = {'cluster', 'pruned'}
+SAME_AS_AUTO = {'test_minus_inf_observations_on_the_large_batch_paths': LARGE_BATCHES_ONLY,
+                'test_pruned_path_adversarial_inputs': LARGE_BATCHES_ONLY,
+                'test_headline_shape_properties': LARGE_BATCHES_ONLY,
+                'test_large_state_shape_properties': LARGE_BATCHES_ONLY,
+                'test_inference_mode_is_supported': LARGE_BATCHES_ONLY,
+                'test_dense_path_edge_shapes': LARGE_BATCHES_ONLY}
 
 
 def pytest_collection_modifyitems(config, items):

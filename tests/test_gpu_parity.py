@@ -18,12 +18,12 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True, params=['auto', 'dense', 'pruned', 'resident', 'cluster'])
 def forward(request):
-    """Every test runs five times: with the automatic path choice (pruned, or dense for narrow-band
-    matrices), with the dense (max,+) GEMM forced, with the exact pruned pass forced wherever it is
-    supported, with the time-resident kernel forced wherever it is supported (64 <= S <= 4096, ANY
-    batch size) -- whole 16-item tiles per workgroup -- and with its cluster form (the next-states of a tile
-    split over up to 16 workgroups that exchange their slices of every posterior row inside the launch).
-    Small batches take the generic kernels on the first three."""
+    """Every test runs under five forward paths: the automatic choice; the dense (max,+) GEMM forced; 'pruned' (the
+    sorted-row scan for batches of up to 16 items -- above that it names the time-resident forms, see conftest.py for
+    what that makes redundant); the time-resident kernel forced wherever it is supported (64 <= S <= 4096, ANY batch
+    size) with whole 16-item tiles per workgroup; and its cluster form (the next-states of a tile split over up to 16
+    workgroups that exchange their slices of every posterior row inside the launch).  Instances that launch exactly the
+    kernels another instance launches are marked slow (tests/conftest.py)."""
     viterbi.set_forward_path(request.param)
     yield request.param
     viterbi.set_forward_path('auto')
@@ -168,7 +168,7 @@ def test_forward_path_selection(forward):
     assert viterbi.forward_path(4, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'pruned': 'rows'}.get(forward, 'generic')
     assert viterbi.forward_path(3, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'pruned': 'rows',
                                              'auto': 'held'}.get(forward, 'generic')   # AUTO: held matrix up to 3 items
-    assert viterbi.forward_path(16, 1440, path='held') == 'held' and viterbi.forward_path(17, 1440, path='held') == 'pruned'
+    assert viterbi.forward_path(16, 1440, path='held') == 'held' and viterbi.forward_path(17, 1440, path='held') == 'cluster'
     assert viterbi.forward_path(1, 4096, path='auto') == 'held' and viterbi.forward_path(1, 4100, path='auto') == 'generic'
     assert viterbi.forward_path(16, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'dense': 'generic'}.get(forward, 'rows')
     assert viterbi.forward_path(2, 4096) == {'dense': 'generic', 'resident': 'resident', 'cluster': 'cluster',
@@ -177,10 +177,10 @@ def test_forward_path_selection(forward):
     assert viterbi.forward_path(4, 40) == 'generic'                # S < 64: no value-only path
     assert viterbi.forward_path(1, 40) == ('held' if forward == 'auto' else 'generic')
     assert viterbi.forward_path(4, 4100) == 'generic'
-    assert viterbi.forward_path(128, 4096) == {'dense': 'dense', 'resident': 'resident', 'pruned': 'pruned'}.get(forward, 'cluster')   # 8-item tiles
+    assert viterbi.forward_path(128, 4096) == {'dense': 'dense', 'resident': 'resident'}.get(forward, 'cluster')   # 8-item tiles
     assert viterbi.forward_path(128, 4100) == 'dense'              # posterior tile does not fit the LDS
-    assert viterbi.forward_path(512, 1440) == {'dense': 'dense', 'resident': 'resident', 'pruned': 'pruned'}.get(forward, 'cluster')
-    assert viterbi.forward_path(64, 130) == {'dense': 'dense', 'resident': 'resident', 'pruned': 'pruned'}.get(forward, 'cluster')
+    assert viterbi.forward_path(512, 1440) == {'dense': 'dense', 'resident': 'resident'}.get(forward, 'cluster')
+    assert viterbi.forward_path(64, 130) == {'dense': 'dense', 'resident': 'resident'}.get(forward, 'cluster')
     # AUTO: a batch that gives more than half the compute units a 16-item workgroup is decoded time-resident with whole
     # tiles per workgroup, a smaller one of more than 16 items (up to 2048 states) in clusters of workgroups per tile
     cus = viterbi.compute_units('cuda:0')
@@ -195,7 +195,8 @@ def test_forward_path_selection(forward):
     assert viterbi.forward_path(16, 1440, path='auto') == 'rows'
     assert viterbi.forward_path(128, 4096, path='auto') == 'cluster'              # 8-item tiles: 16 tiles x 16 members
     assert viterbi.forward_path(128, 4100, path='auto') == 'dense' and viterbi.forward_path(40, 40, path='auto') == 'generic'
-    assert viterbi.forward_path(2 * cus, 1440, path='pruned') == 'pruned'
+    assert viterbi.forward_path(2 * cus, 1440, path='pruned') == 'cluster'       # (its per-timestep tile kernel is gone)
+    assert viterbi.forward_path(16 * cus, 1440, path='pruned') == 'resident' and viterbi.forward_path(9, 1440, path='pruned') == 'rows'
     # the path travels with the call: naming one never changes the process default
     assert viterbi.forward_path(512, 1440, path='dense') == 'dense'
     assert viterbi.workspace_bytes(512, 500, 1440) >= 512 * 500 * 1440 * 4
@@ -682,7 +683,7 @@ def test_posterior_and_statistics_follow_the_route_the_decode_took(forward):
         batches.append((torch.tensor(obs, device=dev), torch.tensor(frames, device=dev)))
         spaces.append(torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev))
         wanted.append(oracle.decode(obs, frames, trans, init, return_posterior=True, num_threads=oracle.max_threads()))
-    for path in ('resident', 'cluster', 'pruned'):
+    for path in ('resident', 'cluster', 'dense'):
         got = viterbi.decode_batches([b[0] for b in batches], [b[1] for b in batches], d_trans, d_init, workspaces=spaces,
                                      path=path)
         for k, (B, T) in enumerate(shapes):
@@ -690,7 +691,7 @@ def test_posterior_and_statistics_follow_the_route_the_decode_took(forward):
             post = viterbi.read_posterior(spaces[k], batches[k][1], B, T, S).cpu().numpy()      # no path named
             assert np.array_equal(post.view(np.uint32), wanted[k][1].view(np.uint32)), (path, k)
         stats = viterbi.scan_stats(spaces[0], shapes[0][0], shapes[0][1], S).cpu()
-        if path != 'pruned':
+        if path != 'dense':
             assert int(stats[64]) > 0 and int(stats[127]) == 0       # wave passes counted, no cluster gave up waiting
 
 
@@ -1086,7 +1087,7 @@ def test_concurrent_host_threads_on_separate_streams():
     n_dev = torch.cuda.device_count()
     S, T = 360, 16
     jobs = []
-    for k, (kind, path, B) in enumerate([('banded', 'dense', 64), ('dense', 'pruned', 48)]):
+    for k, (kind, path, B) in enumerate([('banded', 'dense', 64), ('dense', 'cluster', 48)]):
         obs, frames, trans, init = _device_problem(B, T, S, seed=7 + k, dev=None)
         if kind == 'banded':
             trans = synth.banded_transition(S, 12.0)
@@ -1275,12 +1276,8 @@ def test_many_file_job_at_1440_states(tmp_path, forward):
     """BASELINE configs[3] at its own state count, 560 sequences (two batches: 512 + 48): in-order and
     length-bucketed batching write identical files, and 40 randomly chosen files equal the oracle's decode of
     that file alone (about 1 s of host time each)."""
-    if forward not in ('auto', 'pruned'):
-        pytest.skip('auto (launch group of two batches) and the per-timestep pruned path; the other paths see '
-                    'ragged batches in the other tests')
-    if forward == 'pruned' and os.environ.get('TORBI_RUN_SLOW') != '1':
-        pytest.skip('slow: the per-timestep pruned kernel is not on AUTO\'s path and sees ragged batches in the other tests '
-                    '(TORBI_RUN_SLOW=1 runs it)')
+    if forward != 'auto':
+        pytest.skip('a launch group of two batches under AUTO; the forced paths see ragged batches in the other tests')
     S, count = 1440, 560
     lengths, ins, outs, tf = _ragged_job(tmp_path, count, S, seed=9)
     torbi_amd.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, gpu=0)

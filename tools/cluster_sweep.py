@@ -17,7 +17,7 @@ for B in (1, 4, 8, 16, 17, 32, 64, 128, 192, 256, 384, 512, 768, 1024):
     frames = torch.full((B,), T, dtype=torch.int32, device=dev)
     ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
     line, ref = [], None
-    for path in ('auto', 'pruned', 'cluster'):
+    for path in ('auto', 'dense', 'cluster'):
         for rep in range(3):
             prof = []
             got = torbi_amd.decode(obs, frames, trans, init, workspace=ws, path=path, _profile=prof)

@@ -18,11 +18,11 @@ obs = [viterbi.fill_synthetic((B, T, S), synth.STREAM_OBSERVATION, seed=k, devic
 frames = [torch.full((B,), T, dtype=torch.int32, device=dev) for _ in range(n)]
 ws = [torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev) for _ in range(n)]
 
-ref = [torbi_amd.decode(obs[k], frames[k], trans, init, workspace=ws[k], path='pruned') for k in range(n)]
+ref = [torbi_amd.decode(obs[k], frames[k], trans, init, workspace=ws[k], path='cluster') for k in range(n)]
 torch.cuda.synchronize()
 prof = []
-torbi_amd.decode(obs[0], frames[0], trans, init, workspace=ws[0], path='pruned', _profile=prof)
-print(f'per-step pruned, one batch: forward {prof[0]:.3f} ms ({1e3 * prof[0] / max(prof[2], 1):.2f} us/launch), '
+torbi_amd.decode(obs[0], frames[0], trans, init, workspace=ws[0], path='cluster', _profile=prof)
+print(f'cluster form, one batch: forward {prof[0]:.3f} ms ({1e3 * prof[0] / max(prof[2], 1):.2f} us/launch), '
       f'backtrace {prof[1]:.3f} ms')
 
 for m in sorted({1, 2, 4, n}):

@@ -17,13 +17,13 @@ for B, n in ((128, 1), (128, 2), (128, 4), (128, 8), (128, 16), (512, 1), (512, 
     frames = [torch.full((B,), T, dtype=torch.int32, device=dev)] * n
     ws = [torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev) for _ in range(n)]
     ref, line = None, []
-    for path in ('pruned', 'cluster', 'resident'):
+    for path in ('dense', 'cluster', 'resident'):
         for rep in range(2):
             prof = []
             got = viterbi.decode_batches(obs, frames, trans, init, workspaces=ws, path=path, _profile=prof)
         torch.cuda.synchronize()
         ref = got if ref is None else ref
         same = all(torch.equal(a, b) for a, b in zip(got, ref))
-        fwd = (prof[0] - prof[4]) * (n if path == 'pruned' else 1)        # the per-timestep path profiles its LAST batch only
-        line.append(f'{path} [{viterbi.ROUTES[int(prof[3])]}] {1e3 * fwd / (T - 1):8.2f} us/step ({n * B * T / (fwd + prof[1] * (n if path == "pruned" else 1)) / 1e3:6.2f} M/s) eq {same}')
+        fwd = (prof[0] - prof[4]) * (n if path == 'dense' else 1)        # the per-timestep path profiles its LAST batch only
+        line.append(f'{path} [{viterbi.ROUTES[int(prof[3])]}] {1e3 * fwd / (T - 1):8.2f} us/step ({n * B * T / (fwd + prof[1] * (n if path == "dense" else 1)) / 1e3:6.2f} M/s) eq {same}')
     print(f'S={S} {n} x {B} items: ' + ' | '.join(line), flush=True)

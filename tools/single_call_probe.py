@@ -18,7 +18,7 @@ for B in Bs:
     obs = viterbi.fill_synthetic((B, T, S), synth.STREAM_OBSERVATION, device=dev)
     frames = torch.full((B,), T, dtype=torch.int32, device=dev)
     ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
-    ref = torbi_amd.decode(obs, frames, trans, init, workspace=ws, path='pruned')
+    ref = torbi_amd.decode(obs, frames, trans, init, workspace=ws, path='dense')
     best = None
     for rep in range(4):
         prof = []

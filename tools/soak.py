@@ -18,7 +18,7 @@ for name, frames in (('full', torch.full((B,), T, dtype=torch.int32, device=dev)
     outs = [pipe.decode(obs, frames, trans, init) for _ in range(n)]
     pipe.synchronize()
     bad = sum(int(not torch.equal(o, outs[0])) for o in outs[1:])
-    for path in ('dense', 'pruned'):
+    for path in ('dense', 'resident'):
         viterbi.set_forward_path(path)
         bad += int(not torch.equal(torbi_amd.decode(obs, frames, trans, init), outs[0]))
     viterbi.set_forward_path('auto')

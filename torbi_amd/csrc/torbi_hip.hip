@@ -421,10 +421,9 @@ __global__ __launch_bounds__(256) void gather_final_kernel(const int32_t *__rest
 
 // scan statistics of the last decode by its route record: time-resident forms, per-timestep pruned pass, else zeros
 __global__ __launch_bounds__(128) void gather_stats_kernel(const int32_t *__restrict__ route, const unsigned *__restrict__ resident_stats,
-                                                           const unsigned *__restrict__ pruned_stats,
                                                            const unsigned *__restrict__ held_control, unsigned *__restrict__ dst) {
     const int r = *route;
-    const unsigned *src = (r == 3 || r == 5) ? resident_stats : (r == 2 ? pruned_stats : nullptr);
+    const unsigned *src = (r == 3 || r == 5) ? resident_stats : nullptr;
     unsigned v = src ? src[threadIdx.x] : 0u;
     // held-matrix launch: [127] = workgroups that gave up waiting (the decode was then repaired; 0 on any sane run)
     if (r == 6 && held_control && threadIdx.x == 127) v = held_control[1];
@@ -589,8 +588,9 @@ thread_local char g_last_kernel[160] = "";
 #include <stdio.h>
 #define TORBI_NOTE_KERNEL(...) snprintf(g_last_kernel, sizeof(g_last_kernel), __VA_ARGS__)
 
-// Which forward recurrence runs.  GENERIC materialises the int32 trellis like the reference does; the other three
-// keep the posterior history and recompute backpointers along the decoded path (lazy_backtrace.hpp).
+// Which forward recurrence runs.  GENERIC and HELD materialise the int32 trellis like the reference does; the others
+// keep the posterior history and recompute backpointers along the decoded path (lazy_backtrace.hpp).  (2 was the
+// per-timestep tile kernel of the pruned recurrence, removed in round 4: no route has the number any more.)
 enum Route { ROUTE_GENERIC = 0, ROUTE_DENSE = 1, ROUTE_PRUNED = 2, ROUTE_RESIDENT = 3, ROUTE_ROWS = 4, ROUTE_CLUSTER = 5,
              ROUTE_HELD = 6 };
 
@@ -667,7 +667,10 @@ inline Route route_for(int path, int B, int S, int cus, bool allow_held = true) 
     // 128 x 2000 x 4096 on 8-item tiles 54.2 against 55.9 ms)
     if (path == TORBI_HIP_FORWARD_AUTO && fits && B > 16 && cluster_members(tiles_of(B, S), S, cus) > 1)
         return ROUTE_CLUSTER;
-    if (path != TORBI_HIP_FORWARD_DENSE && pruned::supported(B, S)) return ROUTE_PRUNED;
+    // PRUNED named for more than 16 items: the pruned recurrence in its time-resident form (its per-timestep tile kernel was
+    // removed in round 4; up to 16 items PRUNED means the sorted-row scan below)
+    if (path == TORBI_HIP_FORWARD_PRUNED && fits && B > 16)
+        return cluster_members(tiles_of(B, S), S, cus) > 1 ? ROUTE_CLUSTER : ROUTE_RESIDENT;
     // a handful of sequences: the whole time loop in one launch, the matrix held in registers across the chip
     // (held_matrix_forward.hpp) -- AUTO up to three items, eight above 2048 states (held_auto); any B <= 16 when named
     if (held::supported(B, S, cus) &&
@@ -719,47 +722,7 @@ inline Workspace carve(void *base, int B, int T, int S) {
     return w;
 }
 
-struct PrunedWorkspace {
-    pruned::Plan plan;
-    float *hist;       // [B][T][S] posterior history
-    float2 *sorted;    // [S][SpP] transition rows in descending order: {t, prev-state byte offset}
-    float *tt;         // [S][S]   transposed transition matrix
-    int32_t *row_range;  // [S][2]    finite prev-state range of every transition row
-    int32_t *tile_range; // [n_jt][2] prev-state range (units of 4) each state tile stages
-    unsigned *stats;     // [128]     scan statistics of the last decode (torbi_hip_scan_stats)
-    float *topv;       // [2][n_jt][B][kTop] partial top lists (values), ping-pong by timestep parity
-    int32_t *topi;     // [2][n_jt][B][kTop] their prev-states
-    size_t top_stride; // elements per parity
-    size_t bytes;
-};
-
-inline PrunedWorkspace carve_pruned(void *base, int B, int T, int S, int cus) {
-    PrunedWorkspace w;
-    w.plan = pruned::make_plan(B, S, cus);
-    char *p = static_cast<char *>(base);
-    const size_t hist_bytes = history_bytes(B, T, S);
-    const size_t sorted_bytes = align_up(sizeof(float2) * (size_t)S * w.plan.SpP, 256);
-    const size_t tt_bytes = align_up(sizeof(float) * (size_t)S * S, 256);
-    const size_t range_bytes = align_up(sizeof(int32_t) * 2 * ((size_t)S + pruned::kMaxJT), 256) + 512;
-    w.top_stride = (size_t)w.plan.n_jt * B * pruned::kTop;
-    // sized for the largest plan (kMaxJT state tiles) so the byte count does not depend on the device's CU count
-    const size_t top_cap = (size_t)pruned::kMaxJT * B * pruned::kTop;
-    const size_t topv_bytes = align_up(sizeof(float) * 2 * top_cap, 256);
-    const size_t topi_bytes = align_up(sizeof(int32_t) * 2 * top_cap, 256);
-    w.hist = reinterpret_cast<float *>(p);
-    p += hist_bytes;
-    w.sorted = reinterpret_cast<float2 *>(p);
-    w.tt = reinterpret_cast<float *>(p + sorted_bytes);
-    w.row_range = reinterpret_cast<int32_t *>(p + sorted_bytes + tt_bytes);
-    w.tile_range = w.row_range + 2 * (size_t)S;
-    w.stats = reinterpret_cast<unsigned *>(p + sorted_bytes + tt_bytes + range_bytes - 512);
-    w.topv = reinterpret_cast<float *>(p + sorted_bytes + tt_bytes + range_bytes);
-    w.topi = reinterpret_cast<int32_t *>(p + sorted_bytes + tt_bytes + range_bytes + topv_bytes);
-    w.bytes = hist_bytes + sorted_bytes + tt_bytes + range_bytes + topv_bytes + topi_bytes;
-    return w;
-}
-
-// the time-resident path shares the sorted lists / transposed matrix layout of the pruned path (16-item tiles)
+// the time-resident path: history, tile map, row maxima, sorted lists / transposed matrix, cluster exchange
 struct ResidentWorkspace {
     float *hist;
     float2 *sorted;
@@ -897,7 +860,6 @@ inline DenseWorkspace carve_dense(void *base, int B, int T, int S, int cus) {
 inline size_t layout_bytes(int B, int T, int S, int cus) {
     size_t need = carve(nullptr, B, T, S).bytes;
     if (use_dense(B, S)) need = std::max(need, carve_dense(nullptr, B, T, S, cus).bytes);
-    if (pruned::supported(B, S)) need = std::max(need, carve_pruned(nullptr, B, T, S, cus).bytes);
     if (resident::supported(S)) need = std::max(need, carve_resident(nullptr, B, T, S, cus).bytes);
     if (rowscan::supported(B, S)) need = std::max(need, carve_rows(nullptr, B, T, S).bytes);
     return align_up(need, 256);
@@ -1140,59 +1102,6 @@ void launch_list_preparation(const float *trans, float2 *sorted, int32_t *row_ra
         hipLaunchKernelGGL(pruned::arrange_blocks_kernel<8>, dim3((n + 63) / 64), dim3(64), 0, stream, sorted, S, SpP);
     }
     hipLaunchKernelGGL(pruned::transpose_kernel, dim3((S + 31) / 32, (S + 31) / 32), dim3(256), 0, stream, trans, tt, S);
-}
-
-hipError_t launch_pruned_forward(const float *obs, const int32_t *frames, const float *trans,
-                                 const float *init, const PrunedWorkspace &w, int B, int T, int S,
-                                 hipStream_t stream, int *launches, bool reuse, bool collect) {
-    const pruned::Plan &pl = w.plan;
-    unsigned *const stats = collect ? w.stats : nullptr;
-    if (!reuse) {
-        launch_list_preparation(trans, w.sorted, w.row_range, w.tt, S, pl.SpP, pl.NPOW, pl.NI, stream);
-        hipLaunchKernelGGL(pruned::tile_range_kernel, dim3(pl.n_jt), dim3(64), 0, stream, w.row_range, w.tile_range, S,
-                           pl.JT);
-    }
-    {
-        const size_t n = (size_t)B * S;
-        const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-        hipLaunchKernelGGL(pruned::init_history_kernel, dim3(grid), dim3(256), 0, stream, obs, init, w.hist, B, T, S);
-        // partial top lists of "timestep 0": state tile 0 carries the full list, the others are empty
-        const size_t m = 2 * w.top_stride;
-        const int grid2 = (int)((m + 255) / 256 < 4096 ? (m + 255) / 256 : 4096);
-        hipLaunchKernelGGL(pruned::clear_top_kernel, dim3(grid2), dim3(256), 0, stream, w.topv, w.topi, m, w.stats);
-        if (S <= 512)
-            hipLaunchKernelGGL(pruned::top_kernel<2>, dim3(B), dim3(64), 0, stream, w.hist, w.topv, w.topi, B, T, S);
-        else if (S <= 1536)
-            hipLaunchKernelGGL(pruned::top_kernel<6>, dim3(B), dim3(64), 0, stream, w.hist, w.topv, w.topi, B, T, S);
-        else if (S <= 2048)
-            hipLaunchKernelGGL(pruned::top_kernel<8>, dim3(B), dim3(64), 0, stream, w.hist, w.topv, w.topi, B, T, S);
-        else
-            hipLaunchKernelGGL(pruned::top_kernel<16>, dim3(B), dim3(64), 0, stream, w.hist, w.topv, w.topi, B, T, S);
-    }
-    const size_t lds = pruned::lds_bytes(S, pl.NI);
-    // four instances: items per tile x with/without the scan statistics (the statistics cost 1.6 % even when they
-    // are only compiled in, so the plain instance has none)
-    using StepFn = void (*)(const float *, const int32_t *, const float *, const float2 *, const int32_t *, const float *,
-                            const int32_t *, float *, int32_t *, float *, unsigned *, int, int, int, int, int, int, int, int);
-    StepFn fn;
-    if (pl.NI == pruned::kNB)
-        fn = collect ? &pruned::step_pruned_kernel<pruned::kNB, true> : &pruned::step_pruned_kernel<pruned::kNB, false>;
-    else
-        fn = collect ? &pruned::step_pruned_kernel<pruned::kNB / 2, true>
-                     : &pruned::step_pruned_kernel<pruned::kNB / 2, false>;
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), lds);
-    if (e != hipSuccess) return e;
-    TORBI_NOTE_KERNEL("pruned::step_pruned_kernel<%d, %s>", pl.NI, collect ? "true" : "false");
-    int n = 0;
-    for (int t = 1; t < T; ++t) {
-        const size_t in = ((t - 1) & 1) * w.top_stride, out = (t & 1) * w.top_stride;
-        hipLaunchKernelGGL(fn, dim3(pl.n_bt, pl.n_jt), dim3(64 * pruned::kWaves), lds, stream, obs, frames, w.tt,
-                           w.sorted, w.tile_range, w.topv + in, w.topi + in, w.topv + out, w.topi + out, w.hist, stats,
-                           B, T, S, t, pl.SpP, pl.n_bt, pl.n_jt, pl.JT);
-        ++n;
-    }
-    if (launches) *launches = n;
-    return hipGetLastError();
 }
 
 // (`ranges` / `widest`: the finite range of every transition row and the widest window, or null; with them a banded
@@ -1496,13 +1405,7 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
     if (ev) (void)hipEventRecord(ev[3], s);
     e = stamp_route(workspace, B, T, S, cus, route, s);
     if (e != hipSuccess) return e;
-    if (route == ROUTE_PRUNED) {
-        const PrunedWorkspace w = carve_pruned(workspace, B, T, S, cus);
-        e = launch_pruned_forward(obs, frames, trans, init, w, B, T, S, s, launches, reuse, collect);
-        if (ev) (void)hipEventRecord(ev[1], s);
-        if (e == hipSuccess)
-            e = launch_backtrace_sorted(w.hist, w.sorted, w.plan.SpP, w.plan.NI, trans, frames, out, B, T, S, s);
-    } else if (route == ROUTE_DENSE) {
+    if (route == ROUTE_DENSE) {
         const DenseWorkspace w = carve_dense(workspace, B, T, S, cus);
         e = launch_dense_forward(obs, frames, trans, init, w, B, T, S, s, launches, reuse);
         if (ev) (void)hipEventRecord(ev[1], s);
@@ -1732,13 +1635,11 @@ int torbi_hip_scan_stats(const void *workspace, size_t workspace_bytes, int B, i
     // which statistics: decided on the device by the route the last decode with this workspace took
     const int cus = cu_count(device);
     const unsigned *resident_stats = resident::supported(S) ? carve_resident(const_cast<void *>(workspace), B, T, S, cus).stats : nullptr;
-    const unsigned *pruned_stats = pruned::supported(B, S) ? carve_pruned(const_cast<void *>(workspace), B, T, S, cus).stats : nullptr;
     const unsigned *held_control = carve(const_cast<void *>(workspace), B, T, S).control;
-    if (!resident_stats && !pruned_stats && !held_control) return TORBI_HIP_EUNSUPPORTED;
-    const unsigned *some = resident_stats ? resident_stats : pruned_stats ? pruned_stats : held_control;
+    if (!resident_stats && !held_control) return TORBI_HIP_EUNSUPPORTED;
     hipLaunchKernelGGL(gather_stats_kernel, dim3(1), dim3(2 * pruned::kStatSlots), 0, static_cast<hipStream_t>(stream),
-                       route_record(workspace, B, T, S, cus), resident_stats ? resident_stats : some,
-                       pruned_stats ? pruned_stats : some, held_control, stats_out);
+                       route_record(workspace, B, T, S, cus), resident_stats ? resident_stats : held_control, held_control,
+                       stats_out);
     return (int)hipGetLastError();
 }
 
@@ -1876,13 +1777,6 @@ int torbi_hip_open_heads(const char *const *paths, int count, int threads, int h
 }
 
 }  // extern "C"
-
-#ifdef PRUNED_STAMP
-// instrumentation build only (tools/pruned_stamps.py); not part of include/torbi_hip.h
-extern "C" int torbi_hip_debug_stamps(unsigned long long *host, size_t count) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pruned::g_stamps), count * sizeof(unsigned long long));
-}
-#endif
 
 #ifdef RESIDENT_STAMP
 // instrumentation build only (tools/resident_stamps.py); not part of include/torbi_hip.h

@@ -444,17 +444,17 @@ BANDED_RANGE = 0.25              # rows reaching less than this fraction of the 
 def set_forward_path(path: str = 'auto') -> None:
     """Process-wide DEFAULT of the forward recurrence (include/torbi_hip.h) for calls that do not name one
     (`decode(path=...)`): 'auto' (default), 'dense' (every cell, (max,+) GEMM with -inf block skipping),
-    'pruned' (exact pruned pass, one launch per timestep) or 'resident' (the pruned recurrence with the time
-    loop inside one launch; meant for many items in flight).  The path itself travels with every call
+    'pruned' (the exact pruned recurrence: the sorted-row scan up to 16 items, the time-resident forms above),
+    'resident' / 'cluster' (the pruned recurrence with the time loop inside one launch: whole 16-item tiles per workgroup /
+    tiles split over clusters of workgroups) or 'held' (a handful of sequences, the matrix held in registers).  The path itself travels with every call
     (TORBI_HIP_PATH_FLAG), so concurrent decodes from several host threads never see each other's choice.
     Every path returns identical indices; this is a performance knob and a test hook.
 
-    'auto' in this Python layer refines the library's AUTO (pruned wherever supported) with one
-    look at the transition matrix, cached per tensor version: a matrix whose rows reach only a
-    narrow band of prev-states (mean finite range < 25 % of the states, e.g. the reference's
-    pitch transition, torbi/evaluate/core.py:24-33) runs faster on the dense kernel's -inf
-    chunk skipping (40.8 vs 31.4 M timesteps/s measured); everything else takes the pruned
-    pass.  The look costs one small reduction and a host sync the first time a tensor is seen."""
+    'auto' in this Python layer refines the library's AUTO with one look at the transition matrix, cached per
+    tensor version: ONE batch with a matrix whose rows reach only a narrow band of prev-states (mean finite range
+    < 25 % of the states, e.g. the reference's pitch transition, torbi/evaluate/core.py:24-33) runs faster on the
+    dense kernel's -inf chunk skipping; everything else takes the pruned recurrence.  The look costs one small
+    reduction and a host sync the first time a tensor is seen."""
     global _forced_path
     if path not in FORWARD_PATHS:
         raise ValueError(f'forward path must be one of {sorted(FORWARD_PATHS)}; got {path!r}')
@@ -465,7 +465,7 @@ def set_forward_path(path: str = 'auto') -> None:
 
 def scan_stats(workspace: torch.Tensor, batch: int, frames: int, states: int,
                path: str = 'pruned') -> Optional[torch.Tensor]:
-    """Enqueue a copy of the scan statistics the last pruned (or, `path='resident'`, time-resident) decode left in
+    """Enqueue a copy of the scan statistics the last time-resident (or held-matrix) decode left in
     `workspace` (include/torbi_hip.h, torbi_hip_scan_stats): a (128,) int32 device tensor, valid once the
     current stream reaches it; None when the shape takes neither path."""
     lib = _lib.load()
@@ -505,12 +505,12 @@ def _choose_path(trans: torch.Tensor, original: torch.Tensor, batch: int, states
     return 'dense' if 0.0 < reach < BANDED_RANGE else 'pruned'
 
 
-ROUTES = {0: 'generic', 1: 'dense', 2: 'pruned', 3: 'resident', 4: 'rows', 5: 'cluster', 6: 'held'}
+ROUTES = {0: 'generic', 1: 'dense', 3: 'resident', 4: 'rows', 5: 'cluster', 6: 'held'}      # (2: retired in round 4)
 
 
 def forward_path(batch: int, states: int, path: Optional[str] = None, device: int = 0) -> str:
     """Which forward recurrence the library runs for one (batch, states) problem under `path` (None = the process
-    default): 'generic', 'dense', 'pruned', 'resident' or 'rows' (the pruned recurrence for batches of <= 16 items)."""
+    default): 'generic', 'dense', 'resident', 'cluster', 'held' or 'rows' (the pruned recurrence for batches of <= 16 items)."""
     code = _lib.load().torbi_hip_forward_path_on(int(batch), int(states), int(device),
                                                  _path_flag(_forced_path if path is None else path))
     if code < 0:
