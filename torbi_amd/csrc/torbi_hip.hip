@@ -679,6 +679,9 @@ inline Route route_for(int path, int B, int S, int cus, bool allow_held = true) 
     if ((path == TORBI_HIP_FORWARD_PRUNED && rowscan::supported(B, S)) ||
         (path != TORBI_HIP_FORWARD_DENSE && rowscan::profitable(B, S)))
         return ROUTE_ROWS;
+    // a named path that does not cover the shape falls back as AUTO would (DENSE named below 32 items: the generic kernels)
+    if (path != TORBI_HIP_FORWARD_AUTO && path != TORBI_HIP_FORWARD_DENSE)
+        return route_for(TORBI_HIP_FORWARD_AUTO, B, S, cus, allow_held);
     return use_dense(B, S) ? ROUTE_DENSE : ROUTE_GENERIC;
 }
 
