@@ -31,7 +31,6 @@
 #include "uniform_decode.hpp"
 #include "pruned_forward.hpp"
 #include "resident_forward.hpp"
-#include "wide_forward.hpp"
 #include "small_batch_forward.hpp"
 #include "held_matrix_forward.hpp"
 #include "file_rows.hpp"
@@ -742,7 +741,6 @@ struct ResidentWorkspace {
     float *xchg;          // [tiles][2][S4][16]
     unsigned *flags;      // [tiles][kMaxR] + 16 control words
     size_t flag_bytes;
-    float4 *lists;        // the sorted rows once more, interleaved per lane for wide_forward_kernel (S <= 2048; else null)
     int SpP, NPOW;
     size_t bytes;
 };
@@ -780,9 +778,7 @@ inline ResidentWorkspace carve_resident(void *base, int B, int T, int S, int cus
     p += sorted_bytes + tt_bytes + range_bytes;
     w.xchg = reinterpret_cast<float *>(p);
     w.flags = reinterpret_cast<unsigned *>(p + xchg_bytes);
-    const size_t list_bytes = wide::supported(S) ? align_up(sizeof(float4) * wide::list_chunks(S, w.SpP), 256) : 0;
-    w.lists = list_bytes ? reinterpret_cast<float4 *>(p + xchg_bytes + w.flag_bytes) : nullptr;
-    w.bytes = hist_bytes + order_bytes + rowmax_bytes + sorted_bytes + tt_bytes + range_bytes + xchg_bytes + w.flag_bytes + list_bytes;
+    w.bytes = hist_bytes + order_bytes + rowmax_bytes + sorted_bytes + tt_bytes + range_bytes + xchg_bytes + w.flag_bytes;
     return w;
 }
 
@@ -1253,37 +1249,6 @@ inline hipError_t launch_whole_tiles(const resident::Group &grp, const resident:
     return launch_resident_kernel<12, 11, false>(grp, clu, tiles, w, init, S, s, few);
 }
 
-// whole tiles with one next-state x all 16 items per lane (wide_forward.hpp): one seed per item, 64 <= S <= 2048.
-// TORBI_HIP_WIDE=0 keeps resident_forward_kernel (experiments).
-inline bool wide_enabled() {
-    static const bool v = [] {
-        const char *e = getenv("TORBI_HIP_WIDE");
-        return e && atoi(e) != 0;
-    }();
-    return v;
-}
-template <int MAXP>
-hipError_t launch_wide_variant(const resident::Group &grp, int workgroups, const ResidentWorkspace &w, const float *init, int S,
-                               hipStream_t stream) {
-    constexpr int KW = 8;
-    const size_t lds = wide::lds_bytes(S);
-    const void *fn = reinterpret_cast<const void *>(&wide::wide_forward_kernel<KW, MAXP, true>);
-    hipError_t e = ensure_dynamic_lds(fn, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((wide::wide_forward_kernel<KW, MAXP, true>), dim3(workgroups), dim3(64 * KW), lds, stream, grp, w.tt,
-                       w.lists, init, S, w.SpP / wide::kBlk);
-    TORBI_NOTE_KERNEL("wide::wide_forward_kernel<%d, %d, true>", KW, MAXP);
-    return hipGetLastError();
-}
-inline hipError_t launch_wide(const resident::Group &grp, int workgroups, const ResidentWorkspace &w, const float *init, int S,
-                              hipStream_t stream) {
-    const int passes = (wide::row_groups(S) + 7) / 8;
-    if (passes <= 1) return launch_wide_variant<1>(grp, workgroups, w, init, S, stream);
-    if (passes <= 2) return launch_wide_variant<2>(grp, workgroups, w, init, S, stream);
-    if (passes <= 3) return launch_wide_variant<3>(grp, workgroups, w, init, S, stream);
-    return launch_wide_variant<4>(grp, workgroups, w, init, S, stream);
-}
-
 // batches with B > 0 only; the preparation lives in the first batch's workspace
 hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const float *init, int S, int cus, hipStream_t s,
                         hipEvent_t *ev, int *launches, bool reuse, bool ascending = false, bool clusters = false,
@@ -1330,14 +1295,7 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
         jobs.job[k].route_record = route_record(hb[k].workspace, hb[k].B, hb[k].T, S, cus);
         jobs.job[k].route = (int)(R > 1 ? ROUTE_CLUSTER : ROUTE_RESIDENT);
     }
-    const bool wide_form = !clusters && wide_enabled() && resident_seeds(few) == 1 && wide::supported(S) &&
-                           resident::tile_items(S) == resident::kNI;
-    if (!reuse) {
-        launch_list_preparation(trans, w.sorted, w.row_range, w.tt, S, w.SpP, w.NPOW, resident::tile_items(S), s);
-        if (w.lists && resident::tile_items(S) == resident::kNI)       // the rows again, interleaved per lane (wide_forward.hpp)
-            hipLaunchKernelGGL(wide::lists_by_lane_kernel, dim3(w.SpP / wide::kBlk, wide::row_groups(S)), dim3(64), 0, s, w.sorted,
-                               w.lists, S, w.SpP);
-    }
+    if (!reuse) launch_list_preparation(trans, w.sorted, w.row_range, w.tt, S, w.SpP, w.NPOW, resident::tile_items(S), s);
     hipLaunchKernelGGL(resident::order_items_kernel, dim3((widest + 255) / 256, n), dim3(256), 0, s, jobs);
     for (int k = 0; k < n; ++k) {            // batches too large for the all-pairs ranking: counting sort over the lengths
         const resident::OrderJob &jb = jobs.job[k];
@@ -1375,8 +1333,6 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
             again.only = clu.failed;
             e = launch_whole_tiles(again, clu, tiles, w, init, S, s, few);
         }
-    } else if (wide_form) {
-        e = launch_wide(grp, tiles, w, init, S, s);
     } else {
         e = launch_whole_tiles(grp, clu, tiles, w, init, S, s, few);
     }
