@@ -175,7 +175,7 @@ def test_forward_path_selection(forward):
                                              'auto': 'held'}.get(forward, 'rows')
     assert viterbi.forward_path(9, 4096) == {'dense': 'generic', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'rows')
     assert viterbi.forward_path(4, 40) == 'generic'                # S < 64: no value-only path
-    assert viterbi.forward_path(1, 40) == ('held' if forward == 'auto' else 'generic')
+    assert viterbi.forward_path(1, 40) == ('generic' if forward == 'dense' else 'held')    # (a path that does not cover the shape falls back as AUTO would)
     assert viterbi.forward_path(4, 4100) == 'generic'
     assert viterbi.forward_path(128, 4096) == {'dense': 'dense', 'resident': 'resident'}.get(forward, 'cluster')   # 8-item tiles
     assert viterbi.forward_path(128, 4100) == 'dense'              # posterior tile does not fit the LDS
