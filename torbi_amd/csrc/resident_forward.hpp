@@ -284,13 +284,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void *base, un
 #ifndef RESIDENT_EXTRA_VALU
 #define RESIDENT_EXTRA_VALU 0
 #endif
-// Whole 16-item tiles, one seed per item: a wave pass (16 rows x 16 items in lock step) stops after RESIDENT_CAP list blocks;
-// the lanes whose four (row, item) pairs are not all bounded by then FINISH THEIR ROW ON THEIR OWN behind the wave's last
-// pass -- a loop in which every lane walks the rest of its own sorted row (private 16-entry blocks, no quad sharing) and
-// takes its next unfinished row when it is done.  0 = passes run to the depth of their deepest pair (rounds 2-3).
-#ifndef RESIDENT_CAP
-#define RESIDENT_CAP 0
-#endif
 
 #ifdef RESIDENT_STAMP
 // build-time instrumentation (tools/resident_stamps.py): per-wave cycle sums of the phases of a timestep
@@ -411,7 +404,6 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
     for (int it = 0; it < 4; ++it) ib[it] = sitem[4 * g + it];
 
     float pend[MAXP][4];
-    constexpr int kCap = (!CLUSTER && KR == 1 && NI == 16 && MAXP <= 16) ? RESIDENT_CAP : 0;
     // A cluster member whose waves scan ONE row group per timestep (MAXP == 1) meets the same sorted rows every
     // timestep: their first two list blocks stay in registers, and the next timestep's observations are requested
     // before the wait for the other members (everything a pass needs that does not depend on the exchange).
@@ -495,7 +487,6 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
         // where they would cost ~10 registers per pass)
         int opaque = 0;
         asm volatile("" : "+s"(opaque));
-        unsigned unfinished = 0u;       // kCap: passes in which this lane's row was still open at the cap
 #pragma unroll
         for (int p = 0; p < MAXP; ++p) {
             const int rg = rg_lo + wave + KW * p + opaque;  // wave-uniform
@@ -607,14 +598,11 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
 #pragma unroll
                         for (int r = 0; r < kR; ++r) best[it] = fmaxf(best[it], seedv[it][r] + seedt[it][r]);
                 };
-                bool mine_open = false;          // kCap: this lane's pairs at the last test
                 auto more = [&](const ListBlock<EPL> &blk) {
                     if (RESIDENT_ABL & 1) return nblk < 11;
                     const float tn = group_bcast<G, 0>(blk.e[0].x);
-                    mine_open = jv && ((tn + thr[0] > best[0]) | (tn + thr[1] > best[1]) | (tn + thr[2] > best[2]) |
-                                       (tn + thr[3] > best[3]));
-                    if (kCap > 0 && nblk >= kCap) return false;       // the open lanes finish on their own (below)
-                    return (bool)__any(mine_open);
+                    return (bool)__any(jv && ((tn + thr[0] > best[0]) | (tn + thr[1] > best[1]) | (tn + thr[2] > best[2]) |
+                                              (tn + thr[3] > best[3])));
                 };
                 const int Sp = (S + 15) / 16 * 16;
                 fold_seeds();
@@ -637,81 +625,19 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                 u64 last4[4];
 #pragma unroll
                 for (int it = 0; it < 4; ++it) last4[it] = top[(4 * g + it) * kTop + kTop - 1];
-                // (kCap: a lane whose row is still open keeps its partial maxima in `pend` and finishes below)
-                const bool later = kCap > 0 && nblk >= kCap && mine_open;
-                if (later) unfinished |= 1u << p;
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
 #if RESIDENT_EXTRA_VALU
                     if (dummy[it] == 12345.678f) best[it] = 0.f;
 #endif
-                    const float o = later ? best[it] : ob[it] + best[it];  // post'[j] = obs[t,j] + max
+                    const float o = ob[it] + best[it];                     // post'[j] = obs[t,j] + max
                     pend[p][it] = o;
-                    if (jv && live[it] && !later && !(RESIDENT_ABL & 8)) hist[((size_t)ib[it] * T + t) * S + jr] = o;
+                    if (jv && live[it] && !(RESIDENT_ABL & 8)) hist[((size_t)ib[it] * T + t) * S + jr] = o;
                     const u64 key = top_key(o, jr);
-                    if (jv && !later && key > last4[it] && !(RESIDENT_ABL & 16)) top_insert<kTop>(top + (4 * g + it) * kTop, key);
+                    if (jv && key > last4[it] && !(RESIDENT_ABL & 16)) top_insert<kTop>(top + (4 * g + it) * kTop, key);
                 }
                 RSTAMP(4);
             }
-        }
-        if constexpr (kCap > 0) {
-            // Every lane finishes the rows it left open, one after the other, walking its own sorted row from block kCap on:
-            // 16 private entries per step against the tile (the quad no longer shares a row's entries: a lane's neighbours
-            // are in other rows or done), the same bound, the same arithmetic.  The wave loops until no lane has work.
-            int cur = -1, kb = 0, jr2 = 0;
-            float b4[4] = {0.f, 0.f, 0.f, 0.f}, o4[4] = {0.f, 0.f, 0.f, 0.f};
-            const float2 *rowp = sorted;
-            unsigned steps = 0;
-            while (__any(unfinished != 0u || cur >= 0)) {
-                if (cur < 0 && unfinished != 0u) {          // take the next open row of this lane
-                    cur = __builtin_ctz(unfinished);
-                    unfinished &= unfinished - 1u;
-                    kb = kCap;
-                    jr2 = kRowGroup * (rg_lo + wave + KW * cur) + jl;
-                    rowp = sorted + (size_t)jr2 * SpP;
-#pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        float v = pend[0][it];
-#pragma unroll
-                        for (int q = 1; q < MAXP; ++q) v = cur == q ? pend[q][it] : v;
-                        b4[it] = v;
-                        o4[it] = obs[((size_t)ib[it] * T + t) * S + jr2];
-                    }
-                }
-                if (cur >= 0) {
-                    const float4 *blk = reinterpret_cast<const float4 *>(rowp + kb * kBlk);
-                    float4 ent[kBlk / 2];
-#pragma unroll
-                    for (int h = 0; h < kBlk / 2; ++h) ent[h] = blk[h];
-                    const float tn = rowp[(kb + 1) * kBlk].x;         // (kPad entries of -inf follow every row)
-#pragma unroll
-                    for (int h = 0; h < kBlk / 2; ++h) {
-                        const float4 p0 = *reinterpret_cast<const float4 *>(ptile + __float_as_int(ent[h].y));
-                        const float4 p1 = *reinterpret_cast<const float4 *>(ptile + __float_as_int(ent[h].w));
-                        b4[0] = fmaxf(fmaxf(b4[0], ent[h].x + p0.x), ent[h].z + p1.x);
-                        b4[1] = fmaxf(fmaxf(b4[1], ent[h].x + p0.y), ent[h].z + p1.y);
-                        b4[2] = fmaxf(fmaxf(b4[2], ent[h].x + p0.z), ent[h].z + p1.z);
-                        b4[3] = fmaxf(fmaxf(b4[3], ent[h].x + p0.w), ent[h].z + p1.w);
-                    }
-                    ++kb;
-                    const bool open = (tn + thr[0] > b4[0]) | (tn + thr[1] > b4[1]) | (tn + thr[2] > b4[2]) | (tn + thr[3] > b4[3]);
-                    if (!open) {                            // this row is done: its outputs, like a pass's
-#pragma unroll
-                        for (int it = 0; it < 4; ++it) {
-                            const float o = o4[it] + b4[it];
-#pragma unroll
-                            for (int q = 0; q < MAXP; ++q) pend[q][it] = cur == q ? o : pend[q][it];
-                            if (live[it]) hist[((size_t)ib[it] * T + t) * S + jr2] = o;
-                            const u64 key = top_key(o, jr2);
-                            if (key > top[(4 * g + it) * kTop + kTop - 1]) top_insert<kTop>(top + (4 * g + it) * kTop, key);
-                        }
-                        cur = -1;
-                    }
-                }
-                ++steps;
-            }
-            // (the statistics count what was walked: a step of this loop is a list block)
-            if ((t & 15) == 1) stat_blocks += steps;
         }
         // CLUSTER: every row's 16 outputs go to the other members as one write-through (sc1) 64-byte row, 16 bytes per lane
         // of the quad, in the layout of the LDS tile.  All of a wave's rows are stored HERE, behind its last pass, not pass
