@@ -1,10 +1,11 @@
 // resident_forward.hpp -- the exact pruned forward recurrence (pruned_forward.hpp) with the TIME LOOP INSIDE the
 // kernel: one workgroup owns 16 batch items x ALL next-states for every timestep of those items.
 //
-// Why: a per-timestep launch of step_pruned_kernel spends 6.9 of its 19.3 us scanning; the rest is what a kernel
-// boundary costs when every state tile needs the whole previous posterior -- re-staging the 92 KB posterior tile
-// from L2 in each of the 8 state tiles (23.6 MB per launch), merging per-tile top lists, waiting for the slowest of
-// 256 workgroups.  Here the 16 items' posterior rows never leave the LDS: a timestep is
+// Why: one launch per timestep of this recurrence (step_pruned_kernel, rounds 1-3, since removed) spent 6.9 of its
+// 19.3 us scanning; the rest is what a kernel boundary costs when every state tile needs the whole previous posterior --
+// re-staging the 92 KB posterior tile from L2 in each of the 8 state tiles (23.6 MB per launch), merging per-tile top
+// lists, waiting for the slowest of 256 workgroups (HISTORY.md 4.3).  Here the 16 items' posterior rows never leave the
+// LDS: a timestep is
 //     barrier -> every wave scans its row groups against the LDS tile (outputs stay in registers, go to hist)
 //     -> barrier -> the outputs overwrite the tile -> next timestep
 // with no inter-workgroup traffic at all (batch items are independent: viterbi.cpp:65, viterbi.cu:58).  The price
@@ -384,8 +385,8 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
     }
 
     // lane = next-state jl of the wave's 16 x item group g; quads of lanes -> next-states so that every
-    // ds_read_b128 lane group holds an aligned row quad (as in pruned::step_pruned_kernel)
-    // (8-item tiles: lane pairs -> next-states, aligned groups of eight rows per lane group, as in step_pruned_kernel)
+    // ds_read_b128 lane group holds an aligned row quad (what arrange_blocks_kernel<4> keeps conflict-poor)
+    // (8-item tiles: lane pairs -> next-states, aligned groups of eight rows per lane group: arrange_blocks_kernel<8>)
     const int g = lane & (G - 1);
     const int jl = G == 4 ? (int)((0xFBAE9DC873261540ull >> (4 * (lane >> 2))) & 15)
                           : (int)((0xFE7654DC32BA9810ull >> (4 * ((lane >> 1) & 15))) & 15) + (lane & 32) / 2;

@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void gather_final_kernel(const int32_t *__rest
     }
 }
 
-// scan statistics of the last decode by its route record: time-resident forms, per-timestep pruned pass, else zeros
+// scan statistics of the last decode by its route record: time-resident forms (and the held kernel's give-ups), else zeros
 __global__ __launch_bounds__(128) void gather_stats_kernel(const int32_t *__restrict__ route, const unsigned *__restrict__ resident_stats,
                                                            const unsigned *__restrict__ held_control, unsigned *__restrict__ dst) {
     const int r = *route;
@@ -655,7 +655,7 @@ inline bool held_auto(int B, int S) {
 
 // route of ONE batch.  AUTO: the time-resident kernel -- whole tiles per workgroup when the batch alone gives at least
 // half the compute units a workgroup, tiles split over clusters of workgroups for smaller batches of >= 17 items --
-// else the per-timestep pruned pass where supported, else the dense (max,+) GEMM, else generic.
+// else the sorted-row scan / held-matrix kernel for a handful of sequences, else the dense (max,+) GEMM, else generic.
 inline Route route_for(int path, int B, int S, int cus, bool allow_held = true) {
     const bool fits = resident_fits(S, tiles_of(B, S));
     if (path == TORBI_HIP_FORWARD_RESIDENT && fits) return ROUTE_RESIDENT;

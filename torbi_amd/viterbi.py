@@ -82,9 +82,8 @@ def _resolve_path(trans, transition, B, S, device, path, tiles, count=1):
         #    kernel's -inf skipping costs by the item (80 pieces of a chunked sequence: 1.9 against 3.0 ms; 512 peaked
         #    rows 8.0 against 8.3 ms), a cluster timestep has a floor of ~12 us however few items it carries;
         # unless the scan statistics of an earlier time-resident launch with this matrix say that hardly anything is
-        # pruned (see _watch_resident).  Whether the per-timestep pruned kernel beats the dense one is NOT the question
-        # here: on peaked rows with a dense matrix it does not, and the time-resident kernel still runs at the dense
-        # kernel's rate or better (35-38 against 38-40 us per timestep for one batch, twice its rate in launch groups).
+        # pruned (see _watch_resident).  On peaked rows with a dense matrix the time-resident kernel still runs at the
+        # dense kernel's rate or better (35-38 against 38-40 us per timestep for one batch, twice its rate in launch groups).
         # 'cluster' lets the library pick the form (whole tiles once 2 * tiles > compute units).
         if banded or chosen in ('pruned', 'dense'):
             losing = not banded and _resident_is_losing(transition, S, single=not group_like)
