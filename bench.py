@@ -54,6 +54,8 @@ def parse_args(argv=None):
     ap.add_argument('--states', type=int, default=1440)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary records (other configs / inputs)')
+    ap.add_argument('--no-single-call', action='store_true', help='skip the single_call record (profiling runs: nothing but '
+                                                                  'the launch groups in the trace)')
     ap.add_argument('--reuse-preparation', action='store_true',
                     help='let consecutive decodes share the per-transition preparation (sorted rows / packed panels) '
                          'as a serving loop would; off by default: every timed launch group does all of its work')
@@ -482,11 +484,12 @@ class Bench:
         result['phases_ms'] = {'group_of': g, 'forward_incl_preparation': fwd_ms, 'preparation': prep_ms,
                                'argmax_backtrace': bt_ms}
         result['hbm_roofline_frac_whole_job'] = value / size * algorithmic_bytes_per_timestep(S) / (HBM_PEAK_GBS * 1e9)
-        if rank == 0 and size == 1 and args.transition == 'dense':
+        if rank == 0 and size == 1 and args.transition == 'dense' and not args.no_single_call:
             result['single_call'] = self.single_call(obs[0], frames, trans, init)
         if rank == 0 and size == 1 and not args.no_secondary and args.transition == 'dense':
             result['secondary'] = self.secondary(obs[0], frames, trans, init)
-            result['secondary']['serial'] = dict(result['single_call'], note='= single_call (kept under its old name)')
+            if 'single_call' in result:
+                result['secondary']['serial'] = dict(result['single_call'], note='= single_call (kept under its old name)')
         if rank == 0 and size == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(last_obs, trans, init, indices)
         return result

@@ -14,7 +14,7 @@ try:      # how many batches one forward launch of the profiled command covered 
     groups = json.load(open(os.path.join(out, 'bench_under_trace.json')))['config']['launch_groups']
     summary['_meta'] = {'batches_per_forward_launch': int(groups[0]), 'units': 'FETCH_SIZE / WRITE_SIZE in KiB per dispatch',
                         'git': os.environ.get('GIT_HASH') or None,        # the commit the box's snapshot was taken at
-                        'command': 'python3 bench.py --steps 8 --warmup 8 --no-cpu-baseline --no-secondary --pipeline 1'}
+                        'command': 'python3 bench.py --steps 8 --warmup 8 --no-cpu-baseline --no-secondary --no-single-call --pipeline 1'}
 except (OSError, ValueError, KeyError, IndexError):
     pass
 json.dump(summary, open(os.path.join(out, 'pmc.json'), 'w'), indent=1)

@@ -308,7 +308,9 @@ __device__ unsigned long long g_wgtime[1024 * 4];        // per workgroup: start
 // kernel and this bought nothing (tools/prune_proto5.hip); here the scan IS the kernel.
 // KR: seeds per item (explicit candidates; thr = the (KR+1)-th largest posterior).  CLUSTER: see struct Cluster.
 // NI: items per tile (16; 8 for kMaxS16 < S <= kMaxS: G = NI / 4 lanes per next-state, 64 / G next-states per wave pass).
-template <int KW, int MAXP, bool PIPE, int KR = kR, bool CLUSTER = false, int NI = 16>
+// REPAIR: the launch behind a cluster launch (Cluster::failed): a workgroup decodes its tile only where Group::only says so
+// (an instance of its own, so that its -- normally empty -- dispatches do not count as the forward kernel's in a profile).
+template <int KW, int MAXP, bool PIPE, int KR = kR, bool CLUSTER = false, int NI = 16, bool REPAIR = false>
 __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cluster clu, const float *__restrict__ tt,
                                                                    const float2 *__restrict__ sorted,
                                                                    const float *__restrict__ initial, int S, int SpP) {
@@ -334,8 +336,8 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
     // ticket % R the member
     int cid = blockIdx.x, member = 0;
     const int R = CLUSTER ? clu.R : 1;
-    if constexpr (!CLUSTER) {
-        if (grp.only && grp.only[blockIdx.x] == 0u) return;      // (repair launch: this tile's cluster completed)
+    if constexpr (REPAIR) {
+        if (!grp.only || grp.only[blockIdx.x] == 0u) return;     // (this tile's cluster completed)
     }
     if constexpr (CLUSTER) {
         if (tid == 0) {

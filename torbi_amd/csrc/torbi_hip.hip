@@ -1223,8 +1223,7 @@ hipError_t launch_resident_variant(const resident::Group &grp, const resident::C
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((resident::resident_forward_kernel<KW, MAXP, true, KR, CLUSTER, NI>), dim3(workgroups), dim3(64 * KW), lds,
                        stream, grp, clu, w.tt, w.sorted, init, S, w.SpP);
-    if (!grp.only)
-        TORBI_NOTE_KERNEL("resident::resident_forward_kernel<%d, %d, true, %d, %s, %d>", KW, MAXP, KR, CLUSTER ? "true" : "false", NI);
+    TORBI_NOTE_KERNEL("resident::resident_forward_kernel<%d, %d, true, %d, %s, %d>", KW, MAXP, KR, CLUSTER ? "true" : "false", NI);
     return hipGetLastError();
 }
 
@@ -1234,6 +1233,27 @@ hipError_t launch_resident_kernel(const resident::Group &grp, const resident::Cl
                                   const ResidentWorkspace &w, const float *init, int S, hipStream_t stream, bool few) {
     return resident_seeds(few) == 3 ? launch_resident_variant<KW, MAXP, 3, CLUSTER, NI>(grp, clu, workgroups, w, init, S, stream)
                                     : launch_resident_variant<KW, MAXP, 1, CLUSTER, NI>(grp, clu, workgroups, w, init, S, stream);
+}
+
+// the repair launch behind a cluster launch: whole tiles, only where Group::only is set; ONE instance per seed count and
+// tile size (eleven passes cover every supported state count)
+template <int KR, int NI>
+hipError_t launch_repair_variant(const resident::Group &grp, const resident::Cluster &clu, int tiles, const ResidentWorkspace &w,
+                                 const float *init, int S, hipStream_t stream) {
+    const size_t lds = resident::lds_bytes(S, KR + 1);
+    const void *fn = reinterpret_cast<const void *>(&resident::resident_forward_kernel<12, 11, true, KR, false, NI, true>);
+    hipError_t e = ensure_dynamic_lds(fn, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((resident::resident_forward_kernel<12, 11, true, KR, false, NI, true>), dim3(tiles), dim3(64 * 12), lds,
+                       stream, grp, clu, w.tt, w.sorted, init, S, w.SpP);
+    return hipGetLastError();
+}
+inline hipError_t launch_repair(const resident::Group &grp, const resident::Cluster &clu, int tiles, const ResidentWorkspace &w,
+                                const float *init, int S, hipStream_t s, bool few) {
+    const bool small = resident::tile_items(S) != resident::kNI;
+    if (resident_seeds(few) == 3)
+        return small ? launch_repair_variant<3, 8>(grp, clu, tiles, w, init, S, s) : launch_repair_variant<3, 16>(grp, clu, tiles, w, init, S, s);
+    return small ? launch_repair_variant<1, 8>(grp, clu, tiles, w, init, S, s) : launch_repair_variant<1, 16>(grp, clu, tiles, w, init, S, s);
 }
 
 // every workgroup owns a whole tile (resident_forward_kernel without clusters)
@@ -1331,7 +1351,7 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
         if (e == hipSuccess) {
             resident::Group again = grp;
             again.only = clu.failed;
-            e = launch_whole_tiles(again, clu, tiles, w, init, S, s, few);
+            e = launch_repair(again, clu, tiles, w, init, S, s, few);
         }
     } else {
         e = launch_whole_tiles(grp, clu, tiles, w, init, S, s, few);
