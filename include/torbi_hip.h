@@ -122,7 +122,7 @@ int torbi_hip_forward_path(int B, int S);
 int torbi_hip_forward_path_on(int B, int S, int device, unsigned flags);
 /*
  * (ABI 11) Name of the forward kernel the CALLING THREAD's most recent decode launched, spelled the way rocprofv3
- * prints kernels ("streamed::streamed_forward_kernel<15, 6>", "resident::resident_forward_kernel<12, 1, true, 1, true, 16>",
+ * prints kernels ("streamed::streamed_forward_kernel<15, 6>", "resident::resident_forward_kernel<12, 1, true, 1, true, 16, false>",
  * "dense::step_dense_kernel<8, 6, 8, 12, 8>", ...); empty before the first decode.  Measurement plumbing: bench.py
  * reports counter-derived figures (profiles/ *_pmc.json) only when they were taken on the kernel that is running.
  * No counterpart in the reference.

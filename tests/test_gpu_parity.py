@@ -1286,6 +1286,32 @@ def test_many_file_job_with_the_default_uniform_transition(tmp_path, forward):
             f.unlink()
 
 
+def test_many_file_job_frees_its_scratch_unless_asked_to_keep_it(tmp_path, forward, monkeypatch):
+    """Round-3 advisor: the launch-group pipeline (2 x GROUP_SIZE workspaces) and the staging slabs used to stay allocated
+    for the life of the process.  By default a job now frees them when it ends; KEEP_JOB_MEMORY keeps them for the next
+    job and release_job_memory() drops them."""
+    if forward != 'auto':
+        pytest.skip('host-side memory management: once is enough')
+    from torbi_amd import core, slabs
+    dev = torch.device('cuda', 0)
+    S = 256
+    lengths, ins, outs, tf = _ragged_job(tmp_path, 700, S, seed=5, shortest=20, longest=120)
+    core.release_job_memory()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    floor = torch.cuda.memory_allocated(dev)
+    torbi_amd.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, gpu=0)
+    assert not core._job_pipelines and slabs.pool(dev).held_bytes() == 0 and slabs.pool(None).held_bytes() == 0
+    assert torch.cuda.memory_allocated(dev) - floor < 64 << 20, 'a finished job keeps device memory'
+    first = [torch.load(f) for f in outs]
+    monkeypatch.setattr(core, 'KEEP_JOB_MEMORY', True)
+    torbi_amd.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, gpu=0)
+    assert list(core._job_pipelines) == [str(dev)] and slabs.pool(dev).held_bytes() > 0
+    assert all(torch.equal(a, torch.load(f)) for a, f in zip(first, outs))
+    core.release_job_memory()
+    assert not core._job_pipelines and slabs.pool(dev).held_bytes() == 0
+
+
 def test_many_file_job_at_1440_states(tmp_path, forward):
     """BASELINE configs[3] at its own state count, 560 sequences (two batches: 512 + 48): in-order and
     length-bucketed batching write identical files, and 40 randomly chosen files equal the oracle's decode of

@@ -674,3 +674,24 @@ def test_design_routing_table_is_what_the_library_answers():
     assert viterbi.forward_path(512, 1440) == 'cluster' and viterbi.forward_path(2049, 1440) == 'resident'
     assert viterbi.forward_path(1, 1440) == 'held' and viterbi.forward_path(8, 1440) == 'rows'
     assert os.path.getsize(os.path.join(ROOT, 'DESIGN.md')) <= 25 * 1024 + 512
+
+
+def test_slab_pool_stops_counting_slabs_that_were_dropped():
+    """torbi_amd/slabs.py (round-3 advisor): a slab that is taken and never given back (a batch on a path that does not
+    return its buffers, an exception) must not count as out for ever -- the pool would believe it is at its limit and
+    allocate a fresh buffer for every batch after."""
+    import gc
+    from torbi_amd import slabs
+    pool = slabs.SlabPool(None)
+    first, second = pool.take(1000, limit=2), pool.take(1000, limit=2)
+    assert pool._out == 2
+    del first
+    gc.collect()
+    assert pool._out == 1                       # the dropped slab no longer counts
+    pool.give(second)
+    assert pool._out == 0 and pool.held_bytes() >= 1000
+    again = pool.take(500, limit=2)
+    assert again is second and pool._out == 1   # ... and what was given back is handed out again
+    pool.give(again)
+    pool.give(again)                            # (a second give of the same slab does not drive the count below zero)
+    assert pool._out == 0

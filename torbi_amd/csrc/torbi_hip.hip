@@ -1223,7 +1223,7 @@ hipError_t launch_resident_variant(const resident::Group &grp, const resident::C
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((resident::resident_forward_kernel<KW, MAXP, true, KR, CLUSTER, NI>), dim3(workgroups), dim3(64 * KW), lds,
                        stream, grp, clu, w.tt, w.sorted, init, S, w.SpP);
-    TORBI_NOTE_KERNEL("resident::resident_forward_kernel<%d, %d, true, %d, %s, %d>", KW, MAXP, KR, CLUSTER ? "true" : "false", NI);
+    TORBI_NOTE_KERNEL("resident::resident_forward_kernel<%d, %d, true, %d, %s, %d, false>", KW, MAXP, KR, CLUSTER ? "true" : "false", NI);
     return hipGetLastError();
 }
 
