@@ -100,15 +100,13 @@ struct Cluster {
 constexpr unsigned long long kClusterWaitTicks = 25000000ull;
 
 inline bool supported(int S) { return S >= 64 && S <= pruned::kMaxS; }
-constexpr int kSyncWords = 24;           // cluster ingest: [0] waves done scanning, [1] poller taken, [2] members seen, [4 + m] pieces claimed
-constexpr int kMemberWords = 20;         // ... and behind them [m] the first row of member m (kMaxR + 1 entries), computed once
 
 // dynamic LDS: posterior tile [S4][16] + running top lists (64-bit keys) + decoded top lists + frame counts + items
 // + 4 control words (cluster ticket, gave-up flag)
 inline size_t lds_bytes(int S, int ktop = kTop) {
     const size_t S4 = ((size_t)S + 3) / 4 * 4, ni = (size_t)tile_items(S);
     return sizeof(float) * ni * S4 + sizeof(u64) * kNI * ktop + (sizeof(float) + sizeof(int)) * kNI * ktop +
-           2 * sizeof(int) * kNI + (4 + kSyncWords + kMemberWords) * sizeof(int);
+           2 * sizeof(int) * kNI + 4 * sizeof(int);
 }
 
 // row groups (16 next-states) member m of R scans: [m * nrg / R, (m + 1) * nrg / R)
@@ -287,13 +285,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void *base, un
 #ifndef RESIDENT_EXTRA_VALU
 #define RESIDENT_EXTRA_VALU 0
 #endif
-// Cluster form: the other members' slices are taken in 1 KB pieces by whichever wave has nothing else to do, from the moment
-// a member's flag is seen -- waves that have finished their scan ingest (into registers) while the workgroup's slowest wave
-// is still scanning, so that behind the workgroup barrier only the pieces of the members that finished last are left to
-// fetch.  0 = every thread loads its share of all slices behind the barrier (round 3).
-#ifndef CLUSTER_EARLY_INGEST
-#define CLUSTER_EARLY_INGEST 0
-#endif
 
 #ifdef RESIDENT_STAMP
 // build-time instrumentation (tools/resident_stamps.py): per-wave cycle sums of the phases of a timestep
@@ -334,7 +325,6 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
     int *sframes = mtopi + kNI * kTop;                                // [16] frames per item (0 past the batch)
     int *sitem = sframes + kNI;                                       // [16] item numbers (a valid one past the batch)
     int *smisc = sitem + kNI;                                         // [0] cluster ticket, [1] gave up waiting
-    int *csync = smisc + 4;                                           // [kSyncWords] cluster ingest (CLUSTER_EARLY_INGEST)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -377,13 +367,6 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
         sitem[tid] = item;
     }
     if (tid < kNI * kTop) top[tid] = 0ull;
-    if (CLUSTER && tid < kSyncWords) csync[tid] = 0;
-    if (CLUSTER && tid <= kMaxR) {           // first row of every member (a 64-bit division each: once, not per use)
-        const int groups = (S + kRowGroup - 1) / kRowGroup;
-        const int m = tid < clu.R ? tid : clu.R;
-        const int row = kRowGroup * cluster_first_group(m, groups, clu.R);
-        csync[kSyncWords + tid] = row < S ? row : S;
-    }
     __syncthreads();
     int fmax = 0;
 #pragma unroll
@@ -679,116 +662,6 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
             if (!CLUSTER_LATE_DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             RSTAMP(8);
         }
-#if CLUSTER_EARLY_INGEST
-        // ---- the other members' slices, taken in pieces by whichever wave is free (see CLUSTER_EARLY_INGEST above) ----
-        // piece k of member m: 64 consecutive 16-byte units of m's rows (unit = a row's four items of one lane group);
-        // piece `chunks(m)` = m's partial top lists.  A wave keeps what it takes in `slot` until the tile may be written.
-        constexpr int kSlots = 12;
-        float4 slot[kSlots];
-        int slot_code[kSlots];              // member * 256 + piece (wave-uniform)
-        int nslot = 0;
-        unsigned exhausted = 0u;            // members whose pieces have all been claimed (as far as this wave knows)
-        bool poller = false, asked = false;
-        unsigned poll_spins = 0;
-        unsigned long long poll_since = 0ull;
-        auto member_rows = [&](int m, int &lo, int &hi) {
-            lo = __builtin_amdgcn_readfirstlane(csync[kSyncWords + m]);
-            hi = __builtin_amdgcn_readfirstlane(csync[kSyncWords + m + 1]);
-        };
-        // (`burst`: pieces this wave takes per member and call -- behind the barrier all twelve waves are waiting for the last
-        // members, and a wave that took a whole member's pieces one claim after the other would serialise their loads)
-        auto ingest_step = [&](const __amdgpu_buffer_rsrc_t &xsrc, unsigned *cflags, int burst) {
-            if (!asked) {                   // the first wave to get here polls for the workgroup
-                int old = 1;
-                if (lane == 0) old = atomicCAS(csync + 1, 0, 1);
-                poller = __builtin_amdgcn_readfirstlane(old) == 0;
-                asked = true;
-            }
-            if (poller) {
-                unsigned seen = 0u;
-                if (lane < R && lane != member)
-                    seen = __hip_atomic_load(cflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long there = __builtin_amdgcn_ballot_w64(lane < R && lane != member && seen >= (unsigned)t);
-                if (lane == 0) atomicOr(csync + 2, (int)(unsigned)there);
-                if ((poll_spins++ & 255u) == 0u) {
-                    const unsigned long long now = wall_clock64();
-                    if (poll_since == 0ull) poll_since = now;
-                    if (now - poll_since >= clu.wait_ticks && lane == 0) smisc[1] = 1;
-                }
-            }
-            const unsigned seen_all = (unsigned)__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int *>(csync + 2));
-            if (!(seen_all & ~exhausted & ~(1u << member))) return;         // nothing new
-            for (int m = 0; m < R; ++m) {
-                if (m == member || !((seen_all >> m) & 1u) || ((exhausted >> m) & 1u)) continue;
-                int lo, hi;
-                member_rows(m, lo, hi);
-                const int units = (hi - lo) * G, chunks = (units + 63) / 64;
-                for (int taken = 0; taken < burst && nslot < kSlots; ++taken) {
-                    int k = 0;
-                    if (lane == 0) k = atomicAdd(csync + 4 + m, 1);
-                    k = __builtin_amdgcn_readfirstlane(k);
-                    if (k > chunks) { exhausted |= 1u << m; break; }
-                    int off;                                        // byte offset in the exchange slot
-                    bool on;
-                    if (k < chunks) {
-                        const int c = 64 * k + lane;
-                        on = c < units;
-                        off = ((lo + c / G) * kNI + 4 * (c % G)) * 4;
-                    } else {                                        // the member's partial top lists: two keys per lane
-                        on = lane < kNI * kTop / 2;
-                        off = (int)xrow + (m * kNI * kMaxTop + 2 * lane) * 8;
-                    }
-                    const int code = m * 256 + k;
-#define TORBI_TAKE(Q_) case Q_: if (on) slot[Q_] = load_through(xsrc, off); slot_code[Q_] = code; break;
-                    switch (nslot) {
-                        TORBI_TAKE(0) TORBI_TAKE(1) TORBI_TAKE(2) TORBI_TAKE(3) TORBI_TAKE(4) TORBI_TAKE(5)
-                        TORBI_TAKE(6) TORBI_TAKE(7) TORBI_TAKE(8) TORBI_TAKE(9) TORBI_TAKE(10) TORBI_TAKE(11)
-                        default: break;
-                    }
-#undef TORBI_TAKE
-                    ++nslot;
-                }
-            }
-        };
-        // what this wave holds -> the tile (slices) / the running top lists (keys); only once the tile may be written
-        auto flush_slots = [&]() {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int q = 0; q < kSlots; ++q) {
-                if (q < nslot) {
-                    const int m = slot_code[q] >> 8, k = slot_code[q] & 255;
-                    int lo, hi;
-                    member_rows(m, lo, hi);
-                    const int units = (hi - lo) * G, chunks = (units + 63) / 64;
-                    if (k < chunks) {
-                        const int c = 64 * k + lane;
-                        if (c < units)
-                            *reinterpret_cast<float4 *>(reinterpret_cast<char *>(lds) + ((lo + c / G) * kNI + 4 * (c % G)) * 4) = slot[q];
-                    } else if (lane < kNI * kTop / 2) {
-                        const u64 k0 = ((u64)__float_as_uint(slot[q].y) << 32) | __float_as_uint(slot[q].x);
-                        const u64 k1 = ((u64)__float_as_uint(slot[q].w) << 32) | __float_as_uint(slot[q].z);
-                        if (k0) top_insert<kTop>(top + (2 * lane / kTop) * kTop, k0);
-                        if (k1) top_insert<kTop>(top + ((2 * lane + 1) / kTop) * kTop, k1);
-                    }
-                }
-            }
-            nslot = 0;
-        };
-        if constexpr (CLUSTER) {
-            if (t + 1 < fmax) {
-                // this wave is done scanning; until all of them are it takes what has arrived
-                const __amdgpu_buffer_rsrc_t xsrc =
-                    buffer_of(reinterpret_cast<const char *>(clu.xchg) + (size_t)(2 * cid + (t & 1)) * xbytes, xbytes);
-                unsigned *const cflags = clu.flags + (size_t)cid * kMaxR;
-                if (lane == 0) atomicAdd(csync, 1);
-                while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int *>(csync)) < KW &&
-                       !__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int *>(smisc + 1))) {
-                    ingest_step(xsrc, cflags, kSlots);
-                    __builtin_amdgcn_s_sleep(24);       // (a wave that spins takes issue slots from the ones still scanning)
-                }
-            }
-        }
-#endif
         __syncthreads();      // every wave is done reading the tile and mtop, every output is in `top`
         RSTAMP(5);
 #pragma unroll
@@ -834,24 +707,6 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                     if (tid == 0) __hip_atomic_store(cflags + member, (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 RSTAMP(6);
-#if CLUSTER_EARLY_INGEST
-                // (2') the rest of the other members' pieces: taken as their flags come up; the tile may be written now, so
-                // a wave flushes what it holds whenever its slots are full and at the end
-                {
-                    const unsigned everyone = ((R >= 32 ? 0u : (1u << R)) - 1u) & ~(1u << member);
-                    while (exhausted != everyone && !__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int *>(smisc + 1))) {
-                        ingest_step(xsrc, cflags, 2);
-                        if (nslot == kSlots) flush_slots();
-                        else if (exhausted != everyone) __builtin_amdgcn_s_sleep(CLUSTER_POLL_SLEEP);
-                    }
-                    flush_slots();
-                }
-                RSTAMP(10);
-                __syncthreads();      // the tile holds row t, `top` its largest entries
-                RSTAMP(11);
-                if (tid < kSyncWords) csync[tid] = 0;       // (nobody looks at these before the next timestep's scan is over)
-                if (smisc[1]) break;  // (uniform: read behind the barrier)
-#else
                 // (2) wave 0 waits until the other members have published timestep t (one relaxed poll per member and
                 // round, lanes 0..R-1; bounded: a cluster that cannot complete gives up and reports it), the others for wave 0
                 if (!CLUSTER_ONE_POLLER || wave == 0) {
@@ -920,7 +775,6 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                 __syncthreads();      // the tile holds row t, `top` its largest entries
                 RSTAMP(11);
                 if (smisc[1]) break;  // (uniform: read behind the barrier)
-#endif
             }
         }
         publish_top(t);
