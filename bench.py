@@ -524,7 +524,20 @@ class Bench:
             torch.cuda.synchronize()
             kept.append(time.perf_counter() - t0)
         sec_kept = sorted(kept[1:])[2]
+        plain = []
+        for _ in range(6):          # ... and exactly as the reference's caller writes it: no workspace argument at all
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            self.torbi_amd.decode(obs, frames, trans, init)
+            torch.cuda.synchronize()
+            plain.append(time.perf_counter() - t0)
+        sec_plain = sorted(plain[1:])[2]
         return {'value': rate, 'unit': 'timesteps/s', 'ms_per_decode': sec * 1e3,
+                'without_workspace_argument': {'value': B * T / sec_plain, 'ms_per_decode': sec_plain * 1e3,
+                                               'note': 'decode(observation, batch_frames, transition, initial) as '
+                                                       'torbi/core.py:200-206 calls it: scratch from the caching allocator '
+                                                       'per call, the preparation kept with the transition tensor '
+                                                       '(torbi_hip_viterbi_decode_batches_prepared); first call excluded'},
                 'with_reused_preparation': {'value': B * T / sec_kept, 'ms_per_decode': sec_kept * 1e3,
                                             'note': 'decode(..., workspace=ws, reuse_preparation=True): sorted rows / '
                                                     'transposed matrix taken from the workspace of the previous call with '

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TORBI_HIP_ABI_VERSION 11
+#define TORBI_HIP_ABI_VERSION 12
 
 #define TORBI_HIP_OK 0
 #define TORBI_HIP_EINVAL (-1)      /* null pointer / non-positive dimension            */
@@ -200,6 +200,23 @@ typedef struct torbi_hip_batch {
 int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, const float *transition,
                                      const float *initial, int S, int device, void *stream, unsigned flags,
                                      float *phase_ms);
+
+/*
+ * (ABI 12) The same with the per-transition preparation of the time-resident routes (sorted and arranged transition rows,
+ * transposed matrix: what TORBI_HIP_REUSE_TRANSITION is about) kept by the CALLER in `preparation`
+ * (>= torbi_hip_preparation_bytes(S) bytes of device memory, 256-byte aligned; 25.6 MB at 1440 states) instead of inside the
+ * first batch's workspace.  For callers that allocate scratch per call like the reference's operator does
+ * (viterbi.cu:331-336): the workspace may be new every time, the preparation lives with the matrix.  With
+ * TORBI_HIP_REUSE_TRANSITION the caller promises that `preparation` was filled by an earlier call with the same S and
+ * transition CONTENTS on a route of the same tile size (S <= 2048 / above), ordered before this one; without the flag it
+ * is (re)built.  Routes that keep no such preparation (dense, rows, generic, held) ignore the buffer AND the flag (they
+ * prepare in the workspace as ever).  *filled (may be NULL) = 1 when `preparation` holds the matrix's preparation once the
+ * enqueued work has run -- i.e. whether the NEXT call may pass the flag -- else 0.  preparation NULL = the plain call.
+ */
+size_t torbi_hip_preparation_bytes(int S);
+int torbi_hip_viterbi_decode_batches_prepared(const torbi_hip_batch *batches, int count, const float *transition,
+                                              const float *initial, int S, int device, void *stream, unsigned flags,
+                                              float *phase_ms, void *preparation, size_t preparation_bytes, int *filled);
 
 /*
  * Scan statistics for adaptive path selection (torbi_amd/viterbi.py uses them): copies 128 uint32 to `stats_out`

@@ -586,6 +586,70 @@ def test_preparation_reuse_follows_the_transition_and_the_shape(B):
                                            got.data_ptr(), ws.data_ptr(), ws.numel(), B, T, S, 0, None, 4) == -1
 
 
+def test_calls_without_a_workspace_keep_the_preparation_with_the_matrix():
+    """decode() / decode_batches() allocate their scratch per call like the reference's operator (viterbi.cu:331-336); the
+    time-resident routes' per-transition preparation then lives with the transition tensor (include/torbi_hip.h,
+    torbi_hip_viterbi_decode_batches_prepared): built by the first call, found by the next ones -- on any stream --,
+    dropped when the matrix changes, never trusted by a route that does not use it."""
+    from torbi_amd import state
+    dev = torch.device('cuda:0')
+    B, T, S = 40, 9, 360
+    obs, trans, init = synth.problem(B, T, S, seed=15)
+    obs2 = synth.problem(B, T, S, seed=16)[0]
+    frames = synth.lengths(B, 1, T, seed=3)
+    d = [torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)]
+    resident = viterbi.forward_path(B, S) in viterbi.TIME_RESIDENT           # (not under the forced dense path)
+    small = [torch.as_tensor(x).to(dev) for x in (obs[:4], frames[:4])]
+    # a route that keeps no such preparation first: nothing is marked as filled, its results are right
+    np.testing.assert_array_equal(torbi_amd.decode(small[0], small[1], d[2], d[3]).cpu().numpy(),
+                                  oracle.decode(obs[:4], frames[:4], trans, init))
+    if viterbi.forward_path(4, S) not in viterbi.TIME_RESIDENT:
+        assert not any(k[0] == 'preparation' for k in (state.peek(d[2]) or {}) if isinstance(k, tuple))
+    want1 = oracle.decode(obs, frames, trans, init)
+    want2 = oracle.decode(obs2, frames, trans, init)
+    np.testing.assert_array_equal(torbi_amd.decode(*d).cpu().numpy(), want1)
+    if resident:
+        kept = state.peek(d[2])[('preparation', S, 0)]
+        assert kept.filled is not None and kept.buffer.numel() >= torbi_amd._lib.load().torbi_hip_preparation_bytes(S)
+        pointer = kept.buffer.data_ptr()
+    profile = []
+    np.testing.assert_array_equal(torbi_amd.decode(torch.as_tensor(obs2).to(dev), *d[1:], _profile=profile).cpu().numpy(), want2)
+    if resident:
+        assert state.peek(d[2])[('preparation', S, 0)].buffer.data_ptr() == pointer
+        assert profile[4] < 0.05, profile                                  # ms of preparation: nothing was rebuilt
+    other = torch.cuda.Stream(dev)
+    other.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(other):                                        # another stream: ordered behind the filling call
+        got = torbi_amd.decode(*d)
+    other.synchronize()
+    np.testing.assert_array_equal(got.cpu().numpy(), want1)
+    # a group of batches, and the small route between two uses
+    outs = torbi_amd.decode_batches([d[0], small[0]], [d[1], small[1]], d[2], d[3])
+    np.testing.assert_array_equal(outs[0].cpu().numpy(), want1)
+    np.testing.assert_array_equal(outs[1].cpu().numpy(), oracle.decode(obs[:4], frames[:4], trans, init))
+    np.testing.assert_array_equal(torbi_amd.decode(small[0], small[1], d[2], d[3]).cpu().numpy(),
+                                  oracle.decode(obs[:4], frames[:4], trans, init))
+    d[2].mul_(0.5)                                                        # new version of the matrix: a new preparation
+    want3 = oracle.decode(obs, frames, (trans * np.float32(0.5)).astype(np.float32), init)
+    np.testing.assert_array_equal(torbi_amd.decode(*d).cpu().numpy(), want3)
+    np.testing.assert_array_equal(torbi_amd.decode(*d).cpu().numpy(), want3)
+    # the C entry: too small a buffer is refused, NULL is the plain call
+    lib = torbi_amd._lib.load()
+    ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+    out = torch.empty((B, T), dtype=torch.int32, device=dev)
+    one = (torbi_amd._lib.Batch * 1)(torbi_amd._lib.Batch(d[0].data_ptr(), d[1].data_ptr(), out.data_ptr(), ws.data_ptr(),
+                                                          ws.numel(), B, T))
+    import ctypes
+    filled = ctypes.c_int(7)
+    assert lib.torbi_hip_viterbi_decode_batches_prepared(one, 1, d[2].data_ptr(), d[3].data_ptr(), S, 0, None, 0, None,
+                                                         ws.data_ptr(), 1024, ctypes.byref(filled)) == -2
+    assert filled.value == 0
+    assert lib.torbi_hip_viterbi_decode_batches_prepared(one, 1, d[2].data_ptr(), d[3].data_ptr(), S, 0, None, 0, None,
+                                                         None, 0, ctypes.byref(filled)) == 0
+    assert filled.value == 0
+    np.testing.assert_array_equal(out.cpu().numpy(), want3)
+
+
 def test_decode_pipeline_equals_serial_decodes():
     """torbi_amd.DecodePipeline: consecutive batches on alternating streams, private scratch."""
     dev = torch.device('cuda:0')

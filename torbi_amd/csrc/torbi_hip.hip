@@ -745,6 +745,19 @@ struct ResidentWorkspace {
     size_t bytes;
 };
 
+// The per-transition preparation of the time-resident routes (sorted + arranged rows, transposed matrix, row ranges)
+// may live OUTSIDE the workspace (torbi_hip_viterbi_decode_batches_prepared): a caller that allocates a workspace per call
+// -- the reference's own calling pattern, torbi/core.py:200-206 -- keeps 25 MB per matrix instead of rebuilding it
+// (0.25 ms per call at 1440 states).  Set for the duration of one call on the calling thread.
+thread_local void *g_preparation = nullptr;
+thread_local size_t g_preparation_bytes = 0;
+thread_local bool g_preparation_valid = false;      // holds this matrix's preparation (the caller's promise, or filled by this call)
+inline size_t preparation_bytes(int S) {
+    const int Sp = (S + 15) / 16 * 16;
+    return align_up(sizeof(float2) * (size_t)S * (Sp + pruned::kPad), 256) + align_up(sizeof(float) * (size_t)S * S, 256) +
+           align_up(sizeof(int32_t) * 2 * (size_t)S, 256);
+}
+
 inline ResidentWorkspace carve_resident(void *base, int B, int T, int S, int cus) {
     ResidentWorkspace w;
     char *p = static_cast<char *>(base);
@@ -775,6 +788,12 @@ inline ResidentWorkspace carve_resident(void *base, int B, int T, int S, int cus
     w.sorted = reinterpret_cast<float2 *>(p);
     w.tt = reinterpret_cast<float *>(p + sorted_bytes);
     w.row_range = reinterpret_cast<int32_t *>(p + sorted_bytes + tt_bytes);
+    if (base && g_preparation && g_preparation_bytes >= preparation_bytes(S)) {      // (the caller keeps it: see above)
+        char *q = static_cast<char *>(g_preparation);
+        w.sorted = reinterpret_cast<float2 *>(q);
+        w.tt = reinterpret_cast<float *>(q + sorted_bytes);
+        w.row_range = reinterpret_cast<int32_t *>(q + sorted_bytes + tt_bytes);
+    }
     p += sorted_bytes + tt_bytes + range_bytes;
     w.xchg = reinterpret_cast<float *>(p);
     w.flags = reinterpret_cast<unsigned *>(p + xchg_bytes);
@@ -1315,7 +1334,9 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
         jobs.job[k].route_record = route_record(hb[k].workspace, hb[k].B, hb[k].T, S, cus);
         jobs.job[k].route = (int)(R > 1 ? ROUTE_CLUSTER : ROUTE_RESIDENT);
     }
+    if (g_preparation) reuse = g_preparation_valid;       // the caller's buffer: the promise is about IT, whichever batch
     if (!reuse) launch_list_preparation(trans, w.sorted, w.row_range, w.tt, S, w.SpP, w.NPOW, resident::tile_items(S), s);
+    if (g_preparation) g_preparation_valid = true;
     hipLaunchKernelGGL(resident::order_items_kernel, dim3((widest + 255) / 256, n), dim3(256), 0, s, jobs);
     for (int k = 0; k < n; ++k) {            // batches too large for the all-pairs ranking: counting sort over the lengths
         const resident::OrderJob &jb = jobs.job[k];
@@ -1424,6 +1445,7 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
         return run_resident(&hb, 1, trans, init, S, cus, s, ev, launches, reuse, false, route == ROUTE_CLUSTER,
                             few_seeds(seed_flags, route == ROUTE_CLUSTER));
     }
+    if (g_preparation) reuse = false;       // (the promise was about the caller's buffer; this route prepares in the workspace)
     if (ev) (void)hipEventRecord(ev[0], s);
     if (ev) (void)hipEventRecord(ev[3], s);
     e = stamp_route(workspace, B, T, S, cus, route, s);
@@ -1647,6 +1669,24 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
                            device, s, nullptr, nullptr, reuse && k == 0, (flags & TORBI_HIP_COLLECT_STATS) != 0, path, flags);
     mark_decode_end(device, s);
     return (int)e;
+}
+
+size_t torbi_hip_preparation_bytes(int S) { return S > 0 ? preparation_bytes(S) : 256; }
+
+int torbi_hip_viterbi_decode_batches_prepared(const torbi_hip_batch *batches, int count, const float *transition,
+                                              const float *initial, int S, int device, void *stream, unsigned flags,
+                                              float *phase_ms, void *preparation, size_t preparation_bytes_given,
+                                              int *filled) {
+    if (filled) *filled = 0;
+    if (preparation && (S < 1 || preparation_bytes_given < preparation_bytes(S) || (reinterpret_cast<uintptr_t>(preparation) & 255)))
+        return TORBI_HIP_EWORKSPACE;
+    struct Scope {
+        Scope(void *p, size_t n, bool valid) { g_preparation = p; g_preparation_bytes = n; g_preparation_valid = valid; }
+        ~Scope() { g_preparation = nullptr; g_preparation_bytes = 0; g_preparation_valid = false; }
+    } scope(preparation, preparation_bytes_given, preparation && (flags & TORBI_HIP_REUSE_TRANSITION));
+    const int rc = torbi_hip_viterbi_decode_batches(batches, count, transition, initial, S, device, stream, flags, phase_ms);
+    if (filled && rc == TORBI_HIP_OK) *filled = g_preparation_valid ? 1 : 0;
+    return rc;
 }
 
 int torbi_hip_scan_stats(const void *workspace, size_t workspace_bytes, int B, int T, int S,

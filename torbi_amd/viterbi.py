@@ -255,7 +255,8 @@ def decode(
     if B == 0:
         return indices.to(home)
     need = lib.torbi_hip_workspace_bytes(B, T, S)
-    if workspace is None:
+    own_scratch = workspace is None
+    if own_scratch:
         workspace = torch.empty((need,), dtype=torch.uint8, device=device)
     elif (workspace.device != device or workspace.dtype != torch.uint8
           or workspace.numel() < need or not workspace.is_contiguous()):
@@ -272,7 +273,17 @@ def decode(
         flags |= 1                                  # TORBI_HIP_REUSE_TRANSITION
     if chosen in TIME_RESIDENT:
         flags |= _seed_flag(transition, S)          # TORBI_HIP_FEW_SEEDS / _MANY_SEEDS once the scan depth is known
-    if _profile is None:
+    kept = _kept_preparation(transition, B, S, chosen, device, index) if own_scratch else None
+    if kept is not None:       # the per-call scratch is new every time; the preparation stays with the matrix
+        one = (_lib.Batch * 1)(_lib.Batch(obs.data_ptr(), frames.data_ptr(), indices.data_ptr(), workspace.data_ptr(),
+                                          workspace.numel(), B, T))
+        phases = (ctypes.c_float * 6)() if _profile is not None else None
+        _lib.check(kept.call(device, lambda pointer, size, reuse, filled: lib.torbi_hip_viterbi_decode_batches_prepared(
+            one, 1, trans.data_ptr(), init.data_ptr(), S, index, ctypes.c_void_p(stream), flags | reuse, phases,
+            pointer, size, filled)), 'torbi_hip_viterbi_decode_batches_prepared')
+        if _profile is not None:
+            _profile[:] = list(phases)
+    elif _profile is None:
         _lib.check(lib.torbi_hip_viterbi_decode_ex(*args, flags), 'torbi_hip_viterbi_decode_ex')
     else:
         phases = (ctypes.c_float * 6)()
@@ -314,6 +325,57 @@ def decode_cpu(
         raise RuntimeError(f'torbi_cpu_viterbi_decode failed with code {code}'
                            + (' (out of memory for the posterior history)' if code == -6 else ''))
     return indices
+
+
+class _Preparation:
+    """The time-resident routes' per-transition preparation kept with the transition tensor (include/torbi_hip.h,
+    torbi_hip_viterbi_decode_batches_prepared) for calls that bring no workspace of their own: the reference's calling
+    pattern (torbi/core.py:200-206 allocates per call) would otherwise rebuild it every time (0.25 ms at 1440
+    states).  Lives in the notes of the tensor at its current version (torbi_amd/state.py), so an in-place change or the
+    tensor's death drops it; 25.6 MB at 1440 states."""
+
+    def __init__(self, nbytes, device):
+        import threading
+        self.buffer = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        self.filled = None            # event recorded behind the call that filled the buffer
+        self.stream = None            # the stream that call ran on
+        self.lock = threading.Lock()  # held while the filling call is being enqueued
+
+    def call(self, device, run):
+        """run(pointer, bytes, reuse_flag, filled) with the buffer ordered behind its filling call on the current stream;
+        `filled` is the library's word on whether the buffer holds the preparation afterwards."""
+        current = torch.cuda.current_stream(device)
+        filled = ctypes.c_int(0)
+        with self.lock:
+            if self.filled is None:
+                result = run(self.buffer.data_ptr(), self.buffer.numel(), 0, ctypes.byref(filled))
+                if result == 0 and filled.value:
+                    event = torch.cuda.Event()
+                    event.record(current)
+                    self.filled, self.stream = event, current.cuda_stream
+                return result
+        if current.cuda_stream != self.stream:
+            current.wait_event(self.filled)
+            self.buffer.record_stream(current)
+        return run(self.buffer.data_ptr(), self.buffer.numel(), 1, ctypes.byref(filled))
+
+
+_preparation_lock = __import__('threading').Lock()
+
+
+def _kept_preparation(transition, B, S, chosen, device, index):
+    """The `_Preparation` of `transition` for a call that routes to a time-resident form, else None."""
+    if forward_path(B, S, chosen, index) not in TIME_RESIDENT:
+        return None
+    kept = state.notes(transition)
+    if kept is None:
+        return None
+    key = ('preparation', S, index)
+    with _preparation_lock:
+        found = kept.get(key)
+        if found is None:
+            found = kept[key] = _Preparation(int(_lib.load().torbi_hip_preparation_bytes(S)), device)
+    return found
 
 
 def _reusable(workspace, transition, shape_state, wanted) -> bool:
@@ -385,7 +447,8 @@ def decode_batches(
             raise RuntimeError('decode_batches needs contiguous tensors on one device')
     trans = transition.to(device).contiguous()
     init = initial.to(device).contiguous()
-    if workspaces is None:
+    own_scratch = workspaces is None
+    if own_scratch:
         workspaces = [torch.empty((lib.torbi_hip_workspace_bytes(B, T, S),), dtype=torch.uint8, device=device)
                       for B, T, _ in shapes]
     if len(workspaces) != count:
@@ -421,9 +484,15 @@ def decode_batches(
     if chosen in TIME_RESIDENT:
         flags |= _seed_flag(transition, S)         # TORBI_HIP_FEW_SEEDS / _MANY_SEEDS once the scan depth is known
     phases = (ctypes.c_float * 6)() if _profile is not None else None
-    _lib.check(lib.torbi_hip_viterbi_decode_batches(table, count, trans.data_ptr(), init.data_ptr(), S, index,
-                                                    ctypes.c_void_p(stream), flags, phases),
-               'torbi_hip_viterbi_decode_batches')
+    kept = _kept_preparation(transition, largest, S, chosen, device, index) if own_scratch else None
+    if kept is not None:
+        _lib.check(kept.call(device, lambda pointer, size, reuse, filled: lib.torbi_hip_viterbi_decode_batches_prepared(
+            table, count, trans.data_ptr(), init.data_ptr(), S, index, ctypes.c_void_p(stream), flags | reuse, phases,
+            pointer, size, filled)), 'torbi_hip_viterbi_decode_batches_prepared')
+    else:
+        _lib.check(lib.torbi_hip_viterbi_decode_batches(table, count, trans.data_ptr(), init.data_ptr(), S, index,
+                                                        ctypes.c_void_p(stream), flags, phases),
+                   'torbi_hip_viterbi_decode_batches')
     if _profile is not None:
         _profile[:] = list(phases)
     if chosen in TIME_RESIDENT and (_forced_path if path is None else path) == 'auto':
