@@ -76,8 +76,11 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
 
 /*
  * Forward-recurrence paths (all give identical indices):
- *   GENERIC   S < 64, S > 4096 with B < 32, or DENSE named for a batch below 32 items: trellis kernels shaped like
- *             the reference's
+ *   SMALL     2 <= S <= 64: ONE launch per decode, one wavefront per sequence -- lane j keeps row j of the matrix in
+ *             registers, a timestep is S x (v_readlane, add, compare, select), byte backpointers, and the same wavefront
+ *             walks them back (small_states.hpp).  AUTO's choice for every batch size at these state counts.
+ *   GENERIC   S = 1, S > 4096 with B < 32, or DENSE named for a batch below 32 items (any S): trellis kernels shaped like
+ *             the reference's, one launch per timestep
  *   ROWS      B <= 16, 64 <= S <= 4096: the pruned recurrence with one wave per (item, next-state), 64 list
  *             entries per wave step (small_batch_forward.hpp); one launch per timestep.  AUTO takes it for
  *             B >= 6 or S > 2048 (below that both it and GENERIC are bound by the gap between launches)
@@ -97,7 +100,7 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
  *   HELD      B <= 16, S <= 4096: the reference's scan with the time loop inside ONE launch: ceil(S / 8) workgroups
  *             hold 8 rows of the matrix each in registers for the whole launch and pass the posterior rows to each
  *             other through 8-byte {value, timestep} words (held_matrix_forward.hpp).
- * AUTO: RESIDENT when the call's tiles fill more than half the compute units; CLUSTER for any other batch of more than
+ * AUTO: SMALL up to 64 states; else RESIDENT when the call's tiles fill more than half the compute units; CLUSTER for any other batch of more than
  * 16 items (64 <= S <= 4096: one batch = one forward launch); HELD up to three items (eight above 2048 states); ROWS for
  * 6..16 items (and above 2048 states); DENSE for large batches outside 64..4096 states; else GENERIC.  (The Python layer
  * adds what it knows about the matrix: DENSE for one batch with a narrow band or with scans too deep to prune.)
@@ -107,7 +110,7 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
  * TORBI_HIP_FORWARD=dense|pruned|resident|cluster|held, else AUTO).  A path that does not cover the shape falls
  * back as AUTO would.  A workspace of torbi_hip_workspace_bytes() fits every path.
  * torbi_hip_forward_path_on reports what a (B, S) batch would run on `device` with `flags`:
- * 0 generic, 1 dense, 3 resident, 4 rows, 5 cluster, 6 held (2 is retired); torbi_hip_forward_path is the same for device 0,
+ * 0 generic, 1 dense, 3 resident, 4 rows, 5 cluster, 6 held, 7 small (2 is retired); torbi_hip_forward_path is the same for device 0,
  * flags 0.
  */
 #define TORBI_HIP_FORWARD_AUTO 0
@@ -184,7 +187,7 @@ int torbi_hip_viterbi_decode_ex(const float *observation, const int32_t *batch_f
  * phase_ms: NULL, or a HOST pointer to 6 floats -- the call then brackets its phases with hipEvents on
  * `stream` and SYNCHRONISES it (bench.py):
  *   [0] forward recurrence incl. preparation, ms   [1] argmax + backtrace, ms
- *   [2] forward kernel launches                    [3] route that ran (0 generic .. 4 rows)
+ *   [2] forward kernel launches                    [3] route that ran (0 generic .. 7 small)
  *   [4] per-transition preparation alone, ms       [5] batches the forward launch(es) covered
  * (for batches decoded one after the other [0],[1],[2],[4] describe the LAST batch).
  */

@@ -164,6 +164,77 @@ def test_dense_path_edge_shapes(shape):
     assert np.array_equal(gpu_decode(obs, frames, trans, init), want)
 
 
+@pytest.mark.parametrize('S', [2, 3, 4, 5, 8, 9, 16, 17, 31, 32, 33, 63, 64])
+def test_one_wavefront_per_sequence_up_to_64_states(S):
+    """small_states.hpp: recurrence, byte backpointers and backtrace in one launch.  Lengths around the 4-timestep
+    backpointer words and the 64-timestep chunks of the walk back, ties everywhere (scores on a coarse grid: the lowest
+    prev-state must win, viterbi.cpp:94-100), -inf rows and columns, and the final posterior rows where
+    torbi_hip_read_posterior looks for them."""
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(S)
+    for B, T in [(1, 1), (3, 2), (5, 5), (4, 9), (70, 67), (6, 130), (2, 517)]:
+        obs = -rng.integers(0, 6, size=(B, T, S)).astype(np.float32)          # coarse grid: many exact ties
+        trans = -rng.integers(0, 5, size=(S, S)).astype(np.float32)
+        init = -rng.integers(0, 3, size=(S,)).astype(np.float32)
+        trans[rng.random((S, S)) < 0.2] = -np.inf
+        obs[rng.random((B, T, S)) < 0.05] = -np.inf
+        if S > 2:
+            trans[:, S - 1] = -np.inf                                          # a state nobody can come from
+        frames = np.array([T, 1, max(T - 1, 1), max(T - 3, 1), max(T - 4, 1), max(T // 2, 1), max(T - 63, 1),
+                           max(T - 64, 1), max(T - 65, 1)], np.int32)
+        frames = np.resize(frames, B).astype(np.int32)
+        want, post = oracle.decode(obs, frames, trans, init, return_posterior=True)
+        ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+        profile = []
+        got = torbi_amd.decode(torch.tensor(obs, device=dev), torch.tensor(frames, device=dev), torch.tensor(trans, device=dev),
+                               torch.tensor(init, device=dev), workspace=ws, _profile=profile)
+        np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f'{B} x {T} x {S}')
+        if viterbi.forward_path(B, S) == 'small':
+            assert viterbi.ROUTES[int(profile[3])] == 'small' and profile[2] == 1       # ONE launch
+            assert viterbi.last_forward_kernel().startswith('small::decode_kernel<')
+        back = viterbi.read_posterior(ws, torch.tensor(frames), B, T, S).cpu().numpy()
+        assert np.array_equal(back.view(np.uint32), post.view(np.uint32)), (B, T, S)
+    # random real-valued scores too (no ties): the usual synthetic problem, ragged
+    B, T = 33, 200
+    obs, trans, init = synth.problem(B, T, S, seed=S)
+    frames = np.clip(synth.lengths(B, 1, T, seed=S), 1, T)
+    np.testing.assert_array_equal(gpu_decode(obs, frames, trans, init), oracle.decode(obs, frames, trans, init))
+
+
+@pytest.mark.parametrize('S', [65, 80, 81, 100, 128, 129, 160, 161, 192, 193, 224, 225, 255, 256])
+def test_one_workgroup_per_sequence_up_to_256_states(S):
+    """small_states.hpp, block_decode_kernel: the matrix in the registers of one compute unit, the prev-states in one or
+    two ranges, four running maxima per lane.  Ties everywhere (coarse grid), -inf rows / columns / observations, lengths
+    around the 4-timestep backpointer words and the 64-timestep chunks of the walk back, the final posterior rows."""
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(S)
+    for B, T in [(1, 1), (3, 2), (5, 5), (9, 67), (3, 130), (2, 261)]:
+        obs = -rng.integers(0, 6, size=(B, T, S)).astype(np.float32)
+        trans = -rng.integers(0, 5, size=(S, S)).astype(np.float32)
+        init = -rng.integers(0, 3, size=(S,)).astype(np.float32)
+        trans[rng.random((S, S)) < 0.2] = -np.inf
+        obs[rng.random((B, T, S)) < 0.05] = -np.inf
+        trans[:, S - 1] = -np.inf
+        trans[S // 2, :] = -np.inf                                             # a state nobody can reach
+        frames = np.resize(np.array([T, 1, max(T - 1, 1), max(T - 3, 1), max(T - 4, 1), max(T // 2, 1), max(T - 63, 1),
+                                     max(T - 64, 1), max(T - 65, 1)], np.int32), B).astype(np.int32)
+        want, post = oracle.decode(obs, frames, trans, init, return_posterior=True)
+        ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+        profile = []
+        got = torbi_amd.decode(torch.tensor(obs, device=dev), torch.tensor(frames, device=dev), torch.tensor(trans, device=dev),
+                               torch.tensor(init, device=dev), workspace=ws, _profile=profile)
+        np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f'{B} x {T} x {S}')
+        if viterbi.forward_path(B, S) == 'small':
+            assert viterbi.ROUTES[int(profile[3])] == 'small' and profile[2] == 1
+            assert viterbi.last_forward_kernel().startswith('small::block_decode_kernel<')
+        back = viterbi.read_posterior(ws, torch.tensor(frames), B, T, S).cpu().numpy()
+        assert np.array_equal(back.view(np.uint32), post.view(np.uint32)), (B, T, S)
+    B, T = 21, 150
+    obs, trans, init = synth.problem(B, T, S, seed=S)
+    frames = np.clip(synth.lengths(B, 1, T, seed=S), 1, T)
+    np.testing.assert_array_equal(gpu_decode(obs, frames, trans, init), oracle.decode(obs, frames, trans, init))
+
+
 def test_forward_path_selection(forward):
     assert viterbi.forward_path(4, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'pruned': 'rows'}.get(forward, 'generic')
     assert viterbi.forward_path(3, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'pruned': 'rows',
@@ -174,13 +245,18 @@ def test_forward_path_selection(forward):
     assert viterbi.forward_path(2, 4096) == {'dense': 'generic', 'resident': 'resident', 'cluster': 'cluster',
                                              'auto': 'held'}.get(forward, 'rows')
     assert viterbi.forward_path(9, 4096) == {'dense': 'generic', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'rows')
-    assert viterbi.forward_path(4, 40) == 'generic'                # S < 64: no value-only path
-    assert viterbi.forward_path(1, 40) == ('generic' if forward == 'dense' else 'held')    # (a path that does not cover the shape falls back as AUTO would)
+    # up to 64 states: one wavefront per sequence whatever the batch (a named path that covers the shape keeps it; one that
+    # does not falls back as AUTO would; DENSE named below 32 items or 64 states: the generic kernels)
+    assert viterbi.forward_path(4, 40) == ('generic' if forward == 'dense' else 'small')
+    assert viterbi.forward_path(1, 40) == ('generic' if forward == 'dense' else 'small')
+    assert viterbi.forward_path(512, 256, path='auto') == 'small' and viterbi.forward_path(512, 257, path='auto') == 'cluster'
+    assert viterbi.forward_path(512, 64, path='resident') == 'resident' and viterbi.forward_path(1, 1, path='auto') == 'held'
     assert viterbi.forward_path(4, 4100) == 'generic'
     assert viterbi.forward_path(128, 4096) == {'dense': 'dense', 'resident': 'resident'}.get(forward, 'cluster')   # 8-item tiles
     assert viterbi.forward_path(128, 4100) == 'dense'              # posterior tile does not fit the LDS
     assert viterbi.forward_path(512, 1440) == {'dense': 'dense', 'resident': 'resident'}.get(forward, 'cluster')
-    assert viterbi.forward_path(64, 130) == {'dense': 'dense', 'resident': 'resident'}.get(forward, 'cluster')
+    assert viterbi.forward_path(64, 130) == {'dense': 'dense', 'resident': 'resident', 'cluster': 'cluster', 'pruned': 'cluster'}.get(forward, 'small')
+    assert viterbi.forward_path(64, 300) == {'dense': 'dense', 'resident': 'resident'}.get(forward, 'cluster')
     # AUTO: a batch that gives more than half the compute units a 16-item workgroup is decoded time-resident with whole
     # tiles per workgroup, a smaller one of more than 16 items (up to 2048 states) in clusters of workgroups per tile
     cus = viterbi.compute_units('cuda:0')
@@ -194,7 +270,7 @@ def test_forward_path_selection(forward):
     assert viterbi.forward_path(17, 1440, path='auto') == 'cluster'
     assert viterbi.forward_path(16, 1440, path='auto') == 'rows'
     assert viterbi.forward_path(128, 4096, path='auto') == 'cluster'              # 8-item tiles: 16 tiles x 16 members
-    assert viterbi.forward_path(128, 4100, path='auto') == 'dense' and viterbi.forward_path(40, 40, path='auto') == 'generic'
+    assert viterbi.forward_path(128, 4100, path='auto') == 'dense' and viterbi.forward_path(40, 40, path='auto') == 'small'
     assert viterbi.forward_path(2 * cus, 1440, path='pruned') == 'cluster'       # (its per-timestep tile kernel is gone)
     assert viterbi.forward_path(16 * cus, 1440, path='pruned') == 'resident' and viterbi.forward_path(9, 1440, path='pruned') == 'rows'
     # the path travels with the call: naming one never changes the process default

@@ -182,9 +182,10 @@ def test_auto_path_choice_reads_the_transition_structure_once_per_version():
     pruned; forced paths and unsupported shapes pass through; the look is cached per tensor version."""
     import torch
     from torbi_amd import state, synth, viterbi
-    S = 256
+    S = 320         # (up to 256 states AUTO is a workgroup per sequence whatever the matrix looks like: csrc/small_states.hpp)
     dense = torch.as_tensor(synth.problem(1, 1, S, seed=1)[1])
     band = torch.as_tensor(synth.banded_transition(S, 12.0))
+    assert viterbi._resolve_path(dense, dense, 64, 256, 'cuda:0', 'auto', 4) == 'auto'
     assert viterbi._choose_path(dense, dense, 64, S) == 'pruned'
     assert viterbi._choose_path(band, band, 64, S) == 'dense'
     assert 0.0 < state.notes(band)[('reach', S)] < viterbi.BANDED_RANGE

@@ -1,0 +1,349 @@
+// Up to 64 states: one wavefront decodes one sequence, forward recurrence AND backtrace, in ONE launch.
+//
+// The reference runs these shapes through the same trellis kernels as any other (viterbi.cu:203-241: one block per item,
+// one `__syncthreads` round per timestep); per-timestep LAUNCHES cost 4-5 us each here whatever the state count
+// (torbi_hip.hip, launch_forward), so a 3-state toy or a 40-class posteriorgram paid for launches only.  With S <= 64 a
+// wavefront holds everything: lane j owns next-state j -- its transition row trans[j][*] in registers, its posterior in one
+// VGPR -- and a timestep is the previous row broadcast through the LDS, then S x (add -> strict '>' compare -> select ->
+// max) with the reference's tie rule (viterbi.cpp:91-104, viterbi.cu:82-123: lowest prev-state wins, backpointer 0 unless
+// replaced).  Backpointers are bytes, four timesteps to a dword per lane, in a plane at the start of the workspace; the
+// same wavefront then walks them back from the first maximum of the last posterior row (viterbi.cpp:153-157, :218-221):
+// the rows of 64 timesteps are loaded at once (they do not depend on the path), a path step is one v_readlane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <utility>
+
+namespace small {
+
+constexpr int kMaxS = 64;
+// (4, or the next multiple of 8: never more than 2 S, so the backpointer plane fits where the int32 trellis would lie)
+__host__ __device__ inline int padded_states(int S) { return S <= 4 ? 4 : (S + 7) / 8 * 8; }
+// dwords of the backpointer plane per item: [ceil((T-1)/4)][SP]
+__host__ __device__ inline size_t plane_dwords(int T, int S) { return (size_t)((T - 1 + 3) / 4) * padded_states(S); }
+inline bool supported(int S) { return S >= 2 && S <= kMaxS; }
+
+// Four prev-states lo + 4 K .. lo + 4 K + 3 against the four running maxima of a lane: add, compare, max, select -- written
+// out so that it stays four vector instructions per cell with no candidate kept in a register (left to itself the compiler
+// reduces the values first and recovers the indices afterwards from ~100 saved candidates per lane).  Running maximum c
+// remembers K of its prev-state lo + 4 K + c (an inline constant); the compares land in four scalar pairs, eight
+// instructions ahead of the selects that read them.
+template <int K>
+__device__ __forceinline__ void four_cells(const float4 pv, const float *row, float (&best)[4], uint32_t (&arg)[4]) {
+    float c0, c1, c2, c3;
+    unsigned long long m0, m1, m2, m3;
+    asm volatile(
+        "v_add_f32 %0, %16, %20\n\tv_add_f32 %1, %17, %21\n\tv_add_f32 %2, %18, %22\n\tv_add_f32 %3, %19, %23\n\t"
+        "v_cmp_ngt_f32 %4, %0, %8\n\tv_cmp_ngt_f32 %5, %1, %9\n\tv_cmp_ngt_f32 %6, %2, %10\n\tv_cmp_ngt_f32 %7, %3, %11\n\t"
+        "v_max_f32 %8, %8, %0\n\tv_max_f32 %9, %9, %1\n\tv_max_f32 %10, %10, %2\n\tv_max_f32 %11, %11, %3\n\t"
+        "v_cndmask_b32 %12, %24, %12, %4\n\tv_cndmask_b32 %13, %24, %13, %5\n\t"
+        "v_cndmask_b32 %14, %24, %14, %6\n\tv_cndmask_b32 %15, %24, %15, %7"
+        : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "+v"(best[0]), "+v"(best[1]),
+          "+v"(best[2]), "+v"(best[3]), "+v"(arg[0]), "+v"(arg[1]), "+v"(arg[2]), "+v"(arg[3])
+        : "v"(pv.x), "v"(pv.y), "v"(pv.z), "v"(pv.w), "v"(row[0]), "v"(row[1]), "v"(row[2]), "v"(row[3]), "n"(K));
+}
+
+// L prev-states in groups of 4 G: the broadcasts of group g + 1 are issued before group g is added up (the compiler moves
+// nothing across the blocks above, so the order written here is the order that runs)
+template <int Base, int L, int G, int... Is>
+__device__ __forceinline__ void one_group(const float4 (&pv)[G], const float (&row)[L], float (&best)[4], uint32_t (&arg)[4],
+                                          std::integer_sequence<int, Is...>) {
+    (four_cells<Base + Is>(pv[Is], &row[4 * (Base + Is)], best, arg), ...);
+}
+template <int L, int G, int Gi = 0>
+__device__ __forceinline__ void every_cell(const float4 *src, const float (&row)[L], float4 (&pv)[G], float (&best)[4],
+                                           uint32_t (&arg)[4]) {
+    constexpr int NG = L / (4 * G);
+    float4 next[G];
+    if constexpr (Gi + 1 < NG) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) next[i] = src[(Gi + 1) * G + i];
+    }
+    one_group<Gi * G>(pv, row, best, arg, std::make_integer_sequence<int, G>{});
+    if constexpr (Gi + 1 < NG) every_cell<L, G, Gi + 1>(src, row, next, best, arg);
+}
+template <int L, int G>
+__device__ __forceinline__ void every_cell(const float4 *src, const float (&row)[L], float (&best)[4], uint32_t (&arg)[4]) {
+    static_assert(L % (4 * G) == 0, "whole groups");
+    float4 first[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) first[i] = src[i];
+    every_cell<L, G, 0>(src, row, first, best, arg);
+}
+
+// SP: padded state count (transition entries beyond S are -inf: never a maximum); CH: timesteps whose
+// observation rows are in flight while the previous CH are computed (a multiple of 4)
+template <int SP, int CH>
+__global__ __launch_bounds__(64) void decode_kernel(const float *__restrict__ obs, const int32_t *__restrict__ frames,
+                                                    const float *__restrict__ trans, const float *__restrict__ init,
+                                                    int32_t *__restrict__ out, uint32_t *__restrict__ plane,
+                                                    float *__restrict__ post0, float *__restrict__ post1,
+                                                    int32_t *__restrict__ route_record, int route, int B, int T, int S) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (b == 0 && lane == 0) *route_record = route;
+    int n = __builtin_amdgcn_readfirstlane(frames[b]);
+    n = n < 1 ? 1 : (n > T ? T : n);
+    const bool live = lane < S;
+    const float ninf = -__builtin_huge_valf();
+
+    float row[SP];                                   // trans[lane][i]
+#pragma unroll
+    for (int i = 0; i < SP; ++i) row[i] = trans[(size_t)min(lane, S - 1) * S + min(i, S - 1)];   // (clamped addresses:
+    asm volatile("" ::: "memory");                   //  every load unconditional and in flight before the first use)
+#pragma unroll
+    for (int i = 0; i < SP; ++i) row[i] = fminf(row[i], (live && i < S) ? -ninf : ninf);             // the padding: -inf
+    const float *o = obs + (size_t)b * T * S + min(lane, S - 1);
+    uint32_t *pl = plane + (size_t)b * plane_dwords(T, S);
+    float p = o[0] + init[min(lane, S - 1)];
+    p = live ? p : ninf;
+
+    float cur[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) cur[k] = o[(size_t)min(1 + k, n - 1) * S];
+    for (int t0 = 1; t0 < n; t0 += CH) {
+        float nxt[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) nxt[k] = o[(size_t)min(t0 + CH + k, n - 1) * S];       // (clamped: never past the item)
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q) {
+            if (t0 + 4 * q >= n) break;
+            uint32_t packed = 0u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 4 * q + r;
+                if (t0 + k < n) {                    // (wave-uniform)
+                    // the row through the LDS: one broadcast ds_read_b128 per four prev-states (v_readlane into a scalar
+                    // register costs an instruction and a wait state per prev-state: 4.7 against 3.0 ms at 1 x 5000 x 64);
+                    // four interleaved running maxima (a lone wavefront is bound by the dependent chain otherwise), merged as
+                    // (value, prev-state) pairs: higher value, else lower index = the reference's strict '>' from prev-state 0
+                    __shared__ float4 shared_row[SP / 4];
+                    if (lane < SP) reinterpret_cast<float *>(shared_row)[lane] = p;
+                    __builtin_amdgcn_wave_barrier();
+                    float bests[4] = {ninf, ninf, ninf, ninf};
+                    uint32_t args[4] = {0u, 0u, 0u, 0u};
+                    every_cell<SP, SP / 4>(shared_row, row, bests, args);      // (one wavefront: every broadcast in flight at once)
+                    __builtin_amdgcn_wave_barrier();
+                    float best = bests[0];
+                    uint32_t arg = 4u * args[0];
+#pragma unroll
+                    for (int c = 1; c < 4; ++c) {
+                        const uint32_t mine = 4u * args[c] + (uint32_t)c;
+                        const bool better = bests[c] > best || (bests[c] == best && mine < arg);
+                        best = better ? bests[c] : best;
+                        arg = better ? mine : arg;
+                    }
+                    p = live ? cur[k] + best : ninf;
+                    packed |= arg << (8 * r);
+                }
+            }
+            if (lane < SP) pl[(size_t)((t0 - 1) / 4 + q) * SP + lane] = packed;
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) cur[k] = nxt[k];
+    }
+    if (live) (((n - 1) & 1) ? post1 : post0)[(size_t)b * S + lane] = p;      // (where torbi_hip_read_posterior looks)
+
+    // first maximum of the last row
+    float best = p;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) best = fmaxf(best, __shfl_xor(best, d, 64));
+    const unsigned long long at = __ballot(live && p == best);
+    int idx = at ? __ffsll((long long)at) - 1 : 0;
+    idx = __builtin_amdgcn_readfirstlane(idx);
+    int32_t *ob = out + (size_t)b * T;
+    for (int t = n - 1 + lane; t < T; t += 64) ob[t] = idx;
+    if (n < 2) return;
+    __threadfence_block();                           // this wavefront's own plane stores, read back below
+
+    // walk back: positions n-2 .. 0; group g holds the backpointers of timesteps 4g+1 .. 4g+4
+    const int groups = (n - 1 + 3) / 4;
+    for (int c = (groups - 1) / 16; c >= 0; --c) {
+        uint32_t rows[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g)
+            rows[g] = (16 * c + g < groups && lane < SP) ? pl[(size_t)(16 * c + g) * SP + lane] : 0u;
+        int32_t mine = 0;
+#pragma unroll
+        for (int g = 15; g >= 0; --g) {
+#pragma unroll
+            for (int r = 3; r >= 0; --r) {
+                const int t = 4 * (16 * c + g) + 1 + r;
+                if (t <= n - 1) {                    // (wave-uniform)
+                    const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)rows[g], idx);
+                    idx = (int)((word >> (8 * r)) & 255u);
+                    mine = lane == 4 * g + r ? idx : mine;
+                }
+            }
+        }
+        const int pos = 64 * c + lane;               // position t-1 of timestep t = 64c + lane + 1
+        if (pos <= n - 2) ob[pos] = mine;
+    }
+}
+
+// ---- 65 .. 256 states: one WORKGROUP per sequence --------------------------------------------------------------------
+// The matrix still fits the registers of one compute unit (256 x 256 x 4 B = half of its vector register file): wave
+// (nb, pq) of NB x PQ owns next-states [64 nb, 64 nb + 64) x prev-states [pq L, pq L + L), L <= 64 -- lane j keeps that
+// piece of row j in L registers for the whole launch, and with at most ~110 registers a lane the 4 .. 16 waves of a
+// workgroup hide each other's latencies.  A timestep: the previous posterior row is broadcast from the LDS (one
+// ds_read_b128 per four prev-states), four interleaved running maxima per lane keep the dependent chain short, the PQ
+// pieces of a row meet through the LDS, the waves with pq = 0 add the observation, write the new row and pack the byte
+// backpointers.  Ties: every merge compares (value, prev-state) pairs -- higher value, else lower index -- which is the
+// reference's strict '>' scan from prev-state 0 (viterbi.cpp:94-100).  The walk back reads 64 timesteps of backpointers
+// into the LDS at a time.
+constexpr int kBlockMaxS = 256;
+__host__ __device__ inline int block_splits(int S) { return (S + 63) / 64; }                          // PQ (= NB)
+__host__ __device__ inline int block_row_registers(int S) {                                           // L
+    return (S + block_splits(S) - 1) / block_splits(S) <= 48 ? 48 : 64;
+}
+inline bool block_supported(int S) { return S > kMaxS && S <= kBlockMaxS; }
+// dwords of the backpointer plane per item: [ceil((T-1)/4)][S]
+__host__ __device__ inline size_t block_plane_dwords(int T, int S) { return (size_t)((T - 1 + 3) / 4) * S; }
+
+template <int PQ, int L>
+__global__ __launch_bounds__(64 * PQ * PQ) void block_decode_kernel(
+    const float *__restrict__ obs, const int32_t *__restrict__ frames, const float *__restrict__ trans,
+    const float *__restrict__ init, int32_t *__restrict__ out, uint32_t *__restrict__ plane, float *__restrict__ post0,
+    float *__restrict__ post1, int32_t *__restrict__ route_record, int route, int B, int T, int S, int NB) {
+    __shared__ float4 rows[2][kBlockMaxS / 4];            // posterior rows t-1 / t (entries >= S: -inf)
+    __shared__ float upper_best[PQ - 1][kBlockMaxS];      // what the pieces pq >= 1 of the prev-states offer
+    __shared__ uint32_t upper_arg[PQ - 1][kBlockMaxS];
+    __shared__ uint32_t steps[16 * kBlockMaxS];           // the walk back: 16 backpointer words (64 timesteps) x S
+    __shared__ int shared_idx;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = wave % NB, pq = wave / NB;
+    const int j = nb * 64 + lane;
+    const bool live = j < S;
+    const bool writer = pq == 0;
+    const int lo = pq * L;
+    if (b == 0 && tid == 0) *route_record = route;
+    int n = __builtin_amdgcn_readfirstlane(frames[b]);
+    n = n < 1 ? 1 : (n > T ? T : n);
+    const float ninf = -__builtin_huge_valf();
+
+    float row[L];                                          // trans[j][lo + e]
+#pragma unroll
+    for (int e = 0; e < L; ++e) row[e] = trans[(size_t)min(j, S - 1) * S + min(lo + e, S - 1)];   // (clamped addresses:
+    asm volatile("" ::: "memory");                         //  every load unconditional and in flight before the first use)
+#pragma unroll
+    for (int e = 0; e < L; ++e) row[e] = fminf(row[e], (live && lo + e < S) ? -ninf : ninf);          // the padding: -inf
+    const float *o = obs + (size_t)b * T * S + min(j, S - 1);
+    uint32_t *pl = plane + (size_t)b * block_plane_dwords(T, S);
+    float p = o[0] + init[min(j, S - 1)];
+    p = live ? p : ninf;
+    if (writer) reinterpret_cast<float *>(rows[0])[j] = p;
+    float cur[4] = {0.f, 0.f, 0.f, 0.f};
+    if (writer) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cur[k] = o[(size_t)min(1 + k, n - 1) * S];
+    }
+    __syncthreads();
+
+    for (int t0 = 1; t0 < n; t0 += 4) {
+        float nxt[4] = {0.f, 0.f, 0.f, 0.f};
+        if (writer) {                                       // (the observation rows of the next four timesteps)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nxt[k] = o[(size_t)min(t0 + 4 + k, n - 1) * S];
+        }
+        uint32_t packed = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (t0 + r < n) {                               // (uniform over the workgroup)
+                const float4 *src = rows[(t0 + r - 1) & 1] + lo / 4;
+                float best[4] = {ninf, ninf, ninf, ninf};   // (a running maximum that is never exceeded keeps index 0 of its
+                uint32_t arg[4] = {0u, 0u, 0u, 0u};         // own: the reference's zero default, viterbi.cpp:201-203)
+                every_cell<L, (PQ == 4 ? 2 : 4)>(src, row, best, arg);     // (16 waves: 128 registers a lane)
+                float top = best[0];
+                uint32_t at = 4u * arg[0];
+#pragma unroll
+                for (int c = 1; c < 4; ++c) {               // (value, index) pairs: higher value, else lower prev-state
+                    const uint32_t mine = 4u * arg[c] + (uint32_t)c;
+                    const bool better = best[c] > top || (best[c] == top && mine < at);
+                    top = better ? best[c] : top;
+                    at = better ? mine : at;
+                }
+                at += (uint32_t)lo;
+                if (!writer && live) {
+                    upper_best[pq - 1][j] = top;
+                    upper_arg[pq - 1][j] = at;
+                }
+                __syncthreads();
+                if (writer && live) {                       // the later pieces' prev-states are all larger: strict '>'
+#pragma unroll
+                    for (int u = 0; u < PQ - 1; ++u) {
+                        const float other = upper_best[u][j];
+                        const bool better = other > top;
+                        at = better ? upper_arg[u][j] : at;
+                        top = better ? other : top;
+                    }
+                }
+                if (writer) {
+                    p = live ? cur[r] + top : ninf;
+                    reinterpret_cast<float *>(rows[(t0 + r) & 1])[j] = p;
+                    packed |= at << (8 * r);
+                }
+                __syncthreads();
+            }
+        }
+        if (writer && live) pl[(size_t)((t0 - 1) / 4) * S + j] = packed;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+    }
+    if (writer && live) (((n - 1) & 1) ? post1 : post0)[(size_t)b * S + j] = p;
+
+    // first maximum of the last row (wave 0: four entries per lane, then (value, index) pairs across the lanes)
+    if (wave == 0) {
+        const float *last = reinterpret_cast<const float *>(rows[(n - 1) & 1]);
+        float top = ninf;
+        int at = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < kBlockMaxS / 64; ++k) {
+            const int i = lane + 64 * k;
+            const float v = i < S ? last[i] : ninf;
+            if (i < S && (at == 0x7fffffff || v > top)) { top = v; at = i; }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float v = __shfl_xor(top, d, 64);
+            const int i = __shfl_xor(at, d, 64);
+            const bool better = i != 0x7fffffff && (at == 0x7fffffff || v > top || (v == top && i < at));
+            top = better ? v : top;
+            at = better ? i : at;
+        }
+        if (lane == 0) shared_idx = at;
+    }
+    __threadfence_block();                                  // the plane stores of this workgroup, read back below
+    __syncthreads();
+    int idx = shared_idx;
+    int32_t *ob = out + (size_t)b * T;
+    for (int t = n - 1 + tid; t < T; t += blockDim.x) ob[t] = idx;
+    if (n < 2) return;
+
+    const int groups = (n - 1 + 3) / 4;
+    for (int c = (groups - 1) / 16; c >= 0; --c) {
+        const int have = min(16, groups - 16 * c);
+        for (int e = tid; e < have * S; e += blockDim.x) steps[e] = pl[(size_t)16 * c * S + e];
+        __syncthreads();
+        if (wave == 0) {
+            int32_t mine = 0;
+            for (int g = have - 1; g >= 0; --g) {
+#pragma unroll
+                for (int r = 3; r >= 0; --r) {
+                    const int t = 4 * (16 * c + g) + 1 + r;
+                    if (t <= n - 1) {
+                        idx = (int)((steps[g * S + idx] >> (8 * r)) & 255u);
+                        mine = lane == 4 * g + r ? idx : mine;
+                    }
+                }
+            }
+            const int pos = 64 * c + lane;
+            if (pos <= n - 2) ob[pos] = mine;
+            if (lane == 0) shared_idx = idx;
+        }
+        __syncthreads();
+        idx = shared_idx;
+    }
+}
+
+}  // namespace small

@@ -33,6 +33,7 @@
 #include "resident_forward.hpp"
 #include "small_batch_forward.hpp"
 #include "held_matrix_forward.hpp"
+#include "small_states.hpp"
 #include "file_rows.hpp"
 
 #ifndef TORBI_UNIFORM_DEPTH
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(256) void gather_final_kernel(const int32_t *__rest
                                                            const float *__restrict__ post0, const float *__restrict__ post1,
                                                            const int32_t *__restrict__ frames, float *__restrict__ dst,
                                                            int B, int T, int S) {
-    const bool generic = *route == 0 || *route == 6;       // trellis kernels: per-timestep or held-matrix
+    const bool generic = *route == 0 || *route == 6 || *route == 7;       // trellis kernels: per-timestep, held-matrix, one wavefront
     const size_t n = (size_t)B * S;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const int b = (int)(e / S);
@@ -592,7 +593,7 @@ thread_local char g_last_kernel[160] = "";
 // keep the posterior history and recompute backpointers along the decoded path (lazy_backtrace.hpp).  (2 was the
 // per-timestep tile kernel of the pruned recurrence, removed in round 4: no route has the number any more.)
 enum Route { ROUTE_GENERIC = 0, ROUTE_DENSE = 1, ROUTE_PRUNED = 2, ROUTE_RESIDENT = 3, ROUTE_ROWS = 4, ROUTE_CLUSTER = 5,
-             ROUTE_HELD = 6 };
+             ROUTE_HELD = 6, ROUTE_SMALL = 7 };
 
 inline bool use_dense(int B, int S) { return B >= 32 && S >= 64; }
 
@@ -656,8 +657,16 @@ inline bool held_auto(int B, int S) {
 // route of ONE batch.  AUTO: the time-resident kernel -- whole tiles per workgroup when the batch alone gives at least
 // half the compute units a workgroup, tiles split over clusters of workgroups for smaller batches of >= 17 items --
 // else the sorted-row scan / held-matrix kernel for a handful of sequences, else the dense (max,+) GEMM, else generic.
+inline bool small_block_auto(int B, int S, int cus) {
+    return small::block_supported(S) && (long long)B * S * S <= (1ll << 18) * cus;
+}
 inline Route route_for(int path, int B, int S, int cus, bool allow_held = true) {
     const bool fits = resident_fits(S, tiles_of(B, S));
+    // up to 64 states a wavefront decodes a sequence on its own, time loop and backtrace in one launch (small_states.hpp)
+    // ... up to 256 a workgroup does (the matrix in the registers of one compute unit), while the batch is not so large that
+    // the time-resident forms' pruning overtakes it: tools/small_states_probe.py, 500 frames, small / resident ms --
+    // 4096 x 128: 4.3 / 4.2, 512 x 256: 2.4 / 3.6 (cluster), 4096 x 256: 19.2 / 6.0 -- B S^2 <= 2^18 per compute unit
+    if (path == TORBI_HIP_FORWARD_AUTO && (small::supported(S) || small_block_auto(B, S, cus))) return ROUTE_SMALL;
     if (path == TORBI_HIP_FORWARD_RESIDENT && fits) return ROUTE_RESIDENT;
     if (path == TORBI_HIP_FORWARD_CLUSTER && fits) return cluster_members(tiles_of(B, S), S, cus) > 1 ? ROUTE_CLUSTER : ROUTE_RESIDENT;
     if (path == TORBI_HIP_FORWARD_AUTO && fits && 2 * tiles_of(B, S) > cus) return ROUTE_RESIDENT;
@@ -1050,6 +1059,53 @@ hipError_t launch_finalize(const int32_t *frames, const Workspace &w, int32_t *o
     hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(64), 0, stream, w.post[0], w.post[1],
                        frames, w.trellis, out, B, T, S);
     return hipGetLastError();
+}
+
+// ---- up to 64 states: one wavefront per sequence, one launch per decode (small_states.hpp) ----------------------------
+template <int SP, int CH>
+hipError_t launch_small_as(const float *obs, const int32_t *frames, const float *trans, const float *init, const Workspace &w,
+                           int32_t *out, int32_t *record, int B, int T, int S, hipStream_t stream) {
+    TORBI_NOTE_KERNEL("small::decode_kernel<%d, %d>", SP, CH);
+    hipLaunchKernelGGL((small::decode_kernel<SP, CH>), dim3(B), dim3(64), 0, stream, obs, frames, trans, init, out,
+                       reinterpret_cast<uint32_t *>(w.trellis), w.post[0], w.post[1], record, (int)ROUTE_SMALL, B, T, S);
+    return hipGetLastError();
+}
+hipError_t launch_small(const float *obs, const int32_t *frames, const float *trans, const float *init, const Workspace &w,
+                        int32_t *out, int32_t *record, int B, int T, int S, hipStream_t stream, int *launches) {
+    if (launches) *launches += 1;
+    switch (small::padded_states(S)) {
+        case 4: return launch_small_as<4, 16>(obs, frames, trans, init, w, out, record, B, T, S, stream);
+        case 8: return launch_small_as<8, 16>(obs, frames, trans, init, w, out, record, B, T, S, stream);
+        case 16: return launch_small_as<16, 16>(obs, frames, trans, init, w, out, record, B, T, S, stream);
+        case 24: return launch_small_as<24, 8>(obs, frames, trans, init, w, out, record, B, T, S, stream);
+        case 32: return launch_small_as<32, 8>(obs, frames, trans, init, w, out, record, B, T, S, stream);
+        case 40: return launch_small_as<40, 8>(obs, frames, trans, init, w, out, record, B, T, S, stream);
+        case 48: return launch_small_as<48, 4>(obs, frames, trans, init, w, out, record, B, T, S, stream);
+        case 56: return launch_small_as<56, 4>(obs, frames, trans, init, w, out, record, B, T, S, stream);
+        default: return launch_small_as<64, 4>(obs, frames, trans, init, w, out, record, B, T, S, stream);
+    }
+}
+
+template <int PQ, int L>
+hipError_t launch_block_as(const float *obs, const int32_t *frames, const float *trans, const float *init, const Workspace &w,
+                           int32_t *out, int32_t *record, int B, int T, int S, hipStream_t stream) {
+    const int NB = (S + 63) / 64;
+    TORBI_NOTE_KERNEL("small::block_decode_kernel<%d, %d>", PQ, L);
+    hipLaunchKernelGGL((small::block_decode_kernel<PQ, L>), dim3(B), dim3(64 * NB * PQ), 0, stream, obs, frames, trans, init, out,
+                       reinterpret_cast<uint32_t *>(w.trellis), w.post[0], w.post[1], record, (int)ROUTE_SMALL, B, T, S, NB);
+    return hipGetLastError();
+}
+hipError_t launch_block(const float *obs, const int32_t *frames, const float *trans, const float *init, const Workspace &w,
+                        int32_t *out, int32_t *record, int B, int T, int S, hipStream_t stream, int *launches) {
+    if (launches) *launches += 1;
+    const bool narrow = small::block_row_registers(S) == 48;
+    switch (small::block_splits(S)) {
+        case 2: return narrow ? launch_block_as<2, 48>(obs, frames, trans, init, w, out, record, B, T, S, stream)
+                              : launch_block_as<2, 64>(obs, frames, trans, init, w, out, record, B, T, S, stream);
+        case 3: return narrow ? launch_block_as<3, 48>(obs, frames, trans, init, w, out, record, B, T, S, stream)
+                              : launch_block_as<3, 64>(obs, frames, trans, init, w, out, record, B, T, S, stream);
+        default: return launch_block_as<4, 64>(obs, frames, trans, init, w, out, record, B, T, S, stream);
+    }
 }
 
 // ---- dense path -----------------------------------------------------------------------
@@ -1448,6 +1504,14 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
     if (g_preparation) reuse = false;       // (the promise was about the caller's buffer; this route prepares in the workspace)
     if (ev) (void)hipEventRecord(ev[0], s);
     if (ev) (void)hipEventRecord(ev[3], s);
+    if (route == ROUTE_SMALL) {             // one launch: recurrence, backtrace and the route record
+        // (the byte plane lies where the generic path's trellis does and is never larger: small_states.hpp)
+                e = (small::supported(S) ? launch_small : launch_block)(obs, frames, trans, init, carve(workspace, B, T, S), out,
+                                                                route_record(workspace, B, T, S, cus), B, T, S, s, launches);
+        if (ev) (void)hipEventRecord(ev[1], s);
+        if (ev) (void)hipEventRecord(ev[2], s);
+        return e;
+    }
     e = stamp_route(workspace, B, T, S, cus, route, s);
     if (e != hipSuccess) return e;
     if (route == ROUTE_DENSE) {
@@ -1626,11 +1690,13 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
     // ONE time-resident launch for the whole group: named (whole tiles per workgroup, or clusters), or AUTO with enough
     // items -- half the compute units' worth of tiles, or fewer tiles split over clusters (batches of >= 17 items)
     int largest = 0;
-    for (int k = 0; k < n; ++k) largest = std::max(largest, hb[k].B);
+    long long items = 0;
+    for (int k = 0; k < n; ++k) largest = std::max(largest, hb[k].B), items += hb[k].B;
     const bool split = cluster_members(tiles, S, cus) > 1;
     const bool together = resident_fits(S, tiles) &&
                           (path == TORBI_HIP_FORWARD_RESIDENT || path == TORBI_HIP_FORWARD_CLUSTER ||
-                           (path == TORBI_HIP_FORWARD_AUTO && (2 * tiles > cus || (split && largest > 16))));
+                           (path == TORBI_HIP_FORWARD_AUTO && !small::supported(S) && !small_block_auto((int)std::min(items, 1ll << 30), S, cus) &&      // (a wavefront / workgroup per sequence)
+                            (2 * tiles > cus || (split && largest > 16))));
     const bool clusters = together && split && path != TORBI_HIP_FORWARD_RESIDENT;
     const bool ascending = (flags & TORBI_HIP_SHORTEST_FIRST) != 0;
     if (phase_ms) {

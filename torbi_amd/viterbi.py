@@ -57,13 +57,16 @@ def _path_flag(path: str) -> int:
     return (FORWARD_PATHS[path] + 1) << 4
 
 
-def _resolve_path(trans, transition, B, S, device, path, tiles, count=1):
+def _resolve_path(trans, transition, B, S, device, path, tiles, count=1, items=None):
     """The path name this call passes to the library."""
     forced = _forced_path if path is None else path
     if forced not in FORWARD_PATHS:
         raise ValueError(f'forward path must be one of {sorted(FORWARD_PATHS)}; got {forced!r}')
     if forced != 'auto':
         return forced
+    if 2 <= S <= SMALL_STATES and forward_path(B if items is None else items, S, 'auto',
+                                               torch.device(device).index or 0) == 'small':
+        return 'auto'               # one wavefront / workgroup per sequence, whatever the matrix looks like (csrc/small_states.hpp)
     chosen = _choose_path(trans, transition, B, S)
     banded = chosen == 'dense'
     cus = compute_units(device)
@@ -473,7 +476,8 @@ def decode_batches(
     stream = torch.cuda.current_stream(device).cuda_stream
     largest = max(B for B, _, _ in shapes)
     tiles = sum(tiles_of(B, S) for B, _, _ in shapes)
-    chosen = _resolve_path(trans, transition, largest, S, device, path, tiles, count=count)
+    chosen = _resolve_path(trans, transition, largest, S, device, path, tiles, count=count,
+                           items=sum(B for B, _, _ in shapes))
     flags = _path_flag(chosen)
     first = next((k for k, (B, _, _) in enumerate(shapes) if B > 0), 0)
     if _reusable(workspaces[first], transition, (tuple(shapes), chosen, stream), reuse_preparation) \
@@ -501,6 +505,7 @@ def decode_batches(
     return indices
 
 
+SMALL_STATES = 256                            # small::kBlockMaxS
 TIME_RESIDENT = ('resident', 'cluster')       # the two forms of the time-resident kernel (include/torbi_hip.h)
 FORWARD_PATHS = {'auto': 0, 'dense': 1, 'pruned': 2, 'resident': 3, 'cluster': 4, 'held': 5}
 
@@ -573,12 +578,13 @@ def _choose_path(trans: torch.Tensor, original: torch.Tensor, batch: int, states
     return 'dense' if 0.0 < reach < BANDED_RANGE else 'pruned'
 
 
-ROUTES = {0: 'generic', 1: 'dense', 3: 'resident', 4: 'rows', 5: 'cluster', 6: 'held'}      # (2: retired in round 4)
+ROUTES = {0: 'generic', 1: 'dense', 3: 'resident', 4: 'rows', 5: 'cluster', 6: 'held', 7: 'small'}      # (2: retired in round 4)
 
 
 def forward_path(batch: int, states: int, path: Optional[str] = None, device: int = 0) -> str:
     """Which forward recurrence the library runs for one (batch, states) problem under `path` (None = the process
-    default): 'generic', 'dense', 'resident', 'cluster', 'held' or 'rows' (the pruned recurrence for batches of <= 16 items)."""
+    default): 'generic', 'dense', 'resident', 'cluster', 'held', 'rows' (the pruned recurrence for batches of <= 16 items)
+    or 'small' (up to 64 states: one wavefront per sequence)."""
     code = _lib.load().torbi_hip_forward_path_on(int(batch), int(states), int(device),
                                                  _path_flag(_forced_path if path is None else path))
     if code < 0:
