@@ -76,9 +76,13 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
 
 /*
  * Forward-recurrence paths (all give identical indices):
- *   SMALL     2 <= S <= 64: ONE launch per decode, one wavefront per sequence -- lane j keeps row j of the matrix in
- *             registers, a timestep is S x (v_readlane, add, compare, select), byte backpointers, and the same wavefront
- *             walks them back (small_states.hpp).  AUTO's choice for every batch size at these state counts.
+ *   SMALL     2 <= S <= 256: ONE launch per decode, the matrix in registers for the whole of it, byte backpointers, the
+ *             walk back in the same launch (small_states.hpp).  Up to 64 states one wavefront per sequence: lane j keeps row
+ *             j of the matrix, a timestep is the previous row broadcast through the LDS and S x (add, compare, max, select).
+ *             65 .. 256 states one workgroup of ceil(S / 64)^2 waves per sequence: wave (nb, pq) keeps next-states
+ *             64 nb .. x a quarter / third / half of the prev-states, the pieces of a row meet through the LDS.  AUTO's
+ *             choice up to 64 states, and up to 256 while B S^2 <= 3 * 2^16 per compute unit (larger batches: RESIDENT /
+ *             CLUSTER, whose pruning then wins).  No path name: a named path that covers the shape runs instead.
  *   GENERIC   S = 1, S > 4096 with B < 32, or DENSE named for a batch below 32 items (any S): trellis kernels shaped like
  *             the reference's, one launch per timestep
  *   ROWS      B <= 16, 64 <= S <= 4096: the pruned recurrence with one wave per (item, next-state), 64 list
@@ -100,7 +104,7 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
  *   HELD      B <= 16, S <= 4096: the reference's scan with the time loop inside ONE launch: ceil(S / 8) workgroups
  *             hold 8 rows of the matrix each in registers for the whole launch and pass the posterior rows to each
  *             other through 8-byte {value, timestep} words (held_matrix_forward.hpp).
- * AUTO: SMALL up to 64 states; else RESIDENT when the call's tiles fill more than half the compute units; CLUSTER for any other batch of more than
+ * AUTO: SMALL up to 64 states (up to 256 for batches that are not huge); else RESIDENT when the call's tiles fill more than half the compute units; CLUSTER for any other batch of more than
  * 16 items (64 <= S <= 4096: one batch = one forward launch); HELD up to three items (eight above 2048 states); ROWS for
  * 6..16 items (and above 2048 states); DENSE for large batches outside 64..4096 states; else GENERIC.  (The Python layer
  * adds what it knows about the matrix: DENSE for one batch with a narrow band or with scans too deep to prune.)

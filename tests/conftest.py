@@ -41,7 +41,11 @@ SAME_AS_AUTO = {'test_minus_inf_observations_on_the_large_batch_paths': LARGE_BA
                 'test_headline_shape_properties': LARGE_BATCHES_ONLY,
                 'test_large_state_shape_properties': LARGE_BATCHES_ONLY,
                 'test_inference_mode_is_supported': LARGE_BATCHES_ONLY,
-                'test_dense_path_edge_shapes': LARGE_BATCHES_ONLY}
+                'test_dense_path_edge_shapes': LARGE_BATCHES_ONLY,
+                # up to 256 states every named path but DENSE falls back to (or, from 64 states, repeats other tests' coverage
+                # of) what AUTO runs: the auto and dense instances stay
+                'test_one_wavefront_per_sequence_up_to_64_states': {'pruned', 'resident', 'cluster'},
+                'test_one_workgroup_per_sequence_up_to_256_states': {'pruned', 'resident', 'cluster'}}
 
 
 def pytest_collection_modifyitems(config, items):

@@ -114,24 +114,47 @@ __global__ __launch_bounds__(64) void decode_kernel(const float *__restrict__ ob
                 const int k = 4 * q + r;
                 if (t0 + k < n) {                    // (wave-uniform)
                     // the row through the LDS: one broadcast ds_read_b128 per four prev-states (v_readlane into a scalar
-                    // register costs an instruction and a wait state per prev-state: 4.7 against 3.0 ms at 1 x 5000 x 64);
-                    // four interleaved running maxima (a lone wavefront is bound by the dependent chain otherwise), merged as
-                    // (value, prev-state) pairs: higher value, else lower index = the reference's strict '>' from prev-state 0
+                    // register costs an instruction and a wait state per prev-state: 4.7 against 3.0 ms at 1 x 5000 x 64).
+                    // NC running maxima over consecutive ranges of prev-states (a lone wavefront is bound by the dependent
+                    // compare / select chain otherwise), merged in index order with the same strict '>': the lowest prev-state
+                    // still wins every tie.  (Left to the compiler's scheduling on purpose: the fixed four_cells sequence the
+                    // workgroup kernel below needs is 15-40 % slower here, where nothing else hides a latency.)
+                    constexpr int NC = SP >= 32 ? 4 : SP >= 16 ? 2 : 1;
+                    constexpr int L = SP / NC;
                     __shared__ float4 shared_row[SP / 4];
                     if (lane < SP) reinterpret_cast<float *>(shared_row)[lane] = p;
                     __builtin_amdgcn_wave_barrier();
-                    float bests[4] = {ninf, ninf, ninf, ninf};
-                    uint32_t args[4] = {0u, 0u, 0u, 0u};
-                    every_cell<SP, SP / 4>(shared_row, row, bests, args);      // (one wavefront: every broadcast in flight at once)
-                    __builtin_amdgcn_wave_barrier();
-                    float best = bests[0];
-                    uint32_t arg = 4u * args[0];
+                    float pv[SP];
 #pragma unroll
-                    for (int c = 1; c < 4; ++c) {
-                        const uint32_t mine = 4u * args[c] + (uint32_t)c;
-                        const bool better = bests[c] > best || (bests[c] == best && mine < arg);
-                        best = better ? bests[c] : best;
-                        arg = better ? mine : arg;
+                    for (int i = 0; i < SP / 4; ++i) {
+                        const float4 v = shared_row[i];
+                        pv[4 * i] = v.x; pv[4 * i + 1] = v.y; pv[4 * i + 2] = v.z; pv[4 * i + 3] = v.w;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    float bestc[NC];
+                    uint32_t argc[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        bestc[c] = pv[c * L] + row[c * L];
+                        argc[c] = (uint32_t)(c * L);
+                    }
+#pragma unroll
+                    for (int e = 1; e < L; ++e) {
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            const int i = c * L + e;
+                            const float cand = pv[i] + row[i];
+                            argc[c] = cand > bestc[c] ? (uint32_t)i : argc[c];
+                            bestc[c] = fmaxf(bestc[c], cand);
+                        }
+                    }
+                    float best = bestc[0];
+                    uint32_t arg = argc[0];
+#pragma unroll
+                    for (int c = 1; c < NC; ++c) {
+                        const bool better = bestc[c] > best;
+                        best = better ? bestc[c] : best;
+                        arg = better ? argc[c] : arg;
                     }
                     p = live ? cur[k] + best : ninf;
                     packed |= arg << (8 * r);

@@ -658,14 +658,15 @@ inline bool held_auto(int B, int S) {
 // half the compute units a workgroup, tiles split over clusters of workgroups for smaller batches of >= 17 items --
 // else the sorted-row scan / held-matrix kernel for a handful of sequences, else the dense (max,+) GEMM, else generic.
 inline bool small_block_auto(int B, int S, int cus) {
-    return small::block_supported(S) && (long long)B * S * S <= (1ll << 18) * cus;
+    return small::block_supported(S) && (long long)B * S * S <= (3ll << 16) * cus;
 }
 inline Route route_for(int path, int B, int S, int cus, bool allow_held = true) {
     const bool fits = resident_fits(S, tiles_of(B, S));
     // up to 64 states a wavefront decodes a sequence on its own, time loop and backtrace in one launch (small_states.hpp)
     // ... up to 256 a workgroup does (the matrix in the registers of one compute unit), while the batch is not so large that
     // the time-resident forms' pruning overtakes it: tools/small_states_probe.py, 500 frames, small / resident ms --
-    // 4096 x 128: 4.3 / 4.2, 512 x 256: 2.4 / 3.6 (cluster), 4096 x 256: 19.2 / 6.0 -- B S^2 <= 2^18 per compute unit
+    // 4096 x 128: 3.7 / 4.2, 512 x 256: 2.3 / 3.5 (cluster), 1024 x 256: 4.2 / 3.4, 4096 x 256: 19.2 / 6.0 -- B S^2 <= 3 * 2^16 per
+    // compute unit (768 items at 256 states, 3072 at 128: the kernel runs one workgroup, or four, per unit at a time)
     if (path == TORBI_HIP_FORWARD_AUTO && (small::supported(S) || small_block_auto(B, S, cus))) return ROUTE_SMALL;
     if (path == TORBI_HIP_FORWARD_RESIDENT && fits) return ROUTE_RESIDENT;
     if (path == TORBI_HIP_FORWARD_CLUSTER && fits) return cluster_members(tiles_of(B, S), S, cus) > 1 ? ROUTE_CLUSTER : ROUTE_RESIDENT;
