@@ -1,5 +1,5 @@
 """Randomised parity stress (GPU box): random shapes, lengths, -inf densities, tie levels and peaked rows under the six
-forward paths (and the CPU twin) against the C oracle.   python tools/stress.py [cases] [seed]"""
+named forward paths (and the CPU twin) against the C oracle.   python tools/stress.py [cases] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,9 +13,12 @@ dev = torch.device('cuda:0')
 bad = 0
 t0 = time.time()
 for c in range(cases):
-    S = int(rng.choice([rng.integers(1, 80), rng.integers(16, 560) * 4, rng.integers(64, 2200), rng.integers(513, 1025) * 4]))
+    S = int(rng.choice([rng.integers(1, 80), rng.integers(2, 258), rng.integers(16, 560) * 4, rng.integers(64, 2200),
+                        rng.integers(513, 1025) * 4]))
     B = int(rng.choice([rng.integers(1, 20), rng.integers(17, 70), rng.integers(60, 160), rng.integers(250, 300)]))
     T = int(rng.integers(1, 10)) if B > 16 else int(rng.integers(1, 60))     # a handful of sequences: many timesteps
+    if S <= 256:                                                             # one launch per decode: long walks back
+        T = int(rng.integers(1, 400))
     if B * T * S * S > 6e9:
         B = max(1, int(6e9 / (T * S * S)))
     obs, trans, init = synth.problem(B, T, S, seed=int(rng.integers(1 << 30)))
