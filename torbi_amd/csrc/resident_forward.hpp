@@ -77,7 +77,10 @@ struct Group {
 // That puts a single 512-item batch (32 tiles) on 256 compute units.  Membership is by ARRIVAL (a ticket drawn at
 // kernel entry): nothing depends on dispatch order or placement, and a cluster whose last members have not been
 // dispatched yet only waits -- every cluster that is complete runs to its end and frees its compute units.
-constexpr int kMaxR = 16;                // members per cluster
+#ifndef RESIDENT_MAX_R
+#define RESIDENT_MAX_R 16
+#endif
+constexpr int kMaxR = RESIDENT_MAX_R;    // members per cluster
 constexpr int kMaxTop = 4;               // list entries per item a member publishes (>= KR + 1 of every instantiation)
 // bytes of one exchange slot: a posterior row of the tile + the members' partial top lists
 __host__ __device__ inline size_t cluster_slot_bytes(int S) {
