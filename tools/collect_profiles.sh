@@ -5,11 +5,12 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/profiles_new
+OUT=$R/gpurun_out/${PROFILE_OUT:-profiles_new}
 mkdir -p $OUT
 cd $R
 # one warm-up launch group and one timed launch group of 8 batches on one stream, then the three profiled groups
-CMD="python3 bench.py --steps 8 --warmup 8 --no-cpu-baseline --no-secondary --no-single-call --pipeline 1"
+# (PROFILE_CMD / PROFILE_OUT: another command under the same passes, e.g. "python3 tools/small_states_probe.py 512x500x64")
+CMD=${PROFILE_CMD:-"python3 bench.py --steps 8 --warmup 8 --no-cpu-baseline --no-secondary --no-single-call --pipeline 1"}
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/trace -o x --output-format csv -- $CMD > $OUT/bench_under_trace.json 2> $OUT/trace.err
 # FETCH_SIZE and WRITE_SIZE do not fit one pass ("exceeds the capabilities of the hardware", after which rocprofv3
 # hangs): one pass each, and every pass under its own timeout

@@ -30,7 +30,7 @@ for (B, T, S) in SHAPES:
     ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
     line = f'{B} x {T} x {S}:'
     want, seen = None, set()
-    for path in ('auto', 'dense', 'pruned', 'resident', 'cluster', 'held'):
+    for path in os.environ.get('PROBE_PATHS', 'auto,dense,pruned,resident,cluster,held').split(','):   # (PROBE_PATHS=auto: profiling)
         route = viterbi.forward_path(B, S, path=path)
         if path != 'auto' and route in seen:
             continue
