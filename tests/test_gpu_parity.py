@@ -132,16 +132,26 @@ def test_dense_route_backtrace_reads_the_band_only(width, forward):
 
 
 @pytest.mark.parametrize('shape', [(3, 40, 1440), (70, 9, 360), (5, 1, 64), (2, 33, 4096), (9, 7, 132),
-                                   (4, 6, 63), (130, 5, 256)])
-@pytest.mark.parametrize('ties', [False, True])
-def test_uniform_transition_entry_equals_materialised_matrix(shape, ties):
+                                   (130, 5, 256), (3, 20, 8), (2, 17, 260), (3, 19, 1000), (2, 9, 2048), (2, 10, 3000)])
+@pytest.mark.parametrize('kind', ['plain', 'ties', 'coarse_sums', 'minus_inf'])
+def test_uniform_transition_entry_equals_materialised_matrix(shape, kind):
     """torbi_hip_viterbi_decode_uniform vs the oracle run on torch.full((S,S), c), the matrix the
-    reference builds for transition=None (torbi/core.py:175-180)."""
+    reference builds for transition=None (torbi/core.py:175-180).  The kernel takes the row maxima off the dependent chain
+    (max_i fl(x_i + a) = fl(max_i x_i + a), csrc/uniform_decode.hpp): 'coarse_sums' makes the posteriors ~ -1e7, where
+    one ulp is 1.0 and every addition merges many distinct candidates -- the first index among the MERGED maxima has to
+    win, as in the reference's scan; 'minus_inf' has -inf candidates and whole -inf rows; lengths straddle the 8-row chunks."""
     import math
     B, T, S = shape
     obs, _, init = synth.problem(B, T, S, seed=S + T)
-    if ties:
+    if kind == 'ties':
         obs, init = np.round(obs / 4), np.round(init / 4)
+    elif kind == 'coarse_sums':
+        init = (init - np.float32(1e7)).astype(np.float32)
+    elif kind == 'minus_inf':
+        rng = np.random.default_rng(S)
+        obs = np.where(rng.random(obs.shape) < 0.3, -np.inf, obs).astype(np.float32)
+        if T > 4:
+            obs[0, 3, :] = -np.inf                                  # a whole row: everything after it is -inf
     c = np.float32(math.log(1. / S))
     frames = np.clip(synth.lengths(B, 1, T, seed=7), 1, T)
     frames[0] = T

@@ -6,7 +6,7 @@ import torch
 import torbi_amd
 from torbi_amd import viterbi, synth
 dev = torch.device('cuda:0')
-for B, T, S in ((512, 500, 1440), (4096, 250, 1440), (512, 500, 1024), (128, 2000, 4096)):
+for B, T, S in ((512, 500, 1440), (4096, 250, 1440), (512, 500, 1024), (128, 2000, 4096), (1, 500, 1440), (16, 500, 1440), (64, 5000, 360), (2048, 300, 64)):
     obs = viterbi.fill_synthetic((B, T, S), synth.STREAM_OBSERVATION, device=dev)
     init = viterbi.fill_synthetic((S,), synth.STREAM_INITIAL, device=dev)
     frames = torch.full((B,), T, dtype=torch.int32, device=dev)

@@ -36,10 +36,6 @@
 #include "small_states.hpp"
 #include "file_rows.hpp"
 
-#ifndef TORBI_UNIFORM_DEPTH
-#define TORBI_UNIFORM_DEPTH 4      // observation rows in flight per item in the uniform-transition kernel
-#endif
-
 namespace {
 
 constexpr int kWave = 64;
@@ -1786,17 +1782,23 @@ int torbi_hip_viterbi_decode_uniform(const float *observation, const int32_t *ba
     DeviceGuard guard(device);
     if (guard.err != hipSuccess) return (int)guard.err;
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define TORBI_UNIFORM_CASE(NQ_, DEPTH_)                                                             \
-    if (S <= 1024 * NQ_) {                                                                          \
-        hipLaunchKernelGGL((uniform::uniform_decode_kernel<NQ_, DEPTH_>), dim3(B), dim3(256), 0, s, \
+    // a wave per observation row, the reductions off the dependent chain (uniform_decode.hpp); R rows per wave and chunk:
+    // 1, 2 and 3 run alike (0.27 ms at 512 x 500 x 1440), 4 spills
+#define TORBI_UNIFORM_ROWS(NQW_, R_)                                                                \
+    if (S <= 256 * NQW_) {                                                                          \
+        hipLaunchKernelGGL((uniform::uniform_rows_kernel<NQW_, R_>), dim3(B), dim3(256), 0, s,      \
                            observation, batch_frames, initial, log_transition, indices_out, B, T, S); \
         mark_decode_end(device, s);                                                                 \
         return (int)hipGetLastError();                                                              \
     }
-    TORBI_UNIFORM_CASE(1, TORBI_UNIFORM_DEPTH)
-    TORBI_UNIFORM_CASE(2, TORBI_UNIFORM_DEPTH)
-    TORBI_UNIFORM_CASE(4, TORBI_UNIFORM_DEPTH)
-#undef TORBI_UNIFORM_CASE
+    TORBI_UNIFORM_ROWS(1, 2)
+    TORBI_UNIFORM_ROWS(2, 2)
+    TORBI_UNIFORM_ROWS(4, 2)
+    TORBI_UNIFORM_ROWS(6, 2)
+    TORBI_UNIFORM_ROWS(8, 2)
+    TORBI_UNIFORM_ROWS(12, 1)
+    TORBI_UNIFORM_ROWS(16, 1)
+#undef TORBI_UNIFORM_ROWS
     return TORBI_HIP_EUNSUPPORTED;
 }
 

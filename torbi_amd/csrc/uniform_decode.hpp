@@ -8,8 +8,7 @@
 //     post'[j] = fl(obs[t,j] + m)
 // and the backtrace (viterbi.cpp:153-157) reads bp[t][anything] = k_t:  out[t-1] = k_t.
 // O(S) per timestep instead of O(S*S), no trellis, no posterior history: the decode streams the
-// observations once and is HBM-bound (4S + 4 bytes per timestep).  One wave per batch item; the
-// posterior row lives in registers; observation rows are prefetched DEPTH timesteps ahead.
+// observations once and is HBM-bound (4S + 4 bytes per timestep).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -27,54 +26,24 @@ using wavered::MaxOp;
 
 constexpr int kNone = 0x7fffffff;
 
-// first index (ascending) whose value equals m among this lane's 4*NQ elements, else kNone
-template <int NQ>
-__device__ __forceinline__ int first_equal(const float4 (&v)[NQ], float m, int lane, int S) {
-    int k = kNone;
-#pragma unroll
-    for (int q = NQ - 1; q >= 0; --q) {
-        const int i = 4 * lane + 256 * q;
-        if (i < S) {
-            k = v[q].w == m ? i + 3 : k;
-            k = v[q].z == m ? i + 2 : k;
-            k = v[q].y == m ? i + 1 : k;
-            k = v[q].x == m ? i : k;
-        }
-    }
-    return k;
-}
-
-template <int NQ>
-__device__ __forceinline__ float lane_max(const float4 (&v)[NQ], int lane, int S) {
-    float m = -INFINITY;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-        if (4 * lane + 256 * q < S)
-            m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fmaxf(v[q].x, v[q].y)), __builtin_fmaxf(v[q].z, v[q].w));
-    return m;
-}
-
-template <int NQ>
-__device__ __forceinline__ void load_row(float4 (&r)[NQ], const float *row, int lane, int S) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int i = 4 * lane + 256 * q;
-        r[q] = i < S ? *reinterpret_cast<const float4 *>(row + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
-
-// One workgroup of 4 waves per batch item; thread `tid` owns prev-states {4*tid + 1024*q}, q < NQ
-// (S <= 1024*NQ, S % 4 == 0); DEPTH observation rows in flight.  Per timestep each wave reduces its
-// own (max, first index of that max) with DPP, the four pairs meet in LDS (one barrier, slots
-// double-buffered by timestep parity) and every wave forms
-//     m = max_w m_w,   k = min { k_w : m_w == m }        (lowest index among equal maxima).
-template <int NQ, int DEPTH>
-__global__ __launch_bounds__(256) void uniform_decode_kernel(const float *__restrict__ obs,
-                                                             const int32_t *__restrict__ frames,
-                                                             const float *__restrict__ initial, float c,
-                                                             int32_t *__restrict__ out, int B, int T, int S) {
-    __shared__ float xm[2][4];
-    __shared__ int xk[2][4];
+// ---- the reductions OFF the dependent chain ----------------------------------------------------------------------------
+// (Rounds 1-3 ran the recurrence as written above: one workgroup-wide (max, first index) reduction and one barrier per
+// timestep, 52-56 % of the HBM peak at 512 x 500 x 1440.)  x -> fl(x + a) is monotone, so a maximum commutes with it:  max_i fl(post[i] + c) = fl(max_i post[i] + c)  and
+// max_j fl(obs[t,j] + m) = fl(max_j obs[t,j] + m).  With  M_t = max_j obs[t,j]  (a property of the observation row alone)
+// the recurrence above collapses to two scalar additions per timestep,
+//     m_{t+1} = fl(fl(M_t + m_t) + c)            (t >= 1;  t = 0:  fl(max_i fl(obs[0,i] + initial[i]) + c)),
+// and everything that costs a pass over a row -- M_t, and the backpointer  k_{t+1} = first i with
+// fl(fl(obs[t,i] + m_t) + c) == m_{t+1}  (the same candidates, the same first-index rule, viterbi.cpp:94-100) -- is
+// independent from row to row.  A workgroup (one per batch item) takes 4 R rows at a time: every wave reduces ITS rows by
+// itself (DPP, no exchange), the row maxima meet in the LDS (one barrier per 4 R timesteps instead of one per timestep),
+// every thread runs the 4 R-step scalar chain, then every wave finds the backpointers of its rows; the next 4 R rows are
+// in flight meanwhile.  Identical indices (the candidates are the reference's, only the order of evaluation changed).
+template <int NQW, int R>
+__global__ __launch_bounds__(256) void uniform_rows_kernel(const float *__restrict__ obs, const int32_t *__restrict__ frames,
+                                                           const float *__restrict__ initial, float c,
+                                                           int32_t *__restrict__ out, int B, int T, int S) {
+    constexpr int CH = 4 * R;
+    __shared__ float rowmax[2][CH];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -83,112 +52,98 @@ __global__ __launch_bounds__(256) void uniform_decode_kernel(const float *__rest
     f = f < 1 ? 1 : (f > T ? T : f);
     const float *o = obs + (size_t)b * T * S;
     int32_t *res = out + (size_t)b * T;
+    const float ninf = -INFINITY;
 
-    float4 post[NQ], cand[NQ], rows[DEPTH][NQ];
-    // element addressing shared by every helper below: q-th float4 of this thread
-#define U_IDX(q) (4 * tid + 1024 * (q))
-#define U_LOAD(dst, row)                                                                     \
-    _Pragma("unroll") for (int q = 0; q < NQ; ++q)                                          \
-        (dst)[q] = U_IDX(q) < S ? *reinterpret_cast<const float4 *>((row) + U_IDX(q))      \
-                                : make_float4(0.f, 0.f, 0.f, 0.f)
-    // block-wide (max, first index attaining it) of v[]: returns m, writes k
-    int parity = 0;   // exchange slots alternate on EVERY reduction (a slot is rewritten only after
-                      // the barrier of the next reduction, i.e. after every wave has read it)
-    auto reduce = [&](const float4 (&v)[NQ], int &k_out) -> float {
-        float lm = -INFINITY;
+    float4 cur[R][NQW], nxt[R][NQW];
+    auto load = [&](float4 (&dst)[R][NQW], int first) {       // rows first + R wave + r, clamped to valid memory
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
-            if (U_IDX(q) < S)
-                lm = __builtin_fmaxf(__builtin_fmaxf(lm, __builtin_fmaxf(v[q].x, v[q].y)),
-                                     __builtin_fmaxf(v[q].z, v[q].w));
-        const float wm = wave_reduce_f32(lm, MaxOp());
-        int lk = kNone;
+        for (int r = 0; r < R; ++r) {
+            const int t = first + R * wave + r;
+            const float *row = o + (size_t)(t < T ? t : T - 1) * S;
 #pragma unroll
-        for (int q = NQ - 1; q >= 0; --q) {
-            const int i = U_IDX(q);
-            if (i < S) {
-                int kq = v[q].w == wm ? i + 3 : kNone;
-                kq = v[q].z == wm ? i + 2 : kq;
-                kq = v[q].y == wm ? i + 1 : kq;
-                kq = v[q].x == wm ? i : kq;
-                lk = min(lk, kq);
+            for (int q = 0; q < NQW; ++q) {
+                const int i = 4 * lane + 256 * q;
+                dst[r][q] = *reinterpret_cast<const float4 *>(row + (i < S ? i : 0));
             }
         }
-        const int wk = wave_min_i32(lk);
-        if (lane == 0) { xm[parity][wave] = wm; xk[parity][wave] = wk; }
-        __syncthreads();
-        const float m0 = xm[parity][0], m1 = xm[parity][1], m2 = xm[parity][2], m3 = xm[parity][3];
-        const float m = __builtin_fmaxf(__builtin_fmaxf(m0, m1), __builtin_fmaxf(m2, m3));
-        int k = m0 == m ? xk[parity][0] : kNone;
-        k = min(k, m1 == m ? xk[parity][1] : kNone);
-        k = min(k, m2 == m ? xk[parity][2] : kNone);
-        k = min(k, m3 == m ? xk[parity][3] : kNone);
-        k_out = k;
-        parity ^= 1;
-        return m;
     };
-
-    // t = 0: post = obs[0] + initial                                        (viterbi.cpp:72-76)
-    {
-        float4 a[NQ], i4[NQ];
-        U_LOAD(a, o);
-        U_LOAD(i4, initial);
+    load(cur, 0);
+    if (wave == 0) {                                           // t = 0: post = obs[0] + initial (viterbi.cpp:72-76)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
-            post[q] = make_float4(a[q].x + i4[q].x, a[q].y + i4[q].y, a[q].z + i4[q].z, a[q].w + i4[q].w);
-    }
-    // Observation rows are always fetched (row index clamped to T-1, valid memory), so the
-    // unrolled body has no conditional register-array writes (those would be demoted to scratch).
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-        const int r = 1 + d < T ? 1 + d : T - 1;
-        U_LOAD(rows[d], o + (size_t)r * S);
-    }
-
-    int t0 = 1;
-    for (; t0 + DEPTH <= f; t0 += DEPTH) {                    // whole groups: no per-step test
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            const int t = t0 + d;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                cand[q] = make_float4(post[q].x + c, post[q].y + c, post[q].z + c, post[q].w + c);
-            int k;
-            const float m = reduce(cand, k);
-            if (tid == 0) res[t - 1] = k;                     // the backpointer of every next state
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                post[q] = make_float4(rows[d][q].x + m, rows[d][q].y + m, rows[d][q].z + m, rows[d][q].w + m);
-            const int r = t + DEPTH < T ? t + DEPTH : T - 1;
-            U_LOAD(rows[d], o + (size_t)r * S);
+        for (int q = 0; q < NQW; ++q) {
+            const int i = 4 * lane + 256 * q;
+            const float4 a = *reinterpret_cast<const float4 *>(initial + (i < S ? i : 0));
+            cur[0][q] = make_float4(cur[0][q].x + a.x, cur[0][q].y + a.y, cur[0][q].z + a.z, cur[0][q].w + a.w);
         }
     }
-    // remainder (< DEPTH steps): same body, the new posterior is committed with a select
+    float m = 0.f;                                             // m_t of the first row of the chunk (unused at t = 0)
+    int parity = 0;
+    for (int t0 = 0; t0 < f; t0 += CH) {
+        load(nxt, t0 + CH);
 #pragma unroll
-    for (int d = 0; d < DEPTH - 1; ++d) {
-        const int t = t0 + d;
-        const bool live = t < f;                              // block-uniform
+        for (int r = 0; r < R; ++r) {
+            float lm = ninf;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
-            cand[q] = make_float4(post[q].x + c, post[q].y + c, post[q].z + c, post[q].w + c);
-        int k;
-        const float m = reduce(cand, k);
-        if (live && tid == 0) res[t - 1] = k;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            post[q].x = live ? rows[d][q].x + m : post[q].x;
-            post[q].y = live ? rows[d][q].y + m : post[q].y;
-            post[q].z = live ? rows[d][q].z + m : post[q].z;
-            post[q].w = live ? rows[d][q].w + m : post[q].w;
+            for (int q = 0; q < NQW; ++q)
+                if (4 * lane + 256 * q < S)
+                    lm = __builtin_fmaxf(__builtin_fmaxf(lm, __builtin_fmaxf(cur[r][q].x, cur[r][q].y)),
+                                         __builtin_fmaxf(cur[r][q].z, cur[r][q].w));
+            const float wm = wave_reduce_f32(lm, MaxOp());
+            if (lane == 0) rowmax[parity][R * wave + r] = wm;
         }
+        __syncthreads();
+        float mt[R], mt1[R], top[R];                           // m_t, m_{t+1} and max posterior of this wave's rows
+        float mm = m;
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            const float M = rowmax[parity][s];
+            const float maxpost = t0 + s == 0 ? M : M + mm;
+            const float next = maxpost + c;
+            if (s / R == wave) {                               // (wave-uniform)
+                mt[s % R] = mm;
+                mt1[s % R] = next;
+                top[s % R] = maxpost;
+            }
+            mm = next;
+        }
+        m = mm;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int t = t0 + R * wave + r;
+            if (t <= f - 1) {                                  // (wave-uniform)
+                const bool last = t == f - 1;
+                const float add = t == 0 ? 0.f : mt[r];        // (row 0 already holds obs + initial; x + 0 = x)
+                const float want = last ? top[r] : mt1[r];
+                int lk = kNone;
+#pragma unroll
+                for (int q = NQW - 1; q >= 0; --q) {
+                    const int i = 4 * lane + 256 * q;
+                    if (i < S) {
+                        float4 v = cur[r][q];
+                        if (t != 0) v = make_float4(v.x + add, v.y + add, v.z + add, v.w + add);
+                        if (!last) v = make_float4(v.x + c, v.y + c, v.z + c, v.w + c);
+                        int kq = v.w == want ? i + 3 : kNone;
+                        kq = v.z == want ? i + 2 : kq;
+                        kq = v.y == want ? i + 1 : kq;
+                        kq = v.x == want ? i : kq;
+                        lk = min(lk, kq);
+                    }
+                }
+                int k = wave_min_i32(lk);
+                k = k == kNone ? 0 : k;
+                if (!last) {
+                    if (lane == 0) res[t] = k;                 // out[t] = k_{t+1}: the backpointer of every next state
+                } else {
+                    for (int tt = f - 1 + lane; tt < T; tt += 64) res[tt] = k;     // (viterbi.cpp:218-221)
+                }
+            }
+        }
+        parity ^= 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < NQW; ++q) cur[r][q] = nxt[r][q];
     }
-    // final state = first argmax of the last posterior row (viterbi.cpp:218); it fills every
-    // position t >= frames-1 (viterbi.cpp:219-221)
-    int fin;
-    (void)reduce(post, fin);
-    for (int tt = f - 1 + tid; tt < T; tt += 256) res[tt] = fin;
-#undef U_IDX
-#undef U_LOAD
 }
 
 }  // namespace uniform
