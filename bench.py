@@ -588,6 +588,21 @@ class Bench:
                'log_probs=True, gpu=0): epsilon clamp pass over the batch + workspace allocation (caching allocator) + '
                'decode, host-timed around a synchronised call, median of 3 after one warm-up call',
                {'first_call_ms': samples[0] * 1e3})
+        # the reference's call with EVERY default: probabilities in, no transition, no initial (uniform transition)
+        probs = torch.softmax(obs, dim=-1)
+        sec, _ = self.timed_decodes(lambda: self.torbi_amd.from_probabilities(probs, frames, gpu=0), 3)
+        tiny = torch.finfo(torch.float32).tiny
+        c0 = float(torch.tensor(math.log(1.0 / S), dtype=torch.float32))
+        i0 = torch.full((S,), math.log(1.0 / S + tiny), dtype=torch.float32, device=dev)
+        sec_steps, _ = self.timed_decodes(lambda: self.torbi_amd.decode_uniform(v.log_epsilon_clamp(probs), frames, c0, i0), 3)
+        out['api_from_probabilities_all_defaults'] = {
+            'value': B * T / sec, 'unit': 'timesteps/s', 'ms_per_decode': sec * 1e3,
+            'roofline_frac': B * T * (4 * S + 4) / sec / (HBM_PEAK_GBS * 1e9),
+            'as_two_passes_ms': sec_steps * 1e3,
+            'note': 'torbi_amd.from_probabilities(probabilities[B,T,S] on the device, batch_frames, gpu=0): log(), the epsilon '
+                    'round trip and the uniform-transition decode in ONE pass over the observations '
+                    '(torbi_hip_viterbi_decode_uniform_probabilities); beside it the log + clamp pass followed by the decode'}
+        del probs
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(obs, frames, trans, init, workspace=ws, path='dense'), 2)
         record('every_cell', sec, B * T, S, 'headline batch, dense (max,+) GEMM forced: every (prev, next) cell evaluated',
                {'valu_frac_at_1p5_instr_per_cell': 1.5 * B * T * S * S / sec / VALU_LANE_OPS})

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TORBI_HIP_ABI_VERSION 12
+#define TORBI_HIP_ABI_VERSION 13
 
 #define TORBI_HIP_OK 0
 #define TORBI_HIP_EINVAL (-1)      /* null pointer / non-positive dimension            */
@@ -258,6 +258,16 @@ int torbi_hip_viterbi_decode_uniform(const float *observation, const int32_t *ba
                                      float log_transition, const float *initial,
                                      int32_t *indices_out, int B, int T, int S, int device,
                                      void *stream);
+/*
+ * (ABI 13) The same with the observations given as PROBABILITIES, the way from_probabilities() receives them by default
+ * (log_probs=False): every element goes through the reference's torch.log and the epsilon round trip log(exp(x) + tiny)
+ * (torbi/core.py:189-197; bit-identical to torbi_hip_log_epsilon_clamp, i.e. to the torch ops) as it is read, so the whole
+ * default call -- probabilities in, no transition given -- is ONE pass over the observations.  `probabilities` is not
+ * written (upstream's torch.log is out of place too).  `initial` is in log space as before.
+ */
+int torbi_hip_viterbi_decode_uniform_probabilities(const float *probabilities, const int32_t *batch_frames,
+                                                   float log_transition, const float *initial, int32_t *indices_out,
+                                                   int B, int T, int S, int device, void *stream);
 
 /*
  * Same operator, instrumented for bench.py: torbi_hip_viterbi_decode_batches for one batch with

@@ -34,7 +34,8 @@ def pytest_addoption(parser):
 # 'cluster' / 'pruned' wherever a test has small batches), resident and dense through their forced instances.
 PATH_BLIND = {'test_extension_is_loaded_and_sees_the_gpu', 'test_fused_epsilon_clamp_is_bit_identical_to_the_torch_ops',
               'test_fused_log_and_epsilon_clamp_is_bit_identical_to_the_torch_ops',
-              'test_fill_synthetic_matches_numpy_definition', 'test_uniform_transition_entry_equals_materialised_matrix'}
+              'test_fill_synthetic_matches_numpy_definition', 'test_uniform_transition_entry_equals_materialised_matrix',
+              'test_the_default_call_on_probabilities_is_one_pass_with_the_reference_s_values'}
 LARGE_BATCHES_ONLY = {'cluster', 'pruned'}
 SAME_AS_AUTO = {'test_minus_inf_observations_on_the_large_batch_paths': LARGE_BATCHES_ONLY,
                 'test_pruned_path_adversarial_inputs': LARGE_BATCHES_ONLY,
@@ -59,6 +60,36 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(pytest.mark.slow)
         if not run_slow and item.get_closest_marker('slow') is not None:
             item.add_marker(skip)
+
+
+class CachedOracle:
+    """The oracle with its answers remembered by input CONTENT: tests/test_gpu_parity.py runs every test under five forward
+    paths, and the checker's answer for one seeded input does not depend on which HIP kernel is being checked.  The C
+    restatement runs once per distinct input instead of five times (it is most of the suite's run time on a busy host).
+    Everything else of the `oracle` package passes through."""
+
+    def __init__(self, module):
+        self._module = module
+        self._answers = {}
+
+    def __getattr__(self, name):
+        return getattr(self._module, name)
+
+    def decode(self, observation, batch_frames, transition, initial, num_threads=1, mode=1, return_posterior=False):
+        import hashlib
+        digest = hashlib.blake2b(digest_size=16)
+        for array, kind in ((observation, np.float32), (batch_frames, np.int32), (transition, np.float32), (initial, np.float32)):
+            a = np.ascontiguousarray(np.asarray(array), dtype=kind)
+            digest.update(repr(a.shape).encode())
+            digest.update(a.tobytes() if a.nbytes < (1 << 20) else memoryview(a).cast('B'))
+        key = (digest.digest(), int(mode), bool(return_posterior))
+        if key not in self._answers:
+            if len(self._answers) > 4096:
+                self._answers.clear()
+            self._answers[key] = self._module.decode(observation, batch_frames, transition, initial, num_threads=num_threads,
+                                                     mode=mode, return_posterior=return_posterior)
+        found = self._answers[key]
+        return tuple(x.copy() for x in found) if isinstance(found, tuple) else found.copy()
 
 
 class Golden:

@@ -11,7 +11,9 @@ import torch
 import oracle
 import torbi_amd
 from torbi_amd import synth, viterbi
-from conftest import SMALL_NAMES, LARGE_NAMES
+from conftest import SMALL_NAMES, LARGE_NAMES, CachedOracle
+
+oracle = CachedOracle(oracle)        # (one run of the checker per distinct input, not one per forward path)
 
 pytestmark = pytest.mark.gpu
 
@@ -162,6 +164,44 @@ def test_uniform_transition_entry_equals_materialised_matrix(shape, kind):
                                    float(c), torch.tensor(init, device=dev))
     assert got.dtype == torch.int32
     assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('shape', [(3, 21, 1440), (40, 9, 360), (2, 5, 4096), (5, 12, 64)])
+def test_the_default_call_on_probabilities_is_one_pass_with_the_reference_s_values(shape):
+    """from_probabilities(observation) with every default -- probabilities in, no transition, no initial -- runs log(), the
+    epsilon round trip and the uniform-transition decode in ONE kernel (torbi_hip_viterbi_decode_uniform_probabilities).
+    Against the reference's steps one by one (torbi/core.py:161-206: torch.log, exp_, += tiny, log_, then the operator on
+    the materialised log(1/S) matrix -- the oracle): zeros (log -> -inf -> log(tiny)), denormals, ones, values below tiny;
+    the caller's tensor is left as it was."""
+    import math
+    B, T, S = shape
+    rng = np.random.default_rng(S + T)
+    probs = rng.random((B, T, S)).astype(np.float32)
+    probs /= probs.sum(-1, keepdims=True)
+    probs[rng.random(probs.shape) < 0.05] = 0.0
+    probs[rng.random(probs.shape) < 0.02] = np.float32(1e-42)                  # denormal
+    probs[rng.random(probs.shape) < 0.02] = np.float32(3e-39)                  # below tiny, above the denormals' end
+    probs[0, 0, :4] = [1.0, 0.0, np.float32(1.17549435e-38), 0.5]
+    frames = np.clip(synth.lengths(B, 1, T, seed=3), 1, T)
+    frames[0] = T
+    dev = torch.device('cuda:0')
+    given = torch.tensor(probs, device=dev)
+    before = given.clone()
+    got = torbi_amd.from_probabilities(given, torch.tensor(frames, device=dev), gpu=0)
+    assert torch.equal(given, before)                                          # out of place, like upstream's torch.log
+    tiny = torch.finfo(torch.float32).tiny
+    scores = torch.log(before)
+    scores.exp_()
+    scores += tiny
+    scores.log_()
+    init = np.full((S,), math.log(1. / S + tiny), np.float32)
+    trans = np.full((S, S), np.float32(math.log(1. / S)), np.float32)
+    want = oracle.decode(scores.cpu().numpy(), frames, trans, init, num_threads=oracle.max_threads())
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    # ... and the kernel's scores are the torch ops' scores bit for bit: decode_uniform on them gives the same indices
+    again = torbi_amd.decode_uniform(scores, torch.tensor(frames, device=dev), float(np.float32(math.log(1. / S))),
+                                     torch.tensor(init, device=dev))
+    assert torch.equal(again, got)
 
 
 @pytest.mark.parametrize('shape', [(64, 1, 64), (33, 2, 100), (32, 3, 8192), (48, 4, 6148)])

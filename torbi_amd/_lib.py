@@ -16,7 +16,7 @@ SOURCE = os.path.join(_HERE, 'csrc', 'torbi_hip.hip')
 INCLUDE = os.path.join(ROOT, 'include')
 # TORBI_HIP_LIBRARY: an alternative build of the library (tools/variants_probe.py: -D experiments)
 LIBRARY = os.environ.get('TORBI_HIP_LIBRARY') or os.path.join(_HERE, 'libtorbi_hip.so')
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 # every symbol include/torbi_hip.h declares: name -> (restype, argtypes)
 _c = ctypes
@@ -30,6 +30,9 @@ SYMBOLS = {
         _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
         _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     'torbi_hip_viterbi_decode_uniform': (_c.c_int, [
+        _c.c_void_p, _c.c_void_p, _c.c_float, _c.c_void_p, _c.c_void_p,
+        _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+    'torbi_hip_viterbi_decode_uniform_probabilities': (_c.c_int, [
         _c.c_void_p, _c.c_void_p, _c.c_float, _c.c_void_p, _c.c_void_p,
         _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     'torbi_hip_viterbi_decode_profiled': (_c.c_int, [

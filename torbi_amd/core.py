@@ -12,7 +12,7 @@ import torch
 
 from . import data as _data
 from . import timer
-from .viterbi import decode, decode_uniform, epsilon_clamp_, log_epsilon_clamp, _version_of
+from .viterbi import decode, decode_uniform, epsilon_clamp_, log_epsilon_clamp, uniform_supported, _version_of
 
 # reference torbi/config/defaults.py:80,83
 BATCH_SIZE = 512
@@ -161,6 +161,13 @@ def from_probabilities(
             transition = _prepared_transition(transition, log_probs, device)
         if _model is not None:
             _model.update(initial=initial, transition=transition, uniform=uniform)
+
+    # The whole default call -- probabilities in, no transition given -- as ONE pass over the observations: log(), the
+    # epsilon round trip and the O(S)-per-frame decode in one kernel (same values, same indices; csrc/uniform_decode.hpp)
+    if (uniform is not None and not log_probs and observation.device == device
+            and observation.dtype == torch.float32 and uniform_supported(states)):
+        with timer.context('torbi'):
+            return decode_uniform(observation, batch_frames, uniform, initial, probabilities=True)
 
     # Ensure observation probabilities are in log space (core.py:189-191).  Probabilities that already live on the
     # compute device go through log() and the epsilon round trip below in one pass (same values, tested bitwise)

@@ -1769,10 +1769,11 @@ int torbi_hip_scan_stats(const void *workspace, size_t workspace_bytes, int B, i
     return (int)hipGetLastError();
 }
 
-int torbi_hip_viterbi_decode_uniform(const float *observation, const int32_t *batch_frames,
-                                     float log_transition, const float *initial,
-                                     int32_t *indices_out, int B, int T, int S, int device,
-                                     void *stream) {
+extern "C++" {
+namespace {
+template <bool PROBS>
+int decode_uniform_as(const float *observation, const int32_t *batch_frames, float log_transition, const float *initial,
+                      int32_t *indices_out, int B, int T, int S, int device, void *stream) {
     if (B < 0 || T < 1 || S < 1) return TORBI_HIP_EINVAL;
     if (B == 0) return TORBI_HIP_OK;
     if (!observation || !batch_frames || !initial || !indices_out) return TORBI_HIP_EINVAL;
@@ -1784,12 +1785,12 @@ int torbi_hip_viterbi_decode_uniform(const float *observation, const int32_t *ba
     hipStream_t s = static_cast<hipStream_t>(stream);
     // a wave per observation row, the reductions off the dependent chain (uniform_decode.hpp); R rows per wave and chunk:
     // 1, 2 and 3 run alike (0.27 ms at 512 x 500 x 1440), 4 spills
-#define TORBI_UNIFORM_ROWS(NQW_, R_)                                                                \
-    if (S <= 256 * NQW_) {                                                                          \
-        hipLaunchKernelGGL((uniform::uniform_rows_kernel<NQW_, R_>), dim3(B), dim3(256), 0, s,      \
-                           observation, batch_frames, initial, log_transition, indices_out, B, T, S); \
-        mark_decode_end(device, s);                                                                 \
-        return (int)hipGetLastError();                                                              \
+#define TORBI_UNIFORM_ROWS(NQW_, R_)                                                                     \
+    if (S <= 256 * NQW_) {                                                                               \
+        hipLaunchKernelGGL((uniform::uniform_rows_kernel<NQW_, R_, PROBS>), dim3(B), dim3(256), 0, s,    \
+                           observation, batch_frames, initial, log_transition, indices_out, B, T, S);    \
+        mark_decode_end(device, s);                                                                      \
+        return (int)hipGetLastError();                                                                   \
     }
     TORBI_UNIFORM_ROWS(1, 2)
     TORBI_UNIFORM_ROWS(2, 2)
@@ -1800,6 +1801,21 @@ int torbi_hip_viterbi_decode_uniform(const float *observation, const int32_t *ba
     TORBI_UNIFORM_ROWS(16, 1)
 #undef TORBI_UNIFORM_ROWS
     return TORBI_HIP_EUNSUPPORTED;
+}
+}  // namespace
+}  // extern "C++"
+
+int torbi_hip_viterbi_decode_uniform(const float *observation, const int32_t *batch_frames,
+                                     float log_transition, const float *initial,
+                                     int32_t *indices_out, int B, int T, int S, int device,
+                                     void *stream) {
+    return decode_uniform_as<false>(observation, batch_frames, log_transition, initial, indices_out, B, T, S, device, stream);
+}
+
+int torbi_hip_viterbi_decode_uniform_probabilities(const float *probabilities, const int32_t *batch_frames,
+                                                   float log_transition, const float *initial, int32_t *indices_out,
+                                                   int B, int T, int S, int device, void *stream) {
+    return decode_uniform_as<true>(probabilities, batch_frames, log_transition, initial, indices_out, B, T, S, device, stream);
 }
 
 int torbi_hip_viterbi_decode_profiled(const float *observation, const int32_t *batch_frames,

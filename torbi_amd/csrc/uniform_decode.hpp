@@ -38,7 +38,13 @@ constexpr int kNone = 0x7fffffff;
 // itself (DPP, no exchange), the row maxima meet in the LDS (one barrier per 4 R timesteps instead of one per timestep),
 // every thread runs the 4 R-step scalar chain, then every wave finds the backpointers of its rows; the next 4 R rows are
 // in flight meanwhile.  Identical indices (the candidates are the reference's, only the order of evaluation changed).
-template <int NQW, int R>
+// PROBS: the observations are PROBABILITIES as from_probabilities receives them by default; every element goes through
+// the reference's log() and epsilon round trip log(exp(x) + tiny) (torbi/core.py:189-197: the same three library calls, the
+// same roundings as torch's elementwise kernels) on its way into the registers -- the 2 x 1.47 GB pass that otherwise
+// precedes the decode is gone.  (Out of place like upstream's torch.log: the caller's tensor is not written.)
+__device__ __forceinline__ float score_of_probability(float p) { return logf(expf(logf(p)) + 1.17549435e-38f); }
+
+template <int NQW, int R, bool PROBS = false>
 __global__ __launch_bounds__(256) void uniform_rows_kernel(const float *__restrict__ obs, const int32_t *__restrict__ frames,
                                                            const float *__restrict__ initial, float c,
                                                            int32_t *__restrict__ out, int B, int T, int S) {
@@ -63,7 +69,11 @@ __global__ __launch_bounds__(256) void uniform_rows_kernel(const float *__restri
 #pragma unroll
             for (int q = 0; q < NQW; ++q) {
                 const int i = 4 * lane + 256 * q;
-                dst[r][q] = *reinterpret_cast<const float4 *>(row + (i < S ? i : 0));
+                float4 v = *reinterpret_cast<const float4 *>(row + (i < S ? i : 0));
+                if constexpr (PROBS)
+                    v = make_float4(score_of_probability(v.x), score_of_probability(v.y), score_of_probability(v.z),
+                                    score_of_probability(v.w));
+                dst[r][q] = v;
             }
         }
     };

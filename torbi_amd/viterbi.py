@@ -610,6 +610,7 @@ def decode_uniform(
     batch_frames: torch.Tensor,
     log_transition: float,
     initial: torch.Tensor,
+    probabilities: bool = False,
 ) -> torch.Tensor:
     """`decode` for a transition matrix whose entries all equal `log_transition`
 
@@ -617,8 +618,20 @@ def decode_uniform(
     `torch.full((S, S), log(1/S))`, torbi/core.py:175-180).  O(S) per timestep, no scratch,
     HBM-bound; bit-identical to `decode` on the materialised matrix.  Falls back to
     materialising the matrix for shapes `uniform_supported` rejects.
+
+    probabilities: `observation` holds probabilities (the default input of `from_probabilities`); the reference's
+        `torch.log` and epsilon round trip `log(exp(x) + tiny)` (torbi/core.py:189-197) are applied to every element as
+        it is read (include/torbi_hip.h, torbi_hip_viterbi_decode_uniform_probabilities) -- one pass over the
+        observations for the whole default call; `observation` is not written.  `initial` stays in log space.
     """
     B, T, S = observation.shape
+    if probabilities and not (uniform_supported(S) and observation.dtype == torch.float32):
+        tiny = torch.finfo(torch.float32).tiny             # (the steps of torbi/core.py:189-197, one by one)
+        scores = torch.log(observation).to(dtype=torch.float32)
+        scores.exp_()
+        scores += tiny
+        scores.log_()
+        return decode_uniform(scores, batch_frames, log_transition, initial)
     if not uniform_supported(S):
         transition = torch.full((S, S), float(log_transition), dtype=torch.float32,
                                 device=observation.device)
@@ -637,12 +650,18 @@ def decode_uniform(
         return indices.to(home)
     index = device.index if device.index is not None else torch.cuda.current_device()
     stream = torch.cuda.current_stream(device).cuda_stream
-    code = lib.torbi_hip_viterbi_decode_uniform(
-        obs.data_ptr(), frames.data_ptr(), float(log_transition), init.data_ptr(),
-        indices.data_ptr(), B, T, S, index, ctypes.c_void_p(stream))
+    entry = lib.torbi_hip_viterbi_decode_uniform_probabilities if probabilities else lib.torbi_hip_viterbi_decode_uniform
+    code = entry(obs.data_ptr(), frames.data_ptr(), float(log_transition), init.data_ptr(),
+                 indices.data_ptr(), B, T, S, index, ctypes.c_void_p(stream))
     if code == -5:     # TORBI_HIP_EUNSUPPORTED (e.g. a misaligned view): materialise
+        if probabilities:
+            tiny = torch.finfo(torch.float32).tiny
+            obs = torch.log(obs)
+            obs.exp_()
+            obs += tiny
+            obs.log_()
         transition = torch.full((S, S), float(log_transition), dtype=torch.float32, device=device)
-        return decode(observation, batch_frames, transition, initial)
+        return decode(obs, batch_frames, transition, initial)
     _lib.check(code, 'torbi_hip_viterbi_decode_uniform')
     return indices if home == device else indices.to(home)
 
