@@ -1,4 +1,5 @@
-// Up to 64 states: one wavefront decodes one sequence, forward recurrence AND backtrace, in ONE launch.
+// Up to 256 states: forward recurrence AND backtrace of a sequence in ONE launch, the transition matrix in registers --
+// one wavefront per sequence up to 64 states (first half of this file), one workgroup up to 256 (second half).
 //
 // The reference runs these shapes through the same trellis kernels as any other (viterbi.cu:203-241: one block per item,
 // one `__syncthreads` round per timestep); per-timestep LAUNCHES cost 4-5 us each here whatever the state count
@@ -22,54 +23,6 @@ __host__ __device__ inline int padded_states(int S) { return S <= 4 ? 4 : (S + 7
 // dwords of the backpointer plane per item: [ceil((T-1)/4)][SP]
 __host__ __device__ inline size_t plane_dwords(int T, int S) { return (size_t)((T - 1 + 3) / 4) * padded_states(S); }
 inline bool supported(int S) { return S >= 2 && S <= kMaxS; }
-
-// Four prev-states lo + 4 K .. lo + 4 K + 3 against the four running maxima of a lane: add, compare, max, select -- written
-// out so that it stays four vector instructions per cell with no candidate kept in a register (left to itself the compiler
-// reduces the values first and recovers the indices afterwards from ~100 saved candidates per lane).  Running maximum c
-// remembers K of its prev-state lo + 4 K + c (an inline constant); the compares land in four scalar pairs, eight
-// instructions ahead of the selects that read them.
-template <int K>
-__device__ __forceinline__ void four_cells(const float4 pv, const float *row, float (&best)[4], uint32_t (&arg)[4]) {
-    float c0, c1, c2, c3;
-    unsigned long long m0, m1, m2, m3;
-    asm volatile(
-        "v_add_f32 %0, %16, %20\n\tv_add_f32 %1, %17, %21\n\tv_add_f32 %2, %18, %22\n\tv_add_f32 %3, %19, %23\n\t"
-        "v_cmp_ngt_f32 %4, %0, %8\n\tv_cmp_ngt_f32 %5, %1, %9\n\tv_cmp_ngt_f32 %6, %2, %10\n\tv_cmp_ngt_f32 %7, %3, %11\n\t"
-        "v_max_f32 %8, %8, %0\n\tv_max_f32 %9, %9, %1\n\tv_max_f32 %10, %10, %2\n\tv_max_f32 %11, %11, %3\n\t"
-        "v_cndmask_b32 %12, %24, %12, %4\n\tv_cndmask_b32 %13, %24, %13, %5\n\t"
-        "v_cndmask_b32 %14, %24, %14, %6\n\tv_cndmask_b32 %15, %24, %15, %7"
-        : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "+v"(best[0]), "+v"(best[1]),
-          "+v"(best[2]), "+v"(best[3]), "+v"(arg[0]), "+v"(arg[1]), "+v"(arg[2]), "+v"(arg[3])
-        : "v"(pv.x), "v"(pv.y), "v"(pv.z), "v"(pv.w), "v"(row[0]), "v"(row[1]), "v"(row[2]), "v"(row[3]), "n"(K));
-}
-
-// L prev-states in groups of 4 G: the broadcasts of group g + 1 are issued before group g is added up (the compiler moves
-// nothing across the blocks above, so the order written here is the order that runs)
-template <int Base, int L, int G, int... Is>
-__device__ __forceinline__ void one_group(const float4 (&pv)[G], const float (&row)[L], float (&best)[4], uint32_t (&arg)[4],
-                                          std::integer_sequence<int, Is...>) {
-    (four_cells<Base + Is>(pv[Is], &row[4 * (Base + Is)], best, arg), ...);
-}
-template <int L, int G, int Gi = 0>
-__device__ __forceinline__ void every_cell(const float4 *src, const float (&row)[L], float4 (&pv)[G], float (&best)[4],
-                                           uint32_t (&arg)[4]) {
-    constexpr int NG = L / (4 * G);
-    float4 next[G];
-    if constexpr (Gi + 1 < NG) {
-#pragma unroll
-        for (int i = 0; i < G; ++i) next[i] = src[(Gi + 1) * G + i];
-    }
-    one_group<Gi * G>(pv, row, best, arg, std::make_integer_sequence<int, G>{});
-    if constexpr (Gi + 1 < NG) every_cell<L, G, Gi + 1>(src, row, next, best, arg);
-}
-template <int L, int G>
-__device__ __forceinline__ void every_cell(const float4 *src, const float (&row)[L], float (&best)[4], uint32_t (&arg)[4]) {
-    static_assert(L % (4 * G) == 0, "whole groups");
-    float4 first[G];
-#pragma unroll
-    for (int i = 0; i < G; ++i) first[i] = src[i];
-    every_cell<L, G, 0>(src, row, first, best, arg);
-}
 
 // SP: padded state count (transition entries beyond S are -inf: never a maximum); CH: timesteps whose
 // observation rows are in flight while the previous CH are computed (a multiple of 4)
@@ -222,6 +175,54 @@ __host__ __device__ inline int block_row_registers(int S) {                     
 inline bool block_supported(int S) { return S > kMaxS && S <= kBlockMaxS; }
 // dwords of the backpointer plane per item: [ceil((T-1)/4)][S]
 __host__ __device__ inline size_t block_plane_dwords(int T, int S) { return (size_t)((T - 1 + 3) / 4) * S; }
+
+// Four prev-states lo + 4 K .. lo + 4 K + 3 against the four running maxima of a lane: add, compare, max, select -- written
+// out so that it stays four vector instructions per cell with no candidate kept in a register (left to itself the compiler
+// reduces the values first and recovers the indices afterwards from ~100 saved candidates per lane).  Running maximum c
+// remembers K of its prev-state lo + 4 K + c (an inline constant); the compares land in four scalar pairs, eight
+// instructions ahead of the selects that read them.
+template <int K>
+__device__ __forceinline__ void four_cells(const float4 pv, const float *row, float (&best)[4], uint32_t (&arg)[4]) {
+    float c0, c1, c2, c3;
+    unsigned long long m0, m1, m2, m3;
+    asm volatile(
+        "v_add_f32 %0, %16, %20\n\tv_add_f32 %1, %17, %21\n\tv_add_f32 %2, %18, %22\n\tv_add_f32 %3, %19, %23\n\t"
+        "v_cmp_ngt_f32 %4, %0, %8\n\tv_cmp_ngt_f32 %5, %1, %9\n\tv_cmp_ngt_f32 %6, %2, %10\n\tv_cmp_ngt_f32 %7, %3, %11\n\t"
+        "v_max_f32 %8, %8, %0\n\tv_max_f32 %9, %9, %1\n\tv_max_f32 %10, %10, %2\n\tv_max_f32 %11, %11, %3\n\t"
+        "v_cndmask_b32 %12, %24, %12, %4\n\tv_cndmask_b32 %13, %24, %13, %5\n\t"
+        "v_cndmask_b32 %14, %24, %14, %6\n\tv_cndmask_b32 %15, %24, %15, %7"
+        : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "+v"(best[0]), "+v"(best[1]),
+          "+v"(best[2]), "+v"(best[3]), "+v"(arg[0]), "+v"(arg[1]), "+v"(arg[2]), "+v"(arg[3])
+        : "v"(pv.x), "v"(pv.y), "v"(pv.z), "v"(pv.w), "v"(row[0]), "v"(row[1]), "v"(row[2]), "v"(row[3]), "n"(K));
+}
+
+// L prev-states in groups of 4 G: the broadcasts of group g + 1 are issued before group g is added up (the compiler moves
+// nothing across the blocks above, so the order written here is the order that runs)
+template <int Base, int L, int G, int... Is>
+__device__ __forceinline__ void one_group(const float4 (&pv)[G], const float (&row)[L], float (&best)[4], uint32_t (&arg)[4],
+                                          std::integer_sequence<int, Is...>) {
+    (four_cells<Base + Is>(pv[Is], &row[4 * (Base + Is)], best, arg), ...);
+}
+template <int L, int G, int Gi = 0>
+__device__ __forceinline__ void every_cell(const float4 *src, const float (&row)[L], float4 (&pv)[G], float (&best)[4],
+                                           uint32_t (&arg)[4]) {
+    constexpr int NG = L / (4 * G);
+    float4 next[G];
+    if constexpr (Gi + 1 < NG) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) next[i] = src[(Gi + 1) * G + i];
+    }
+    one_group<Gi * G>(pv, row, best, arg, std::make_integer_sequence<int, G>{});
+    if constexpr (Gi + 1 < NG) every_cell<L, G, Gi + 1>(src, row, next, best, arg);
+}
+template <int L, int G>
+__device__ __forceinline__ void every_cell(const float4 *src, const float (&row)[L], float (&best)[4], uint32_t (&arg)[4]) {
+    static_assert(L % (4 * G) == 0, "whole groups");
+    float4 first[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) first[i] = src[i];
+    every_cell<L, G, 0>(src, row, first, best, arg);
+}
 
 template <int PQ, int L>
 __global__ __launch_bounds__(64 * PQ * PQ) void block_decode_kernel(
