@@ -1,6 +1,6 @@
 """Randomised parity stress (GPU box): random shapes, lengths, -inf densities, tie levels and peaked rows under the six
 named forward paths (and the CPU twin) against the C oracle.   python tools/stress.py [cases] [seed]"""
-import os, sys, time
+import math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
@@ -11,6 +11,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = torch.device('cuda:0')
 bad = 0
+uniform_cases = 0
 t0 = time.time()
 for c in range(cases):
     S = int(rng.choice([rng.integers(1, 80), rng.integers(2, 258), rng.integers(16, 560) * 4, rng.integers(64, 2200),
@@ -52,6 +53,30 @@ for c in range(cases):
         if not np.array_equal(got, want):
             bad += 1
             print('MISMATCH', dict(B=B, T=T, S=S, kind=int(kind), path=path, used=viterbi.forward_path(B, S)), int((got != want).sum()))
+    # the uniform-transition entry on the same observations (every other case whose state count it takes): scores as they
+    # are, and as probabilities through the fused log + epsilon round trip, against the oracle on the materialised matrix
+    if S % 4 == 0 and S <= 4096 and c % 2 == 0:
+        viterbi.set_forward_path('auto')
+        cu = np.float32(math.log(1.0 / S))
+        full = np.full((S, S), cu, np.float32)
+        want_u = oracle.decode(obs.astype(np.float32), frames, full, init.astype(np.float32), num_threads=oracle.max_threads())
+        got_u = torbi_amd.decode_uniform(args[0], args[1], float(cu), args[3]).cpu().numpy()
+        uniform_cases += 1
+        if not np.array_equal(got_u, want_u):
+            bad += 1
+            print('MISMATCH', dict(B=B, T=T, S=S, kind=int(kind), path='uniform'), int((got_u != want_u).sum()))
+        if kind != 4:                                # (a row of -inf scores has no softmax)
+            probs = torch.softmax(args[0], dim=-1)
+            scores = torch.log(probs)
+            scores.exp_()
+            scores += torch.finfo(torch.float32).tiny
+            scores.log_()
+            want_p = oracle.decode(scores.cpu().numpy(), frames, full, init.astype(np.float32), num_threads=oracle.max_threads())
+            got_p = torbi_amd.decode_uniform(probs, args[1], float(cu), args[3], probabilities=True).cpu().numpy()
+            if not np.array_equal(got_p, want_p):
+                bad += 1
+                print('MISMATCH', dict(B=B, T=T, S=S, kind=int(kind), path='uniform, probabilities'), int((got_p != want_p).sum()))
 viterbi.set_forward_path('auto')
-print(f'{cases} cases x (6 HIP paths + the CPU twin), {bad} mismatches, {time.time() - t0:.0f} s')
+print(f'{cases} cases x (6 HIP paths + the CPU twin) + {uniform_cases} x the uniform entry (scores, probabilities), {bad} mismatches, '
+      f'{time.time() - t0:.0f} s')
 sys.exit(1 if bad else 0)
