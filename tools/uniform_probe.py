@@ -6,7 +6,8 @@ import torch
 import torbi_amd
 from torbi_amd import viterbi, synth
 dev = torch.device('cuda:0')
-for B, T, S in ((512, 500, 1440), (4096, 250, 1440), (512, 500, 1024), (128, 2000, 4096), (1, 500, 1440), (16, 500, 1440), (64, 5000, 360), (2048, 300, 64)):
+SHAPES = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:]]      # e.g. 512x500x1440; default: the list below
+for B, T, S in SHAPES or ((512, 500, 1440), (4096, 250, 1440), (512, 500, 1024), (128, 2000, 4096), (1, 500, 1440), (16, 500, 1440), (64, 5000, 360), (2048, 300, 64)):
     obs = viterbi.fill_synthetic((B, T, S), synth.STREAM_OBSERVATION, device=dev)
     init = viterbi.fill_synthetic((S,), synth.STREAM_INITIAL, device=dev)
     frames = torch.full((B,), T, dtype=torch.int32, device=dev)
