@@ -1311,6 +1311,52 @@ def test_concurrent_host_threads_on_separate_streams():
     assert not errors, errors
 
 
+def test_host_threads_share_one_kept_preparation():
+    """Four host threads, each on its own stream, call decode() WITHOUT a workspace on the SAME transition tensor at the same
+    time: one of them fills the preparation kept with the tensor (torbi_amd/viterbi.py::_Preparation), the others wait for
+    that call to be enqueued and order their streams behind it with its event; every result equals the oracle, and one
+    buffer serves them all."""
+    import threading
+    from torbi_amd import state
+    dev = torch.device('cuda:0')
+    S, T = 360, 12
+    _, trans, init = synth.problem(1, 1, S, seed=31)
+    d_trans, d_init = torch.tensor(trans, device=dev), torch.tensor(init, device=dev)
+    jobs = []
+    for k, B in enumerate((40, 33, 64, 21)):
+        obs = synth.scores(synth.STREAM_OBSERVATION, (B, T, S), seed=300 + k)
+        frames = np.clip(synth.lengths(B, 1, T, seed=k), 1, T)
+        jobs.append((obs, frames, oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())))
+    if viterbi.forward_path(40, S) not in viterbi.TIME_RESIDENT:
+        pytest.skip('this forced path keeps no preparation')
+    errors, start = [], threading.Barrier(len(jobs))
+
+    def work(job):
+        try:
+            obs, frames, want = job
+            stream = torch.cuda.Stream(device=dev)
+            d_obs, d_frames = torch.tensor(obs, device=dev), torch.tensor(frames, device=dev)
+            torch.cuda.synchronize(dev)
+            start.wait()
+            with torch.cuda.stream(stream):
+                for _ in range(10):
+                    got = torbi_amd.decode(d_obs, d_frames, d_trans, d_init)
+                    if not np.array_equal(got.cpu().numpy(), want):
+                        errors.append('indices differ from the oracle')
+                        return
+        except Exception as exc:
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=work, args=(job,)) for job in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    kept = [v for k, v in state.peek(d_trans).items() if isinstance(k, tuple) and k[0] == 'preparation']
+    assert len(kept) == 1 and kept[0].filled is not None
+
+
 # ---- vectors produced by the reference's own Python on its CPU operator (tests/golden/generate_api.py) -------
 
 API = np.load(__import__('conftest').GOLDEN + '/golden_api.npz')
