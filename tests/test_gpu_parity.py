@@ -285,6 +285,27 @@ def test_one_workgroup_per_sequence_up_to_256_states(S):
     np.testing.assert_array_equal(gpu_decode(obs, frames, trans, init), oracle.decode(obs, frames, trans, init))
 
 
+def test_every_state_count_up_to_256(forward):
+    """Every S in 2..256 once (each template instance of small_states.hpp at its edges: padded state counts, the pieces
+    of the prev-states, workgroups of 4 / 9 / 16 waves), a ragged 5 x 23 batch of coarse-grid scores with -inf entries."""
+    if forward != 'auto':
+        pytest.skip('the one-launch kernels are what AUTO runs')
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(256)
+    B, T = 5, 23
+    frames = np.array([23, 1, 22, 9, 17], np.int32)
+    for S in range(2, 257):
+        obs = -rng.integers(0, 7, size=(B, T, S)).astype(np.float32)
+        trans = -rng.integers(0, 6, size=(S, S)).astype(np.float32)
+        trans[rng.random((S, S)) < 0.15] = -np.inf
+        init = -rng.integers(0, 3, size=(S,)).astype(np.float32)
+        want = oracle.decode(obs, frames, trans, init)
+        got = torbi_amd.decode(torch.tensor(obs, device=dev), torch.tensor(frames, device=dev), torch.tensor(trans, device=dev),
+                               torch.tensor(init, device=dev))
+        assert viterbi.forward_path(B, S) == 'small'
+        np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f'S = {S}')
+
+
 def test_forward_path_selection(forward):
     assert viterbi.forward_path(4, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'pruned': 'rows'}.get(forward, 'generic')
     assert viterbi.forward_path(3, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'pruned': 'rows',
