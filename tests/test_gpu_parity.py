@@ -166,6 +166,34 @@ def test_uniform_transition_entry_equals_materialised_matrix(shape, kind):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+def test_uniform_entry_at_every_state_count_it_takes(forward):
+    """Multiples of 4 up to 516 and the edges of every template instance up to 4096 (a wave owns ceil(S / 256) float4 per
+    row): a ragged 3 x 19 batch, scores as they are and as probabilities, against the oracle on the materialised matrix."""
+    import math
+    if forward != 'auto':
+        pytest.skip('no forward path involved')
+    dev = torch.device('cuda:0')
+    B, T = 3, 19
+    frames = np.array([19, 1, 10], np.int32)
+    tiny = torch.finfo(torch.float32).tiny
+    for S in list(range(4, 520, 4)) + [1020, 1024, 1028, 1536, 1540, 2044, 2048, 2052, 3072, 3076, 4092, 4096]:
+        obs, _, init = synth.problem(B, T, S, seed=S)
+        c = np.float32(math.log(1. / S))
+        full = np.full((S, S), c, np.float32)
+        d_obs, d_frames, d_init = torch.tensor(obs, device=dev), torch.tensor(frames, device=dev), torch.tensor(init, device=dev)
+        got = torbi_amd.decode_uniform(d_obs, d_frames, float(c), d_init)
+        np.testing.assert_array_equal(got.cpu().numpy(), oracle.decode(obs, frames, full, init, num_threads=oracle.max_threads()),
+                                      err_msg=f'S = {S}')
+        probs = torch.softmax(d_obs, dim=-1)
+        scores = torch.log(probs)
+        scores.exp_()
+        scores += tiny
+        scores.log_()
+        got = torbi_amd.decode_uniform(probs, d_frames, float(c), d_init, probabilities=True)
+        want = oracle.decode(scores.cpu().numpy(), frames, full, init, num_threads=oracle.max_threads())
+        np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f'S = {S}, probabilities')
+
+
 @pytest.mark.parametrize('shape', [(3, 21, 1440), (40, 9, 360), (2, 5, 4096), (5, 12, 64)])
 def test_the_default_call_on_probabilities_is_one_pass_with_the_reference_s_values(shape):
     """from_probabilities(observation) with every default -- probabilities in, no transition, no initial -- runs log(), the
