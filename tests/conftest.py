@@ -35,7 +35,8 @@ def pytest_addoption(parser):
 PATH_BLIND = {'test_extension_is_loaded_and_sees_the_gpu', 'test_fused_epsilon_clamp_is_bit_identical_to_the_torch_ops',
               'test_fused_log_and_epsilon_clamp_is_bit_identical_to_the_torch_ops',
               'test_fill_synthetic_matches_numpy_definition', 'test_uniform_transition_entry_equals_materialised_matrix',
-              'test_the_default_call_on_probabilities_is_one_pass_with_the_reference_s_values'}
+              'test_the_default_call_on_probabilities_is_one_pass_with_the_reference_s_values',
+              'test_uniform_entry_at_every_state_count_it_takes', 'test_every_state_count_up_to_256'}
 LARGE_BATCHES_ONLY = {'cluster', 'pruned'}
 SAME_AS_AUTO = {'test_minus_inf_observations_on_the_large_batch_paths': LARGE_BATCHES_ONLY,
                 'test_pruned_path_adversarial_inputs': LARGE_BATCHES_ONLY,
