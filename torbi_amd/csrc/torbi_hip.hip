@@ -77,106 +77,6 @@ __global__ __launch_bounds__(256) void init_posterior_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// One timestep for all batch items as a tiled (max,+) GEMM.        (viterbi.cpp:78-108)
-//   tile = BM batch items x BN next-states, contraction over prev-state i in chunks of BK
-//   256 threads as 16 (ty: batch) x 16 (tx: state); each thread owns 4 x 4 outputs:
-//     b = b0 + 4*ty + bb,   j = j0 + tx + 16*jj
-//   LDS images keep the global orientation ([row][k], k contiguous, +4 pad): fragment reads
-//   are ds_read_b128 along k, conflict-free for the 16 distinct transition rows of a lane
-//   group (row stride 36 dwords -> 16 distinct 4-bank slots) and broadcast for the batch rows.
-//   The running (max, argmax) per output is the reference's own scan: k ascends, strict '>'.
-// ---------------------------------------------------------------------------------------
-template <int BM, int BN, int BK>
-__global__ __launch_bounds__(256) void step_tile_kernel(
-    const float *__restrict__ obs, const int32_t *__restrict__ frames,
-    const float *__restrict__ trans, const float *__restrict__ pcur, float *__restrict__ pnext,
-    int32_t *__restrict__ trellis, int B, int T, int S, int t) {
-    static_assert(BM == 64 && BN == 64 && BK % 4 == 0, "thread map assumes 64x64 tiles");
-    constexpr int LD = BK + 4;
-    __shared__ __attribute__((aligned(16))) float Ps[BM * LD];
-    __shared__ __attribute__((aligned(16))) float Ts[BN * LD];
-    __shared__ int any_live;
-
-    const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
-    const int b0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
-
-    // skip tiles whose batch items have all ended (t >= batch_frames[b])
-    if (tid == 0) any_live = 0;
-    __syncthreads();
-    if (tid < BM && b0 + tid < B && t < frames[b0 + tid]) any_live = 1;
-    __syncthreads();
-    if (!any_live) return;
-
-    float best[4][4];
-    int arg[4][4];
-#pragma unroll
-    for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) { best[bb][jj] = -INFINITY; arg[bb][jj] = 0; }
-
-    for (int k0 = 0; k0 < S; k0 += BK) {
-        // stage: BM x BK posterior values and BN x BK transition values, k contiguous
-#pragma unroll
-        for (int r = 0; r < BM * BK / 256; ++r) {
-            const int e = tid + 256 * r;
-            const int row = e / BK, col = e % BK;
-            const int k = k0 + col;
-            const int b = b0 + row;
-            float v = -INFINITY;                       // k >= S: can never win a strict '>'
-            if (k < S) v = (b < B) ? pcur[(size_t)b * S + k] : 0.0f;
-            Ps[row * LD + col] = v;
-        }
-#pragma unroll
-        for (int r = 0; r < BN * BK / 256; ++r) {
-            const int e = tid + 256 * r;
-            const int row = e / BK, col = e % BK;
-            const int k = k0 + col;
-            const int j = j0 + row;
-            Ts[row * LD + col] = (k < S && j < S) ? trans[(size_t)j * S + k] : 0.0f;
-        }
-        __syncthreads();
-
-#pragma unroll 2
-        for (int kk = 0; kk < BK; kk += 4) {
-            float4 p[4], q[4];
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb)
-                p[bb] = *reinterpret_cast<const float4 *>(&Ps[(4 * ty + bb) * LD + kk]);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                q[jj] = *reinterpret_cast<const float4 *>(&Ts[(tx + 16 * jj) * LD + kk]);
-            const int k = k0 + kk;
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    float c;
-                    c = p[bb].x + q[jj].x; if (c > best[bb][jj]) { best[bb][jj] = c; arg[bb][jj] = k; }
-                    c = p[bb].y + q[jj].y; if (c > best[bb][jj]) { best[bb][jj] = c; arg[bb][jj] = k + 1; }
-                    c = p[bb].z + q[jj].z; if (c > best[bb][jj]) { best[bb][jj] = c; arg[bb][jj] = k + 2; }
-                    c = p[bb].w + q[jj].w; if (c > best[bb][jj]) { best[bb][jj] = c; arg[bb][jj] = k + 3; }
-                }
-        }
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int bb = 0; bb < 4; ++bb) {
-        const int b = b0 + 4 * ty + bb;
-        if (b >= B || t >= frames[b]) continue;
-        const size_t row = ((size_t)b * T + t) * S;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int j = j0 + tx + 16 * jj;
-            if (j >= S) continue;
-            trellis[row + j] = arg[bb][jj];
-            pnext[(size_t)b * S + j] = obs[row + j] + best[bb][jj];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
 // One timestep, small-batch form: grid = (state tiles, batch items); each wave owns 4
 // next-states, its 64 lanes stride the prev-state axis (coalesced transition-row reads,
 // posterior row staged once in LDS), then a wave (value,index) reduction that keeps the
@@ -941,18 +841,13 @@ hipError_t launch_forward(const float *obs, const int32_t *frames, const float *
         hipLaunchKernelGGL(init_posterior_kernel, dim3(grid), dim3(256), 0, stream, obs, init,
                            w.post[0], B, T, S);
     }
-    // the 64 x 64 tile kernel only pays for many items over a tiny state space; everything else that lands here
-    // (B < 32, or shapes the value-only paths do not take) runs one workgroup per (rows, item)
-    const bool tiled = B >= 64 && S < 64;
+    // one workgroup per (rows, item).  (Rounds 1-3 had a 64 x 64 tile kernel here for many items over fewer than 64
+    // states; those shapes are decoded in one launch by small_states.hpp now.)
     int n = 0;
     for (int t = 1; t < T; ++t) {
         const float *pc = w.post[(t - 1) & 1];
         float *pn = w.post[t & 1];
-        if (tiled) {
-            dim3 grid((S + 63) / 64, (B + 63) / 64);
-            hipLaunchKernelGGL((step_tile_kernel<64, 64, 32>), grid, dim3(256), 0, stream, obs,
-                               frames, trans, pc, pn, w.trellis, B, T, S, t);
-        } else if (S % 4 == 0 && S >= 256 && (reinterpret_cast<uintptr_t>(trans) & 15) == 0) {
+        if (S % 4 == 0 && S >= 256 && (reinterpret_cast<uintptr_t>(trans) & 15) == 0) {
             dim3 grid((S + 3) / 4, B);
             hipLaunchKernelGGL(step_rows4_kernel, grid, dim3(256), sizeof(float) * (size_t)S,
                                stream, obs, frames, trans, pc, pn, w.trellis, B, T, S, t);
@@ -1540,7 +1435,7 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
             e = launch_backtrace_sorted(w.hist, w.sorted, w.SpP, pruned::kNB, trans, frames, out, B, T, S, s, w.rowmax);
     } else {
         const Workspace w = carve(workspace, B, T, S);
-        TORBI_NOTE_KERNEL(route == ROUTE_HELD ? "held::held_forward_kernel" : "step_rows_kernel / step_tile_kernel");
+        TORBI_NOTE_KERNEL(route == ROUTE_HELD ? "held::held_forward_kernel" : "step_rows_kernel / step_rows4_kernel");
         e = route == ROUTE_HELD ? launch_held_forward(obs, frames, trans, init, w, B, T, S, s, launches)
                                 : launch_forward(obs, frames, trans, init, w, B, T, S, s, launches);
         if (ev) (void)hipEventRecord(ev[1], s);
