@@ -393,7 +393,7 @@ class Bench:
                                             f'(the reference default, transition=None; secondary workload)'}
             result['roofline'] = {'bound': 'hbm', 'achieved': nbytes / per / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                   'frac': nbytes / per / 1e9 / HBM_PEAK_GBS, 'traffic': None,
-                                  'kernel': 'uniform_decode_kernel (whole decode, host-timed incl. launch)',
+                                  'kernel': 'uniform::uniform_rows_kernel (whole decode, host-timed incl. launch)',
                                   'algorithmic_bytes_per_launch': nbytes}
             return result
 
