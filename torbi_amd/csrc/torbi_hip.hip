@@ -1680,10 +1680,20 @@ int decode_uniform_as(const float *observation, const int32_t *batch_frames, flo
     hipStream_t s = static_cast<hipStream_t>(stream);
     // a wave per observation row, the reductions off the dependent chain (uniform_decode.hpp); R rows per wave and chunk:
     // 1, 2 and 3 run alike (0.27 ms at 512 x 500 x 1440), 4 spills
+    // at most one workgroup per compute unit: the rows in flight per item are the only parallelism there is -- 16 waves
+    // per workgroup (8 above 2048 states: 128 registers a lane do not hold two rows there).  tools/uniform_probe.py, ms per
+    // 500 x 1440 decode, 16 / 4 waves: 1 item 0.081 / 0.148, 128: 0.107 / 0.160, 256: 0.141 / 0.206; two 8-wave workgroups
+    // per unit for 257..512 items run like the 4-wave ones
+    const bool few = B <= cu_count(device);
 #define TORBI_UNIFORM_ROWS(NQW_, R_)                                                                     \
     if (S <= 256 * NQW_) {                                                                               \
-        hipLaunchKernelGGL((uniform::uniform_rows_kernel<NQW_, R_, PROBS>), dim3(B), dim3(256), 0, s,    \
-                           observation, batch_frames, initial, log_transition, indices_out, B, T, S);    \
+        constexpr int NWF = NQW_ <= 8 ? 16 : 8;                                                          \
+        if (few)                                                                                         \
+            hipLaunchKernelGGL((uniform::uniform_rows_kernel<NQW_, 1, PROBS, NWF>), dim3(B), dim3(64 * NWF), 0, s, \
+                               observation, batch_frames, initial, log_transition, indices_out, B, T, S); \
+        else                                                                                             \
+            hipLaunchKernelGGL((uniform::uniform_rows_kernel<NQW_, R_, PROBS>), dim3(B), dim3(256), 0, s, \
+                               observation, batch_frames, initial, log_transition, indices_out, B, T, S); \
         mark_decode_end(device, s);                                                                      \
         return (int)hipGetLastError();                                                                   \
     }
