@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TORBI_HIP_ABI_VERSION 13
+#define TORBI_HIP_ABI_VERSION 14
 
 #define TORBI_HIP_OK 0
 #define TORBI_HIP_EINVAL (-1)      /* null pointer / non-positive dimension            */
@@ -104,6 +104,12 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
  *   HELD      B <= 16, S <= 4096: the reference's scan with the time loop inside ONE launch: ceil(S / 8) workgroups
  *             hold 8 rows of the matrix each in registers for the whole launch and pass the posterior rows to each
  *             other through 8-byte {value, timestep} words (held_matrix_forward.hpp).
+ *   BAND      (ABI 14; torbi_hip_viterbi_decode_banded only, which is told the band) a transition matrix that is -inf outside a
+ *             band j - reach_left <= i <= j + reach_right -- the reference's own pitch model, torbi/evaluate/core.py:24-33 --
+ *             with the time loop inside ONE launch: R workgroups share a 16-item tile, each keeps its slab of the band
+ *             (diagonal-major), its window of the previous posterior row and nothing else in the LDS, evaluates every cell
+ *             inside the band and none outside, and receives the hl + hr rows it needs from its two neighbours as
+ *             self-validating 16-byte granules while it works on the cells that need only its own rows (band_forward.hpp).
  * AUTO: SMALL up to 64 states (up to 256 for batches that are not huge); else RESIDENT when the call's tiles fill more than half the compute units; CLUSTER for any other batch of more than
  * 16 items (64 <= S <= 4096: one batch = one forward launch); HELD up to three items (eight above 2048 states); ROWS for
  * 6..16 items (and above 2048 states); DENSE for large batches outside 64..4096 states; else GENERIC.  (The Python layer
@@ -114,7 +120,8 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
  * TORBI_HIP_FORWARD=dense|pruned|resident|cluster|held, else AUTO).  A path that does not cover the shape falls
  * back as AUTO would.  A workspace of torbi_hip_workspace_bytes() fits every path.
  * torbi_hip_forward_path_on reports what a (B, S) batch would run on `device` with `flags`:
- * 0 generic, 1 dense, 3 resident, 4 rows, 5 cluster, 6 held, 7 small (2 is retired); torbi_hip_forward_path is the same for device 0,
+ * 0 generic, 1 dense, 3 resident, 4 rows, 5 cluster, 6 held, 7 small (2 is retired; 8 = band is reported by
+ * torbi_hip_viterbi_decode_banded's phase_ms[3] and by the route record only); torbi_hip_forward_path is the same for device 0,
  * flags 0.
  */
 #define TORBI_HIP_FORWARD_AUTO 0
@@ -123,6 +130,7 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
 #define TORBI_HIP_FORWARD_RESIDENT 3
 #define TORBI_HIP_FORWARD_CLUSTER 4
 #define TORBI_HIP_FORWARD_HELD 5       /* B <= 16, S <= 4096: ONE launch, the matrix held in registers across the chip */
+#define TORBI_HIP_FORWARD_BAND 6       /* (ABI 14) banded matrices through torbi_hip_viterbi_decode_banded; elsewhere = AUTO */
 #define TORBI_HIP_PATH_FLAG(path) (((unsigned)(path) + 1u) << 4)   /* bits 4..6 of `flags`; 0 = process default */
 int torbi_hip_set_forward_path(int path);
 int torbi_hip_forward_path(int B, int S);
@@ -224,6 +232,35 @@ size_t torbi_hip_preparation_bytes(int S);
 int torbi_hip_viterbi_decode_batches_prepared(const torbi_hip_batch *batches, int count, const float *transition,
                                               const float *initial, int S, int device, void *stream, unsigned flags,
                                               float *phase_ms, void *preparation, size_t preparation_bytes, int *filled);
+
+/*
+ * (ABI 14) Banded transition matrices.  No counterpart in the reference's operator, which walks all S x S cells whatever
+ * the matrix holds (viterbi.cpp:81-104, viterbi.cu:89-117); its evaluation workload is banded all the same
+ * (torbi/evaluate/core.py:24-33: at most 175 finite entries per 1440-state row).
+ *
+ * torbi_hip_band_reach: the smallest reach_left / reach_right such that transition[j][i] == -inf whenever i < j - reach_left
+ * or i > j + reach_right (0 / 0 for a matrix without any finite entry).  Runs one small kernel over the matrix on
+ * `stream` and SYNCHRONISES it: call it once per matrix and keep the answer.
+ *
+ * torbi_hip_band_members: workgroups per 16-item tile the band kernel would use for `items` sequences with that band on
+ * `device` (1 .. 16), or 0 when it does not cover the shape -- S % 4 == 0, 64 <= S <= 3072, a member's slab of the band
+ * + window + merge buffer within the 160 KB LDS (at 1440 states: reach_left + reach_right <= 175 with 8 members per tile,
+ * up to 16 members for fewer than 16 tiles), each reach at most a member's share of the states, reach_left + reach_right <= 508.
+ *
+ * torbi_hip_viterbi_decode_banded: torbi_hip_viterbi_decode_batches for a matrix whose band the caller states -- a
+ * PROMISE: finite entries outside it are ignored, the decoded indices then differ from the reference's.  Same arguments,
+ * same workspaces (torbi_hip_workspace_bytes covers the route), same phase_ms (phase_ms[3] = 8 when the band kernel ran).
+ * `transition` must be 16-byte aligned for the band kernel.  The band kernel runs for TORBI_HIP_FORWARD_AUTO and
+ * TORBI_HIP_FORWARD_BAND when its plan covers the group -- under AUTO except for shapes SMALL decodes and for the handful
+ * of sequences HELD takes --; otherwise, and for every other named path, the call IS torbi_hip_viterbi_decode_batches
+ * (BAND named: as AUTO).  Waits inside the launch are bounded and repaired as in the CLUSTER form (give-ups are counted
+ * in torbi_hip_scan_stats [127]; TORBI_HIP_CLUSTER_WAIT_US overrides the budget).
+ */
+int torbi_hip_band_reach(const float *transition, int S, int device, void *stream, int *reach_left_out, int *reach_right_out);
+int torbi_hip_band_members(int items, int S, int reach_left, int reach_right, int device);
+int torbi_hip_viterbi_decode_banded(const torbi_hip_batch *batches, int count, const float *transition, const float *initial,
+                                    int S, int reach_left, int reach_right, int device, void *stream, unsigned flags,
+                                    float *phase_ms);
 
 /*
  * Scan statistics for adaptive path selection (torbi_amd/viterbi.py uses them): copies 128 uint32 to `stats_out`

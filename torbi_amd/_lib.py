@@ -16,7 +16,7 @@ SOURCE = os.path.join(_HERE, 'csrc', 'torbi_hip.hip')
 INCLUDE = os.path.join(ROOT, 'include')
 # TORBI_HIP_LIBRARY: an alternative build of the library (tools/variants_probe.py: -D experiments)
 LIBRARY = os.environ.get('TORBI_HIP_LIBRARY') or os.path.join(_HERE, 'libtorbi_hip.so')
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 # every symbol include/torbi_hip.h declares: name -> (restype, argtypes)
 _c = ctypes
@@ -41,6 +41,12 @@ SYMBOLS = {
         _c.POINTER(_c.c_float)]),
     'torbi_hip_viterbi_decode_batches': (_c.c_int, [
         _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint,
+        _c.POINTER(_c.c_float)]),
+    'torbi_hip_band_reach': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.POINTER(_c.c_int),
+                                        _c.POINTER(_c.c_int)]),
+    'torbi_hip_band_members': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    'torbi_hip_viterbi_decode_banded': (_c.c_int, [
+        _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint,
         _c.POINTER(_c.c_float)]),
     'torbi_hip_preparation_bytes': (_c.c_size_t, [_c.c_int]),
     'torbi_hip_viterbi_decode_batches_prepared': (_c.c_int, [

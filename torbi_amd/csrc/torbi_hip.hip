@@ -34,6 +34,7 @@
 #include "small_batch_forward.hpp"
 #include "held_matrix_forward.hpp"
 #include "small_states.hpp"
+#include "band_forward.hpp"
 #include "file_rows.hpp"
 
 namespace {
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256) void gather_final_kernel(const int32_t *__rest
 __global__ __launch_bounds__(128) void gather_stats_kernel(const int32_t *__restrict__ route, const unsigned *__restrict__ resident_stats,
                                                            const unsigned *__restrict__ held_control, unsigned *__restrict__ dst) {
     const int r = *route;
-    const unsigned *src = (r == 3 || r == 5) ? resident_stats : nullptr;
+    const unsigned *src = (r == 3 || r == 5 || r == 8) ? resident_stats : nullptr;      // (band launches count their give-ups in [127] too)
     unsigned v = src ? src[threadIdx.x] : 0u;
     // held-matrix launch: [127] = workgroups that gave up waiting (the decode was then repaired; 0 on any sane run)
     if (r == 6 && held_control && threadIdx.x == 127) v = held_control[1];
@@ -489,7 +490,7 @@ thread_local char g_last_kernel[160] = "";
 // keep the posterior history and recompute backpointers along the decoded path (lazy_backtrace.hpp).  (2 was the
 // per-timestep tile kernel of the pruned recurrence, removed in round 4: no route has the number any more.)
 enum Route { ROUTE_GENERIC = 0, ROUTE_DENSE = 1, ROUTE_PRUNED = 2, ROUTE_RESIDENT = 3, ROUTE_ROWS = 4, ROUTE_CLUSTER = 5,
-             ROUTE_HELD = 6, ROUTE_SMALL = 7 };
+             ROUTE_HELD = 6, ROUTE_SMALL = 7, ROUTE_BAND = 8 };
 
 inline bool use_dense(int B, int S) { return B >= 32 && S >= 64; }
 
@@ -505,7 +506,8 @@ inline int default_path() {
                : e[0] == 'p' ? TORBI_HIP_FORWARD_PRUNED
                : e[0] == 'r' ? TORBI_HIP_FORWARD_RESIDENT
                : e[0] == 'c' ? TORBI_HIP_FORWARD_CLUSTER
-               : e[0] == 'h' ? TORBI_HIP_FORWARD_HELD : TORBI_HIP_FORWARD_AUTO;
+               : e[0] == 'h' ? TORBI_HIP_FORWARD_HELD
+               : e[0] == 'b' ? TORBI_HIP_FORWARD_BAND : TORBI_HIP_FORWARD_AUTO;
         g_forward_path.store(v, std::memory_order_relaxed);
     }
     return v;
@@ -518,7 +520,7 @@ inline int requested_path(unsigned flags) {
 constexpr unsigned kKnownFlags = TORBI_HIP_REUSE_TRANSITION | TORBI_HIP_COLLECT_STATS | (7u << 4) | TORBI_HIP_SHORTEST_FIRST |
                                  TORBI_HIP_FEW_SEEDS | TORBI_HIP_MANY_SEEDS;
 inline bool flags_ok(unsigned flags) {
-    return !(flags & ~kKnownFlags) && ((flags >> 4) & 7u) <= (unsigned)TORBI_HIP_FORWARD_HELD + 1u;
+    return !(flags & ~kKnownFlags) && ((flags >> 4) & 7u) <= (unsigned)TORBI_HIP_FORWARD_BAND + 1u;
 }
 
 constexpr int kMaxGroupTiles = 16384;     // 16-item tiles one launch group may hold (262 144 items)
@@ -557,6 +559,7 @@ inline bool small_block_auto(int B, int S, int cus) {
     return small::block_supported(S) && (long long)B * S * S <= (3ll << 16) * cus;
 }
 inline Route route_for(int path, int B, int S, int cus, bool allow_held = true) {
+    if (path == TORBI_HIP_FORWARD_BAND) path = TORBI_HIP_FORWARD_AUTO;     // (a band is known to torbi_hip_viterbi_decode_banded only)
     const bool fits = resident_fits(S, tiles_of(B, S));
     // up to 64 states a wavefront decodes a sequence on its own, time loop and backtrace in one launch (small_states.hpp)
     // ... up to 256 a workgroup does (the matrix in the registers of one compute unit), while the batch is not so large that
@@ -707,6 +710,30 @@ inline ResidentWorkspace carve_resident(void *base, int B, int T, int S, int cus
     return w;
 }
 
+// the band route (band_forward.hpp): the time-resident layout's history, tile map, statistics and item order, and BEHIND that
+// layout the batch's exchange buffers and (first batch of a launch) the tickets and the give-up flags of the tiles
+inline bool band_shape(int S) { return S % 4 == 0 && resident::supported(S) && S <= 64 * band::kMaxBlocks * band::kMaxR; }
+struct BandWorkspace {
+    ResidentWorkspace base;
+    char *xchg;
+    size_t xchg_bytes;
+    unsigned *words;      // [0] tickets, [16 ..] failed[kMaxGroupTiles]
+    size_t bytes;
+};
+inline BandWorkspace carve_band(void *base, int B, int T, int S, int cus) {
+    BandWorkspace w;
+    void *const kept = g_preparation;
+    g_preparation = nullptr;                     // (the band route keeps nothing in a caller's preparation buffer)
+    w.base = carve_resident(base, B, T, S, cus);
+    g_preparation = kept;
+    char *p = static_cast<char *>(base) + w.base.bytes;
+    w.xchg_bytes = align_up(band::xchg_bytes(B, S), 256);
+    w.xchg = p;
+    w.words = reinterpret_cast<unsigned *>(p + w.xchg_bytes);
+    w.bytes = w.base.bytes + w.xchg_bytes + sizeof(unsigned) * (kMaxGroupTiles + 64);
+    return w;
+}
+
 // small batches (B <= 16): history + sorted rows (small_batch_forward.hpp)
 struct RowsWorkspace {
     float *hist;
@@ -790,6 +817,7 @@ inline size_t layout_bytes(int B, int T, int S, int cus) {
     if (use_dense(B, S)) need = std::max(need, carve_dense(nullptr, B, T, S, cus).bytes);
     if (resident::supported(S)) need = std::max(need, carve_resident(nullptr, B, T, S, cus).bytes);
     if (rowscan::supported(B, S)) need = std::max(need, carve_rows(nullptr, B, T, S).bytes);
+    if (band_shape(S)) need = std::max(need, carve_band(nullptr, B, T, S, cus).bytes);
     return align_up(need, 256);
 }
 // ... plus the ROUTE RECORD behind every layout: the forward path the last decode with this workspace actually took
@@ -1373,6 +1401,120 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
     return hipGetLastError();
 }
 
+
+// ---- band route: several batches, one forward launch (band_forward.hpp), one backtrace launch ------------------------
+inline int band_tiles(int B) { return (B + band::kNI - 1) / band::kNI; }
+
+// batches with B > 0 only; tile map, statistics, tickets and give-up flags live in the first batch's workspace
+hipError_t run_band(const HostBatch *hb, int n, const float *trans, const float *init, int S, const band::Plan &pl, int cus,
+                    hipStream_t s, hipEvent_t *ev, int *launches, bool ascending) {
+    resident::Group grp{};
+    resident::OrderJobs jobs{};
+    band::Exchange ex{};
+    band::ClearJobs clear{};
+    jobs.ascending = ascending ? 1 : 0;
+    grp.n = n;
+    int tiles = 0, items = 0, widest = 0;
+    size_t most = 0;
+    for (int k = 0; k < n; ++k) {
+        resident::Batch &b = grp.batch[k];
+        const BandWorkspace wk = carve_band(hb[k].workspace, hb[k].B, hb[k].T, S, cus);
+        b.obs = hb[k].obs;
+        b.frames = hb[k].frames;
+        b.out = hb[k].out;
+        b.hist = wk.base.hist;
+        b.order = wk.base.order;
+        b.rowmax = wk.base.rowmax;
+        jobs.job[k] = resident::OrderJob{hb[k].frames, wk.base.order, hb[k].B, hb[k].T, tiles, wk.base.lengths_hist,
+                                         route_record(hb[k].workspace, hb[k].B, hb[k].T, S, cus), (int)ROUTE_BAND};
+        ex.xchg[k] = wk.xchg;
+        clear.xchg[k] = wk.xchg;
+        clear.bytes[k] = pl.R > 1 ? band::xchg_bytes(hb[k].B, S) : 0;
+        most = std::max(most, clear.bytes[k]);
+        widest = std::max(widest, hb[k].B);
+        b.B = hb[k].B;
+        b.T = hb[k].T;
+        b.tile0 = tiles;
+        b.item0 = items;
+        tiles += band_tiles(hb[k].B);
+        items += hb[k].B;
+    }
+    if (tiles > kMaxGroupTiles) return hipErrorInvalidValue;
+    const BandWorkspace w = carve_band(hb[0].workspace, hb[0].B, hb[0].T, S, cus);
+    grp.tile_map = w.base.tile_map;
+    grp.stats = w.base.stats;
+    jobs.stats = w.base.stats;
+    jobs.n = n;
+    jobs.tiles = tiles;
+    jobs.tile_map = w.base.tile_map;
+    jobs.ni = band::kNI;
+    ex.control = w.words;
+    ex.failed = w.words + 16;
+    const char *wait_env = getenv("TORBI_HIP_CLUSTER_WAIT_US");         // (read per launch: the tests switch it)
+    ex.wait_ticks = wait_env ? 100ull * strtoull(wait_env, nullptr, 10) : resident::kClusterWaitTicks;
+    clear.words = w.words;
+    clear.nwords = 16 + tiles;
+    clear.n = n;
+    if (ev) (void)hipEventRecord(ev[0], s);
+    hipLaunchKernelGGL(resident::order_items_kernel, dim3((widest + 255) / 256, n), dim3(256), 0, s, jobs);
+    for (int k = 0; k < n; ++k) {            // batches too large for the all-pairs ranking: counting sort over the lengths
+        const resident::OrderJob &jb = jobs.job[k];
+        if (jb.B <= resident::kMaxOrdered) continue;
+        const BandWorkspace wk = carve_band(hb[k].workspace, hb[k].B, hb[k].T, S, cus);
+        hipError_t me = hipMemsetAsync(wk.base.lengths_hist, 0, wk.base.lengths_hist_bytes, s);
+        if (me != hipSuccess) return me;
+        hipLaunchKernelGGL(resident::order_large_count_kernel, dim3((jb.B + 255) / 256), dim3(256), 0, s, jb);
+        hipLaunchKernelGGL(resident::order_large_scan_kernel, dim3(1), dim3(1024), 0, s, jb, jobs.ascending);
+        hipLaunchKernelGGL(resident::order_large_place_kernel, dim3((jb.B + 255) / 256), dim3(256), 0, s, jb);
+    }
+    hipLaunchKernelGGL(resident::order_tiles_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, jobs);
+    {
+        const size_t blocks = std::max<size_t>(1, std::min<size_t>(2048, (most / 16 + 255) / 256));
+        hipLaunchKernelGGL(band::clear_exchange_kernel, dim3((unsigned)blocks, n), dim3(256), 0, s, clear);
+    }
+    if (ev) (void)hipEventRecord(ev[3], s);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&band::band_forward_kernel), (size_t)pl.lds_bytes);
+    if (e != hipSuccess) return e;
+    TORBI_NOTE_KERNEL("band::band_forward_kernel");
+    hipLaunchKernelGGL(band::band_forward_kernel, dim3(tiles * pl.R), dim3(64 * pl.waves), (size_t)pl.lds_bytes, s, grp, ex, pl,
+                       trans, init);
+    if (pl.R > 1) {          // does nothing unless a member gave up waiting (band_forward.hpp)
+        const size_t lds = 32 * (size_t)S;
+        e = ensure_dynamic_lds(reinterpret_cast<const void *>(&band::band_repair_kernel), lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(band::band_repair_kernel, dim3(tiles), dim3(1024), lds, s, grp, ex.failed, trans, init, S, pl.hl,
+                           pl.hr);
+    }
+    if (launches) *launches = 1;
+    if (ev) (void)hipEventRecord(ev[1], s);
+    if (S <= 512)
+        hipLaunchKernelGGL(band::group_backtrace_band_kernel<2>, dim3(items), dim3(64), 0, s, grp, trans, S, pl.hl, pl.hr);
+    else if (S <= 1536)
+        hipLaunchKernelGGL(band::group_backtrace_band_kernel<6>, dim3(items), dim3(64), 0, s, grp, trans, S, pl.hl, pl.hr);
+    else if (S <= 2048)
+        hipLaunchKernelGGL(band::group_backtrace_band_kernel<8>, dim3(items), dim3(64), 0, s, grp, trans, S, pl.hl, pl.hr);
+    else
+        hipLaunchKernelGGL(band::group_backtrace_band_kernel<16>, dim3(items), dim3(64), 0, s, grp, trans, S, pl.hl, pl.hr);
+    if (ev) (void)hipEventRecord(ev[2], s);
+    return hipGetLastError();
+}
+
+// AUTO takes the band kernel for a promised band when its plan covers the group -- except for shapes a wavefront or a
+// workgroup decodes alone (small_states.hpp) and for the handful of sequences of the held-matrix kernel
+inline bool band_plan_for(const HostBatch *hb, int n, int S, int hl, int hr, int cus, int path, band::Plan &pl) {
+    if (path != TORBI_HIP_FORWARD_AUTO && path != TORBI_HIP_FORWARD_BAND) return false;
+    if (!band_shape(S)) return false;
+    int tiles = 0;
+    long long items = 0;
+    for (int k = 0; k < n; ++k) tiles += band_tiles(hb[k].B), items += hb[k].B;
+    if (tiles < 1 || tiles > kMaxGroupTiles) return false;
+    if (path == TORBI_HIP_FORWARD_AUTO) {
+        if (small::supported(S) || small_block_auto((int)std::min(items, 1ll << 30), S, cus)) return false;
+        if (n == 1 && held::supported(hb[0].B, S, cus) && held_auto(hb[0].B, S)) return false;
+    }
+    return band::make_plan(S, hl, hr, tiles, cus, pl);
+}
+
 // one decode on `s`; optional events bracket the forward and backtrace phases (ev[3]: end of the preparation)
 hipError_t run_decode(const float *obs, const int32_t *frames, const float *trans, const float *init,
                       int32_t *out, void *workspace, int B, int T, int S, int device, hipStream_t s,
@@ -1515,7 +1657,7 @@ int torbi_hip_last_forward_kernel(char *name_out, size_t capacity) {
 }
 
 int torbi_hip_set_forward_path(int path) {
-    if (path < TORBI_HIP_FORWARD_AUTO || path > TORBI_HIP_FORWARD_HELD) return TORBI_HIP_EINVAL;
+    if (path < TORBI_HIP_FORWARD_AUTO || path > TORBI_HIP_FORWARD_BAND) return TORBI_HIP_EINVAL;
     g_forward_path.store(path, std::memory_order_relaxed);
     return TORBI_HIP_OK;
 }
@@ -1625,6 +1767,88 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
         for (int k = 0; k < n && e == hipSuccess; ++k)
             e = run_decode(hb[k].obs, hb[k].frames, transition, initial, hb[k].out, hb[k].workspace, hb[k].B, hb[k].T, S,
                            device, s, nullptr, nullptr, reuse && k == 0, (flags & TORBI_HIP_COLLECT_STATS) != 0, path, flags);
+    mark_decode_end(device, s);
+    return (int)e;
+}
+
+
+int torbi_hip_band_reach(const float *transition, int S, int device, void *stream, int *reach_left_out, int *reach_right_out) {
+    if (!transition || S < 1 || !reach_left_out || !reach_right_out) return TORBI_HIP_EINVAL;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return (int)guard.err;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int32_t *dev = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&dev), 2 * sizeof(int32_t));
+    if (e != hipSuccess) return (int)e;
+    int32_t host[2] = {0, 0};
+    e = hipMemsetAsync(dev, 0, 2 * sizeof(int32_t), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(band::band_reach_kernel, dim3(S), dim3(64), 0, s, transition, dev, S);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return (int)e;
+    *reach_left_out = host[0];
+    *reach_right_out = host[1];
+    return TORBI_HIP_OK;
+}
+
+int torbi_hip_band_members(int items, int S, int reach_left, int reach_right, int device) {
+    if (items < 1 || S < 1 || reach_left < 0 || reach_right < 0) return TORBI_HIP_EINVAL;
+    band::Plan pl;
+    if (!band_shape(S) || !band::make_plan(S, reach_left, reach_right, band_tiles(items), cu_count(device), pl)) return 0;
+    return pl.R;
+}
+
+int torbi_hip_viterbi_decode_banded(const torbi_hip_batch *batches, int count, const float *transition, const float *initial,
+                                    int S, int reach_left, int reach_right, int device, void *stream, unsigned flags,
+                                    float *phase_ms) {
+    if (!flags_ok(flags) || count < 0 || count > TORBI_HIP_MAX_BATCHES || S < 1 || reach_left < 0 || reach_right < 0)
+        return TORBI_HIP_EINVAL;
+    if (count == 0) return TORBI_HIP_OK;
+    if (!batches || !transition || !initial) return TORBI_HIP_EINVAL;
+    const int cus = cu_count(device);
+    HostBatch hb[TORBI_HIP_MAX_BATCHES];
+    int n = 0;
+    for (int k = 0; k < count; ++k) {
+        const torbi_hip_batch &b = batches[k];
+        const int rc = check_args(b.observation, b.batch_frames, transition, initial, b.indices_out, b.workspace,
+                                  b.workspace_bytes, b.B, b.T, S, device);
+        if (rc != TORBI_HIP_OK) return rc;
+        if (b.B == 0) continue;
+        hb[n++] = HostBatch{b.observation, b.batch_frames, b.indices_out, b.workspace, b.B, b.T};
+    }
+    band::Plan pl;
+    const int path = requested_path(flags);
+    const bool vec = (reinterpret_cast<uintptr_t>(transition) & 15) == 0;
+    if (n == 0 || !vec || !band_plan_for(hb, n, S, reach_left, reach_right, cus, path, pl)) {
+        // not a shape of the band kernel: whatever the plain entry point does with it (BAND named: as AUTO)
+        unsigned f = flags;
+        if (path == TORBI_HIP_FORWARD_BAND) f = (flags & ~(7u << 4)) | TORBI_HIP_PATH_FLAG(TORBI_HIP_FORWARD_AUTO);
+        return torbi_hip_viterbi_decode_batches(batches, count, transition, initial, S, device, stream, f, phase_ms);
+    }
+    if (phase_ms)
+        for (int i = 0; i < 6; ++i) phase_ms[i] = 0.0f;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return (int)guard.err;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool ascending = (flags & TORBI_HIP_SHORTEST_FIRST) != 0;
+    hipError_t e;
+    if (phase_ms) {
+        PhaseEvents pe;
+        if (pe.err != hipSuccess) return (int)pe.err;
+        int launches = 0;
+        e = run_band(hb, n, transition, initial, S, pl, cus, s, pe.ev, &launches, ascending);
+        mark_decode_end(device, s);
+        if (e == hipSuccess) e = pe.read(phase_ms);
+        phase_ms[2] = (float)launches;
+        phase_ms[3] = (float)ROUTE_BAND;
+        phase_ms[5] = (float)n;
+        return (int)e;
+    }
+    e = run_band(hb, n, transition, initial, S, pl, cus, s, nullptr, nullptr, ascending);
     mark_decode_end(device, s);
     return (int)e;
 }

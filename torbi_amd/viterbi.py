@@ -62,10 +62,20 @@ def _resolve_path(trans, transition, B, S, device, path, tiles, count=1, items=N
     forced = _forced_path if path is None else path
     if forced not in FORWARD_PATHS:
         raise ValueError(f'forward path must be one of {sorted(FORWARD_PATHS)}; got {forced!r}')
-    if forced != 'auto':
+    if forced not in ('auto', 'band'):
         return forced
-    if 2 <= S <= SMALL_STATES and forward_path(B if items is None else items, S, 'auto',
-                                               torch.device(device).index or 0) == 'small':
+    index = torch.device(device).index or 0
+    total = B if items is None else items
+    small = 2 <= S <= SMALL_STATES and forward_path(total, S, 'auto', index) == 'small'
+    if not (small and forced == 'auto'):
+        # a banded matrix (the reference's pitch model, torbi/evaluate/core.py:24-33) whose band the band kernel covers
+        # (csrc/band_forward.hpp): every finite cell and no other, the time loop inside one launch.  AUTO leaves the
+        # handful of sequences the held-matrix kernel decodes to it.
+        reach = band_reach(trans, transition, S)
+        if reach is not None and _lib.load().torbi_hip_band_members(int(total), S, reach[0], reach[1], index) > 0 \
+                and (forced == 'band' or not (count == 1 and forward_path(B, S, 'auto', index) == 'held')):
+            return 'band'
+    if small or forced == 'band':
         return 'auto'               # one wavefront / workgroup per sequence, whatever the matrix looks like (csrc/small_states.hpp)
     chosen = _choose_path(trans, transition, B, S)
     banded = chosen == 'dense'
@@ -181,6 +191,25 @@ def _watch_resident(transition, workspace, batch, frames, states, seeds=3) -> No
     known[1] = (stats, done)
 
 
+def band_reach(trans: torch.Tensor, original: torch.Tensor, states: int):
+    """(reach_left, reach_right) of a transition matrix the band kernel could take -- transition[j][i] is -inf unless
+    j - reach_left <= i <= j + reach_right (include/torbi_hip.h, torbi_hip_band_reach) -- else None.  One small kernel and
+    a host sync the first time a tensor version is seen; kept with the tensor's notes (torbi_amd/state.py)."""
+    if states % 4 or not 64 <= states <= BAND_MAX_STATES or not trans.is_cuda or trans.data_ptr() % 16:
+        return None
+    kept = state.notes(original)
+    found = kept.get(('band', states)) if kept is not None else None
+    if found is None:
+        left, right = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(_lib.load().torbi_hip_band_reach(trans.data_ptr(), states, trans.device.index or 0,
+                                                    ctypes.c_void_p(torch.cuda.current_stream(trans.device).cuda_stream),
+                                                    ctypes.byref(left), ctypes.byref(right)), 'torbi_hip_band_reach')
+        found = (left.value, right.value)
+        if kept is not None:
+            kept[('band', states)] = found
+    return found if found[0] + found[1] + 4 <= BAND_MAX_WINDOW else None
+
+
 def tiles_of(batch: int, states: int) -> int:
     """Tiles of a batch in the time-resident kernel: 16 items each up to 2048 states, 8 above (the posterior tile has to
     fit the 160 KB LDS; csrc/resident_forward.hpp)."""
@@ -233,8 +262,8 @@ def decode(
             TORBI_HIP_REUSE_TRANSITION)
         workspace: optional uint8 scratch tensor on the compute device with at least
             `workspace_bytes(N, T, S)` bytes; allocated from torch's caching allocator if None
-        path: forward recurrence for THIS call ('auto', 'dense', 'pruned', 'resident', 'cluster', 'held'; None = the
-            process default of `set_forward_path`).  Every path returns the same indices.
+        path: forward recurrence for THIS call ('auto', 'dense', 'pruned', 'resident', 'cluster', 'held', 'band'; None =
+            the process default of `set_forward_path`).  Every path returns the same indices.
 
     Return:
         indices: :math:`(N, T)` int32 decoded bin indices, on the device of `observation`
@@ -276,8 +305,18 @@ def decode(
         flags |= 1                                  # TORBI_HIP_REUSE_TRANSITION
     if chosen in TIME_RESIDENT:
         flags |= _seed_flag(transition, S)          # TORBI_HIP_FEW_SEEDS / _MANY_SEEDS once the scan depth is known
-    kept = _kept_preparation(transition, B, S, chosen, device, index) if own_scratch else None
-    if kept is not None:       # the per-call scratch is new every time; the preparation stays with the matrix
+    kept = _kept_preparation(transition, B, S, chosen, device, index) if own_scratch and chosen != 'band' else None
+    if chosen == 'band':
+        one = (_lib.Batch * 1)(_lib.Batch(obs.data_ptr(), frames.data_ptr(), indices.data_ptr(), workspace.data_ptr(),
+                                          workspace.numel(), B, T))
+        left, right = band_reach(trans, transition, S)
+        phases = (ctypes.c_float * 6)() if _profile is not None else None
+        _lib.check(lib.torbi_hip_viterbi_decode_banded(one, 1, trans.data_ptr(), init.data_ptr(), S, left, right, index,
+                                                       ctypes.c_void_p(stream), flags, phases),
+                   'torbi_hip_viterbi_decode_banded')
+        if _profile is not None:
+            _profile[:] = list(phases)
+    elif kept is not None:       # the per-call scratch is new every time; the preparation stays with the matrix
         one = (_lib.Batch * 1)(_lib.Batch(obs.data_ptr(), frames.data_ptr(), indices.data_ptr(), workspace.data_ptr(),
                                           workspace.numel(), B, T))
         phases = (ctypes.c_float * 6)() if _profile is not None else None
@@ -488,8 +527,13 @@ def decode_batches(
     if chosen in TIME_RESIDENT:
         flags |= _seed_flag(transition, S)         # TORBI_HIP_FEW_SEEDS / _MANY_SEEDS once the scan depth is known
     phases = (ctypes.c_float * 6)() if _profile is not None else None
-    kept = _kept_preparation(transition, largest, S, chosen, device, index) if own_scratch else None
-    if kept is not None:
+    kept = _kept_preparation(transition, largest, S, chosen, device, index) if own_scratch and chosen != 'band' else None
+    if chosen == 'band':
+        left, right = band_reach(trans, transition, S)
+        _lib.check(lib.torbi_hip_viterbi_decode_banded(table, count, trans.data_ptr(), init.data_ptr(), S, left, right, index,
+                                                       ctypes.c_void_p(stream), flags, phases),
+                   'torbi_hip_viterbi_decode_banded')
+    elif kept is not None:
         _lib.check(kept.call(device, lambda pointer, size, reuse, filled: lib.torbi_hip_viterbi_decode_batches_prepared(
             table, count, trans.data_ptr(), init.data_ptr(), S, index, ctypes.c_void_p(stream), flags | reuse, phases,
             pointer, size, filled)), 'torbi_hip_viterbi_decode_batches_prepared')
@@ -507,10 +551,12 @@ def decode_batches(
 
 SMALL_STATES = 256                            # small::kBlockMaxS
 TIME_RESIDENT = ('resident', 'cluster')       # the two forms of the time-resident kernel (include/torbi_hip.h)
-FORWARD_PATHS = {'auto': 0, 'dense': 1, 'pruned': 2, 'resident': 3, 'cluster': 4, 'held': 5}
+FORWARD_PATHS = {'auto': 0, 'dense': 1, 'pruned': 2, 'resident': 3, 'cluster': 4, 'held': 5, 'band': 6}
+BAND_MAX_STATES = 3072                        # 16 members x 192 next-states (csrc/band_forward.hpp)
+BAND_MAX_WINDOW = 512                         # band::kMaxWindow: reach_left + reach_right + 4 prev-states per backtrace step
 
 
-_forced_path = {'d': 'dense', 'p': 'pruned', 'r': 'resident', 'c': 'cluster', 'h': 'held'}.get(os.environ.get('TORBI_HIP_FORWARD', 'a')[:1], 'auto')
+_forced_path = {'d': 'dense', 'p': 'pruned', 'r': 'resident', 'c': 'cluster', 'h': 'held', 'b': 'band'}.get(os.environ.get('TORBI_HIP_FORWARD', 'a')[:1], 'auto')
 BANDED_RANGE = 0.25              # rows reaching less than this fraction of the states: dense + -inf skipping
 
 
@@ -578,7 +624,7 @@ def _choose_path(trans: torch.Tensor, original: torch.Tensor, batch: int, states
     return 'dense' if 0.0 < reach < BANDED_RANGE else 'pruned'
 
 
-ROUTES = {0: 'generic', 1: 'dense', 3: 'resident', 4: 'rows', 5: 'cluster', 6: 'held', 7: 'small'}      # (2: retired in round 4)
+ROUTES = {0: 'generic', 1: 'dense', 3: 'resident', 4: 'rows', 5: 'cluster', 6: 'held', 7: 'small', 8: 'band'}      # (2: retired in round 4)
 
 
 def forward_path(batch: int, states: int, path: Optional[str] = None, device: int = 0) -> str:
