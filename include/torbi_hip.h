@@ -250,7 +250,7 @@ int torbi_hip_viterbi_decode_batches_prepared(const torbi_hip_batch *batches, in
  * torbi_hip_viterbi_decode_banded: torbi_hip_viterbi_decode_batches for a matrix whose band the caller states -- a
  * PROMISE: finite entries outside it are ignored, the decoded indices then differ from the reference's.  Same arguments,
  * same workspaces (torbi_hip_workspace_bytes covers the route), same phase_ms (phase_ms[3] = 8 when the band kernel ran).
- * `transition` must be 16-byte aligned for the band kernel.  The band kernel runs for TORBI_HIP_FORWARD_AUTO and
+ * `transition` and the observations must be 16-byte aligned for the band kernel.  The band kernel runs for TORBI_HIP_FORWARD_AUTO and
  * TORBI_HIP_FORWARD_BAND when its plan covers the group -- under AUTO except for shapes SMALL decodes and for the handful
  * of sequences HELD takes --; otherwise, and for every other named path, the call IS torbi_hip_viterbi_decode_batches
  * (BAND named: as AUTO).  Waits inside the launch are bounded and repaired as in the CLUSTER form (give-ups are counted

@@ -24,9 +24,14 @@
 // item groups; the waves of a 64-next block split its diagonals four ways and merge through M.
 //
 // Halo.  Per timestep a member needs hl + hr rows x 16 items from its two neighbours.  They travel as self-validating
-// 16-byte granules {v0, tag, v1, tag} (tag = timestep + 1; write-through stores, L1-bypassing loads; the granule's two
-// 8-byte halves are each {value, tag}: MI355X_MICROARCH.md "R2's granule") through a per-tile exchange buffer by timestep
-// parity -- one trip, no flag, no fence.  Each wave evaluates the dquads that touch only its member's own rows FIRST (50-66 %
+// 16-byte granules {v0, tag, v1, tag} (tag = timestep + 1; the granule's two 8-byte halves are each {value, tag}:
+// MI355X_MICROARCH.md "R2's granule") through a per-tile exchange buffer by timestep parity -- one trip, no flag, no
+// fence.  The members of a tile are drawn from ONE dispatch class (workgroups b, b + 8, b + 16, ... -- the GPU places
+// them on one XCD) and say at kernel entry which XCD they run on: when all R agree the granules are PLAIN stores that stay
+// in that XCD's L2 and L1-bypassing loads that hit it (the exchange buffer is rewritten every other timestep and never
+// leaves the L2); when they do not -- nothing promises the placement -- write-through stores carry them across XCDs.
+// Write-through granules cost 2.2 of 9 us per timestep at 512 x 1440 (23 KB per workgroup and timestep, 5.9 MB across
+// the chip, every byte through the fabric; profiles/r05_band_ablations.txt).  Each wave evaluates the dquads that touch only its member's own rows FIRST (50-66 %
 // of its work), asks for the halo granules half-way through them, and only then waits: the hand-off (~1.5-2 us) hides
 // behind ~2 us of own-row work.  Membership is by arrival ticket as in the cluster form of resident_forward.hpp; every
 // wait is bounded (Exchange::wait_ticks), a member that gives up flags its tile and band_repair_kernel decodes it again
@@ -67,19 +72,23 @@ struct Plan {
     int ig_stride;           // floats between the item groups' windows (== 4 mod 64: conflict-free 16-byte reads)
     int td_off, w_off, m_off, misc_off, lds_bytes;
     int rounds;              // halo granules per thread and timestep
-    // per wave, in dquads: [0],[1] and [2],[3] the ones that read only the member's own rows (the halo granules are asked
-    // for between the two runs), [4],[5] and [6],[7] the ones that read halo rows
-    short seg[kMaxWaves][8];
+    // per wave, in dquads.  Before the halo is in the window: [0],[1) and [2],[3) read only the member's own rows (the halo
+    // granules are asked for between the two runs) -- the same number of dquads for every wave, so that no wave idles at
+    // the barrier in the middle of the timestep; behind it: [4],[5) the wave's other own-row dquads, [6],[7) and [8],[9)
+    // the ones that read halo rows
+    short seg[kMaxWaves][10];
 };
 
 struct Exchange {
-    char *xchg[resident::kMaxBatches];   // per batch: [tiles][2 parities][4 item groups][S][2][16 bytes]
-    unsigned *control;                   // [0] tickets drawn (zeroed before the launch)
+    char *xchg[resident::kMaxBatches];   // per batch: [tiles] x { [2 parities][16 items][2 halves][S / 4] granules of 16 bytes,
+                                         // [16] the members' XCDs + 1 (256 bytes) }
+    int tiles;                           // tiles of the group
+    unsigned *control;                   // [0 .. 7] tickets drawn per dispatch class (zeroed before the launch)
     unsigned *failed;                    // [tiles of the group] set by a member that gave up waiting (zeroed before the launch)
     unsigned long long wait_ticks;       // budget of one wait (100 MHz ticks)
 };
 
-__host__ __device__ inline size_t xchg_tile_bytes(int S) { return (size_t)2 * 4 * (size_t)S * 32; }
+__host__ __device__ inline size_t xchg_tile_bytes(int S) { return (size_t)2 * kNI * (size_t)S * 8 + 256; }
 __host__ __device__ inline size_t xchg_bytes(int B, int S) { return (size_t)((B + kNI - 1) / kNI) * xchg_tile_bytes(S); }
 
 // The plan for `tiles` tiles on `cus` compute units, or false when the band kernel does not cover the shape.
@@ -108,7 +117,7 @@ inline bool make_plan(int S, int hl, int hr, int tiles, int cus, Plan &pl) {
         p.misc_off = p.m_off + 16 * p.n_own * 4;
         p.lds_bytes = p.misc_off + 256;
         if (p.lds_bytes > kLdsBytes) continue;
-        p.rounds = R > 1 ? ((hl + hr) * 8 + 64 * p.waves - 1) / (64 * p.waves) : 0;
+        p.rounds = R > 1 ? (((hl + 1) / 2 + (hr + 1) / 2) * kNI + 64 * p.waves - 1) / (64 * p.waves) : 0;
         if (p.rounds > kMaxRounds) continue;
         if (best == 0 || R <= want) { best = R; found = p; }
         if (R >= want) break;
@@ -116,6 +125,7 @@ inline bool make_plan(int S, int hl, int hr, int tiles, int cus, Plan &pl) {
     if (best == 0) return false;
     pl = found;
     // the waves' dquads: per 64-next block the own-rows range [qa, qb) and the halo ranges [0, qa), [qb, Dq), four ways
+    int own[kMaxWaves][2], pre = Dq;
     for (int blk = 0; blk < pl.nblk; ++blk) {
         const int a_lo = 64 * blk, a_hi = std::min(64 * blk + 64, pl.n_own);
         int qa = 0, qb = Dq;
@@ -132,16 +142,22 @@ inline bool make_plan(int S, int hl, int hr, int tiles, int cus, Plan &pl) {
             short *sg = pl.seg[4 * blk + p];
             const int na = nA / 4 + (p < nA % 4 ? 1 : 0);
             const int nb = nB / 4 + (p >= 4 - nB % 4 ? 1 : 0);
-            const int a_mid = a_at + (na + 1) / 2;
-            sg[0] = (short)a_at; sg[1] = (short)a_mid; sg[2] = (short)a_mid; sg[3] = (short)(a_at + na);
+            own[4 * blk + p][0] = a_at;
+            own[4 * blk + p][1] = a_at + na;
+            pre = std::min(pre, na);
             a_at += na;
             // halo dquads in the order [0, qa) then [qb, Dq): b_at counts through their concatenation
             const int b_end = b_at + nb;
-            const int l0 = std::min(b_at, qa), l1 = std::min(b_end, qa);
-            const int r0 = std::max(b_at, qa) - qa + qb, r1 = std::max(b_end, qa) - qa + qb;
-            sg[4] = (short)l0; sg[5] = (short)l1; sg[6] = (short)r0; sg[7] = (short)r1;
+            sg[6] = (short)std::min(b_at, qa); sg[7] = (short)std::min(b_end, qa);
+            sg[8] = (short)(std::max(b_at, qa) - qa + qb); sg[9] = (short)(std::max(b_end, qa) - qa + qb);
             b_at = b_end;
         }
+    }
+    if (pl.R == 1) pre = Dq;          // (no halo: no barrier in the middle)
+    for (int wv = 0; wv < pl.waves; ++wv) {
+        short *sg = pl.seg[wv];
+        const int lo = own[wv][0], hi = own[wv][1], cut = std::min(hi, lo + pre), mid = lo + (cut - lo + 1) / 2;
+        sg[0] = (short)lo; sg[1] = (short)mid; sg[2] = (short)mid; sg[3] = (short)cut; sg[4] = (short)cut; sg[5] = (short)hi;
     }
     return true;
 }
@@ -158,30 +174,45 @@ __device__ __forceinline__ float comp(const float4 &v) {
 
 // One dquad of one lane: 4 diagonals x 4 next-states x 4 items.  Window rows of the dquad: m = 0 .. 6 (row of diagonal d,
 // next-state k: m = d + k) in slots (4 PH + m) & 7, PH = parity of the dquad; rows 0 .. 2 are the previous dquad's 4 .. 6.
-template <int PH, int K>
-__device__ __forceinline__ void dquad_row(float (&acc)[16], const float4 (&w)[8], const float4 (&t)[4]) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const float4 r0 = w[(4 * PH + 2 * h + K) & 7], r1 = w[(4 * PH + 2 * h + 1 + K) & 7];
-        const float t0 = comp<K>(t[2 * h]), t1 = comp<K>(t[2 * h + 1]);
-        acc[4 * K + 0] = fmaxf(fmaxf(acc[4 * K + 0], r0.x + t0), r1.x + t1);
-        acc[4 * K + 1] = fmaxf(fmaxf(acc[4 * K + 1], r0.y + t0), r1.y + t1);
-        acc[4 * K + 2] = fmaxf(fmaxf(acc[4 * K + 2], r0.z + t0), r1.z + t1);
-        acc[4 * K + 3] = fmaxf(fmaxf(acc[4 * K + 3], r0.w + t0), r1.w + t1);
-    }
+//
+// Software pipeline without a register to spare: a dquad's operands are all ON THEIR WAY when it starts, and while it
+// runs it asks for the NEXT dquad's -- each into a register that has just seen its last use:
+//     start:                      next row 3 -> the one free slot of the ring
+//     diagonals 0, 1 (rows 0 .. 4): then next t[0], t[1] and next rows 4, 5 -> the slots of rows 0, 1
+//     diagonals 2, 3 (rows 2 .. 6): then next t[2], t[3] and next row 6 -> the slot of row 2
+// so every ds_read has at least half a dquad (128 issue cycles) to land, and a wave that has its SIMD to itself -- the
+// last of three to finish a phase -- still runs at the vector ALU's rate.
+template <int PH, int D0, int K>
+__device__ __forceinline__ void dquad_cells(float (&acc)[16], const float4 (&w)[8], const float4 (&t)[4]) {
+    const float4 r0 = w[(4 * PH + D0 + K) & 7], r1 = w[(4 * PH + D0 + 1 + K) & 7];
+    const float t0 = comp<K>(t[D0]), t1 = comp<K>(t[D0 + 1]);
+    acc[4 * K + 0] = fmaxf(fmaxf(acc[4 * K + 0], r0.x + t0), r1.x + t1);
+    acc[4 * K + 1] = fmaxf(fmaxf(acc[4 * K + 1], r0.y + t0), r1.y + t1);
+    acc[4 * K + 2] = fmaxf(fmaxf(acc[4 * K + 2], r0.z + t0), r1.z + t1);
+    acc[4 * K + 3] = fmaxf(fmaxf(acc[4 * K + 3], r0.w + t0), r1.w + t1);
 }
 
+// tp / wp: this dquad's Tq block and first window row; tn / wn: the next dquad's (anything readable behind the last one)
 template <int PH>
-__device__ __forceinline__ void dquad(float (&acc)[16], float4 (&w)[8], const char *tp, const char *wp) {
-    float4 t[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) t[d] = lds_f4(tp + 16 * d);
-#pragma unroll
-    for (int m = 3; m < 7; ++m) w[(4 * PH + m) & 7] = lds_f4(wp + 16 * m);
-    dquad_row<PH, 0>(acc, w, t);
-    dquad_row<PH, 1>(acc, w, t);
-    dquad_row<PH, 2>(acc, w, t);
-    dquad_row<PH, 3>(acc, w, t);
+__device__ __forceinline__ void dquad(float (&acc)[16], float4 (&w)[8], float4 (&t)[4], const char *tn, const char *wn) {
+    w[(4 * PH + 7) & 7] = lds_f4(wn + 16 * 3);
+    dquad_cells<PH, 0, 0>(acc, w, t);
+    dquad_cells<PH, 0, 1>(acc, w, t);
+    dquad_cells<PH, 0, 2>(acc, w, t);
+    dquad_cells<PH, 0, 3>(acc, w, t);
+    __builtin_amdgcn_sched_barrier(0);
+    t[0] = lds_f4(tn);
+    t[1] = lds_f4(tn + 16);
+    w[(4 * PH + 8) & 7] = lds_f4(wn + 16 * 4);
+    w[(4 * PH + 9) & 7] = lds_f4(wn + 16 * 5);
+    dquad_cells<PH, 2, 0>(acc, w, t);
+    dquad_cells<PH, 2, 1>(acc, w, t);
+    dquad_cells<PH, 2, 2>(acc, w, t);
+    dquad_cells<PH, 2, 3>(acc, w, t);
+    __builtin_amdgcn_sched_barrier(0);
+    t[2] = lds_f4(tn + 32);
+    t[3] = lds_f4(tn + 48);
+    w[(4 * PH + 10) & 7] = lds_f4(wn + 16 * 6);
 }
 
 // dquads [lo, hi) of a lane (wave-uniform bounds): tq0 = Tq[0][jg], w0 = W[ig][4 jg]
@@ -189,29 +220,42 @@ __device__ __forceinline__ void scan(float (&acc)[16], float4 (&w)[8], const cha
                                      int tq_step) {
     if (lo >= hi) return;
     const char *tp = tq0 + (size_t)lo * tq_step, *wp = w0 + (size_t)lo * 64;
+    float4 t[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) t[d] = lds_f4(tp + 16 * d);
     int q = lo;
     if (q & 1) {
 #pragma unroll
-        for (int m = 0; m < 3; ++m) w[(4 + m) & 7] = lds_f4(wp + 16 * m);
-        dquad<1>(acc, w, tp, wp);
+        for (int m = 0; m < 7; ++m) w[(4 + m) & 7] = lds_f4(wp + 16 * m);
+        dquad<1>(acc, w, t, tp + tq_step, wp + 64);
         ++q;
         tp += tq_step;
         wp += 64;
     } else {
 #pragma unroll
-        for (int m = 0; m < 3; ++m) w[m] = lds_f4(wp + 16 * m);
+        for (int m = 0; m < 7; ++m) w[m] = lds_f4(wp + 16 * m);
     }
     for (; q + 1 < hi; q += 2) {
-        dquad<0>(acc, w, tp, wp);
-        dquad<1>(acc, w, tp + tq_step, wp + 64);
+        dquad<0>(acc, w, t, tp + tq_step, wp + 64);
+        dquad<1>(acc, w, t, tp + 2 * tq_step, wp + 128);
         tp += 2 * tq_step;
         wp += 128;
     }
-    if (q < hi) dquad<0>(acc, w, tp, wp);
+    if (q < hi) dquad<0>(acc, w, t, tp + tq_step, wp + 64);
 }
 
 #ifndef BAND_ABL
-#define BAND_ABL 0       // build-time ablations (timing only, results wrong): 1 no waiting for the halo, 2 no history stores
+#define BAND_ABL 0       // build-time ablations (timing only, results wrong): 1 no waiting for the halo, 2 no history stores,
+                         // 4 no merge through M, 8 no exchange stores, 16 the scans alone (no hand-off, merge, finish, barriers),
+                         // 32 write-through granules even inside one XCD (results right)
+#endif
+#ifdef BAND_STAMP
+// build-time instrumentation (tools/band_stamps.py): per-wave cycle sums of the phases of a timestep
+constexpr int kPhases = 12;
+__device__ unsigned long long g_phase[1024 * kMaxWaves * kPhases];
+#define BSTAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); bacc[i] += now_ - blast; blast = now_; }
+#else
+#define BSTAMP(i)
 #endif
 
 // grid = tiles of the group x R, block = 64 * pl.waves, dynamic LDS = pl.lds_bytes
@@ -231,13 +275,22 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
     const int nthreads = 64 * pl.waves;
     const int S = pl.S, hl = pl.hl, hr = pl.hr, R = pl.R, n_own = pl.n_own, n_jg = pl.n_jg;
 
-    if (tid == 0) {
-        smisc[0] = (int)__hip_atomic_fetch_add(ex.control, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        smisc[1] = 0;
+    // Membership by arrival WITHIN a dispatch class (blockIdx mod 8): tile = class + 8 x (ticket / R), member = ticket mod R.
+    // A class holds exactly R x ceil(tiles / 8) workgroups (grid = 8 x that), so every tile gets its R members whatever the
+    // dispatch order; the GPU places a class on one XCD (observed, not promised: the members compare notes below).
+    int cid = blockIdx.x, member = 0;
+    if (R > 1) {
+        const int cls = blockIdx.x & 7;
+        if (tid == 0) {
+            smisc[0] = (int)__hip_atomic_fetch_add(ex.control + cls, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            smisc[1] = 0;
+        }
+        __syncthreads();
+        const int ticket = __builtin_amdgcn_readfirstlane(smisc[0]);
+        member = ticket % R;
+        cid = (ticket / R) * 8 + cls;
+        if (cid >= ex.tiles) return;            // (the grid is padded to whole classes)
     }
-    __syncthreads();
-    const int ticket = __builtin_amdgcn_readfirstlane(smisc[0]);
-    const int cid = ticket / R, member = ticket - cid * R;
     const int code = grp.tile_map[cid];
     const int bk = code >> 20, tile = code & 0xfffff;
     const Batch &bat = grp.batch[bk];
@@ -274,75 +327,112 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
 #pragma unroll
     for (int it = 0; it < kNI; ++it) fmax = max(fmax, sframes[it]);
 
-    // ---- the thread as a finisher: one (item group, own row) per thread --------------------------------------------
-    const bool fin = tid < 4 * n_own;
-    const int fig = fin ? tid / n_own : 0, fa = fin ? tid - fig * n_own : 0;
-    const int fj = j0 + fa;
-    const bool fin_row = fin && fj < S;
-    size_t item_at[4];           // element offset of item bb's row 0, state fj
-    int flen[4];
-#pragma unroll
-    for (int bb = 0; bb < 4; ++bb) {
-        item_at[bb] = (size_t)sitem[4 * fig + bb] * T * S + (fin_row ? fj : 0);
-        flen[bb] = sframes[4 * fig + bb];
-    }
-    const int fm_at = ((fa & 3) * 4) * n_own + (fa >> 2) * 4 + fig;            // M[(k * 4 + bb)][jg * 4 + ig], bb = 0
-    float *const fw_at = wq + fig * pl.ig_stride + 4 * (hl + fa);
+    // ---- the thread as a finisher: one (item, four consecutive own rows) per thread -----------------------------------
+    const bool fin = tid < kNI * n_jg;
+    const int fit = fin ? tid / n_jg : 0, fjg = fin ? tid - fit * n_jg : 0;       // tile item, group of four next-states
+    const int fig = fit >> 2, fbb = fit & 3;
+    const int fj = j0 + 4 * fjg;
+    const bool fin_row = fin && fj < S;                  // (S % 4 == 0: the four rows are inside the matrix or none is)
+    const size_t item_at = (size_t)sitem[fit] * T * S + (fin_row ? fj : 0);        // element offset of row 0, state fj
+    const int flen = sframes[fit];
+    float *const fm_at = mq + fbb * n_own + fjg * 4 + fig;                  // M[(k * 4 + bb)][jg * 4 + ig], k = 0
+    float *const fw_at = wq + fig * pl.ig_stride + 4 * (hl + 4 * fjg) + fbb;
     char *const xtile = ex.xchg[bk] + (size_t)tile * xchg_tile_bytes(S);
-    const unsigned xpar = (unsigned)(4 * S * 32);                                // bytes of one parity
+    const unsigned xpar = (unsigned)(kNI * S * 8);               // bytes of one parity: [16 items][2 halves][S / 4] granules
     const __amdgpu_buffer_rsrc_t xbuf = buffer_of(xtile, 2u * xpar);
-    const int fx_at = (fig * S + fj) * 32;
+    const int xhalf = (S / 4) * 16;                              // bytes of one half plane of an item
+    const int fx_at = fit * 2 * xhalf + (fj >> 2) * 16;          // granule {fj, fj + 1}; {fj + 2, fj + 3} one plane on
     const bool publishes = fin_row && R > 1;
-    float ob[4] = {0.f, 0.f, 0.f, 0.f};
-
-    auto finish = [&](int t, const float (&best)[4], bool more) {
-        // post'[j] = obs[t][j] + max (viterbi.cpp:102) -> the window, the history, the neighbours
-        float v[4];
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) v[bb] = ob[bb] + best[bb];
-        *reinterpret_cast<float4 *>(fw_at) = make_float4(v[0], v[1], v[2], v[3]);
-        if (fin_row && !(BAND_ABL & 2)) {
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb)
-                if (t < flen[bb]) hist[item_at[bb] + (size_t)t * S] = v[bb];
+    // do the R members run on one XCD?  Each says where it is (write-through), all read all R answers (bounded wait)
+    bool local = false;
+    if (R > 1) {
+        unsigned *const where = reinterpret_cast<unsigned *>(xtile + 2u * xpar);
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u;      // HW_REG_XCC_ID
+        if (wave == 0) {
+            if (lane == 0) __hip_atomic_store(where + member, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long since = 0ull;
+            unsigned seen = xcc + 1u;
+            for (;;) {
+                if (lane < R) seen = __hip_atomic_load(where + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(seen != 0u)) break;
+                const unsigned long long now = wall_clock64();
+                if (since == 0ull) since = now;
+                if (now - since >= ex.wait_ticks) { if (lane == 0) smisc[1] = 1; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            const bool same = __all(seen == xcc + 1u);
+            if (lane == 0) smisc[2] = same ? 1 : 0;
         }
-        if (publishes && more) {
+        __syncthreads();
+        local = smisc[2] != 0 && !(BAND_ABL & 32);
+    }
+    const bool incomplete = R > 1 && smisc[1] != 0;        // (a member never showed up in time: no waiting for it later either)
+    // (the observations of row t + 2 are asked for when row t is finished: a wave's loads return in order, and a halo
+    // granule asked for behind a first-touch HBM read would wait for it)
+    float4 ob = make_float4(0.f, 0.f, 0.f, 0.f), ob_next = ob;
+
+    auto finish = [&](int t, const float4 &best, bool more) {
+        // post'[j] = obs[t][j] + max (viterbi.cpp:102) -> the neighbours, the window, the history
+        const float4 v = make_float4(ob.x + best.x, ob.y + best.y, ob.z + best.z, ob.w + best.w);
+        ob = ob_next;       // (ahead of this row's stores: behind them the wait for the older load would cover them too)
+        asm volatile("" : "+v"(ob.x), "+v"(ob.y), "+v"(ob.z), "+v"(ob.w));
+        if (publishes && more && !(BAND_ABL & 8)) {
             const unsigned tag = (unsigned)t + 1u;
             const int at = (int)((unsigned)(t & 1) * xpar) + fx_at;
-            v4u g0 = {__float_as_uint(v[0]), tag, __float_as_uint(v[1]), tag};
-            v4u g1 = {__float_as_uint(v[2]), tag, __float_as_uint(v[3]), tag};
-            __builtin_amdgcn_raw_buffer_store_b128(g0, xbuf, at, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(g1, xbuf, at + 16, 0, 16);
+            v4u g0 = {__float_as_uint(v.x), tag, __float_as_uint(v.y), tag};
+            v4u g1 = {__float_as_uint(v.z), tag, __float_as_uint(v.w), tag};
+            if (local) {            // one XCD: the granules stay in its L2
+                __builtin_amdgcn_raw_buffer_store_b128(g0, xbuf, at, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(g1, xbuf, at + xhalf, 0, 0);
+            } else {                // write-through: visible to every XCD
+                __builtin_amdgcn_raw_buffer_store_b128(g0, xbuf, at, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(g1, xbuf, at + xhalf, 0, 16);
+            }
         }
-        if (more && fin_row) {
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) ob[bb] = obs[item_at[bb] + (size_t)(t + 1) * S];
-        }
+        fw_at[0] = v.x;
+        fw_at[4] = v.y;
+        fw_at[8] = v.z;
+        fw_at[12] = v.w;
+        if (fin_row && t < flen && !(BAND_ABL & 2)) *reinterpret_cast<float4 *>(hist + item_at + (size_t)t * S) = v;
+        if (fin_row && t + 2 < fmax) ob_next = *reinterpret_cast<const float4 *>(obs + item_at + (size_t)(t + 2) * S);
     };
 
     // t = 0: posterior row 0 = obs[b][0][:] + initial (viterbi.cpp:72-76)
     if (fin) {
-        float first[4];
-        const float ini = fin_row ? initial[fj] : 0.0f;
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-            ob[bb] = fin_row ? obs[item_at[bb]] : 0.0f;
-            first[bb] = ini;
+        float4 first = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fin_row) {
+            ob = *reinterpret_cast<const float4 *>(obs + item_at);
+            if (fmax > 1) ob_next = *reinterpret_cast<const float4 *>(obs + item_at + (size_t)S);
+            first = make_float4(initial[fj], initial[fj + 1], initial[fj + 2], initial[fj + 3]);
         }
         finish(0, first, fmax > 1);
     }
 
-    // ---- the thread as a reader of halo granules --------------------------------------------------------------------
+    // ---- the thread as a reader of halo granules: two consecutive states of one item, {v, tag, v', tag} ---------------------
     int hx_at[kMaxRounds], hw_at[kMaxRounds];           // byte offset in a parity of the exchange (-1: none), LDS byte address
+    bool need0[kMaxRounds], need1[kMaxRounds];          // which of the two states the window wants
+    {
+        const int left_first = (j0 - hl) >> 1;                      // granule g holds states 2 g, 2 g + 1 (j0 is even)
+        const int nleft = (j0 >> 1) - left_first;                   // granules left of the own rows
+        const int right_first = (j0 + n_own) >> 1, nright = (hr + 1) / 2;
+        const int ncg = nleft + nright;                             // granules per item
 #pragma unroll
-    for (int r = 0; r < kMaxRounds; ++r) {
-        const int p = tid + r * nthreads;
-        const int half = p & 1, ig = (p >> 1) & 3, hrow = p >> 3;
-        const int wrow = hrow < hl ? hrow : hrow + n_own;
-        const int grow = j0 - hl + wrow;
-        const bool valid = r < pl.rounds && hrow < hl + hr && grow >= 0 && grow < S;
-        hx_at[r] = valid ? ((ig * S + grow) * 2 + half) * 16 : -1;
-        hw_at[r] = pl.w_off + (ig * pl.ig_stride + 4 * wrow + 2 * half) * 4;
+        for (int r = 0; r < kMaxRounds; ++r) {
+            const int p = tid + r * nthreads;
+            const int item = (p / ncg) & (kNI - 1), c = p % ncg;
+            const int g = c < nleft ? left_first + c : right_first + (c - nleft);
+            const int st = 2 * g;                                  // first state of the granule
+            const int wrow = st - (j0 - hl);                       // its row of the window (may be -1)
+            auto wanted = [&](int state) {
+                const bool in_halo = (state >= j0 - hl && state < j0) || (state >= j0 + n_own && state < j0 + n_own + hr);
+                return in_halo && state >= 0 && state < S;
+            };
+            const bool listed = r < pl.rounds && p < kNI * ncg;
+            need0[r] = listed && wanted(st);
+            need1[r] = listed && wanted(st + 1);
+            hx_at[r] = (need0[r] || need1[r]) ? (item * 2 + (g & 1)) * xhalf + (g >> 1) * 16 : -1;
+            hw_at[r] = pl.w_off + ((item >> 2) * pl.ig_stride + 4 * wrow + (item & 3)) * 4;
+        }
     }
 
     // ---- the thread as a lane of the scan: 4 next-states (jg) x 4 items (ig) ---------------------------------------------
@@ -356,16 +446,34 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
     const int tq_step = n_jg * 64;
     float *const m_at = mq + jg * 4 + ig;
     const short *const sg = pl.seg[wave];
-    const int s0 = sg[0], s1 = sg[1], s2 = sg[2], s3 = sg[3], s4 = sg[4], s5 = sg[5], s6 = sg[6], s7 = sg[7];
-    bool gave_up = false;
+    const int s0 = sg[0], s1 = sg[1], s2 = sg[2], s3 = sg[3], s4 = sg[4], s5 = sg[5], s6 = sg[6], s7 = sg[7], s8 = sg[8],
+              s9 = sg[9];
+    bool gave_up = incomplete;
 
     __syncthreads();
+#ifdef BAND_STAMP
+    unsigned long long bacc[kPhases] = {};
+    unsigned long long blast = __builtin_readcyclecounter();
+#endif
     for (int t = 1; t < fmax; ++t) {
         float acc[16];
         float4 w[8];
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = -INFINITY;
+        if (BAND_ABL & 16) {
+            scan(acc, w, tq0, w0, s0, s1, tq_step);
+            scan(acc, w, tq0, w0, s2, s3, tq_step);
+            scan(acc, w, tq0, w0, s4, s5, tq_step);
+            scan(acc, w, tq0, w0, s6, s7, tq_step);
+            scan(acc, w, tq0, w0, s8, s9, tq_step);
+            float sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sum += acc[e];
+            if (sum == 12345.678f) mq[tid] = sum;
+            continue;
+        }
         scan(acc, w, tq0, w0, s0, s1, tq_step);
+        BSTAMP(0);
         // the neighbours' rows t - 1: asked for now, looked at behind the second run of own-row dquads
         v4u got[kMaxRounds];
         const int par_at = (int)((unsigned)((t - 1) & 1) * xpar);
@@ -376,6 +484,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
         }
         __builtin_amdgcn_sched_barrier(0);
         scan(acc, w, tq0, w0, s2, s3, tq_step);
+        BSTAMP(1);
         if (R > 1) {
             const unsigned tag = (unsigned)t;
             unsigned long long since = 0ull;
@@ -383,7 +492,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
                 bool ok = true;
 #pragma unroll
                 for (int r = 0; r < kMaxRounds; ++r)
-                    if (hx_at[r] >= 0) ok = ok && got[r].y == tag && got[r].w == tag;
+                    if (hx_at[r] >= 0) ok = ok && (!need0[r] || got[r].y == tag) && (!need1[r] || got[r].w == tag);
                 if (__all(ok) || gave_up || (BAND_ABL & 1)) break;
                 const unsigned long long now = wall_clock64();
                 if (since == 0ull) since = now;
@@ -391,34 +500,53 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
                 __builtin_amdgcn_s_sleep(1);
 #pragma unroll
                 for (int r = 0; r < kMaxRounds; ++r)
-                    if (hx_at[r] >= 0 && !(got[r].y == tag && got[r].w == tag))
+                    if (hx_at[r] >= 0 && !((!need0[r] || got[r].y == tag) && (!need1[r] || got[r].w == tag)))
                         got[r] = __builtin_amdgcn_raw_buffer_load_b128(xbuf, par_at + hx_at[r], 0, 16);
+#ifdef BAND_STAMP
+                bacc[9] += 1;
+#endif
             }
+            BSTAMP(2);
 #pragma unroll
-            for (int r = 0; r < kMaxRounds; ++r)
-                if (hx_at[r] >= 0)
-                    *reinterpret_cast<float2 *>(lds + hw_at[r]) = make_float2(__uint_as_float(got[r].x), __uint_as_float(got[r].z));
+            for (int r = 0; r < kMaxRounds; ++r) {
+                if (need0[r]) *reinterpret_cast<float *>(lds + hw_at[r]) = __uint_as_float(got[r].x);
+                if (need1[r]) *reinterpret_cast<float *>(lds + hw_at[r] + 16) = __uint_as_float(got[r].z);
+            }
             __syncthreads();            // the halo rows t - 1 are in the window
+            BSTAMP(3);
             scan(acc, w, tq0, w0, s4, s5, tq_step);
             scan(acc, w, tq0, w0, s6, s7, tq_step);
+            scan(acc, w, tq0, w0, s8, s9, tq_step);
+            BSTAMP(4);
         }
-        if (scans) {
+        if (scans && !(BAND_ABL & 4)) {
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float *)(m_at + e * n_own), acc[e], 0, 0, false);
         }
+        BSTAMP(5);
         __syncthreads();                // every wave is done with the window; M holds the maxima
+        BSTAMP(6);
         if (fin) {
-            float best[4];
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                best[bb] = mq[fm_at + bb * n_own];
-                mq[fm_at + bb * n_own] = -INFINITY;
-            }
+            float4 best;
+            best.x = fm_at[0];
+            best.y = fm_at[4 * n_own];
+            best.z = fm_at[8 * n_own];
+            best.w = fm_at[12 * n_own];
+            fm_at[0] = -INFINITY;
+            fm_at[4 * n_own] = -INFINITY;
+            fm_at[8 * n_own] = -INFINITY;
+            fm_at[12 * n_own] = -INFINITY;
             finish(t, best, t + 1 < fmax);
         }
+        BSTAMP(7);
         __syncthreads();                // the window holds the own rows t
+        BSTAMP(8);
     }
+#ifdef BAND_STAMP
+    if (lane == 0 && blockIdx.x < 1024)
+        for (int i = 0; i < kPhases; ++i) g_phase[((size_t)blockIdx.x * kMaxWaves + wave) * kPhases + i] = bacc[i];
+#endif
     if (gave_up && lane == 0) {
         ex.failed[cid] = 1u;
         atomicAdd(&grp.stats[127], 1u);

@@ -1450,6 +1450,7 @@ hipError_t run_band(const HostBatch *hb, int n, const float *trans, const float 
     jobs.ni = band::kNI;
     ex.control = w.words;
     ex.failed = w.words + 16;
+    ex.tiles = tiles;
     const char *wait_env = getenv("TORBI_HIP_CLUSTER_WAIT_US");         // (read per launch: the tests switch it)
     ex.wait_ticks = wait_env ? 100ull * strtoull(wait_env, nullptr, 10) : resident::kClusterWaitTicks;
     clear.words = w.words;
@@ -1476,7 +1477,9 @@ hipError_t run_band(const HostBatch *hb, int n, const float *trans, const float 
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&band::band_forward_kernel), (size_t)pl.lds_bytes);
     if (e != hipSuccess) return e;
     TORBI_NOTE_KERNEL("band::band_forward_kernel");
-    hipLaunchKernelGGL(band::band_forward_kernel, dim3(tiles * pl.R), dim3(64 * pl.waves), (size_t)pl.lds_bytes, s, grp, ex, pl,
+    // (R > 1: eight dispatch classes of R x ceil(tiles / 8) workgroups each -- band_forward.hpp, membership)
+    const int grid = pl.R > 1 ? 8 * ((tiles + 7) / 8) * pl.R : tiles;
+    hipLaunchKernelGGL(band::band_forward_kernel, dim3(grid), dim3(64 * pl.waves), (size_t)pl.lds_bytes, s, grp, ex, pl,
                        trans, init);
     if (pl.R > 1) {          // does nothing unless a member gave up waiting (band_forward.hpp)
         const size_t lds = 32 * (size_t)S;
@@ -1822,7 +1825,8 @@ int torbi_hip_viterbi_decode_banded(const torbi_hip_batch *batches, int count, c
     }
     band::Plan pl;
     const int path = requested_path(flags);
-    const bool vec = (reinterpret_cast<uintptr_t>(transition) & 15) == 0;
+    bool vec = (reinterpret_cast<uintptr_t>(transition) & 15) == 0;       // (16-byte reads of matrix rows and observation rows)
+    for (int k = 0; k < n; ++k) vec = vec && (reinterpret_cast<uintptr_t>(hb[k].obs) & 15) == 0;
     if (n == 0 || !vec || !band_plan_for(hb, n, S, reach_left, reach_right, cus, path, pl)) {
         // not a shape of the band kernel: whatever the plain entry point does with it (BAND named: as AUTO)
         unsigned f = flags;
@@ -2055,6 +2059,12 @@ int torbi_hip_open_heads(const char *const *paths, int count, int threads, int h
 
 }  // extern "C"
 
+#ifdef BAND_STAMP
+// instrumentation build only (tools/band_stamps.py); not part of include/torbi_hip.h
+extern "C" int torbi_hip_debug_band_phases(unsigned long long *host, size_t count) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(band::g_phase), count * sizeof(unsigned long long));
+}
+#endif
 #ifdef RESIDENT_STAMP
 // instrumentation build only (tools/resident_stamps.py); not part of include/torbi_hip.h
 extern "C" int torbi_hip_debug_phases(unsigned long long *host, size_t count) {
