@@ -33,7 +33,7 @@ VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz lane-instr
 METRIC = 'timesteps decoded/sec, 1440 states batch=512'
 KERNELS = {'resident': 'resident::resident_forward_kernel', 'cluster': 'resident::resident_forward_kernel',
            'dense': 'dense::step_dense_kernel', 'generic': 'step_rows', 'rows': 'rowscan::step_rows_sorted_kernel'}
-ROUTES = {0: 'generic', 1: 'dense', 3: 'resident', 4: 'rows', 5: 'cluster', 6: 'held', 7: 'small'}
+ROUTES = {0: 'generic', 1: 'dense', 3: 'resident', 4: 'rows', 5: 'cluster', 6: 'held', 7: 'small', 8: 'band'}
 
 
 def parse_args(argv=None):
@@ -413,7 +413,7 @@ class Bench:
         launches = max(int(prof[2]), 1)
         covered = max(int(prof[5]), 1)                     # batches one forward launch (chain) covers
         kernel_s = (fwd_ms - prep_ms) * 1e-3 / launches
-        timesteps_per_launch = float(covered) * B * (T if route in ('resident', 'cluster') else 1)
+        timesteps_per_launch = float(covered) * B * (T if route in ('resident', 'cluster', 'band') else 1)
         bytes_per_launch = timesteps_per_launch * algorithmic_bytes_per_timestep(S)
         achieved = bytes_per_launch / kernel_s / 1e9
         cells_per_launch = timesteps_per_launch * S * S
@@ -471,7 +471,7 @@ class Bench:
                             f'{covered} batches per launch; above the algorithmic bytes: the sorted transition lists and seed '
                             'rows that miss the 4 MB L2s (served by the Infinity Cache)',
             'kernel': running + (f' (ONE launch = the whole forward pass of {covered} batches)'
-                                 if route in ('resident', 'cluster') else ' (one launch = one timestep of one batch)'),
+                                 if route in ('resident', 'cluster', 'band') else ' (one launch = one timestep of one batch)'),
             'launch_us': kernel_s * 1e6, 'launches_per_group': launches, 'batches_per_launch': covered,
             'algorithmic_bytes_per_launch': bytes_per_launch,
             'executed': executed,
@@ -615,14 +615,36 @@ class Bench:
         peaked = torch.log_softmax(logits, dim=-1).clamp_(min=math.log(torch.finfo(torch.float32).tiny))
         del logits
         band = torch.from_numpy(synth.banded_transition(S, args.half_width)).to(dev)
+        finite = int((band != float('-inf')).sum())            # cells per timestep and item the band holds
+
+        def executed(seconds, timesteps, forward_ms=None):
+            """The finite cells of the band over the decode (and over its forward pass), priced against the vector ALU:
+            add, add, 1/2 max3 = 1.5 instructions (4 issue cycles per wave) per cell."""
+            cells = float(finite) * timesteps
+            found = {'finite_cells_per_timestep': finite, 'fraction_of_all_cells': finite / float(S * S),
+                     'cells_per_s': cells / seconds,
+                     'valu_frac_at_1p5_instr_per_cell': 1.5 * cells / seconds / VALU_LANE_OPS}
+            if forward_ms:
+                found['forward_cells_per_s'] = cells / (forward_ms * 1e-3)
+                found['forward_valu_frac_at_1p5_instr_per_cell'] = 1.5 * cells / (forward_ms * 1e-3) / VALU_LANE_OPS
+            return found
+
         for _ in range(4):
             self.torbi_amd.decode(peaked, frames, band, init, workspace=ws)
         prof = []
         self.torbi_amd.decode(peaked, frames, band, init, workspace=ws, _profile=prof)
+        kernel = v.last_forward_kernel()
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(peaked, frames, band, init, workspace=ws), 3, warmup=0)
         record('peaked_banded', sec, B * T, S,
                'posteriorgram-like rows (log_softmax of peaked logits, clamped at log tiny) with the reference\'s banded '
-               'pitch transition; path = what AUTO settled on', {'forward_path': ROUTES[int(prof[3])]})
+               'pitch transition (torbi/evaluate/core.py:24-33); path = what AUTO settled on',
+               {'forward_path': ROUTES[int(prof[3])], 'kernel': kernel, 'forward_ms': prof[0], 'backtrace_ms': prof[1],
+                'us_per_timestep_forward': (prof[0] - prof[4]) * 1e3 / max(T - 1, 1),
+                'executed': executed(sec, B * T, prof[0]),
+                'statistics_gave_up': int(v.scan_stats(ws, B, T, S).cpu()[127])})
+        sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(peaked, frames, band, init, workspace=ws, path='dense'), 2)
+        record('peaked_banded_dense_kernel', sec, B * T, S, 'the same on the dense kernel\'s -inf chunk skipping (AUTO\'s choice '
+               'until round 4)')
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(peaked, frames, trans, init, workspace=ws), 3, warmup=4)
         self.torbi_amd.decode(peaked, frames, trans, init, workspace=ws, _profile=prof)
         record('peaked_dense_transition', sec, B * T, S, 'the same peaked rows with the dense random transition (AUTO)',
@@ -633,7 +655,9 @@ class Bench:
         v.decode_batches([peaked] * 8, [frames] * 8, band, init, workspaces=spaces, _profile=prof)
         sec, _ = self.timed_decodes(lambda: v.decode_batches([peaked] * 8, [frames] * 8, band, init, workspaces=spaces), 2)
         record('peaked_banded_launch_group', sec, 8 * B * T, S,
-               'eight batches of the peaked rows + banded pitch transition in one call', {'forward_path': ROUTES[int(prof[3])]})
+               'eight batches of the peaked rows + banded pitch transition in one call',
+               {'forward_path': ROUTES[int(prof[3])], 'forward_ms': prof[0], 'backtrace_ms': prof[1],
+                'executed': executed(sec, 8 * B * T, prof[0])})
         sec, _ = self.timed_decodes(lambda: v.decode_batches([peaked] * 8, [frames] * 8, band, init, workspaces=spaces,
                                                              path='resident'), 2)
         record('peaked_banded_launch_group_resident', sec, 8 * B * T, S, 'the same, time-resident kernel forced')

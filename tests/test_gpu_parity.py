@@ -612,8 +612,9 @@ def test_concurrent_held_launches_from_several_streams(forward):
 
 
 def test_auto_looks_at_the_transition_once_per_tensor_version(forward):
-    """The Python layer's look at the transition decides where ONE batch of more than 16 items goes: dense + -inf
-    skipping for a narrow band, clusters otherwise (16- and 8-item tiles alike) -- once per tensor version."""
+    """The Python layer's look at the transition decides where ONE batch of more than 16 items goes: the band kernel for a
+    matrix that is -inf outside a band it covers (csrc/band_forward.hpp; dense + -inf skipping until round 4), clusters
+    otherwise (16- and 8-item tiles alike) -- once per tensor version."""
     if forward != 'auto':
         pytest.skip('path forced')
     dev = torch.device('cuda:0')
@@ -626,7 +627,7 @@ def test_auto_looks_at_the_transition_once_per_tensor_version(forward):
     assert int(prof[3]) == 5                                         # dense random matrix: time-resident clusters
     band = torch.as_tensor(synth.banded_transition(S, 20.0)).to(dev)
     torbi_amd.decode(args[0], args[1], band, args[3], _profile=prof)
-    assert int(prof[3]) == 1                                         # narrow band: dense + -inf skipping
+    assert int(prof[3]) == 8                                         # narrow band: the band kernel
     B, T, S = 40, 3, 2064
     obs, trans, init = synth.problem(B, T, S, seed=3)
     frames = np.full(B, T, dtype=np.int32)
@@ -635,7 +636,7 @@ def test_auto_looks_at_the_transition_once_per_tensor_version(forward):
     assert int(prof[3]) == 5                                         # dense random matrix: clusters on 8-item tiles
     band = torch.as_tensor(synth.banded_transition(S, 20.0)).to(dev)
     torbi_amd.decode(args[0], args[1], band, args[3], _profile=prof)
-    assert int(prof[3]) == 1                                         # narrow band: dense + -inf skipping
+    assert int(prof[3]) == 8                                         # narrow band: the band kernel
     band.fill_(-1.0)                                                 # same storage, new version
     torbi_amd.decode(args[0], args[1], band, args[3], _profile=prof)
     assert int(prof[3]) == 5
@@ -1228,19 +1229,19 @@ def test_decode_batches_auto_goes_resident_when_the_group_fills_the_chip(forward
     assert int(prof[3]) == 5 and int(prof[5]) == 2 and int(prof[2]) == 1
     for k in range(2):
         np.testing.assert_array_equal(got[k].cpu().numpy(), want[k])
-    # a narrow band goes to the dense kernel one batch at a time, to the time-resident kernel as a group
+    # a narrow band goes to the band kernel (csrc/band_forward.hpp): one batch, a few, a group that fills the chip -- one launch
     band = synth.banded_transition(S, 12.0)
     d_band = torch.as_tensor(band).to(dev)
     got = viterbi.decode_batches(obs_list, frame_list, d_band, d_init, path='auto', _profile=prof)
-    assert int(prof[3]) == 3 and int(prof[5]) == 8
+    assert int(prof[3]) == 8 and int(prof[5]) == 8 and int(prof[2]) == 1
     for k in (0, 7):
         ref = oracle.decode(obs_list[k].cpu().numpy(), frame_list[k].cpu().numpy(), band, init,
                             num_threads=oracle.max_threads())
         np.testing.assert_array_equal(got[k].cpu().numpy(), ref)
     viterbi.decode_batches(obs_list[:1], frame_list[:1], d_band, d_init, path='auto', _profile=prof)
-    assert int(prof[3]) == 1
+    assert int(prof[3]) == 8
     got = viterbi.decode_batches(obs_list[:3], frame_list[:3], d_band, d_init, path='auto', _profile=prof)
-    assert int(prof[3]) == 5 and int(prof[5]) == 3
+    assert int(prof[3]) == 8 and int(prof[5]) == 3
     ref = oracle.decode(obs_list[2].cpu().numpy(), frame_list[2].cpu().numpy(), band, init, num_threads=oracle.max_threads())
     np.testing.assert_array_equal(got[2].cpu().numpy(), ref)
 
@@ -1724,3 +1725,184 @@ def test_auto_leaves_the_time_resident_kernel_when_nothing_is_pruned(forward):
             for k in want:
                 np.testing.assert_array_equal(got[k].cpu().numpy(), want[k], err_msg=name)
         assert routes[0] == 3 and routes[-1] == later, (name, routes)
+
+
+# ---- the band kernel (csrc/band_forward.hpp): banded transition matrices, the time loop inside one launch ----------------
+
+def _banded(S, left, right, seed=0):
+    """A transition matrix that is finite exactly where -left <= prev - next <= right."""
+    _, trans, _ = synth.problem(1, 1, S, seed=seed)
+    idx = np.arange(S)
+    d = idx[None, :] - idx[:, None]
+    return np.where((d >= -left) & (d <= right), trans, -np.inf).astype(np.float32)
+
+
+def _decode_band(obs, frames, trans, init, want_route='band'):
+    dev = torch.device('cuda:0')
+    args = [torch.as_tensor(np.ascontiguousarray(x)).to(dev) for x in (obs, frames, trans, init)]
+    prof = []
+    got = torbi_amd.decode(*args, path='band', _profile=prof).cpu().numpy()
+    if want_route is not None:
+        assert viterbi.ROUTES[int(prof[3])] == want_route, (viterbi.ROUTES[int(prof[3])], want_route)
+    return got
+
+
+@pytest.mark.parametrize('case', [(40, 12, 1440, 87, 87), (17, 9, 360, 10, 3), (64, 25, 360, 22, 22), (100, 7, 1440, 0, 0),
+                                  (33, 11, 1024, 5, 60), (16, 6, 1440, 87, 87), (5, 8, 1440, 40, 40), (600, 5, 1440, 87, 87),
+                                  (48, 9, 3072, 30, 30), (70, 6, 132, 8, 8), (260, 4, 1444, 86, 88), (24, 10, 512, 100, 100),
+                                  (1, 30, 1440, 87, 87), (530, 3, 64, 3, 3), (31, 7, 2048, 120, 0), (96, 5, 768, 0, 150)])
+@pytest.mark.parametrize('ties', [False, True])
+def test_band_kernel_matches_the_oracle(case, ties, forward):
+    """torbi_hip_viterbi_decode_banded on matrices that are -inf outside a band (viterbi.cpp:81-104 with -inf candidates never
+    winning the strict '>'): one tile and many, ragged lengths, 1 .. 16 members per tile, asymmetric and one-sided bands, a
+    band of the diagonal alone, a next-state nothing leads to, coarse grids (many exactly equal candidates: lowest index
+    wins), states the members' shares do not divide evenly."""
+    if forward != 'auto':
+        pytest.skip('names its path itself')
+    B, T, S, left, right = case
+    obs, _, init = synth.problem(B, T, S, seed=B + S)
+    trans = _banded(S, left, right, seed=S)
+    if ties:
+        obs, trans, init = np.round(obs * 2) / 2, np.round(trans * 2) / 2, np.round(init)
+    trans[S // 3] = -np.inf
+    frames = np.clip(synth.lengths(B, 1, T, seed=3), 1, T).astype(np.int32)
+    frames[0] = T
+    want = oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())
+    np.testing.assert_array_equal(_decode_band(obs, frames, trans, init), want)
+
+
+@pytest.mark.parametrize('width', [1, 7, 44, 87, 88, 89, 93, 122, 123, 254, 300])
+def test_band_width_sweep_at_1440_states(width, forward):
+    """Half widths from the diagonal alone over the reference's pitch model (reach 87 either way, torbi/evaluate/core.py:24-33)
+    to the widest band 1440 states allow (reach 121: eleven members of 132 next-states), and bands the kernel does not cover
+    (the call then is torbi_hip_viterbi_decode_batches); a dead row; ties."""
+    if forward != 'auto':
+        pytest.skip('names its path itself')
+    B, T, S = 40, 7, 1440
+    obs, trans, init = synth.problem(B, T, S, seed=width)
+    obs = np.round(obs * 2) / 2
+    trans = np.round(trans * 2) / 2
+    idx = np.arange(S)
+    trans = np.where(np.abs(idx[:, None] - idx[None, :]) < width, trans, -np.inf).astype(np.float32)
+    trans[S // 3] = -np.inf
+    frames = np.clip(synth.lengths(B, 1, T, seed=2), 1, T).astype(np.int32)
+    frames[0] = T
+    want = oracle.decode(obs.astype(np.float32), frames, trans, init)
+    reach = width - 1
+    covered = torbi_amd._lib.load().torbi_hip_band_members(B, S, reach, reach, 0) > 0
+    assert covered == (reach <= 121)
+    got = _decode_band(obs.astype(np.float32), frames, trans, init, want_route='band' if covered else None)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_auto_takes_the_band_kernel_for_the_pitch_transition(forward):
+    """The reference's own evaluation workload (torbi/evaluate/core.py:24-33): peaked posteriorgram-like rows, the triangular
+    pitch band, ragged 512 x 500 x 1440 -- AUTO routes it to the band kernel (one batch and a launch group), the first 64
+    items equal the oracle's, and every named path agrees on all of them."""
+    if forward != 'auto':
+        pytest.skip('AUTO routing is the subject')
+    import math
+    dev = torch.device('cuda:0')
+    B, T, S = 512, 500, 1440
+    gen = torch.Generator(device=dev).manual_seed(11)
+    logits = torch.randn((B, T, S), device=dev, generator=gen) * 2.0
+    centre = torch.randint(0, S, (B, T, 1), device=dev, generator=gen)
+    logits -= ((torch.arange(S, device=dev)[None, None, :] - centre).abs().float() / 12.0) ** 2
+    peaked = torch.log_softmax(logits, dim=-1).clamp_(min=math.log(torch.finfo(torch.float32).tiny))
+    del logits
+    band_np = synth.banded_transition(S, 87.2)
+    band = torch.from_numpy(band_np).to(dev)
+    init_np = np.full((S,), math.log(1.0 / S), np.float32)
+    init = torch.from_numpy(init_np).to(dev)
+    frames_np = np.clip(synth.lengths(B, 300, T, seed=5), 1, T).astype(np.int32)
+    frames_np[0] = T
+    frames = torch.from_numpy(frames_np).to(dev)
+    assert viterbi.band_reach(band, band, S) == (87, 87)
+    prof = []
+    got = torbi_amd.decode(peaked, frames, band, init, _profile=prof)
+    assert viterbi.ROUTES[int(prof[3])] == 'band'
+    got_np = got.cpu().numpy()
+    want = oracle.decode(peaked[:64].cpu().numpy(), frames_np[:64], band_np, init_np, num_threads=oracle.max_threads())
+    np.testing.assert_array_equal(got_np[:64], want)
+    for path in ('dense', 'cluster'):
+        np.testing.assert_array_equal(torbi_amd.decode(peaked, frames, band, init, path=path).cpu().numpy(), got_np)
+    group = viterbi.decode_batches([peaked, peaked[:100], peaked[:17]], [frames, frames[:100], frames[:17]], band, init,
+                                   _profile=prof)
+    assert viterbi.ROUTES[int(prof[3])] == 'band'
+    for g, n in zip(group, (B, 100, 17)):
+        np.testing.assert_array_equal(g.cpu().numpy(), got_np[:n])
+    stats = viterbi.scan_stats(torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev), B, T, S)
+    del stats
+
+
+@pytest.mark.parametrize('shape', [(40, 12, 360, 10), (17, 9, 1440, 87), (130, 7, 724, 30)])
+def test_band_launch_that_gives_up_waiting_is_repaired(shape, forward, monkeypatch):
+    """The members of a tile wait for each other's halo rows inside the launch; every wait is bounded.  With a budget of 0
+    every failed poll gives up: the members flag their tile and band_repair_kernel decodes it again without hand-offs --
+    indices and final posterior rows are the oracle's, the give-ups are counted; without the limit nothing gives up."""
+    if forward != 'auto':
+        pytest.skip('names its path itself')
+    B, T, S, reach = shape
+    obs, _, init = synth.problem(B, T, S, seed=41)
+    trans = _banded(S, reach, reach, seed=7)
+    frames = np.clip(synth.lengths(B, 1, T, seed=6), 1, T).astype(np.int32)
+    frames[0] = T
+    dev = torch.device('cuda:0')
+    args = [torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)]
+    space = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+    want, want_post = oracle.decode(obs, frames, trans, init, return_posterior=True)
+    for limit, gave_up in (('0', True), (None, False), ('0', True)):
+        if limit is None:
+            monkeypatch.delenv('TORBI_HIP_CLUSTER_WAIT_US', raising=False)
+        else:
+            monkeypatch.setenv('TORBI_HIP_CLUSTER_WAIT_US', limit)
+        prof = []
+        got = torbi_amd.decode(*args, workspace=space, path='band', _profile=prof)
+        assert viterbi.ROUTES[int(prof[3])] == 'band'
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+        post = viterbi.read_posterior(space, args[1], B, T, S).cpu().numpy()
+        assert np.array_equal(post.view(np.uint32), want_post.view(np.uint32))
+        stats = viterbi.scan_stats(space, B, T, S).cpu()
+        assert (int(stats[127]) > 0) == gave_up, (limit, int(stats[127]))
+
+
+def test_band_entry_point_falls_back_and_validates(forward):
+    """torbi_hip_viterbi_decode_banded through ctypes: a band it does not cover, a path other than AUTO / BAND and a
+    misaligned matrix all decode as torbi_hip_viterbi_decode_batches would (same indices); negative reaches are EINVAL."""
+    if forward != 'auto':
+        pytest.skip('names its path itself')
+    import ctypes
+    from torbi_amd import _lib
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    B, T, S = 48, 6, 360
+    obs, _, init = synth.problem(B, T, S, seed=2)
+    trans = _banded(S, 9, 9, seed=3)
+    frames = np.full((B,), T, np.int32)
+    want = oracle.decode(obs, frames, trans, init)
+    o, f, i = (torch.as_tensor(x).to(dev) for x in (obs, frames, init))
+    padded = torch.zeros((S * S + 1,), dtype=torch.float32, device=dev)
+    padded[1:] = torch.as_tensor(trans).reshape(-1).to(dev)
+    aligned = torch.as_tensor(trans).to(dev)
+    ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+    out = torch.empty((B, T), dtype=torch.int32, device=dev)
+    one = (_lib.Batch * 1)(_lib.Batch(o.data_ptr(), f.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B, T))
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    phases = (ctypes.c_float * 6)()
+    for matrix, left, right, flags, route in ((aligned, 9, 9, viterbi._path_flag('band'), 'band'),
+                                              (aligned, 9, 9, viterbi._path_flag('auto'), 'band'),
+                                              (aligned, 9, 9, viterbi._path_flag('dense'), 'dense'),
+                                              (aligned, 300, 300, viterbi._path_flag('band'), 'cluster'),
+                                              (padded[1:], 9, 9, viterbi._path_flag('band'), 'cluster')):
+        out.zero_()
+        rc = lib.torbi_hip_viterbi_decode_banded(one, 1, matrix.data_ptr(), i.data_ptr(), S, left, right, 0, stream, flags, phases)
+        assert rc == 0
+        assert viterbi.ROUTES[int(phases[3])] == route, (viterbi.ROUTES[int(phases[3])], route)
+        np.testing.assert_array_equal(out.cpu().numpy(), want)
+    assert lib.torbi_hip_viterbi_decode_banded(one, 1, aligned.data_ptr(), i.data_ptr(), S, -1, 9, 0, stream, 0, None) == -1
+    left, right = ctypes.c_int(-1), ctypes.c_int(-1)
+    assert lib.torbi_hip_band_reach(aligned.data_ptr(), S, 0, stream, ctypes.byref(left), ctypes.byref(right)) == 0
+    assert (left.value, right.value) == (9, 9)
+    lop = torch.as_tensor(_banded(S, 4, 31, seed=1)).to(dev)
+    assert lib.torbi_hip_band_reach(lop.data_ptr(), S, 0, stream, ctypes.byref(left), ctypes.byref(right)) == 0
+    assert (left.value, right.value) == (4, 31)

@@ -696,3 +696,26 @@ def test_slab_pool_stops_counting_slabs_that_were_dropped():
     pool.give(again)
     pool.give(again)                            # (a second give of the same slab does not drive the count below zero)
     assert pool._out == 0
+
+
+def test_band_plan_covers_the_reference_pitch_band_and_says_so_without_a_gpu():
+    """torbi_hip_band_members (include/torbi_hip.h): members per 16-item tile of the band kernel, 0 where it does not cover the
+    shape.  The plan is host arithmetic (LDS budget of a member: its slab of the band + window + merge buffer within 160 KB;
+    every reach within a member's share): the reference's pitch band -- reach 87 of 1440 states, torbi/evaluate/core.py:24-33 --
+    fits with eight members per tile, which is what a 512-item batch needs to fill 256 compute units."""
+    lib = _lib.load()
+    members = lambda items, S, left, right: lib.torbi_hip_band_members(items, S, left, right, 0)
+    assert members(512, 1440, 87, 87) == 8                      # 32 tiles x 8 = one workgroup per compute unit
+    assert members(4096, 1440, 87, 87) == 8                     # a launch group of eight batches: as few members as fit
+    assert members(16, 1440, 87, 87) == 16                      # one tile: as many as the reach allows (16 x 92 next-states)
+    assert members(512, 1440, 88, 88) == 9                      # one diagonal more does not fit eight members' LDS: nine
+    assert members(40, 1440, 88, 88) == 16                      # three tiles: as many members as there are compute units for
+    assert members(40, 1440, 120, 120) == 12 and members(40, 1440, 121, 121) == 11 and members(40, 1440, 122, 122) == 0
+    assert members(512, 1440, 0, 0) == 8 and members(512, 1440, 0, 175) == 8 and members(512, 1440, 176, 0) == 0
+    assert members(64, 1442, 87, 87) == 0 and members(64, 32, 3, 3) == 0 and members(64, 4096, 10, 10) == 0
+    assert members(64, 1440, 300, 300) == 0
+    assert members(0, 1440, 87, 87) == -1 and members(64, 1440, -1, 0) == -1
+    from torbi_amd import viterbi
+    import torch
+    cpu = torch.zeros((1440, 1440))
+    assert viterbi.band_reach(cpu, cpu, 1440) is None           # (asked of device tensors only)

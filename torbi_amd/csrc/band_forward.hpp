@@ -162,7 +162,16 @@ inline bool make_plan(int S, int hl, int hr, int tiles, int cus, Plan &pl) {
     return true;
 }
 
-__device__ __forceinline__ float4 lds_f4(const char *p) { return *reinterpret_cast<const float4 *>(p); }
+#ifndef BAND_ABL
+#define BAND_ABL 0       // build-time ablations (timing only, results wrong): 1 no waiting for the halo, 2 no history stores,
+                         // 4 no merge through M, 8 no exchange stores, 16 the scans alone (no hand-off, merge, finish, barriers),
+                         // 32 write-through granules even inside one XCD (results right), 64 scans without LDS reads, 128 scans without arithmetic
+#endif
+
+__device__ __forceinline__ float4 lds_f4(const char *p) {
+    if (BAND_ABL & 64) return make_float4(1.f, 2.f, 3.f, 4.f);
+    return *reinterpret_cast<const float4 *>(p);
+}
 
 template <int K>
 __device__ __forceinline__ float comp(const float4 &v) {
@@ -186,6 +195,10 @@ template <int PH, int D0, int K>
 __device__ __forceinline__ void dquad_cells(float (&acc)[16], const float4 (&w)[8], const float4 (&t)[4]) {
     const float4 r0 = w[(4 * PH + D0 + K) & 7], r1 = w[(4 * PH + D0 + 1 + K) & 7];
     const float t0 = comp<K>(t[D0]), t1 = comp<K>(t[D0 + 1]);
+    if (BAND_ABL & 128) {
+        if (D0 == 2) asm volatile("" :: "v"(r0.x), "v"(r1.w), "v"(t0), "v"(t1));
+        return;
+    }
     acc[4 * K + 0] = fmaxf(fmaxf(acc[4 * K + 0], r0.x + t0), r1.x + t1);
     acc[4 * K + 1] = fmaxf(fmaxf(acc[4 * K + 1], r0.y + t0), r1.y + t1);
     acc[4 * K + 2] = fmaxf(fmaxf(acc[4 * K + 2], r0.z + t0), r1.z + t1);
@@ -195,7 +208,10 @@ __device__ __forceinline__ void dquad_cells(float (&acc)[16], const float4 (&w)[
 // tp / wp: this dquad's Tq block and first window row; tn / wn: the next dquad's (anything readable behind the last one)
 template <int PH>
 __device__ __forceinline__ void dquad(float (&acc)[16], float4 (&w)[8], float4 (&t)[4], const char *tn, const char *wn) {
+    // (the requests of a half are pinned AHEAD of its arithmetic: left to itself the scheduler sinks them towards their
+    // first use, half a dquad later at best)
     w[(4 * PH + 7) & 7] = lds_f4(wn + 16 * 3);
+    __builtin_amdgcn_sched_barrier(0);
     dquad_cells<PH, 0, 0>(acc, w, t);
     dquad_cells<PH, 0, 1>(acc, w, t);
     dquad_cells<PH, 0, 2>(acc, w, t);
@@ -205,6 +221,7 @@ __device__ __forceinline__ void dquad(float (&acc)[16], float4 (&w)[8], float4 (
     t[1] = lds_f4(tn + 16);
     w[(4 * PH + 8) & 7] = lds_f4(wn + 16 * 4);
     w[(4 * PH + 9) & 7] = lds_f4(wn + 16 * 5);
+    __builtin_amdgcn_sched_barrier(0);
     dquad_cells<PH, 2, 0>(acc, w, t);
     dquad_cells<PH, 2, 1>(acc, w, t);
     dquad_cells<PH, 2, 2>(acc, w, t);
@@ -213,12 +230,14 @@ __device__ __forceinline__ void dquad(float (&acc)[16], float4 (&w)[8], float4 (
     t[2] = lds_f4(tn + 32);
     t[3] = lds_f4(tn + 48);
     w[(4 * PH + 10) & 7] = lds_f4(wn + 16 * 6);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
-// dquads [lo, hi) of a lane (wave-uniform bounds): tq0 = Tq[0][jg], w0 = W[ig][4 jg]
+// dquads [lo, hi) of a lane (wave-uniform bounds): tq0 = Tq[0][jg], w0 = W[ig][4 jg]; `hook` runs ahead of dquad `at`
+template <typename Hook>
 __device__ __forceinline__ void scan(float (&acc)[16], float4 (&w)[8], const char *tq0, const char *w0, int lo, int hi,
-                                     int tq_step) {
-    if (lo >= hi) return;
+                                     int tq_step, int at, Hook hook) {
+    if (lo >= hi) { if (at >= lo) hook(); return; }
     const char *tp = tq0 + (size_t)lo * tq_step, *wp = w0 + (size_t)lo * 64;
     float4 t[4];
 #pragma unroll
@@ -227,6 +246,7 @@ __device__ __forceinline__ void scan(float (&acc)[16], float4 (&w)[8], const cha
     if (q & 1) {
 #pragma unroll
         for (int m = 0; m < 7; ++m) w[(4 + m) & 7] = lds_f4(wp + 16 * m);
+        if (q == at) hook();
         dquad<1>(acc, w, t, tp + tq_step, wp + 64);
         ++q;
         tp += tq_step;
@@ -236,19 +256,25 @@ __device__ __forceinline__ void scan(float (&acc)[16], float4 (&w)[8], const cha
         for (int m = 0; m < 7; ++m) w[m] = lds_f4(wp + 16 * m);
     }
     for (; q + 1 < hi; q += 2) {
+        if (q == at) hook();
         dquad<0>(acc, w, t, tp + tq_step, wp + 64);
+        if (q + 1 == at) hook();
         dquad<1>(acc, w, t, tp + 2 * tq_step, wp + 128);
         tp += 2 * tq_step;
         wp += 128;
     }
-    if (q < hi) dquad<0>(acc, w, t, tp + tq_step, wp + 64);
+    if (q < hi) {
+        if (q == at) hook();
+        dquad<0>(acc, w, t, tp + tq_step, wp + 64);
+        ++q;
+    }
+    if (at >= q) hook();         // (a hook at or behind the end of the run)
+}
+__device__ __forceinline__ void scan(float (&acc)[16], float4 (&w)[8], const char *tq0, const char *w0, int lo, int hi,
+                                     int tq_step) {
+    scan(acc, w, tq0, w0, lo, hi, tq_step, -1, [] {});
 }
 
-#ifndef BAND_ABL
-#define BAND_ABL 0       // build-time ablations (timing only, results wrong): 1 no waiting for the halo, 2 no history stores,
-                         // 4 no merge through M, 8 no exchange stores, 16 the scans alone (no hand-off, merge, finish, barriers),
-                         // 32 write-through granules even inside one XCD (results right)
-#endif
 #ifdef BAND_STAMP
 // build-time instrumentation (tools/band_stamps.py): per-wave cycle sums of the phases of a timestep
 constexpr int kPhases = 12;
@@ -362,6 +388,9 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
             }
             const bool same = __all(seen == xcc + 1u);
             if (lane == 0) smisc[2] = same ? 1 : 0;
+            // (a budget of zero means "do not wait at all": the member reports that it gave up whether or not a poll
+            // failed -- the tests of the repair launch rely on it)
+            if (lane == 0 && ex.wait_ticks == 0ull) smisc[1] = 1;
         }
         __syncthreads();
         local = smisc[2] != 0 && !(BAND_ABL & 32);
@@ -371,11 +400,19 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
     // granule asked for behind a first-touch HBM read would wait for it)
     float4 ob = make_float4(0.f, 0.f, 0.f, 0.f), ob_next = ob;
 
-    auto finish = [&](int t, const float4 &best, bool more) {
-        // post'[j] = obs[t][j] + max (viterbi.cpp:102) -> the neighbours, the window, the history
+    // post'[j] = obs[t][j] + max (viterbi.cpp:102).  `settle`: into the window; `send`: to the neighbours and the history
+    // (measured: sending behind the barrier that opens the next timestep, so that the stores issue under its first dquads,
+    // is 2 % slower -- the granules leave later); `fetch`: the observations of row t + 2 (behind the halo granules of the timestep: a wave's loads return in
+    // order, and a granule asked for behind a first-touch HBM read would wait for it)
+    auto settle = [&](const float4 &best) {
         const float4 v = make_float4(ob.x + best.x, ob.y + best.y, ob.z + best.z, ob.w + best.w);
-        ob = ob_next;       // (ahead of this row's stores: behind them the wait for the older load would cover them too)
-        asm volatile("" : "+v"(ob.x), "+v"(ob.y), "+v"(ob.z), "+v"(ob.w));
+        fw_at[0] = v.x;
+        fw_at[4] = v.y;
+        fw_at[8] = v.z;
+        fw_at[12] = v.w;
+        return v;
+    };
+    auto send = [&](int t, const float4 &v, bool more) {
         if (publishes && more && !(BAND_ABL & 8)) {
             const unsigned tag = (unsigned)t + 1u;
             const int at = (int)((unsigned)(t & 1) * xpar) + fx_at;
@@ -389,12 +426,11 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
                 __builtin_amdgcn_raw_buffer_store_b128(g1, xbuf, at + xhalf, 0, 16);
             }
         }
-        fw_at[0] = v.x;
-        fw_at[4] = v.y;
-        fw_at[8] = v.z;
-        fw_at[12] = v.w;
         if (fin_row && t < flen && !(BAND_ABL & 2)) *reinterpret_cast<float4 *>(hist + item_at + (size_t)t * S) = v;
-        if (fin_row && t + 2 < fmax) ob_next = *reinterpret_cast<const float4 *>(obs + item_at + (size_t)(t + 2) * S);
+    };
+    auto fetch = [&](int t) {       // called in timestep t: row t is already in `ob_next`
+        ob = ob_next;
+        if (fin_row && t + 1 < fmax) ob_next = *reinterpret_cast<const float4 *>(obs + item_at + (size_t)(t + 1) * S);
     };
 
     // t = 0: posterior row 0 = obs[b][0][:] + initial (viterbi.cpp:72-76)
@@ -405,7 +441,8 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
             if (fmax > 1) ob_next = *reinterpret_cast<const float4 *>(obs + item_at + (size_t)S);
             first = make_float4(initial[fj], initial[fj + 1], initial[fj + 2], initial[fj + 3]);
         }
-        finish(0, first, fmax > 1);
+        send(0, settle(first), fmax > 1);
+        ob = ob_next;                 // row 1; row 2 is asked for in timestep 1
     }
 
     // ---- the thread as a reader of halo granules: two consecutive states of one item, {v, tag, v', tag} ---------------------
@@ -461,8 +498,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = -INFINITY;
         if (BAND_ABL & 16) {
-            scan(acc, w, tq0, w0, s0, s1, tq_step);
-            scan(acc, w, tq0, w0, s2, s3, tq_step);
+            scan(acc, w, tq0, w0, s0, s3, tq_step);
             scan(acc, w, tq0, w0, s4, s5, tq_step);
             scan(acc, w, tq0, w0, s6, s7, tq_step);
             scan(acc, w, tq0, w0, s8, s9, tq_step);
@@ -472,18 +508,16 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
             if (sum == 12345.678f) mq[tid] = sum;
             continue;
         }
-        scan(acc, w, tq0, w0, s0, s1, tq_step);
-        BSTAMP(0);
-        // the neighbours' rows t - 1: asked for now, looked at behind the second run of own-row dquads
+        // the neighbours' rows t - 1: asked for half-way through the own-row dquads, looked at behind them
         v4u got[kMaxRounds];
         const int par_at = (int)((unsigned)((t - 1) & 1) * xpar);
-        if (R > 1) {
+        scan(acc, w, tq0, w0, s0, s3, tq_step, s1, [&] {
+            if (R > 1) {
 #pragma unroll
-            for (int r = 0; r < kMaxRounds; ++r)
-                if (hx_at[r] >= 0) got[r] = __builtin_amdgcn_raw_buffer_load_b128(xbuf, par_at + hx_at[r], 0, 16);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        scan(acc, w, tq0, w0, s2, s3, tq_step);
+                for (int r = 0; r < kMaxRounds; ++r)
+                    if (hx_at[r] >= 0) got[r] = __builtin_amdgcn_raw_buffer_load_b128(xbuf, par_at + hx_at[r], 0, 16);
+            }
+        });
         BSTAMP(1);
         if (R > 1) {
             const unsigned tag = (unsigned)t;
@@ -512,6 +546,9 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
                 if (need0[r]) *reinterpret_cast<float *>(lds + hw_at[r]) = __uint_as_float(got[r].x);
                 if (need1[r]) *reinterpret_cast<float *>(lds + hw_at[r] + 16) = __uint_as_float(got[r].z);
             }
+        }
+        if (fin) fetch(t);              // the observations of row t + 1 (row t is in `ob` already)
+        if (R > 1) {
             __syncthreads();            // the halo rows t - 1 are in the window
             BSTAMP(3);
             scan(acc, w, tq0, w0, s4, s5, tq_step);
@@ -537,7 +574,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
             fm_at[4 * n_own] = -INFINITY;
             fm_at[8 * n_own] = -INFINITY;
             fm_at[12 * n_own] = -INFINITY;
-            finish(t, best, t + 1 < fmax);
+            send(t, settle(best), t + 1 < fmax);
         }
         BSTAMP(7);
         __syncthreads();                // the window holds the own rows t
@@ -646,6 +683,9 @@ __global__ __launch_bounds__(256) void clear_exchange_kernel(ClearJobs jobs) {
 // final state, tail fill and backtrace of every item of the group: the first argmax of fl(hist[t-1][i] + trans[j][i]) over
 // the band of the state on the path (viterbi.cpp:81-100, 140-160), as lazy::backtrace_ranged_kernel finds it inside a
 // row's finite range.  grid = items of the group, one wave per item; S % 4 == 0, S <= 256 NQ, hl + hr + 4 <= 512.
+// (Measured and dropped: asking for the next step's posteriors over [j - 2 hl, j + 2 hr] a step ahead and handing them over
+// through the LDS -- 0.64 against 0.36 ms for 512 x 500 x 1440, 1.6 against 0.5 ms for eight batches: the step is not bound
+// by the history read, and the wider window is three times the bytes.)
 // ---------------------------------------------------------------------------------------
 template <int NQ>
 __global__ __launch_bounds__(64) void group_backtrace_band_kernel(Group grp, const float *__restrict__ trans, int S, int hl,

@@ -75,8 +75,12 @@ struct Group {
 // through `xchg` (write-through stores, one flag per member and timestep, MI355X_MICROARCH.md "handoff-flag" /
 // cdna_hip_programming.md Guideline 16 R1) -- no kernel boundary, no grid-wide barrier, the clusters drift freely.
 // That puts a single 512-item batch (32 tiles) on 256 compute units.  Membership is by ARRIVAL (a ticket drawn at
-// kernel entry): nothing depends on dispatch order or placement, and a cluster whose last members have not been
-// dispatched yet only waits -- every cluster that is complete runs to its end and frees its compute units.
+// kernel entry) within a DISPATCH CLASS (workgroups b, b + 8, b + 16, ...): nothing depends on dispatch order or placement,
+// and a cluster whose last members have not been dispatched yet only waits -- every cluster that is complete runs to its
+// end and frees its compute units.  The GPU places a class on one XCD (observed, not promised); the members compare notes
+// at kernel entry, and a cluster that finds itself on ONE XCD exchanges through that XCD's L2 -- plain stores that stay in
+// it, L1-bypassing loads that hit it -- instead of write-through stores and reads across the fabric: the three dependent
+// trips of a timestep (slices + flag, flag poll, slice reads) then cost an L2 round trip each, not a fabric one (round 5).
 #ifndef RESIDENT_MAX_R
 #define RESIDENT_MAX_R 16
 #endif
@@ -90,7 +94,10 @@ struct Cluster {
     float *xchg;           // [tiles][2] slots by timestep parity: the members' slices of the newest posterior row
                            // [S4][16] floats, then their partial top lists [kMaxR][16 * kMaxTop] 64-bit keys
     unsigned *flags;       // [tiles][kMaxR] newest timestep each member has published (zeroed before the launch)
-    unsigned *control;     // [0] tickets drawn (zeroed before the launch); give-ups are counted in Group::stats[127]
+    unsigned *where;       // [tiles][kMaxR] the XCD each member runs on, + 1 (zeroed before the launch)
+    int tiles;             // tiles of the launch (the grid is padded to whole dispatch classes: 8 x ceil(tiles / 8) x R)
+    unsigned *control;     // [0 .. 7] tickets drawn per dispatch class (zeroed before the launch); give-ups are counted
+                           // in Group::stats[127]
     unsigned *failed;      // [tiles] set by a member that gave up waiting for the others (zeroed before the launch): the
                            // tile's history is incomplete and the launch that follows decodes it again, whole
     int R;
@@ -252,9 +259,19 @@ __device__ __forceinline__ void store_through(__amdgpu_buffer_rsrc_t buffer, int
     v4u x = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
     __builtin_amdgcn_raw_buffer_store_b128(x, buffer, offset, 0, 16);
 }
+__device__ __forceinline__ void store_plain(__amdgpu_buffer_rsrc_t buffer, int offset, float4 v) {
+    v4u x = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(x, buffer, offset, 0, 0);
+}
 __device__ __forceinline__ float4 load_through(__amdgpu_buffer_rsrc_t buffer, int offset) {
     const v4u x = __builtin_amdgcn_raw_buffer_load_b128(buffer, offset, 0, 16);
     return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
+}
+// a member's flag: behind its drained payload.  One XCD: a plain store (the word stays in the L2 the pollers read);
+// else write-through
+__device__ __forceinline__ void raise_flag(unsigned *flag, unsigned value, bool local) {
+    if (local) *reinterpret_cast<volatile unsigned *>(flag) = value;
+    else __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void *base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
@@ -342,15 +359,43 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
     if constexpr (REPAIR) {
         if (!grp.only || grp.only[blockIdx.x] == 0u) return;     // (this tile's cluster completed)
     }
+    bool local = false;                  // CLUSTER: every member of this cluster runs on one XCD
     if constexpr (CLUSTER) {
+        const int cls = blockIdx.x & 7;
         if (tid == 0) {
-            smisc[0] = (int)__hip_atomic_fetch_add(clu.control, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            smisc[0] = (int)__hip_atomic_fetch_add(clu.control + cls, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             smisc[1] = 0;
         }
         __syncthreads();
         const int ticket = __builtin_amdgcn_readfirstlane(smisc[0]);
-        cid = ticket / R;
-        member = ticket - cid * R;
+        member = ticket % R;
+        cid = (ticket / R) * 8 + cls;
+        if (cid >= clu.tiles) return;        // (the grid is padded to whole classes)
+        // where do the R members run?  Each says so (write-through), all read all R answers (bounded wait; a cluster that
+        // cannot complete in time exchanges write-through and gives up at its first hand-off as before)
+        if (wave == 0) {
+            unsigned *const where = clu.where + (size_t)cid * kMaxR;
+            const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u;      // HW_REG_XCC_ID
+            if (lane == 0) __hip_atomic_store(where + member, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long since = 0ull;
+            unsigned seen = xcc + 1u;
+            bool complete = true;
+            for (;;) {
+                if (lane < R) seen = __hip_atomic_load(where + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(seen != 0u)) break;
+                const unsigned long long now = wall_clock64();
+                if (since == 0ull) since = now;
+                if (now - since >= clu.wait_ticks) { complete = false; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            const bool same = complete && __all(seen == xcc + 1u);
+            if (lane == 0) smisc[2] = same ? 1 : 0;
+        }
+        __syncthreads();
+#ifndef CLUSTER_LOCAL_EXCHANGE
+#define CLUSTER_LOCAL_EXCHANGE 1             // (0: write-through exchange whatever the placement -- experiments)
+#endif
+        local = CLUSTER_LOCAL_EXCHANGE && smisc[2] != 0;
     }
     const int code = grp.tile_map[cid];
     const Batch &bat = grp.batch[code >> 20];
@@ -658,8 +703,11 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                 for (int p = 0; p < MAXP; ++p) {
                     const int rg = rg_lo + wave + KW * p + opaque;
                     const int jj = kRowGroup * rg + jl;
-                    if (rg < rg_hi && jj < S)
-                        store_through(xdst, (jj * kNI + 4 * g) * 4, make_float4(pend[p][0], pend[p][1], pend[p][2], pend[p][3]));
+                    if (rg < rg_hi && jj < S) {
+                        const float4 row4 = make_float4(pend[p][0], pend[p][1], pend[p][2], pend[p][3]);
+                        if (local) store_plain(xdst, (jj * kNI + 4 * g) * 4, row4);       // (stays in this XCD's L2)
+                        else store_through(xdst, (jj * kNI + 4 * g) * 4, row4);
+                    }
                 }
             }
             if (!CLUSTER_LATE_DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -695,11 +743,12 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                     if (lane < kNI * kTop / 2) {
                         const u64 k0 = top[2 * lane], k1 = top[2 * lane + 1];
                         v4u x = {(unsigned)k0, (unsigned)(k0 >> 32), (unsigned)k1, (unsigned)(k1 >> 32)};
-                        __builtin_amdgcn_raw_buffer_store_b128(x, xsrc, (int)xrow + (member * kNI * kMaxTop + 2 * lane) * 8, 0, 16);
+                        if (local) __builtin_amdgcn_raw_buffer_store_b128(x, xsrc, (int)xrow + (member * kNI * kMaxTop + 2 * lane) * 8, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(x, xsrc, (int)xrow + (member * kNI * kMaxTop + 2 * lane) * 8, 0, 16);
                     }
                     if (!CLUSTER_LATE_DRAIN) {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        if (lane == 0) __hip_atomic_store(cflags + member, (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane == 0) raise_flag(cflags + member, (unsigned)t, local);
                     }
                 }
                 if (CLUSTER_LATE_DRAIN) {
@@ -707,7 +756,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                     // stored before the barrier above and have been on their way since), then the flag
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
-                    if (tid == 0) __hip_atomic_store(cflags + member, (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid == 0) raise_flag(cflags + member, (unsigned)t, local);
                 }
                 RSTAMP(6);
                 // (2) wave 0 waits until the other members have published timestep t (one relaxed poll per member and

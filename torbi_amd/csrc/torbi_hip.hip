@@ -682,7 +682,7 @@ inline ResidentWorkspace carve_resident(void *base, int B, int T, int S, int cus
     const size_t order_bytes = align_up(sizeof(int32_t) * (size_t)B, 256) + sizeof(int32_t) * (kMaxGroupTiles + 128) + hist_len;
     const size_t ctiles = (size_t)std::max(cus / 2, 1);                 // a cluster launch holds at most this many tiles
     const size_t xchg_bytes = align_up(ctiles * 2 * resident::cluster_slot_bytes(S), 256);
-    w.flag_bytes = align_up(sizeof(unsigned) * (ctiles * resident::kMaxR + 16 + ctiles), 256);    // flags, control, failed
+    w.flag_bytes = align_up(sizeof(unsigned) * (2 * ctiles * resident::kMaxR + 16 + ctiles), 256);    // flags, control, failed, where
     w.hist = reinterpret_cast<float *>(p);
     p += hist_bytes;
     w.tile_map = reinterpret_cast<int32_t *>(p);   // ahead of the preparation: offsets depend on B and T only
@@ -1304,7 +1304,8 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
     unsigned *const control = w.flags + (size_t)std::max(cus / 2, 1) * resident::kMaxR;
     const char *wait_env = getenv("TORBI_HIP_CLUSTER_WAIT_US");         // (read per launch: the tests switch it)
     const unsigned long long wait_ticks = wait_env ? 100ull * strtoull(wait_env, nullptr, 10) : resident::kClusterWaitTicks;
-    resident::Cluster clu{w.xchg, w.flags, control, control + 16, R, wait_ticks};
+    // (flags [ctiles][kMaxR], control [16], failed [ctiles], where [ctiles][kMaxR]: all zeroed by order_tiles_kernel)
+    resident::Cluster clu{w.xchg, w.flags, control + 16 + std::max(cus / 2, 1), tiles, control, control + 16, R, wait_ticks};
     if (ev) (void)hipEventRecord(ev[0], s);
     for (int k = 0; k < n; ++k) {            // (order_items_kernel stamps the batches' route records)
         jobs.job[k].route_record = route_record(hb[k].workspace, hb[k].B, hb[k].T, S, cus);
@@ -1334,15 +1335,17 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
     const bool small = resident::tile_items(S) != resident::kNI;       // 8-item tiles (2048 < S <= 4096)
     if (R > 1) {
         const int passes = ((nrg + R - 1) / R + 11) / 12;       // row groups of the largest share over 12 waves
+        // (eight dispatch classes of R x ceil(tiles / 8) workgroups each: resident_forward.hpp, struct Cluster)
+        const int grid = 8 * ((tiles + 7) / 8) * R;
         if (small) {
-            if (passes <= 1) e = launch_resident_kernel<12, 1, true, 8>(grp, clu, tiles * R, w, init, S, s, few);
-            else if (passes <= 2) e = launch_resident_kernel<12, 2, true, 8>(grp, clu, tiles * R, w, init, S, s, few);
-            else if (passes <= 4) e = launch_resident_kernel<12, 4, true, 8>(grp, clu, tiles * R, w, init, S, s, few);
-            else e = launch_resident_kernel<12, 6, true, 8>(grp, clu, tiles * R, w, init, S, s, few);
-        } else if (passes <= 1) e = launch_resident_kernel<12, 1, true>(grp, clu, tiles * R, w, init, S, s, few);
-        else if (passes <= 2) e = launch_resident_kernel<12, 2, true>(grp, clu, tiles * R, w, init, S, s, few);
-        else if (passes <= 4) e = launch_resident_kernel<12, 4, true>(grp, clu, tiles * R, w, init, S, s, few);
-        else e = launch_resident_kernel<12, 6, true>(grp, clu, tiles * R, w, init, S, s, few);
+            if (passes <= 1) e = launch_resident_kernel<12, 1, true, 8>(grp, clu, grid, w, init, S, s, few);
+            else if (passes <= 2) e = launch_resident_kernel<12, 2, true, 8>(grp, clu, grid, w, init, S, s, few);
+            else if (passes <= 4) e = launch_resident_kernel<12, 4, true, 8>(grp, clu, grid, w, init, S, s, few);
+            else e = launch_resident_kernel<12, 6, true, 8>(grp, clu, grid, w, init, S, s, few);
+        } else if (passes <= 1) e = launch_resident_kernel<12, 1, true>(grp, clu, grid, w, init, S, s, few);
+        else if (passes <= 2) e = launch_resident_kernel<12, 2, true>(grp, clu, grid, w, init, S, s, few);
+        else if (passes <= 4) e = launch_resident_kernel<12, 4, true>(grp, clu, grid, w, init, S, s, few);
+        else e = launch_resident_kernel<12, 6, true>(grp, clu, grid, w, init, S, s, few);
         // a cluster that could not complete in time (resident_forward.hpp: CLUSTER_WAIT_TICKS) has flagged its tile: the
         // launch behind decodes those tiles again, whole -- it returns at once wherever nothing was flagged (every run so far)
         if (e == hipSuccess) {
