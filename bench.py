@@ -438,12 +438,14 @@ class Bench:
                 # instruction); + bound test, list loads, epilogue: 2.5 instructions per cell measured (SQ_INSTS_VALU of
                 # profiles/r03_pmc.json / executed cells)
                 'valu_instr_per_cell': 2.5,
+                'per_cell_costs': 'MODELLED, not live: constants from profiles/r03_pmc.json (2.5 VALU instructions per cell, 1.43 '
+                                  'LDS conflict factor) at a 2.4 GHz clock; only list_blocks_per_wave_pass is measured in this run',
                 'valu_busy_frac': cells * 2.5 * 2.5 / 64.0 / (256 * 4 * clock * kernel_s),
                 # one ds_read_b128 per 4 cells and lane = 4 LDS cycles per wave instruction x 1.43 (bank conflicts left by
                 # the arrangement pass: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.30)
                 'lds_busy_frac': cells / 256.0 * 4.0 * 1.43 / (256 * clock * kernel_s),
                 'statistics_gave_up': int(stats[127]),
-                'note': 'live: list blocks per wave pass from torbi_hip_scan_stats (every 16th timestep sampled) x 16 '
+                'note': 'list blocks per wave pass live from torbi_hip_scan_stats (every 16th timestep sampled) x 16 '
                         'entries x 256 (row, item) pairs; the busy fractions price those cells with the per-cell costs '
                         'stated here at 2.4 GHz -- both pipes are more than half busy and do not overlap fully: that, '
                         'not HBM, is what binds this kernel'}

@@ -1906,3 +1906,25 @@ def test_band_entry_point_falls_back_and_validates(forward):
     lop = torch.as_tensor(_banded(S, 4, 31, seed=1)).to(dev)
     assert lib.torbi_hip_band_reach(lop.data_ptr(), S, 0, stream, ctypes.byref(left), ctypes.byref(right)) == 0
     assert (left.value, right.value) == (4, 31)
+
+
+def test_generic_route_takes_more_items_than_one_grid_dimension_holds(forward):
+    """The per-timestep trellis kernels index the item by gridDim.y (at most 65535): a batch of 70 000 sequences over ONE
+    state (AUTO: generic -- nothing else covers S == 1) and over 8 states with DENSE named (generic below 64 states) used to
+    fail with hipErrorInvalidConfiguration once the 64 x 64 tile kernel was gone (round-4 advisor); now a timestep is
+    launched in slices.  One state: every index is 0; eight states: the oracle's on a sample, every row within range."""
+    if forward != 'auto':
+        pytest.skip('names its path itself')
+    dev = torch.device('cuda:0')
+    B, T = 70000, 3
+    for S, path in ((1, 'auto'), (8, 'dense')):
+        obs, trans, init = synth.problem(B, T, S, seed=9)
+        frames = np.full((B,), T, np.int32)
+        prof = []
+        got = torbi_amd.decode(*[torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)], path=path, _profile=prof)
+        assert viterbi.ROUTES[int(prof[3])] == 'generic'
+        got = got.cpu().numpy()
+        pick = np.r_[0:40, 65500:65600, B - 40:B]
+        want = oracle.decode(obs[pick], frames[pick], trans, init)
+        np.testing.assert_array_equal(got[pick], want)
+        assert got.min() >= 0 and got.max() < S

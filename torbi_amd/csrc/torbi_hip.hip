@@ -89,9 +89,9 @@ constexpr int kRowsPerBlock = 16;
 __global__ __launch_bounds__(256) void step_rows_kernel(
     const float *__restrict__ obs, const int32_t *__restrict__ frames,
     const float *__restrict__ trans, const float *__restrict__ pcur, float *__restrict__ pnext,
-    int32_t *__restrict__ trellis, int B, int T, int S, int t) {
+    int32_t *__restrict__ trellis, int B, int T, int S, int t, int b0) {
     extern __shared__ __attribute__((aligned(16))) float pl[];
-    const int b = blockIdx.y;
+    const int b = b0 + blockIdx.y;            // (gridDim.y holds at most 65535 items: larger batches take several launches)
     if (t >= frames[b]) return;
     const int tid = threadIdx.x;
     for (int i = tid; i < S; i += 256) pl[i] = pcur[(size_t)b * S + i];
@@ -141,9 +141,9 @@ __global__ __launch_bounds__(256) void step_rows_kernel(
 __global__ __launch_bounds__(256) void step_rows4_kernel(
     const float *__restrict__ obs, const int32_t *__restrict__ frames,
     const float *__restrict__ trans, const float *__restrict__ pcur, float *__restrict__ pnext,
-    int32_t *__restrict__ trellis, int B, int T, int S, int t) {
+    int32_t *__restrict__ trellis, int B, int T, int S, int t, int b0) {
     extern __shared__ __attribute__((aligned(16))) float pl[];
-    const int b = blockIdx.y;
+    const int b = b0 + blockIdx.y;
     if (t >= frames[b]) return;
     const int tid = threadIdx.x;
     {
@@ -875,14 +875,19 @@ hipError_t launch_forward(const float *obs, const int32_t *frames, const float *
     for (int t = 1; t < T; ++t) {
         const float *pc = w.post[(t - 1) & 1];
         float *pn = w.post[t & 1];
-        if (S % 4 == 0 && S >= 256 && (reinterpret_cast<uintptr_t>(trans) & 15) == 0) {
-            dim3 grid((S + 3) / 4, B);
-            hipLaunchKernelGGL(step_rows4_kernel, grid, dim3(256), sizeof(float) * (size_t)S,
-                               stream, obs, frames, trans, pc, pn, w.trellis, B, T, S, t);
-        } else {
-            dim3 grid((S + kRowsPerBlock - 1) / kRowsPerBlock, B);
-            hipLaunchKernelGGL(step_rows_kernel, grid, dim3(256), sizeof(float) * (size_t)S,
-                               stream, obs, frames, trans, pc, pn, w.trellis, B, T, S, t);
+        // (the item index is gridDim.y, which holds at most 65535: a larger batch -- S == 1 under AUTO, DENSE named below
+        // 64 states -- takes its timestep in slices of that many items)
+        for (int b0 = 0; b0 < B; b0 += 65535) {
+            const int nb = std::min(65535, B - b0);
+            if (S % 4 == 0 && S >= 256 && (reinterpret_cast<uintptr_t>(trans) & 15) == 0) {
+                dim3 grid((S + 3) / 4, nb);
+                hipLaunchKernelGGL(step_rows4_kernel, grid, dim3(256), sizeof(float) * (size_t)S,
+                                   stream, obs, frames, trans, pc, pn, w.trellis, B, T, S, t, b0);
+            } else {
+                dim3 grid((S + kRowsPerBlock - 1) / kRowsPerBlock, nb);
+                hipLaunchKernelGGL(step_rows_kernel, grid, dim3(256), sizeof(float) * (size_t)S,
+                                   stream, obs, frames, trans, pc, pn, w.trellis, B, T, S, t, b0);
+            }
         }
         ++n;
     }

@@ -22,7 +22,7 @@ class SlabPool:
 
     def __init__(self, device: Optional[torch.device] = None):
         self.device = device
-        self._lock = threading.Lock()
+        self._lock = threading.RLock()
         self._free: List[torch.Tensor] = []
         self._busy: List[Tuple[torch.Tensor, Optional[torch.cuda.Event]]] = []
         self._out = 0            # slabs handed out and not given back yet
@@ -106,7 +106,7 @@ class SlabPool:
 
 
 _pools = {}
-_pools_lock = threading.Lock()
+_pools_lock = threading.RLock()
 
 
 def pool(device: Optional[torch.device] = None) -> SlabPool:

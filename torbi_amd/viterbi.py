@@ -379,6 +379,7 @@ class _Preparation:
     def __init__(self, nbytes, device):
         import threading
         self.buffer = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        self.home = torch.cuda.current_stream(device).cuda_stream      # the stream the caching allocator knows the block by
         self.filled = None            # event recorded behind the call that filled the buffer
         self.stream = None            # the stream that call ran on
         self.lock = threading.Lock()  # held while the filling call is being enqueued
@@ -388,6 +389,10 @@ class _Preparation:
         `filled` is the library's word on whether the buffer holds the preparation afterwards."""
         current = torch.cuda.current_stream(device)
         filled = ctypes.c_int(0)
+        if current.cuda_stream != self.home:
+            # (also on the filling call: the allocator would otherwise hand the block out again on its home stream while a
+            # decode on another stream still reads it, once the tensor's notes -- and with them this object -- are dropped)
+            self.buffer.record_stream(current)
         with self.lock:
             if self.filled is None:
                 result = run(self.buffer.data_ptr(), self.buffer.numel(), 0, ctypes.byref(filled))
@@ -398,7 +403,6 @@ class _Preparation:
                 return result
         if current.cuda_stream != self.stream:
             current.wait_event(self.filled)
-            self.buffer.record_stream(current)
         return run(self.buffer.data_ptr(), self.buffer.numel(), 1, ctypes.byref(filled))
 
 
@@ -707,7 +711,7 @@ def decode_uniform(
             obs += tiny
             obs.log_()
         transition = torch.full((S, S), float(log_transition), dtype=torch.float32, device=device)
-        return decode(obs, batch_frames, transition, initial)
+        return decode(obs, batch_frames, transition, initial).to(home)      # (like every other return of this function)
     _lib.check(code, 'torbi_hip_viterbi_decode_uniform')
     return indices if home == device else indices.to(home)
 
