@@ -30,6 +30,14 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec
 PCIE_PEAK_GBS = 63.0                  # MI355X_MICROARCH.md: host link, PCIe Gen5 x16 (spec)
 VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz lane-instructions/s
+# The exact cell is add, add, 1/2 max3; tools/ubench2: v_add_f32 issues in 2 cycles per wave, v_max3_f32 in 4 -> 4 issue
+# cycles per cell and wave = 16 cells per cycle and SIMD.  The ceiling of any kernel that evaluates its cells this way:
+CELLS_PER_CYCLE = 256 * 4 * 16        # x the shader clock DELIVERED under the kernel's load (torbi_hip_scan_stats [120], [121])
+
+
+def valu_ceiling(clock_hz):
+    """Cells per second the vector ALUs can evaluate at `clock_hz` (None: the data sheet's 2.4 GHz)."""
+    return CELLS_PER_CYCLE * (clock_hz or 2.4e9)
 METRIC = 'timesteps decoded/sec, 1440 states batch=512'
 KERNELS = {'resident': 'resident::resident_forward_kernel', 'cluster': 'resident::resident_forward_kernel',
            'dense': 'dense::step_dense_kernel', 'generic': 'step_rows', 'rows': 'rowscan::step_rows_sorted_kernel'}
@@ -423,13 +431,15 @@ class Bench:
         executed = None
         if route in ('resident', 'cluster'):
             stats = v.scan_stats(spaces[0], B, T, S, path='resident').cpu().to(torch.int64)
-            blocks = float(stats[:64].sum()) / max(1.0, float(stats[64:127].sum()))
+            blocks = float(stats[:64].sum()) / max(1.0, float(stats[64:120].sum()))
+            measured = v.delivered_clock_hz(stats)
             ni = 16 if S <= 2048 else 8
             rows_per_pass = 64 // (ni // 4)
             passes = covered * math.ceil(B / ni) * math.ceil(S / rows_per_pass) * (T - 1)
             cells = passes * blocks * 16.0 * rows_per_pass * ni
-            clock = 2.4e9
+            clock = measured or 2.4e9
             executed = {
+                'clock_hz_measured': measured,
                 'list_blocks_per_wave_pass': blocks, 'row_blocks': math.ceil(S / 16),
                 'cells_per_launch': cells, 'cells_per_s': cells / kernel_s,
                 'fraction_of_all_cells': cells / cells_per_launch if cells_per_launch else None,
@@ -439,7 +449,8 @@ class Bench:
                 # profiles/r03_pmc.json / executed cells)
                 'valu_instr_per_cell': 2.5,
                 'per_cell_costs': 'MODELLED, not live: constants from profiles/r03_pmc.json (2.5 VALU instructions per cell, 1.43 '
-                                  'LDS conflict factor) at a 2.4 GHz clock; only list_blocks_per_wave_pass is measured in this run',
+                                  'LDS conflict factor); list_blocks_per_wave_pass and the clock (shader-clock over wall-clock ticks '
+                                  'of the kernel\'s workgroup 0) are measured in this run',
                 'valu_busy_frac': cells * 2.5 * 2.5 / 64.0 / (256 * 4 * clock * kernel_s),
                 # one ds_read_b128 per 4 cells and lane = 4 LDS cycles per wave instruction x 1.43 (bank conflicts left by
                 # the arrangement pass: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.30)
@@ -447,7 +458,7 @@ class Bench:
                 'statistics_gave_up': int(stats[127]),
                 'note': 'list blocks per wave pass live from torbi_hip_scan_stats (every 16th timestep sampled) x 16 '
                         'entries x 256 (row, item) pairs; the busy fractions price those cells with the per-cell costs '
-                        'stated here at 2.4 GHz -- both pipes are more than half busy and do not overlap fully: that, '
+                        'stated here at the measured clock -- both pipes are more than half busy and do not overlap fully: that, '
                         'not HBM, is what binds this kernel'}
         del spaces
         result['config'] = {
@@ -481,6 +492,11 @@ class Bench:
                     'are VALU-bound; the pruned recurrence is bound by LDS gathers + VALU issue (DESIGN.md 4)'}
         result['valu'] = {
             'dense_equivalent_cells_per_s': cells_per_launch / kernel_s, 'lane_instr_peak_per_s': VALU_LANE_OPS,
+            'clock_hz_measured': (executed or {}).get('clock_hz_measured'),
+            'ceiling_cells_per_s_at_measured_clock': valu_ceiling((executed or {}).get('clock_hz_measured')),
+            'ceiling_note': 'add, add, 1/2 max3 per cell = 4 issue cycles per wave (v_add_f32 2, v_max3_f32 4: tools/ubench2) = 16 '
+                            'cells per cycle and SIMD x 1024 SIMDs x the clock delivered under the forward kernel\'s own load '
+                            '(39.3 Tcell/s at the data sheet\'s 2.4 GHz)',
             'note': 'dense-equivalent = every (prev, next) cell of the launch, pruned or not, over the kernel time: a '
                     'speed-up figure against kernels that evaluate every cell, NOT a utilisation (roofline.executed has that)'}
         result['phases_ms'] = {'group_of': g, 'forward_incl_preparation': fwd_ms, 'preparation': prep_ms,
@@ -606,8 +622,12 @@ class Bench:
                     '(torbi_hip_viterbi_decode_uniform_probabilities); beside it the log + clamp pass followed by the decode'}
         del probs
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(obs, frames, trans, init, workspace=ws, path='dense'), 2)
+        dense_clock = v.delivered_clock_hz(v.scan_stats(ws, B, T, S))
         record('every_cell', sec, B * T, S, 'headline batch, dense (max,+) GEMM forced: every (prev, next) cell evaluated',
-               {'valu_frac_at_1p5_instr_per_cell': 1.5 * B * T * S * S / sec / VALU_LANE_OPS})
+               {'valu_frac_at_1p5_instr_per_cell': 1.5 * B * T * S * S / sec / VALU_LANE_OPS,
+                'clock_hz_measured': dense_clock, 'cells_per_s': B * T * S * S / sec,
+                'ceiling_cells_per_s_at_measured_clock': valu_ceiling(dense_clock),
+                'frac_of_ceiling_at_measured_clock': B * T * S * S / sec / valu_ceiling(dense_clock)})
         # posteriorgram-like input: per-frame log_softmax of peaked logits clamped at log(tiny), the reference's
         # banded pitch transition (torbi/evaluate/core.py:23-34); AUTO's choice after it has settled
         gen = torch.Generator(device=dev).manual_seed(7)
@@ -619,16 +639,18 @@ class Bench:
         band = torch.from_numpy(synth.banded_transition(S, args.half_width)).to(dev)
         finite = int((band != float('-inf')).sum())            # cells per timestep and item the band holds
 
-        def executed(seconds, timesteps, forward_ms=None):
-            """The finite cells of the band over the decode (and over its forward pass), priced against the vector ALU:
-            add, add, 1/2 max3 = 1.5 instructions (4 issue cycles per wave) per cell."""
+        def executed(seconds, timesteps, forward_ms=None, space=None):
+            """The finite cells of the band over the decode (and over its forward pass), priced against the vector ALU's
+            ceiling (add, add, 1/2 max3 = 4 issue cycles per cell and wave) at the clock the kernel was delivered."""
             cells = float(finite) * timesteps
+            clock = v.delivered_clock_hz(v.scan_stats(space if space is not None else ws, B, T, S))
             found = {'finite_cells_per_timestep': finite, 'fraction_of_all_cells': finite / float(S * S),
-                     'cells_per_s': cells / seconds,
-                     'valu_frac_at_1p5_instr_per_cell': 1.5 * cells / seconds / VALU_LANE_OPS}
+                     'cells_per_s': cells / seconds, 'clock_hz_measured': clock,
+                     'ceiling_cells_per_s_at_measured_clock': valu_ceiling(clock),
+                     'frac_of_ceiling_at_measured_clock': cells / seconds / valu_ceiling(clock)}
             if forward_ms:
                 found['forward_cells_per_s'] = cells / (forward_ms * 1e-3)
-                found['forward_valu_frac_at_1p5_instr_per_cell'] = 1.5 * cells / (forward_ms * 1e-3) / VALU_LANE_OPS
+                found['forward_frac_of_ceiling_at_measured_clock'] = cells / (forward_ms * 1e-3) / valu_ceiling(clock)
             return found
 
         for _ in range(4):
@@ -659,7 +681,7 @@ class Bench:
         record('peaked_banded_launch_group', sec, 8 * B * T, S,
                'eight batches of the peaked rows + banded pitch transition in one call',
                {'forward_path': ROUTES[int(prof[3])], 'forward_ms': prof[0], 'backtrace_ms': prof[1],
-                'executed': executed(sec, 8 * B * T, prof[0])})
+                'executed': executed(sec, 8 * B * T, prof[0], spaces[0])})
         sec, _ = self.timed_decodes(lambda: v.decode_batches([peaked] * 8, [frames] * 8, band, init, workspaces=spaces,
                                                              path='resident'), 2)
         record('peaked_banded_launch_group_resident', sec, 8 * B * T, S, 'the same, time-resident kernel forced')

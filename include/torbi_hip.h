@@ -272,6 +272,11 @@ int torbi_hip_viterbi_decode_banded(const torbi_hip_batch *batches, int count, c
  *     stats_out[0]       list blocks walked by the sampled wave passes (every 16th timestep)
  *     stats_out[64]      wave passes counted
  *     stats_out[127]     (CLUSTER) workgroups that gave up waiting for their cluster; 0 on any sane run
+ *   RESIDENT / CLUSTER / BAND / DENSE (ABI 14): stats_out[120], [121] = shader-clock ticks and 100 MHz wall-clock ticks of the
+ *                        forward kernel's workgroup 0 (same unit both; DENSE: of the last timestep's launch) -- their ratio
+ *                        x 100 MHz is the clock the kernel was delivered under its own load (measurement plumbing: bench.py
+ *                        prices the vector ALU's ceiling at it)
+ *   BAND: stats_out[127] = members that gave up waiting (as CLUSTER)
  *   HELD: stats_out[127] = workgroups that ran out of polls (the launch could not be resident as a whole); the decode
  *                        was then redone by the repair kernel and its results are correct.  0 on any sane run.
  * sum(first half) / sum(second half) = list blocks per scan: about 11 of the S/16 = 90 on the 1440-state benchmark;

@@ -299,6 +299,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nthreads = 64 * pl.waves;
+    const unsigned long long clock_0 = clock64(), wall_0 = wall_clock64();      // (stats[120], [121]: the clock under this load)
     const int S = pl.S, hl = pl.hl, hr = pl.hr, R = pl.R, n_own = pl.n_own, n_jg = pl.n_jg;
 
     // Membership by arrival WITHIN a dispatch class (blockIdx mod 8): tile = class + 8 x (ticket / R), member = ticket mod R.
@@ -587,6 +588,10 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
     if (gave_up && lane == 0) {
         ex.failed[cid] = 1u;
         atomicAdd(&grp.stats[127], 1u);
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        grp.stats[120] = (unsigned)((clock64() - clock_0) >> 4);
+        grp.stats[121] = (unsigned)((wall_clock64() - wall_0) >> 4);
     }
 }
 

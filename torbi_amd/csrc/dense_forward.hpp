@@ -324,8 +324,11 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
                        const float *__restrict__ trp, const float *__restrict__ pcur,
                        float *__restrict__ pnext, float *__restrict__ hist,
                        const int32_t *__restrict__ chunks, int B, int T, int S, int t, int n_bt, int n_jt,
-                       int JT, int Kp, int NCH, int RB) {
+                       int JT, int Kp, int NCH, int RB, unsigned *__restrict__ clock_out) {
     using Sh = StepShape<BL, JL, NW, KC, MSL>;
+    // (workgroup 0 leaves the shader-clock ticks and the 100 MHz wall-clock ticks of its run behind: the clock the vector
+    // ALU's ceiling has to be priced at is the one delivered under this kernel's load, not the 2.4 GHz of the data sheet)
+    const unsigned long long clock_0 = clock64(), wall_0 = wall_clock64();
     constexpr int W = Sh::W, BT = Sh::BT;
     constexpr int RW = BT / NW;                     // tile rows (batch positions) finalised per wave
     static_assert(RW % 4 == 0 && RW >= 4, "each wave finalises whole groups of 4 batch rows");
@@ -532,6 +535,10 @@ void step_dense_kernel(const float *__restrict__ obs, const int32_t *__restrict_
             dst[h] = make_float4(out[4 * h], out[4 * h + 1], out[4 * h + 2], out[4 * h + 3]);
     }
     DENSE_STAMP(4);
+    if (clock_out && blockIdx.x == 0 && threadIdx.x == 0) {
+        clock_out[0] = (unsigned)(clock64() - clock_0);
+        clock_out[1] = (unsigned)(wall_clock64() - wall_0);
+    }
 }
 
 template <int BL, int JL, int NW, int KC, int MSL = 8>

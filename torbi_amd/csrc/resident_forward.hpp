@@ -348,6 +348,9 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (workgroup 0 leaves the shader-clock and the 100 MHz wall-clock ticks of its run in stats[120], [121]: the clock
+    // delivered under this kernel's load -- what the vector ALU's ceiling is priced at)
+    const unsigned long long clock_0 = clock64(), wall_0 = wall_clock64();
 #ifdef RESIDENT_STAMP
     const unsigned long long wg_start = wall_clock64();
 #endif
@@ -841,6 +844,10 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
     if (lane == 0 && stat_passes) {
         atomicAdd(&grp.stats[0], stat_blocks);
         atomicAdd(&grp.stats[64], stat_passes);
+    }
+    if (!REPAIR && blockIdx.x == 0 && tid == 0) {
+        grp.stats[120] = (unsigned)((clock64() - clock_0) >> 4);         // (in units of 16 ticks: a launch may run for seconds)
+        grp.stats[121] = (unsigned)((wall_clock64() - wall_0) >> 4);
     }
 #ifdef RESIDENT_STAMP
     if (lane == 0 && blockIdx.x < 1024)

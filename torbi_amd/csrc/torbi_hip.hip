@@ -325,6 +325,9 @@ __global__ __launch_bounds__(128) void gather_stats_kernel(const int32_t *__rest
     unsigned v = src ? src[threadIdx.x] : 0u;
     // held-matrix launch: [127] = workgroups that gave up waiting (the decode was then repaired; 0 on any sane run)
     if (r == 6 && held_control && threadIdx.x == 127) v = held_control[1];
+    // dense launches: [120], [121] = shader-clock / 100 MHz wall-clock ticks of workgroup 0 of the last timestep's launch (the
+    // time-resident and band kernels leave theirs in the statistics themselves)
+    if (r == 1 && (threadIdx.x == 120 || threadIdx.x == 121)) v = (unsigned)route[2 + (threadIdx.x - 120)];
     dst[threadIdx.x] = v;
 }
 
@@ -1036,7 +1039,7 @@ hipError_t launch_block(const float *obs, const int32_t *frames, const float *tr
 // ---- dense path -----------------------------------------------------------------------
 template <int BL, int JL, int NW, int KC, int MSL>
 hipError_t launch_dense_steps(const float *obs, const int32_t *frames, const DenseWorkspace &w,
-                              int B, int T, int S, hipStream_t stream, int *launches) {
+                              int B, int T, int S, hipStream_t stream, int *launches, unsigned *clock_out) {
     const dense::Plan &pl = w.plan;
     const size_t lds = dense::lds_bytes<BL, JL, NW, KC, MSL>();
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&dense::step_dense_kernel<BL, JL, NW, KC, MSL>), lds);
@@ -1048,7 +1051,7 @@ hipError_t launch_dense_steps(const float *obs, const int32_t *frames, const Den
     for (int t = 1; t < T; ++t) {
         hipLaunchKernelGGL((dense::step_dense_kernel<BL, JL, NW, KC, MSL>), dim3(grid), dim3(64 * NW), lds, stream, obs,
                            frames, w.trp, w.panel[(t - 1) & 1], w.panel[t & 1], w.hist, w.chunks, B, T, S,
-                           t, pl.n_bt, pl.n_jt, pl.JT, pl.Kp, pl.NCH, pl.RB);
+                           t, pl.n_bt, pl.n_jt, pl.JT, pl.Kp, pl.NCH, pl.RB, clock_out);
         ++n;
     }
     if (launches) *launches = n;
@@ -1057,7 +1060,7 @@ hipError_t launch_dense_steps(const float *obs, const int32_t *frames, const Den
 
 hipError_t launch_dense_forward(const float *obs, const int32_t *frames, const float *trans,
                                 const float *init, const DenseWorkspace &w, int B, int T, int S,
-                                hipStream_t stream, int *launches, bool reuse) {
+                                hipStream_t stream, int *launches, bool reuse, unsigned *clock_out) {
     const dense::Plan &pl = w.plan;
     if (!reuse) {      // per-transition preparation: packed panels + per-tile lists of chunks that are not all -inf
         hipLaunchKernelGGL(dense::pack_transition_kernel, dim3((pl.Kp + 63) / 64, pl.n_jt), dim3(256), 0,
@@ -1079,7 +1082,7 @@ hipError_t launch_dense_forward(const float *obs, const int32_t *frames, const f
     if (e != hipSuccess) return e;
 #define TORBI_DENSE_CASE(BL_, JL_, NW_, KC_, MSL_)                                             \
     if (pl.BL == BL_ && pl.JL == JL_ && pl.NW == NW_ && pl.KC == KC_ && pl.MSL == MSL_)         \
-        return launch_dense_steps<BL_, JL_, NW_, KC_, MSL_>(obs, frames, w, B, T, S, stream, launches)
+        return launch_dense_steps<BL_, JL_, NW_, KC_, MSL_>(obs, frames, w, B, T, S, stream, launches, clock_out)
     TORBI_DENSE_CASE(8, 6, 8, 12, 8);
     TORBI_DENSE_CASE(8, 6, 16, 6, 8);
     TORBI_DENSE_CASE(8, 4, 8, 12, 8);
@@ -1561,7 +1564,9 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
     if (e != hipSuccess) return e;
     if (route == ROUTE_DENSE) {
         const DenseWorkspace w = carve_dense(workspace, B, T, S, cus);
-        e = launch_dense_forward(obs, frames, trans, init, w, B, T, S, s, launches, reuse);
+        // (the route record's words [2], [3]: shader-clock and wall-clock ticks of the last timestep's workgroup 0)
+        e = launch_dense_forward(obs, frames, trans, init, w, B, T, S, s, launches, reuse,
+                                 reinterpret_cast<unsigned *>(route_record(workspace, B, T, S, cus)) + 2);
         if (ev) (void)hipEventRecord(ev[1], s);
         if (e == hipSuccess)
             e = launch_backtrace_on(w.hist, trans, frames, out, B, T, S, s, w.ranges, w.ranges + 2 * (size_t)S);

@@ -606,8 +606,17 @@ def scan_stats(workspace: torch.Tensor, batch: int, frames: int, states: int,
 def critical_blocks(stats: torch.Tensor) -> float:
     """Mean number of 16-entry list blocks on the critical path of a launch (host sync)."""
     host = (stats if not stats.is_cuda else stats.cpu()).to(torch.int64)
-    # ([127] is not a count of passes: workgroups of the cluster form that gave up waiting -- 0 on any sane run)
-    return float(host[:64].sum()) / max(1.0, float(host[64:127].sum()))
+    # ([120], [121] hold clock ticks and [127] the workgroups that gave up waiting: not counts of passes)
+    return float(host[:64].sum()) / max(1.0, float(host[64:120].sum()))
+
+
+def delivered_clock_hz(stats: torch.Tensor) -> Optional[float]:
+    """Shader clock the forward kernel of the last decode ran at, from the ticks its workgroup 0 left in the statistics
+    (include/torbi_hip.h, torbi_hip_scan_stats [120], [121]: shader-clock ticks over 100 MHz wall-clock ticks); None for a
+    route that leaves none (host sync)."""
+    host = (stats if not stats.is_cuda else stats.cpu()).to(torch.int64)
+    ticks, wall = int(host[120]) & 0xffffffff, int(host[121]) & 0xffffffff
+    return ticks / wall * 1e8 if ticks > 0 and wall > 0 else None
 
 
 def _choose_path(trans: torch.Tensor, original: torch.Tensor, batch: int, states: int) -> str:
