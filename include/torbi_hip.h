@@ -239,7 +239,7 @@ int torbi_hip_viterbi_decode_batches_prepared(const torbi_hip_batch *batches, in
  * (torbi/evaluate/core.py:24-33: at most 175 finite entries per 1440-state row).
  *
  * torbi_hip_band_reach: the smallest reach_left / reach_right such that transition[j][i] == -inf whenever i < j - reach_left
- * or i > j + reach_right (0 / 0 for a matrix without any finite entry).  Runs one small kernel over the matrix on
+ * or i > j + reach_right (-1 / -1 for a matrix without any finite entry: pass 0 / 0 on).  Runs one small kernel over the matrix on
  * `stream` and SYNCHRONISES it: call it once per matrix and keep the answer.
  *
  * torbi_hip_band_members: workgroups per 16-item tile the band kernel would use for `items` sequences with that band on

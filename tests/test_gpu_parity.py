@@ -1928,3 +1928,54 @@ def test_generic_route_takes_more_items_than_one_grid_dimension_holds(forward):
         want = oracle.decode(obs[pick], frames[pick], trans, init)
         np.testing.assert_array_equal(got[pick], want)
         assert got.min() >= 0 and got.max() < S
+
+
+def test_auto_gates_follow_the_data_not_the_first_call(forward):
+    """AUTO's data-dependent gates (torbi_amd/viterbi.py: scan depth of the time-resident kernel against the dense kernel) used
+    to be measured once per matrix: peaked batches first, flat ones later left the matrix on clusters through a 3-4x cliff,
+    the reverse on the dense kernel for ever (round-4 review).  Now every time-resident launch AUTO chose leaves a sample,
+    the depth is a mean that leans on the newest one, and a matrix the gates keep on the dense kernel is looked at again every
+    third call.  Peaked batches, then flat ones, then peaked ones with ONE transition tensor: the route changes within three
+    calls each time, and every call's indices are the oracle's."""
+    if forward != 'auto':
+        pytest.skip('AUTO routing is the subject')
+    dev = torch.device('cuda:0')
+    B, T, S = 256, 10, 1440
+    _, trans, init = synth.problem(1, 1, S, seed=3)
+    rng = np.random.default_rng(8)
+    # Eight prev-states nothing likes to come from (their columns hold the matrix's minimum).  Rows that put their largest
+    # posteriors THERE defeat the bound: the seeds' candidates are poor, every other posterior is far below the threshold,
+    # and a scan runs down its list until the entries themselves are as poor (~85 of 90 blocks).  Flat rows are pruned after
+    # ~6 blocks by the matrix's own spread.
+    bad = np.arange(8) * 170 + 40
+    trans = trans.copy()
+    trans[:, bad] = np.float32(-16.0)
+    peaked = (rng.integers(0, 2, size=(B, T, S)) * np.float32(2.0 ** -12)).astype(np.float32)      # "peaked" = prunable
+    flat = peaked.copy()
+    flat[:, :, bad] += np.float32(15.0)                                                           # "flat" = nothing to prune
+    frames = np.full((B,), T, np.int32)
+    d_trans, d_init, d_frames = (torch.as_tensor(x).to(dev) for x in (trans, init, frames))
+    want = {'flat': oracle.decode(flat, frames, trans, init, num_threads=oracle.max_threads()),
+            'peaked': oracle.decode(peaked, frames, trans, init, num_threads=oracle.max_threads())}
+    data = {'flat': torch.as_tensor(flat).to(dev), 'peaked': torch.as_tensor(peaked).to(dev)}
+    ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+    torbi_amd.reset_path_state()
+
+    def calls_until(kind, route, limit):
+        for n in range(1, limit + 1):
+            prof = []
+            got = torbi_amd.decode(data[kind], d_frames, d_trans, d_init, workspace=ws, _profile=prof)
+            np.testing.assert_array_equal(got.cpu().numpy(), want[kind])
+            if viterbi.ROUTES[int(prof[3])] == route:
+                return n
+        return None
+
+    assert calls_until('peaked', 'cluster', 1) == 1                     # nothing known: clusters
+    for _ in range(2):
+        assert calls_until('peaked', 'cluster', 1) == 1                 # shallow scans: stays
+    assert calls_until('flat', 'dense', 3) is not None                  # flat rows: the dense kernel within three calls
+    assert calls_until('flat', 'cluster', 3) is not None                # ... which is looked at again every third call
+    assert calls_until('flat', 'dense', 2) is not None                  # ... and found as deep as before
+    assert calls_until('peaked', 'cluster', 3) is not None              # peaked rows again: back on clusters within three calls
+    assert calls_until('peaked', 'cluster', 1) == 1
+    torbi_amd.reset_path_state()

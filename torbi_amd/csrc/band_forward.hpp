@@ -750,20 +750,20 @@ __global__ __launch_bounds__(64) void group_backtrace_band_kernel(Group grp, con
     }
 }
 
-// reach of a matrix: *left = max over finite entries of (j - i), *right = max of (i - j), both >= 0; grid = S, block = 64;
-// `reach` zeroed by the caller
+// reach of a matrix: *left = max over finite entries of max(j - i, 0), *right = of max(i - j, 0); grid = S, block = 64;
+// `reach` set to -1, -1 by the caller -- what a matrix without a finite entry leaves
 __global__ __launch_bounds__(64) void band_reach_kernel(const float *__restrict__ trans, int32_t *__restrict__ reach, int S) {
     const int j = blockIdx.x, lane = threadIdx.x;
     const float *row = trans + (size_t)j * S;
-    int left = 0, right = 0;
+    int left = -1, right = -1;
     for (int i = lane; i < S; i += 64)
         if (row[i] != -INFINITY) {
-            left = max(left, j - i);
-            right = max(right, i - j);
+            left = max(left, max(j - i, 0));
+            right = max(right, max(i - j, 0));
         }
     left = -wavered::wave_min_i32(-left);
     right = -wavered::wave_min_i32(-right);
-    if (lane == 0) {
+    if (lane == 0 && left >= 0) {
         atomicMax(reach, left);
         atomicMax(reach + 1, right);
     }

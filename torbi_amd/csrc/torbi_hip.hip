@@ -1796,8 +1796,8 @@ int torbi_hip_band_reach(const float *transition, int S, int device, void *strea
     int32_t *dev = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&dev), 2 * sizeof(int32_t));
     if (e != hipSuccess) return (int)e;
-    int32_t host[2] = {0, 0};
-    e = hipMemsetAsync(dev, 0, 2 * sizeof(int32_t), s);
+    int32_t host[2] = {-1, -1};
+    e = hipMemsetAsync(dev, 0xff, 2 * sizeof(int32_t), s);           // (-1, -1: what a matrix without a finite entry leaves)
     if (e == hipSuccess) {
         hipLaunchKernelGGL(band::band_reach_kernel, dim3(S), dim3(64), 0, s, transition, dev, S);
         e = hipGetLastError();

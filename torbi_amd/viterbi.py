@@ -118,13 +118,24 @@ SINGLE_BATCH_GATE = 0.43
 ONE_SEED_DEPTH = 1.25
 
 
+# AUTO's data-dependent gates follow the DATA, not the first call: every time-resident launch AUTO chose leaves a sample of
+# its scan depth (copied to pinned memory behind the decode, folded in by a later call without waiting), the depth a gate
+# sees is an exponentially weighted mean that leans on the newest sample, and while the gates keep a matrix on the dense
+# kernel -- which leaves no statistics -- every DENSE_PROBE_EVERY-th call takes the time-resident kernel anyway to look again.
+# Peaked batches followed by flat ones (or the reverse) with ONE matrix change route within three calls.
+DEPTH_NEWEST_WEIGHT = 0.75
+DENSE_PROBE_EVERY = 3
+
+
 def _depth_record(transition: torch.Tensor, states: int):
-    """[blocks per scan of a time-resident launch with this matrix (None until known), pending (pinned stats, event),
-    seeds per item of the launch that was measured], kept with the tensor's notes (torbi_amd/state.py)."""
+    """[scan depth of time-resident launches with this matrix in list blocks per wave pass, on the scale of a three-seed
+    launch (None until known), pending sample (pinned stats, event, seeds per item of that launch) or None, 3 (unused),
+    the pinned buffer kept for the samples, consecutive calls the gates sent to the dense kernel], kept with the tensor's
+    notes (torbi_amd/state.py)."""
     kept = state.notes(transition)
     if kept is None:
         return None
-    return kept.setdefault(('depth', states), [None, None, 3])
+    return kept.setdefault(('depth', states), [None, None, 3, None, 0])
 
 
 def _known_depth(transition: torch.Tensor, states: int):
@@ -132,20 +143,30 @@ def _known_depth(transition: torch.Tensor, states: int):
     known = _depth_record(transition, states)
     if known is None:
         return None
-    if known[0] is None and known[1] is not None and known[1][1].query():
-        known[0] = critical_blocks(known[1][0])
+    if known[1] is not None and known[1][1].query():
+        stats, _, seeds = known[1]
         known[1] = None
-    if known[0] is None:
-        return None
-    return known[0] / (ONE_SEED_DEPTH if known[2] == 1 else 1.0)
+        if int(stats[64:120].sum()) > 0:
+            sample = critical_blocks(stats) / (ONE_SEED_DEPTH if seeds == 1 else 1.0)
+            known[0] = sample if known[0] is None else DEPTH_NEWEST_WEIGHT * sample + (1.0 - DEPTH_NEWEST_WEIGHT) * known[0]
+    return known[0]
 
 
 def _resident_is_losing(transition: torch.Tensor, states: int, single: bool = False) -> bool:
     """Time-resident launches with this matrix walk so many list blocks per scan that the dense kernel is faster
-    (flat or nearly flat matrices: nothing to prune).  Read without blocking from the statistics the kernel leaves.
-    `single`: the question is asked for ONE batch below half the chip (clusters against one dense batch)."""
+    (flat or nearly flat rows: nothing to prune).  Read without blocking from the statistics the kernel leaves.
+    `single`: the question is asked for ONE batch below half the chip (clusters against one dense batch).  Every
+    DENSE_PROBE_EVERY-th consecutive "yes" is answered "no": the dense kernel leaves no statistics, and data that have become
+    prunable again would otherwise never be seen."""
     depth = _known_depth(transition, states)
-    return depth is not None and depth > (SINGLE_BATCH_GATE if single else RESIDENT_GATE) * states / 16.0
+    losing = depth is not None and depth > (SINGLE_BATCH_GATE if single else RESIDENT_GATE) * states / 16.0
+    known = _depth_record(transition, states)
+    if known is not None:
+        known[4] = known[4] + 1 if losing else 0
+        if known[4] >= DENSE_PROBE_EVERY:
+            known[4] = 0
+            return False
+    return losing
 
 
 # scans this shallow (fraction of a row's S/16 list blocks per wave pass; 0.12 on the benchmark, 0.28-0.47 on peaked rows
@@ -177,18 +198,18 @@ def _few_seeds(transition: torch.Tensor, states: int) -> bool:
 
 
 def _watch_resident(transition, workspace, batch, frames, states, seeds=3) -> None:
-    """After a time-resident launch chosen by AUTO: once per matrix, copy the scan statistics it leaves in its first
-    workspace to pinned host memory (asynchronously; looked at by a later call, never waited for).  `seeds`: what the
-    launch kept per item."""
+    """After a time-resident launch chosen by AUTO: copy the scan statistics it leaves in its first workspace to pinned
+    host memory (asynchronously; folded in by a later call, never waited for) -- unless the previous sample is still on its
+    way.  `seeds`: what the launch kept per item."""
     known = _depth_record(transition, states)
-    if known is None or known[0] is not None or known[1] is not None:
+    if known is None or known[1] is not None:
         return
-    known[2] = seeds
-    stats = torch.empty((128,), dtype=torch.int32, pin_memory=True)
-    stats.copy_(scan_stats(workspace, batch, frames, states, path='resident'), non_blocking=True)
+    if known[3] is None:
+        known[3] = torch.empty((128,), dtype=torch.int32, pin_memory=True)
+    known[3].copy_(scan_stats(workspace, batch, frames, states, path='resident'), non_blocking=True)
     done = torch.cuda.Event()
     done.record(torch.cuda.current_stream(workspace.device))
-    known[1] = (stats, done)
+    known[1] = (known[3], done, seeds)
 
 
 def band_reach(trans: torch.Tensor, original: torch.Tensor, states: int):
@@ -197,6 +218,13 @@ def band_reach(trans: torch.Tensor, original: torch.Tensor, states: int):
     a host sync the first time a tensor version is seen; kept with the tensor's notes (torbi_amd/state.py)."""
     if states % 4 or not 64 <= states <= BAND_MAX_STATES or not trans.is_cuda or trans.data_ptr() % 16:
         return None
+    found = _device_reach(trans, original, states)
+    found = (max(found[0], 0), max(found[1], 0))              # (-1, -1: no finite entry at all -- a band of the diagonal)
+    return found if found[0] + found[1] + 4 <= BAND_MAX_WINDOW else None
+
+
+def _device_reach(trans: torch.Tensor, original: torch.Tensor, states: int):
+    """(reach_left, reach_right) of a device matrix (torbi_hip_band_reach), looked at once per tensor version."""
     kept = state.notes(original)
     found = kept.get(('band', states)) if kept is not None else None
     if found is None:
@@ -207,7 +235,7 @@ def band_reach(trans: torch.Tensor, original: torch.Tensor, states: int):
         found = (left.value, right.value)
         if kept is not None:
             kept[('band', states)] = found
-    return found if found[0] + found[1] + 4 <= BAND_MAX_WINDOW else None
+    return found
 
 
 def tiles_of(batch: int, states: int) -> int:
@@ -626,6 +654,14 @@ def _choose_path(trans: torch.Tensor, original: torch.Tensor, batch: int, states
         return 'auto'
     kept = state.notes(original)                     # None for tensors without a version counter: looked at, not kept
     reach = kept.get(('reach', states)) if kept is not None else None
+    if reach is None and trans.is_cuda:
+        # ONE blocking look per tensor version on the device, shared with the band kernel's (torbi_hip_band_reach: a small
+        # kernel and a sync, ~30 us): the widest row's reach instead of the mean of the rows' -- no second reduction, no
+        # second sync.  (Routing the first call blind instead would cost a decode on the wrong kernel: milliseconds.)
+        left, right = _device_reach(trans, original, states)
+        reach = min(1.0, (left + right + 1) / states) if left >= 0 else 0.0       # (a matrix without a finite entry: 0)
+        if kept is not None:
+            kept[('reach', states)] = reach
     if reach is None:
         finite = trans != float('-inf')
         index = torch.arange(states, device=trans.device)
