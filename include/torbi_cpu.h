@@ -46,19 +46,34 @@ int torbi_cpu_viterbi_decode(const float *observation, const int32_t *batch_fram
                              const float *initial, int32_t *indices_out, int B, int T, int S, int num_threads);
 
 /*
- * Host side of the many-file job for callers WITHOUT a HIP runtime (gpu=None): the same two entry points as
- * torbi_hip_read_rows / torbi_hip_write_files (include/torbi_hip.h; same arguments, same return codes:
- * 0, TORBI_CPU_EINVAL, or -(100 + index) of the first item that could not be read / written in full with its errno
- * in *error_out).  They replace torch.load + pad_sequence (torbi/data/dataset.py:18-20, collate.py:24-31) and the
- * per-file torch.save (torbi/core.py:466-473) of the reference's loop; plain pread / write on native threads, so
- * libtorbi_cpu.so keeps linking nothing but libgomp / libstdc++.
+ * Host side of a many-file job, for GPU jobs and gpu=None alike (no device is touched; all pointers are HOST pointers;
+ * plain pread / write on native threads, so libtorbi_cpu.so keeps linking nothing but libgomp / libstdc++ and a reader thread's
+ * first call never meets the HIP runtime's start-up).
+ *
+ * torbi_cpu_read_rows: item k's `bytes[k]` bytes at `offsets[k]` of the open file `fds[k]` are read into `rows[k]`, and the
+ * `zero_bytes[k]` bytes behind them are cleared, by `threads` native threads.  Replaces torch.load + pad_sequence per batch
+ * (reference torbi/data/dataset.py:18-20, torbi/data/collate.py:24-31): the float32 payload of a torch.save()d observation
+ * goes from the page cache to its row of the (pinned) batch buffer in one pass, outside the Python interpreter
+ * (torbi_amd/fastio.py finds the payloads and builds the same batch tuples as the reference's collate).
+ *
+ * torbi_cpu_write_files: `count` whole files, file k = the `bytes[k]` bytes at `data[k]`, created or truncated at `paths[k]`.
+ * Replaces the one-by-one torch.save of the reference's driver (torbi/core.py:449-457, 466-473: ~0.1 ms of interpreter time
+ * per decoded sequence); the caller hands over finished torch.save containers (torbi_amd/fastio.py builds them from a
+ * prebuilt image per length).
+ *
+ * torbi_cpu_open_heads: the step before read_rows: open `count` files and read the first `head_bytes` bytes of each (where a
+ * torch.save container keeps its record headers and data.pkl; 4096 is enough): fds_out[k] (-1 where open() failed; the caller
+ * closes every descriptor >= 0, also after an error), heads_out[k * head_bytes ..], lengths_out[k] = bytes actually read (a
+ * short file reads short).  512 open + pread pairs take 30 ms under Python's interpreter lock and well under a millisecond here.
+ *
+ * All three return 0, TORBI_CPU_EINVAL, or TORBI_CPU_EIO_BASE - k = -(100 + k) for the first item k that could not be read /
+ * written / opened in full, with its errno in *error_out (0 = the file ended early).
  */
 #define TORBI_CPU_EIO_BASE (-100)
 int torbi_cpu_read_rows(const int *fds, const int64_t *offsets, const int64_t *bytes, void *const *rows,
                         const int64_t *zero_bytes, int count, int threads, int *error_out);
 int torbi_cpu_write_files(const char *const *paths, const void *const *data, const int64_t *bytes, int count,
                           int threads, int *error_out);
-/* (torbi_hip_open_heads: the files' descriptors and first bytes, on native threads) */
 int torbi_cpu_open_heads(const char *const *paths, int count, int threads, int head_bytes, int *fds_out,
                          unsigned char *heads_out, int *lengths_out, int *error_out);
 

@@ -51,7 +51,6 @@ extern "C" {
 #define TORBI_HIP_ERANGE (-3)      /* dimension too large for this build               */
 #define TORBI_HIP_ENODEVICE (-4)   /* no usable HIP device / wrong architecture        */
 #define TORBI_HIP_EUNSUPPORTED (-5) /* shape not covered by this specialised entry point */
-#define TORBI_HIP_EIO_BASE (-100)  /* torbi_hip_read_rows / write_files: item k failed -> -(100 + k) */
 
 /* Build/ABI version of the loaded library (== TORBI_HIP_ABI_VERSION). */
 int torbi_hip_abi_version(void);
@@ -358,38 +357,12 @@ int torbi_hip_fill_synthetic(float *dst, uint64_t count, uint64_t start, int str
                              int seed, int device, void *stream);
 
 /*
- * Host side of a many-file job (no device is touched; all pointers are HOST pointers): item k's `bytes[k]`
- * bytes at `offsets[k]` of the open file `fds[k]` are read into `rows[k]`, and the `zero_bytes[k]` bytes behind
- * them are cleared, by `threads` native threads.  Replaces torch.load + pad_sequence per batch (reference
- * torbi/data/dataset.py:18-20, torbi/data/collate.py:24-31): the float32 payload of a torch.save()d observation
- * goes from the page cache to its row of the (pinned) batch buffer in one pass, outside the Python interpreter
- * (torbi_amd/fastio.py finds the payloads and builds the same batch tuples as the reference's collate).
- * Returns TORBI_HIP_OK, TORBI_HIP_EINVAL, or TORBI_HIP_EIO_BASE - k for the first item k that could not be read in
- * full (*error_out, if given, holds its errno; 0 = the file ended early).
+ * (ABI 14) The host side of a many-file job -- reading the payloads of torch.save()d observations into a batch buffer,
+ * writing the decoded sequences' files, opening a batch of files -- lives in libtorbi_cpu.so ALONE (include/torbi_cpu.h:
+ * torbi_cpu_read_rows, torbi_cpu_write_files, torbi_cpu_open_heads).  Rounds 2-4 exported the same functions from this
+ * library as torbi_hip_read_rows / _write_files / _open_heads; they touch no device, and their first call from a reader thread
+ * used to wait behind the HIP runtime's start-up on the calling thread (0.35-0.65 s per early batch of a cold job).
  */
-int torbi_hip_read_rows(const int *fds, const int64_t *offsets, const int64_t *bytes, void *const *rows,
-                        const int64_t *zero_bytes, int count, int threads, int *error_out);
-
-/*
- * The other direction: `count` whole files, file k = the `bytes[k]` bytes at `data[k]`, created or truncated at
- * `paths[k]` by `threads` native threads (HOST pointers, no device touched).  Replaces the one-by-one torch.save of the
- * reference's driver (torbi/core.py:449-457, 466-473: ~0.1 ms of interpreter time per decoded sequence); the caller
- * hands over finished torch.save containers (torbi_amd/fastio.py builds them from a prebuilt image per length).
- * Returns TORBI_HIP_OK, TORBI_HIP_EINVAL, or TORBI_HIP_EIO_BASE - k for the first file k that failed (*error_out = errno).
- */
-int torbi_hip_write_files(const char *const *paths, const void *const *data, const int64_t *bytes, int count, int threads,
-                          int *error_out);
-
-/*
- * ... and the step before torbi_hip_read_rows: open `count` files and read the first `head_bytes` bytes of each (where a
- * torch.save container keeps its record headers and data.pkl; 4096 is enough) on `threads` native threads: fds_out[k]
- * (-1 where open() failed; the caller closes every descriptor >= 0, also after an error), heads_out[k * head_bytes ..],
- * lengths_out[k] = bytes actually read (a short file reads short).  512 open + pread pairs take 30 ms under Python's
- * interpreter lock -- more than their payload's 26 ms on the PCIe link -- and well under a millisecond here.
- * Returns TORBI_HIP_OK, TORBI_HIP_EINVAL, or TORBI_HIP_EIO_BASE - k for the first file k that could not be opened / read.
- */
-int torbi_hip_open_heads(const char *const *paths, int count, int threads, int head_bytes, int *fds_out,
-                         unsigned char *heads_out, int *lengths_out, int *error_out);
 
 #ifdef __cplusplus
 }

@@ -66,11 +66,6 @@ SYMBOLS = {
         _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint]),
     'torbi_hip_epsilon_clamp': (_c.c_int, [_c.c_void_p, _c.c_uint64, _c.c_int, _c.c_void_p]),
     'torbi_hip_log_epsilon_clamp': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_int, _c.c_void_p]),
-    'torbi_hip_read_rows': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int,
-                                       _c.c_int, _c.POINTER(_c.c_int)]),
-    'torbi_hip_write_files': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.POINTER(_c.c_int)]),
-    'torbi_hip_open_heads': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p,
-                                        _c.POINTER(_c.c_int)]),
     'torbi_hip_fill_synthetic': (_c.c_int, [
         _c.c_void_p, _c.c_uint64, _c.c_uint64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
 }
@@ -181,33 +176,32 @@ def load_cpu():
     lib.torbi_cpu_abi_version.argtypes = []
     lib.torbi_cpu_viterbi_decode.restype = _c.c_int
     lib.torbi_cpu_viterbi_decode.argtypes = [_c.c_void_p] * 5 + [_c.c_int] * 4
-    # host side of the many-file job (same signatures as torbi_hip_read_rows / torbi_hip_write_files)
+    # host side of the many-file job (include/torbi_cpu.h)
     lib.torbi_cpu_read_rows.restype = _c.c_int
-    lib.torbi_cpu_read_rows.argtypes = SYMBOLS['torbi_hip_read_rows'][1]
+    lib.torbi_cpu_read_rows.argtypes = [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int,
+                                        _c.POINTER(_c.c_int)]
     lib.torbi_cpu_write_files.restype = _c.c_int
-    lib.torbi_cpu_write_files.argtypes = SYMBOLS['torbi_hip_write_files'][1]
+    lib.torbi_cpu_write_files.argtypes = [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.POINTER(_c.c_int)]
     lib.torbi_cpu_open_heads.restype = _c.c_int
-    lib.torbi_cpu_open_heads.argtypes = SYMBOLS['torbi_hip_open_heads'][1]
+    lib.torbi_cpu_open_heads.argtypes = [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                         _c.POINTER(_c.c_int)]
     if lib.torbi_cpu_abi_version() != CPU_ABI_VERSION:
         raise RuntimeError('libtorbi_cpu.so ABI mismatch: rebuild')
     _CPU_LIB = lib
     return lib
 
 
-def host_io(gpu: bool):
-    """(read_rows, write_files) of the many-file job's host side.  A GPU job takes them from libtorbi_hip.so (the
-    library it needs anyway; include/torbi_hip.h), a CPU job (`gpu=None`) from libtorbi_cpu.so -- the same host code
-    (csrc/file_rows.hpp) behind include/torbi_cpu.h, so the CPU route never needs the HIP runtime."""
-    if gpu:
-        lib = load()
-        return lib.torbi_hip_read_rows, lib.torbi_hip_write_files
+def host_io(gpu: bool = False):
+    """(read_rows, write_files) of the many-file job's host side: libtorbi_cpu.so for GPU jobs and CPU jobs alike (the same
+    host code, csrc/file_rows.hpp, behind include/torbi_cpu.h; `gpu` is accepted for the callers of rounds 2-4, which took
+    these from libtorbi_hip.so for a GPU job -- a reader thread's first call then waited behind the HIP runtime's start-up)."""
     lib = load_cpu()
     return lib.torbi_cpu_read_rows, lib.torbi_cpu_write_files
 
 
-def host_open_heads(gpu: bool):
-    """`open_heads` of the library `host_io(gpu)` takes its entry points from."""
-    return load().torbi_hip_open_heads if gpu else load_cpu().torbi_cpu_open_heads
+def host_open_heads(gpu: bool = False):
+    """`open_heads` of the library `host_io` takes its entry points from."""
+    return load_cpu().torbi_cpu_open_heads
 
 
 def check_io(code, what):

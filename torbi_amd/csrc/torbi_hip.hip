@@ -35,7 +35,6 @@
 #include "held_matrix_forward.hpp"
 #include "small_states.hpp"
 #include "band_forward.hpp"
-#include "file_rows.hpp"
 
 namespace {
 
@@ -1645,7 +1644,6 @@ const char *torbi_hip_error_string(int code) {
         default: break;
     }
     if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
-    if (code <= TORBI_HIP_EIO_BASE) return "torbi_hip_read_rows / torbi_hip_write_files: item -(code + 100) could not be read or written in full";
     return "unknown torbi_hip error";
 }
 
@@ -2034,40 +2032,6 @@ int torbi_hip_fill_synthetic(float *dst, uint64_t count, uint64_t start, int str
     hipLaunchKernelGGL(fill_synthetic_kernel, dim3(grid), dim3(256), 0,
                        static_cast<hipStream_t>(stream), dst, count, start, key);
     return (int)hipGetLastError();
-}
-
-int torbi_hip_read_rows(const int *fds, const int64_t *offsets, const int64_t *bytes, void *const *rows,
-                        const int64_t *zero_bytes, int count, int threads, int *error_out) {
-    if (count < 0 || threads < 1) return TORBI_HIP_EINVAL;
-    if (count == 0) return TORBI_HIP_OK;
-    if (!fds || !offsets || !bytes || !rows || !zero_bytes) return TORBI_HIP_EINVAL;
-    for (int k = 0; k < count; ++k)
-        if (fds[k] < 0 || offsets[k] < 0 || bytes[k] < 0 || zero_bytes[k] < 0 || (!rows[k] && bytes[k] + zero_bytes[k] > 0))
-            return TORBI_HIP_EINVAL;
-    const int rc = filerows::read_rows(fds, offsets, bytes, rows, zero_bytes, count, threads, error_out);
-    return rc == 0 ? TORBI_HIP_OK : TORBI_HIP_EIO_BASE + rc + 1;      // -(100 + index)
-}
-
-int torbi_hip_write_files(const char *const *paths, const void *const *data, const int64_t *bytes, int count, int threads,
-                          int *error_out) {
-    if (count < 0 || threads < 1) return TORBI_HIP_EINVAL;
-    if (count == 0) return TORBI_HIP_OK;
-    if (!paths || !data || !bytes) return TORBI_HIP_EINVAL;
-    for (int k = 0; k < count; ++k)
-        if (!paths[k] || bytes[k] < 0 || (!data[k] && bytes[k] > 0)) return TORBI_HIP_EINVAL;
-    const int rc = filerows::write_files(paths, data, bytes, count, threads, error_out);
-    return rc == 0 ? TORBI_HIP_OK : TORBI_HIP_EIO_BASE + rc + 1;      // -(100 + index)
-}
-
-int torbi_hip_open_heads(const char *const *paths, int count, int threads, int head_bytes, int *fds_out,
-                         unsigned char *heads_out, int *lengths_out, int *error_out) {
-    if (count < 0 || threads < 1 || head_bytes < 1) return TORBI_HIP_EINVAL;
-    if (count == 0) return TORBI_HIP_OK;
-    if (!paths || !fds_out || !heads_out || !lengths_out) return TORBI_HIP_EINVAL;
-    for (int k = 0; k < count; ++k)
-        if (!paths[k]) return TORBI_HIP_EINVAL;
-    const int rc = filerows::open_heads(paths, count, threads, head_bytes, fds_out, heads_out, lengths_out, error_out);
-    return rc == 0 ? TORBI_HIP_OK : TORBI_HIP_EIO_BASE + rc + 1;      // -(100 + index)
 }
 
 }  // extern "C"

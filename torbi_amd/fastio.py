@@ -8,7 +8,7 @@ takes a few milliseconds on an MI355X, so a many-file job is bound by exactly th
 `FileBatches` yields the same `(observation, batch_frames, batch_chunks, input_files)` tuples as
 `data.loader(...)`'s collate (zero padding included), but a file's float32 payload is `pread` from its place in the
 `torch.save` container directly into its row of the pinned batch buffer by native threads
-(`torbi_hip_read_rows`, csrc/file_rows.hpp): one pass over the bytes, outside the interpreter, the next batch
+(`torbi_cpu_read_rows`, csrc/file_rows.hpp): one pass over the bytes, outside the interpreter, the next batch
 assembled while the current one is copied and decoded.
 
 Only what `torch.save` writes for a plain contiguous float32 CPU tensor is taken this way (an uncompressed zip
@@ -179,7 +179,7 @@ HEAD_BYTES = 4096
 
 def _open_payloads(paths, gpu, threads):
     """`_open_payload` for a batch: the files are opened and their heads read by native threads in one call
-    (torbi_hip_open_heads); the interpreter only walks the headers it is handed.  [(fd, frames, states, offset)];
+    (torbi_cpu_open_heads); the interpreter only walks the headers it is handed.  [(fd, frames, states, offset)];
     on any failure every descriptor is closed again."""
     count = len(paths)
     names = [os.fsencode(os.fspath(p)) for p in paths]
@@ -462,7 +462,7 @@ def _filled_image(indices):
 
 def save_index_rows(rows, files, lengths, threads=8, gpu=None):
     """`save_indices(rows[k][:lengths[k]], files[k])` for a whole batch: the containers are put together here and
-    written by native threads in one call (`torbi_hip_write_files`)."""
+    written by native threads in one call (`torbi_cpu_write_files`)."""
     images, names = [], []
     for row, file, length in zip(rows, files, lengths):
         piece = row if length is None else row[..., :length]
