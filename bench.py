@@ -707,7 +707,7 @@ class Bench:
                {'us_per_timestep': sec / max(T - 1, 1) * 1e6})
         # state counts below the reference's pitch bins (a 3-state toy like BASELINE configs[0], 40 classes, 256 bins):
         # one wavefront / workgroup per sequence, recurrence and walk back in ONE launch (csrc/small_states.hpp)
-        for Bs, Ss in ((1, 3), (512, 40), (512, 256)):
+        for Bs, Ss in ((1, 3), (512, 40), (512, 256), (4096, 64)):
             os_ = v.fill_synthetic((Bs, T, Ss), synth.STREAM_OBSERVATION, seed=7, device=dev)
             ts_ = v.fill_synthetic((Ss, Ss), synth.STREAM_TRANSITION, seed=7, device=dev)
             is_ = v.fill_synthetic((Ss,), synth.STREAM_INITIAL, seed=7, device=dev)
@@ -715,9 +715,10 @@ class Bench:
             self.torbi_amd.decode(os_, fs_, ts_, is_, _profile=prof)
             sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(os_, fs_, ts_, is_), 3)
             extra = {'us_per_timestep': sec / max(T - 1, 1) * 1e6, 'forward_path': ROUTES[int(prof[3])],
-                     'launches': int(prof[2])}
-            sec_steps, _ = self.timed_decodes(lambda: self.torbi_amd.decode(os_, fs_, ts_, is_, path='dense'), 2)
-            extra['one_launch_per_timestep_ms'] = sec_steps * 1e3
+                     'launches': int(prof[2]), 'kernel': v.last_forward_kernel()}
+            if Bs * T <= 512 * 500:       # (the per-timestep kernels beside it; not for the large batch: seconds)
+                sec_steps, _ = self.timed_decodes(lambda: self.torbi_amd.decode(os_, fs_, ts_, is_, path='dense'), 2)
+                extra['one_launch_per_timestep_ms'] = sec_steps * 1e3
             record(f'small_states_{Bs}x{T}x{Ss}', sec, Bs * T, Ss, 'up to 256 states: the whole decode in one launch, the matrix '
                                                                    'in registers; beside it the per-timestep kernels (DENSE named)',
                    extra)

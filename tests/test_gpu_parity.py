@@ -1979,3 +1979,36 @@ def test_auto_gates_follow_the_data_not_the_first_call(forward):
     assert calls_until('peaked', 'cluster', 3) is not None              # peaked rows again: back on clusters within three calls
     assert calls_until('peaked', 'cluster', 1) == 1
     torbi_amd.reset_path_state()
+
+
+@pytest.mark.parametrize('S', [2, 3, 5, 17, 31, 32, 33, 40, 63, 64])
+def test_value_only_form_of_the_wavefront_kernel(S, forward, monkeypatch):
+    """small::decode_value_kernel (csrc/small_states.hpp): no backpointers, the posterior rows kept and the first argmax
+    recomputed along the decoded path from the matrix in the LDS -- AUTO's choice from 32 padded states and 512 sequences
+    up, forced here for every state count: ties on a coarse grid, -inf entries, a state nobody can come from, ragged
+    lengths incl. 1, more sequences than one workgroup holds; and the byte-backpointer form forced on the same inputs."""
+    if forward != 'auto':
+        pytest.skip('names its kernel itself')
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(S)
+    for B, T in [(1, 1), (5, 5), (70, 67), (6, 130), (530, 19)]:
+        obs = -rng.integers(0, 6, size=(B, T, S)).astype(np.float32)
+        trans = -rng.integers(0, 5, size=(S, S)).astype(np.float32)
+        init = -rng.integers(0, 3, size=(S,)).astype(np.float32)
+        trans[rng.random((S, S)) < 0.2] = -np.inf
+        obs[rng.random((B, T, S)) < 0.05] = -np.inf
+        if S > 2:
+            trans[:, S - 1] = -np.inf
+        frames = np.resize(np.array([T, 1, max(T - 1, 1), max(T - 3, 1), max(T // 2, 1), max(T - 16, 1), max(T - 17, 1)],
+                                    np.int32), B).astype(np.int32)
+        want, post = oracle.decode(obs, frames, trans, init, return_posterior=True)
+        args = [torch.tensor(x, device=dev) for x in (obs, frames, trans, init)]
+        ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+        for form, name in (('1', 'small::decode_value_kernel<'), ('0', 'small::decode_kernel<')):
+            monkeypatch.setenv('TORBI_HIP_SMALL_VALUE', form)
+            got = torbi_amd.decode(*args, workspace=ws)
+            assert viterbi.last_forward_kernel().startswith(name)
+            np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f'{B} x {T} x {S} form {form}')
+            last = viterbi.read_posterior(ws, args[1], B, T, S).cpu().numpy()
+            assert np.array_equal(last.view(np.uint32), post.view(np.uint32))
+    monkeypatch.delenv('TORBI_HIP_SMALL_VALUE')

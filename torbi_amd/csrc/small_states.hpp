@@ -15,6 +15,8 @@
 #include <stdint.h>
 #include <utility>
 
+#include "wave_reduce.hpp"
+
 namespace small {
 
 constexpr int kMaxS = 64;
@@ -154,6 +156,121 @@ __global__ __launch_bounds__(64) void decode_kernel(const float *__restrict__ ob
         }
         const int pos = 64 * c + lane;               // position t-1 of timestep t = 64c + lane + 1
         if (pos <= n - 2) ob[pos] = mine;
+    }
+}
+
+// ---- up to 64 states, MANY sequences: the same wavefront-per-sequence decode, value-only -------------------------------
+// With several wavefronts per SIMD the kernel above is bound by instruction issue: 4.3 vector instructions per cell (add,
+// compare, max, select).  Here a cell is add, add, 1/2 max3 = 1.5: the forward pass keeps no backpointers, it stores the
+// posterior rows (fp32: hist[b][t][:], where the int32 trellis of the generic route would lie) and the walk back recomputes
+// the first argmax of fl(hist[t-1][i] + trans[j][i]) for the state j on the path alone (viterbi.cpp:81-100: strict '>'
+// from prev-state 0 = the lowest index among the maxima; every candidate -inf = the zero default).  The walk needs row j of
+// the matrix per step: the four sequences of a workgroup share one copy of it in the LDS (16 KB at 64 states), lane i reads
+// trans[j][i] -- one conflict-free ds_read_b32 behind the v_readfirstlane of the step before.  A lone wavefront gains
+// nothing from this (its walk back is a dependent chain of ~300 cycles per step against ~10 through byte backpointers):
+// the launcher takes this kernel when the batch keeps every SIMD busy with several sequences (torbi_hip.hip, launch_small).
+template <int SP, int CH>
+__global__ __launch_bounds__(256) void decode_value_kernel(const float *__restrict__ obs, const int32_t *__restrict__ frames,
+                                                           const float *__restrict__ trans, const float *__restrict__ init,
+                                                           int32_t *__restrict__ out, float *__restrict__ hist,
+                                                           float *__restrict__ post0, float *__restrict__ post1,
+                                                           int32_t *__restrict__ route_record, int route, int B, int T, int S) {
+    __shared__ float matrix[kMaxS * kMaxS];           // trans[j][i] at j * SP + i (the padding is never read)
+    __shared__ float4 shared_rows[4][SP / 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (blockIdx.x == 0 && tid == 0) *route_record = route;
+    for (int e = tid; e < S * S; e += 256) matrix[(e / S) * SP + e % S] = trans[e];
+    __syncthreads();
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;                               // (behind the only workgroup barrier)
+    int n = __builtin_amdgcn_readfirstlane(frames[b]);
+    n = n < 1 ? 1 : (n > T ? T : n);
+    const bool live = lane < S;
+    const float ninf = -__builtin_huge_valf();
+
+    float row[SP];                                    // trans[lane][i]
+#pragma unroll
+    for (int i = 0; i < SP; ++i) row[i] = (live && i < S) ? matrix[lane * SP + i] : ninf;
+    const float *o = obs + (size_t)b * T * S + min(lane, S - 1);
+    float *h = hist + (size_t)b * T * S;
+    float p = o[0] + init[min(lane, S - 1)];
+    p = live ? p : ninf;
+    if (live) h[lane] = p;
+    float4 *const shared_row = shared_rows[wave];
+
+    float cur[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) cur[k] = o[(size_t)min(1 + k, n - 1) * S];
+    for (int t0 = 1; t0 < n; t0 += CH) {
+        float nxt[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) nxt[k] = o[(size_t)min(t0 + CH + k, n - 1) * S];       // (clamped: never past the item)
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (t0 + k < n) {                         // (wave-uniform)
+                if (lane < SP) reinterpret_cast<float *>(shared_row)[lane] = p;
+                __builtin_amdgcn_wave_barrier();
+                float pv[SP];
+#pragma unroll
+                for (int i = 0; i < SP / 4; ++i) {
+                    const float4 v = shared_row[i];
+                    pv[4 * i] = v.x; pv[4 * i + 1] = v.y; pv[4 * i + 2] = v.z; pv[4 * i + 3] = v.w;
+                }
+                __builtin_amdgcn_wave_barrier();
+                // four running maxima over interleaved prev-states (max is exact and order independent: any tree gives the value)
+                float best[4] = {ninf, ninf, ninf, ninf};
+#pragma unroll
+                for (int i = 0; i + 8 <= SP; i += 8) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        best[c] = fmaxf(fmaxf(best[c], pv[i + c] + row[i + c]), pv[i + 4 + c] + row[i + 4 + c]);
+                }
+                if (SP % 8) {                          // (SP = 4: one group of four)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) best[c] = fmaxf(best[c], pv[SP - 4 + c] + row[SP - 4 + c]);
+                }
+                const float top = fmaxf(fmaxf(best[0], best[1]), fmaxf(best[2], best[3]));
+                p = live ? cur[k] + top : ninf;
+                if (live) h[(size_t)(t0 + k) * S + lane] = p;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) cur[k] = nxt[k];
+    }
+    if (live) (((n - 1) & 1) ? post1 : post0)[(size_t)b * S + lane] = p;      // (where torbi_hip_read_posterior looks)
+
+    // first maximum of the last row
+    float best = p;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) best = fmaxf(best, __shfl_xor(best, d, 64));
+    unsigned long long at = __ballot(live && p == best);
+    int idx = at ? __ffsll((long long)at) - 1 : 0;
+    idx = __builtin_amdgcn_readfirstlane(idx);
+    int32_t *ob = out + (size_t)b * T;
+    for (int t = n - 1 + lane; t < T; t += 64) ob[t] = idx;
+    if (n < 2) return;
+    __threadfence_block();                            // this wavefront's own history stores, read back below
+
+    // walk back: timestep t -> position t - 1 holds the first argmax over i of hist[t-1][i] + trans[idx][i]; the rows of
+    // 16 timesteps are asked for together (they do not depend on the path)
+    for (int hi = n - 1; hi >= 1; hi -= 16) {
+        float rows[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) rows[g] = (hi - g >= 1 && live) ? h[(size_t)(hi - g - 1) * S + lane] : ninf;
+        int32_t mine = 0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            if (hi - g >= 1) {                        // (wave-uniform)
+                const float cand = live ? rows[g] + matrix[idx * SP + lane] : ninf;
+                const float m = wavered::wave_reduce_f32(cand, wavered::MaxOp());      // (DPP: no trip through the LDS crossbar)
+                at = __ballot(live && cand == m);
+                idx = __builtin_amdgcn_readfirstlane(at ? __ffsll((long long)at) - 1 : 0);
+                mine = lane == g ? idx : mine;
+            }
+        }
+        const int pos = hi - 1 - lane;                // position of timestep hi - lane
+        if (lane < 16 && pos >= 0) ob[pos] = mine;
     }
 }
 

@@ -989,27 +989,43 @@ hipError_t launch_finalize(const int32_t *frames, const Workspace &w, int32_t *o
 }
 
 // ---- up to 64 states: one wavefront per sequence, one launch per decode (small_states.hpp) ----------------------------
+// The value-only form (no backpointers, lazy argmax on the path, the matrix shared through the LDS) from 32 padded states
+// and 2 x compute-units sequences up -- tools/small_value_probe.py, ms per decode, backpointers / value-only:
+// 512 x 500 x 40 0.259 / 0.233, 512 x 500 x 64 0.343 / 0.294, 4096 x 500 x 64 0.848 / 0.713, 4096 x 500 x 40 0.553 / 0.450;
+// below 32 states the walk back costs more than the cells save (512 x 500 x 3 0.121 / 0.171, 8192 x 500 x 16 0.468 / 0.495).
+// TORBI_HIP_SMALL_VALUE=0|1 forces either form (read per launch: the tests switch it).
+inline bool small_value_form(int B, int S, int cus) {
+    if (const char *e = getenv("TORBI_HIP_SMALL_VALUE")) return atoi(e) != 0;
+    return small::padded_states(S) >= 32 && (long long)B >= 2ll * cus;
+}
 template <int SP, int CH>
 hipError_t launch_small_as(const float *obs, const int32_t *frames, const float *trans, const float *init, const Workspace &w,
-                           int32_t *out, int32_t *record, int B, int T, int S, hipStream_t stream) {
+                           int32_t *out, int32_t *record, int B, int T, int S, hipStream_t stream, bool value_form) {
+    if (value_form) {
+        TORBI_NOTE_KERNEL("small::decode_value_kernel<%d, %d>", SP, CH);
+        hipLaunchKernelGGL((small::decode_value_kernel<SP, CH>), dim3((B + 3) / 4), dim3(256), 0, stream, obs, frames, trans, init,
+                           out, reinterpret_cast<float *>(w.trellis), w.post[0], w.post[1], record, (int)ROUTE_SMALL, B, T, S);
+        return hipGetLastError();
+    }
     TORBI_NOTE_KERNEL("small::decode_kernel<%d, %d>", SP, CH);
     hipLaunchKernelGGL((small::decode_kernel<SP, CH>), dim3(B), dim3(64), 0, stream, obs, frames, trans, init, out,
                        reinterpret_cast<uint32_t *>(w.trellis), w.post[0], w.post[1], record, (int)ROUTE_SMALL, B, T, S);
     return hipGetLastError();
 }
 hipError_t launch_small(const float *obs, const int32_t *frames, const float *trans, const float *init, const Workspace &w,
-                        int32_t *out, int32_t *record, int B, int T, int S, hipStream_t stream, int *launches) {
+                        int32_t *out, int32_t *record, int B, int T, int S, hipStream_t stream, int *launches, int cus = 256) {
     if (launches) *launches += 1;
+    const bool v = small_value_form(B, S, cus);
     switch (small::padded_states(S)) {
-        case 4: return launch_small_as<4, 16>(obs, frames, trans, init, w, out, record, B, T, S, stream);
-        case 8: return launch_small_as<8, 16>(obs, frames, trans, init, w, out, record, B, T, S, stream);
-        case 16: return launch_small_as<16, 16>(obs, frames, trans, init, w, out, record, B, T, S, stream);
-        case 24: return launch_small_as<24, 8>(obs, frames, trans, init, w, out, record, B, T, S, stream);
-        case 32: return launch_small_as<32, 8>(obs, frames, trans, init, w, out, record, B, T, S, stream);
-        case 40: return launch_small_as<40, 8>(obs, frames, trans, init, w, out, record, B, T, S, stream);
-        case 48: return launch_small_as<48, 4>(obs, frames, trans, init, w, out, record, B, T, S, stream);
-        case 56: return launch_small_as<56, 4>(obs, frames, trans, init, w, out, record, B, T, S, stream);
-        default: return launch_small_as<64, 4>(obs, frames, trans, init, w, out, record, B, T, S, stream);
+        case 4: return launch_small_as<4, 16>(obs, frames, trans, init, w, out, record, B, T, S, stream, v);
+        case 8: return launch_small_as<8, 16>(obs, frames, trans, init, w, out, record, B, T, S, stream, v);
+        case 16: return launch_small_as<16, 16>(obs, frames, trans, init, w, out, record, B, T, S, stream, v);
+        case 24: return launch_small_as<24, 8>(obs, frames, trans, init, w, out, record, B, T, S, stream, v);
+        case 32: return launch_small_as<32, 8>(obs, frames, trans, init, w, out, record, B, T, S, stream, v);
+        case 40: return launch_small_as<40, 8>(obs, frames, trans, init, w, out, record, B, T, S, stream, v);
+        case 48: return launch_small_as<48, 4>(obs, frames, trans, init, w, out, record, B, T, S, stream, v);
+        case 56: return launch_small_as<56, 4>(obs, frames, trans, init, w, out, record, B, T, S, stream, v);
+        default: return launch_small_as<64, 4>(obs, frames, trans, init, w, out, record, B, T, S, stream, v);
     }
 }
 
@@ -1553,8 +1569,11 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
     if (ev) (void)hipEventRecord(ev[3], s);
     if (route == ROUTE_SMALL) {             // one launch: recurrence, backtrace and the route record
         // (the byte plane lies where the generic path's trellis does and is never larger: small_states.hpp)
-                e = (small::supported(S) ? launch_small : launch_block)(obs, frames, trans, init, carve(workspace, B, T, S), out,
-                                                                route_record(workspace, B, T, S, cus), B, T, S, s, launches);
+        // (and so does the value-only form's fp32 history: the trellis region itself)
+        const Workspace w = carve(workspace, B, T, S);
+        int32_t *const record = route_record(workspace, B, T, S, cus);
+        e = small::supported(S) ? launch_small(obs, frames, trans, init, w, out, record, B, T, S, s, launches, cus)
+                                : launch_block(obs, frames, trans, init, w, out, record, B, T, S, s, launches);
         if (ev) (void)hipEventRecord(ev[1], s);
         if (ev) (void)hipEventRecord(ev[2], s);
         return e;
