@@ -21,4 +21,4 @@ json.dump(summary, open(os.path.join(out, 'pmc.json'), 'w'), indent=1)
 for f in glob.glob(os.path.join(out, 'trace', '**', '*kernel_stats.csv'), recursive=True):
     shutil.copy(f, os.path.join(out, 'kernel_stats.csv'))
 print(json.dumps({k: {c: v['mean_per_dispatch'] for c, v in cs.items()} for k, cs in summary.items()
-                  if k != '_meta' and ('step' in k or 'resident' in k or 'small::' in k)}, indent=1))
+                  if k != '_meta' and ('step' in k or 'resident' in k or 'small::' in k or 'band' in k)}, indent=1))
