@@ -165,7 +165,8 @@ inline bool make_plan(int S, int hl, int hr, int tiles, int cus, Plan &pl) {
 #ifndef BAND_ABL
 #define BAND_ABL 0       // build-time ablations (timing only, results wrong): 1 no waiting for the halo, 2 no history stores,
                          // 4 no merge through M, 8 no exchange stores, 16 the scans alone (no hand-off, merge, finish, barriers),
-                         // 32 write-through granules even inside one XCD (results right), 64 scans without LDS reads, 128 scans without arithmetic
+                         // 32 write-through granules even inside one XCD (results right), 64 scans without LDS reads, 128 scans without arithmetic,
+                         // 256 / 512 without the barrier in the middle of the timestep / behind the merge
 #endif
 
 __device__ __forceinline__ float4 lds_f4(const char *p) {
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
         }
         if (fin) fetch(t);              // the observations of row t + 1 (row t is in `ob` already)
         if (R > 1) {
-            __syncthreads();            // the halo rows t - 1 are in the window
+            if (!(BAND_ABL & 256)) __syncthreads();            // the halo rows t - 1 are in the window
             BSTAMP(3);
             scan(acc, w, tq0, w0, s4, s5, tq_step);
             scan(acc, w, tq0, w0, s6, s7, tq_step);
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
                 __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float *)(m_at + e * n_own), acc[e], 0, 0, false);
         }
         BSTAMP(5);
-        __syncthreads();                // every wave is done with the window; M holds the maxima
+        if (!(BAND_ABL & 512)) __syncthreads();                // every wave is done with the window; M holds the maxima
         BSTAMP(6);
         if (fin) {
             float4 best;
