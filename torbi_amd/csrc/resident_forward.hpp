@@ -72,15 +72,15 @@ struct Group {
 
 // CLUSTER form: R workgroups (a cluster) share one 16-item tile.  Every member keeps the WHOLE posterior tile in its
 // LDS but scans only its share of the next-states; after a timestep the members exchange their slices of the new row
-// through `xchg` (write-through stores, one flag per member and timestep, MI355X_MICROARCH.md "handoff-flag" /
-// cdna_hip_programming.md Guideline 16 R1) -- no kernel boundary, no grid-wide barrier, the clusters drift freely.
+// through `xchg` (write-through stores of self-validating data, a hint per member and timestep: cluster_slot_bytes below;
+// MI355X_MICROARCH.md "transport-variants") -- no kernel boundary, no grid-wide barrier, the clusters drift freely.
 // That puts a single 512-item batch (32 tiles) on 256 compute units.  Membership is by ARRIVAL (a ticket drawn at
 // kernel entry) within a DISPATCH CLASS (workgroups b, b + 8, b + 16, ...): nothing depends on dispatch order or placement,
 // and a cluster whose last members have not been dispatched yet only waits -- every cluster that is complete runs to its
 // end and frees its compute units.  The GPU places a class on one XCD (observed, not promised); the members compare notes
 // at kernel entry, and a cluster that finds itself on ONE XCD exchanges through that XCD's L2 -- plain stores that stay in
-// it, L1-bypassing loads that hit it -- instead of write-through stores and reads across the fabric: the three dependent
-// trips of a timestep (slices + flag, flag poll, slice reads) then cost an L2 round trip each, not a fabric one (round 5).
+// it, L1-bypassing loads that hit it -- instead of write-through stores and reads across the fabric (round 5; no faster
+// on the benchmark: profiles/r05_cluster_exchange.txt).
 #ifndef RESIDENT_MAX_R
 #define RESIDENT_MAX_R 16
 #endif
@@ -98,24 +98,12 @@ constexpr int kMaxTop = 4;               // list entries per item a member publi
 // (issued behind the reset, awaited before any output exists: vmcnt counts in order) between the two.
 // (An input that makes the recurrence produce this very NaN -- NaNs are out of contract -- runs into the bounded wait and is
 // decoded again by the repair launch, like any cluster that cannot complete.)
-#ifndef CLUSTER_TAGGED
-#define CLUSTER_TAGGED 1
-#endif
-// CLUSTER_EARLY: a wave that has finished its pass does not idle at the workgroup barrier until the slowest of the twelve is
-// done: it takes the other members' slices into REGISTERS right away (pieces assigned to threads once, asked for when the
-// producer's hint is up, validated as above) and writes them to the tile behind the barrier.  The hint -- and the member's
-// partial top lists, tagged -- is sent by whichever wave of the workgroup finishes LAST (an LDS arrival counter), not
-// behind a barrier, so nobody's progress depends on anybody's barrier.  What is left on the critical path of a timestep:
-// the slowest wave of the cluster, one trip of its rows to the others, two workgroup barriers.
-#ifndef CLUSTER_EARLY
-#define CLUSTER_EARLY 0
-#endif
 constexpr unsigned kAbsentBits = 0x7fd5a5a5u;
-constexpr int kSlots = CLUSTER_TAGGED ? 4 : 2;
+constexpr int kSlots = 4;
 // bytes of one exchange slot: a posterior row of the tile + the members' partial top lists
 __host__ __device__ inline size_t cluster_slot_bytes(int S) {
     return ((size_t)S + 3) / 4 * 4 * kNI * sizeof(float) +
-           (size_t)kMaxR * kNI * kMaxTop * (CLUSTER_TAGGED ? 2 : 1) * sizeof(u64);
+           (size_t)kMaxR * kNI * kMaxTop * 2 * sizeof(u64);
 }
 struct Cluster {
     float *xchg;           // [tiles][kSlots] slots by timestep: the members' slices of the newest posterior rows
@@ -129,7 +117,6 @@ struct Cluster {
     unsigned *failed;      // [tiles] set by a member that gave up waiting for the others (zeroed before the launch): the
                            // tile's history is incomplete and the launch that follows decodes it again, whole
     int R;
-    int staged;            // pieces per thread the LDS behind the tile holds for the early ingest (cluster_staged)
     unsigned long long wait_ticks;     // how long a member waits for the others' flags (100 MHz ticks; 0: not at all)
 };
 // Cluster::wait_ticks, default (ticks of the 100 MHz wall clock): a quarter of a second -- members that have not been
@@ -146,11 +133,6 @@ inline size_t lds_bytes(int S, int ktop = kTop) {
     const size_t S4 = ((size_t)S + 3) / 4 * 4, ni = (size_t)tile_items(S);
     return sizeof(float) * ni * S4 + sizeof(u64) * kNI * ktop + (sizeof(float) + sizeof(int)) * kNI * ktop +
            2 * sizeof(int) * kNI + 4 * sizeof(int);
-}
-// cluster form: 16-byte pieces per thread (768 threads) that fit behind all that in the 160 KB of a compute unit, at most 8
-inline int cluster_staged(int S, int ktop = kTop) {
-    const size_t room = 160 * 1024 - lds_bytes(S, ktop);
-    return (int)std::min<size_t>(room / (768 * 16), 8);
 }
 
 // row groups (16 next-states) member m of R scans: [m * nrg / R, (m + 1) * nrg / R)
@@ -332,18 +314,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void *base, un
 #ifndef CLUSTER_POLL_SLEEP
 #define CLUSTER_POLL_SLEEP 1
 #endif
-#ifndef CLUSTER_FIRST_SLEEP
-#define CLUSTER_FIRST_SLEEP 0
-#endif
-#ifndef CLUSTER_ONE_POLLER
-#define CLUSTER_ONE_POLLER 1
-#endif
-#ifndef CLUSTER_EARLY_SLEEP
-#define CLUSTER_EARLY_SLEEP 4          // (64-cycle units) between two rounds of a wave that waits for slices
-#endif
-// the slice stores are drained together with the keys behind the workgroup barrier (1) instead of by every wave before it (0)
-#ifndef CLUSTER_LATE_DRAIN
-#define CLUSTER_LATE_DRAIN 1
+#ifndef CLUSTER_ROUND
+#define CLUSTER_ROUND 8                // 16-byte pieces of the other members' slices a thread asks for at once
 #endif
 #ifndef RESIDENT_EXTRA_VALU
 #define RESIDENT_EXTRA_VALU 0
@@ -501,11 +473,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
     for (int it = 0; it < 4; ++it) ib[it] = sitem[4 * g + it];
 
     float pend[MAXP][4];
-    // CLUSTER (early ingest): thread tid takes the 16-byte pieces tid + u * 768 of the other members' slices.  Pieces
-    // u < n_staged wait in the LDS behind the tile (Cluster::staged of them fit), the next kHeld in registers, for the
-    // workgroup barrier; any beyond those (2048 / 4096 states: the tile leaves room for two) are taken behind the barrier.
-    constexpr bool EARLY = CLUSTER && CLUSTER_TAGGED && CLUSTER_EARLY;
-    constexpr int kHeld = 2, kBatch = 4;
+    // CLUSTER: the 16-byte pieces of the other members' slices (every row but this member's own), thread by thread
     const int own_lo = kRowGroup * rg_lo, own_hi = kRowGroup * rg_hi < S ? kRowGroup * rg_hi : S;
     const int pieces = CLUSTER ? (S - (own_hi - own_lo)) * G : 0;
     auto place = [&](int c) {          // byte offset of piece c (tile and slot alike)
@@ -513,17 +481,6 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
         row = row < own_lo ? row : row + (own_hi - own_lo);
         return (row * kNI + 4 * (c % G)) * 4;
     };
-    const int n_staged = EARLY ? clu.staged : 0;
-    const unsigned member_inv = CLUSTER ? (unsigned)((0x100000000ull + (unsigned)nrg - 1u) / (unsigned)nrg) : 0u;
-    auto sender = [&](int c) {         // the member piece c comes from: (row group + 1) * R - 1 over the row groups, exactly
-        const unsigned rgc = (unsigned)(place(c) / (kNI * 4)) / (unsigned)kRowGroup;
-        return __umulhi((rgc + 1u) * (unsigned)R - 1u, member_inv);
-    };
-    float4 *const stage = reinterpret_cast<float4 *>(smisc + 4) + tid;      // [n_staged][64 * KW]
-    if constexpr (CLUSTER) {
-        if (tid == 0) smisc[3] = 0;             // EARLY: waves that have finished their pass (running count); else: members up
-    }
-    float4 got[kHeld];
     // A cluster member whose waves scan ONE row group per timestep (MAXP == 1) meets the same sorted rows every
     // timestep: their first two list blocks stay in registers, and the next timestep's observations are requested
     // before the wait for the other members (everything a pass needs that does not depend on the exchange).
@@ -766,7 +723,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
         // of the quad, in the layout of the LDS tile.  All of a wave's rows are stored HERE, behind its last pass, not pass
         // by pass: a write-through store stays in the wave's memory queue until memory has acknowledged it, and the history
         // stores and list loads of the next pass queued up behind it (14 of 50 us per timestep with two passes per wave).
-        // The slice stores must have left before the workgroup raises its flag: every storing wave drains.
+        // Nobody waits for the acknowledgement: the data validates itself at the consumer (cluster_slot_bytes).
         if constexpr (CLUSTER) {
             if (t + 1 < fmax && !(RESIDENT_ABL & 128)) {
                 const __amdgpu_buffer_rsrc_t xdst = buffer_of(
@@ -782,116 +739,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                     }
                 }
             }
-            if (!CLUSTER_LATE_DRAIN && !CLUSTER_TAGGED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             RSTAMP(8);
-        }
-        if constexpr (EARLY) {
-            if (t + 1 < fmax) {
-                unsigned *const cflags = clu.flags + (size_t)cid * kMaxR;
-                const __amdgpu_buffer_rsrc_t xsrc = buffer_of(
-                    reinterpret_cast<const char *>(clu.xchg) + (size_t)(kSlots * cid + (t & (kSlots - 1))) * xbytes, xbytes);
-                // the wave that finishes last sends the member's partial top lists (every wave's inserts precede its count in
-                // the LDS queue) and the hint
-                int arrived = 0;
-                if (lane == 0) arrived = atomicAdd(&smisc[3], 1) + 1;
-                arrived = __builtin_amdgcn_readfirstlane(arrived);
-                if (arrived % KW == 0) {
-                    if (lane < kNI * kTop) {
-                        const u64 k = top[lane];
-                        v4u x = {(unsigned)k, (unsigned)t, (unsigned)(k >> 32), (unsigned)t};
-                        const int at = (int)xrow + (member * kNI * kMaxTop + lane) * 16;
-                        if (local) __builtin_amdgcn_raw_buffer_store_b128(x, xsrc, at, 0, 0);
-                        else __builtin_amdgcn_raw_buffer_store_b128(x, xsrc, at, 0, 16);
-                    }
-                    if (lane == 0) raise_flag(cflags + member, (unsigned)t, local);
-                }
-                // the others' slices -> registers, their top lists -> this workgroup's lists
-                const int kpair = kNI * kTop / 2;          // keys: two per thread (R * 16 * kTop / 2 <= 512 threads)
-                const int km = tid / kpair, ks = tid - km * kpair;
-                bool want_keys = km < R && km != member;
-                const int kat = (int)xrow + (km * kNI * kMaxTop + 2 * ks) * 16;
-                const int n_early = min((pieces - tid + 64 * KW - 1) / (64 * KW), n_staged + kHeld);   // this thread's
-                unsigned missing = (1u << n_early) - 1u;
-                unsigned have = 0u, spins = 0;           // members whose hint has been acted on (wave-uniform)
-                unsigned long long since = 0ull;
-                for (;;) {
-                    unsigned seen = 0xffffffffu;
-                    if (lane < R && lane != member)
-                        seen = __hip_atomic_load(cflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned up = (unsigned)__ballot(seen >= (unsigned)t);      // members that have sent timestep t
-                    // a round of loads when a new member is up, or something asked for before was not there yet
-                    if ((up & ~have) != 0u || __any((missing != 0u || want_keys) && have != 0u)) {
-                        have = up;
-                        const bool keys_now = want_keys && ((up >> km) & 1u);
-                        v4u key0 = {0u, 0u, 0u, 0u}, key1 = {0u, 0u, 0u, 0u};
-                        if (keys_now) {
-                            key0 = __builtin_amdgcn_raw_buffer_load_b128(xsrc, kat, 0, 16);
-                            key1 = __builtin_amdgcn_raw_buffer_load_b128(xsrc, kat + 16, 0, 16);
-                        }
-                        auto present = [&](const float4 &v) {
-                            return __float_as_uint(v.x) != kAbsentBits && __float_as_uint(v.y) != kAbsentBits &&
-                                   __float_as_uint(v.z) != kAbsentBits && __float_as_uint(v.w) != kAbsentBits;
-                        };
-                        for (int u0 = 0; u0 < n_staged; u0 += kBatch) {             // (wave-uniform bounds)
-                            float4 v[kBatch];
-                            unsigned now = 0u;
-#pragma unroll
-                            for (int k = 0; k < kBatch; ++k) {
-                                const int u = u0 + k, c = tid + u * 64 * KW;
-                                if (u < n_staged && ((missing >> u) & 1u) && ((up >> sender(c)) & 1u)) {
-                                    v[k] = load_through(xsrc, place(c));
-                                    now |= 1u << k;
-                                }
-                            }
-#pragma unroll
-                            for (int k = 0; k < kBatch; ++k) {
-                                if (((now >> k) & 1u) && present(v[k])) {
-                                    stage[(u0 + k) * 64 * KW] = v[k];
-                                    missing &= ~(1u << (u0 + k));
-                                }
-                            }
-                        }
-                        {
-                            float4 v[kHeld];
-                            unsigned now = 0u;
-#pragma unroll
-                            for (int k = 0; k < kHeld; ++k) {
-                                const int u = n_staged + k, c = tid + u * 64 * KW;
-                                if (((missing >> u) & 1u) && ((up >> sender(c)) & 1u)) {
-                                    v[k] = load_through(xsrc, place(c));
-                                    now |= 1u << k;
-                                }
-                            }
-#pragma unroll
-                            for (int k = 0; k < kHeld; ++k) {
-                                if (((now >> k) & 1u) && present(v[k])) {
-                                    got[k] = v[k];
-                                    missing &= ~(1u << (n_staged + k));
-                                }
-                            }
-                        }
-                        if (keys_now && key0.y == (unsigned)t && key0.w == (unsigned)t && key1.y == (unsigned)t &&
-                            key1.w == (unsigned)t) {
-                            want_keys = false;
-                            const u64 k0 = ((u64)key0.z << 32) | key0.x, k1 = ((u64)key1.z << 32) | key1.x;
-                            if (k0) top_insert<kTop>(top + (2 * ks / kTop) * kTop, k0);
-                            if (k1) top_insert<kTop>(top + ((2 * ks + 1) / kTop) * kTop, k1);
-                        }
-                    }
-                    if (!__any(missing != 0u || want_keys)) break;
-                    RCOUNT(7, 1);
-                    __builtin_amdgcn_s_sleep(CLUSTER_EARLY_SLEEP);
-                    if ((spins++ & 63u) == 0u) {                 // (the clock is read at the first round that fails, then every 64th)
-                        const unsigned long long at = wall_clock64();
-                        if (since == 0ull) since = at;
-                        if (at - since >= clu.wait_ticks) {
-                            if (lane == 0) smisc[1] = 1;
-                            break;
-                        }
-                    }
-                }
-                RSTAMP(9);
-            }
         }
         __syncthreads();      // every wave is done reading the tile and mtop, every output is in `top`
         RSTAMP(5);
@@ -903,49 +751,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                 *reinterpret_cast<float4 *>(lds + (size_t)jj * kNI + 4 * g) =
                     make_float4(pend[p][0], pend[p][1], pend[p][2], pend[p][3]);
         }
-        if constexpr (EARLY) {
-            if (t + 1 < fmax) {
-                for (int u = 0; u < n_staged; ++u) {
-                    const int c = tid + u * 64 * KW;
-                    if (c < pieces) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(lds) + place(c)) = stage[u * 64 * KW];
-                }
-#pragma unroll
-                for (int k = 0; k < kHeld; ++k) {
-                    const int c = tid + (n_staged + k) * 64 * KW;
-                    if (c < pieces) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(lds) + place(c)) = got[k];
-                }
-                // (pieces beyond those: every producer's hint has been seen by now)
-                if (pieces > (n_staged + kHeld) * 64 * KW && !smisc[1]) {
-                    const __amdgpu_buffer_rsrc_t xsrc = buffer_of(
-                        reinterpret_cast<const char *>(clu.xchg) + (size_t)(kSlots * cid + (t & (kSlots - 1))) * xbytes, xbytes);
-                    unsigned spins = 0;
-                    unsigned long long since = 0ull;
-                    for (int c = (n_staged + kHeld) * 64 * KW + tid; c < pieces + tid; c += 64 * KW) {   // (one trip count per wave)
-                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        bool there = c >= pieces;
-                        for (;;) {
-                            if (!there) {
-                                v = load_through(xsrc, place(c));
-                                there = __float_as_uint(v.x) != kAbsentBits && __float_as_uint(v.y) != kAbsentBits &&
-                                        __float_as_uint(v.z) != kAbsentBits && __float_as_uint(v.w) != kAbsentBits;
-                            }
-                            if (__all(there)) break;
-                            __builtin_amdgcn_s_sleep(2);
-                            if ((spins++ & 63u) == 0u) {
-                                const unsigned long long at = wall_clock64();
-                                if (since == 0ull) since = at;
-                                if (at - since >= clu.wait_ticks) {
-                                    if (lane == 0) smisc[1] = 1;
-                                    break;
-                                }
-                            }
-                        }
-                        if (c < pieces) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(lds) + place(c)) = v;
-                    }
-                }
-            }
-        }
-        if constexpr (CLUSTER && CLUSTER_TAGGED) {
+        if constexpr (CLUSTER) {
             // this wave's rows of the slot row t - 2 went to: absent again, two timesteps before row t + 2 arrives there
             if (t + 1 < fmax) {
                 const __amdgpu_buffer_rsrc_t xold = buffer_of(
@@ -974,14 +780,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                 for (int it = 0; it < 4; ++it) obnext[it] = obs[((size_t)ib[it] * T + t + 1) * S + jr];
             }
         }
-        if constexpr (EARLY) {
-            if (t + 1 < fmax) {
-                __syncthreads();      // the tile holds row t, `top` its largest entries
-                RSTAMP(11);
-                if (smisc[1]) break;  // (uniform: read behind the barrier)
-            }
-        }
-        if constexpr (CLUSTER && CLUSTER_TAGGED && !EARLY) {
+        if constexpr (CLUSTER) {
             if (t + 1 < fmax) {
                 unsigned *const cflags = clu.flags + (size_t)cid * kMaxR;
                 const __amdgpu_buffer_rsrc_t xsrc = buffer_of(
@@ -999,129 +798,10 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                     if (lane == 0) raise_flag(cflags + member, (unsigned)t, local);
                 }
                 RSTAMP(6);
-                // (2) their slices of row t -> the tile (every 16-byte piece except this member's own rows), their partial
-                // top lists -> this workgroup's lists, MEMBER BY MEMBER as the hints come in: wave 0 polls the hints and
-                // leaves what it sees in the LDS, every wave asks for the pieces of the members that are newly up -- the
-                // bulk of the 80 KB is on its way while the slowest member is still scanning.  A piece that still reads
-                // absent (the hint overtook it), a key with another timestep's tag, is asked for again; all of it bounded.
-                {
-                    const int kpair = kNI * kTop / 2;          // keys: two per thread (R * 16 * kTop / 2 <= 512 threads)
-                    const int km = tid / kpair, ks = tid - km * kpair;
-                    bool want_keys = km < R && km != member;
-                    const int kat = (int)xrow + (km * kNI * kMaxTop + 2 * ks) * 16;
-                    const int n_mine = (pieces - tid + 64 * KW - 1) / (64 * KW);          // this thread's pieces
-                    const int n_most = (pieces + 64 * KW - 1) / (64 * KW);               // (wave-uniform bound)
-                    unsigned missing = (1u << n_mine) - 1u;
-                    unsigned have = 0u, spins = 0;           // members whose hint has been acted on (wave-uniform)
-                    unsigned long long since = 0ull;
-                    auto present = [&](const float4 &v) {
-                        return __float_as_uint(v.x) != kAbsentBits && __float_as_uint(v.y) != kAbsentBits &&
-                               __float_as_uint(v.z) != kAbsentBits && __float_as_uint(v.w) != kAbsentBits;
-                    };
-                    for (;;) {
-                        unsigned up;
-                        if (wave == 0) {
-                            unsigned seen = 0xffffffffu;
-                            if (lane < R && lane != member)
-                                seen = __hip_atomic_load(cflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            up = (unsigned)__ballot(seen >= (unsigned)t);      // members that have sent timestep t
-                            if (lane == 0) *reinterpret_cast<volatile int *>(smisc + 3) = (int)up;
-                        } else {
-                            up = (unsigned)__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int *>(smisc + 3));
-                        }
-                        // a round of loads when a new member is up, or something asked for before was not there yet
-                        if ((up & ~have) != 0u || __any((missing != 0u || want_keys) && have != 0u)) {
-                            have = up;
-                            const bool keys_now = want_keys && ((up >> km) & 1u);
-                            v4u key0 = {0u, 0u, 0u, 0u}, key1 = {0u, 0u, 0u, 0u};
-                            if (keys_now) {
-                                key0 = __builtin_amdgcn_raw_buffer_load_b128(xsrc, kat, 0, 16);
-                                key1 = __builtin_amdgcn_raw_buffer_load_b128(xsrc, kat + 16, 0, 16);
-                            }
-                            for (int u0 = 0; u0 < n_most; u0 += kBatch) {
-                                float4 v[kBatch];
-                                unsigned now = 0u;
-#pragma unroll
-                                for (int k = 0; k < kBatch; ++k) {
-                                    const int u = u0 + k, c = tid + u * 64 * KW;
-                                    if (((missing >> u) & 1u) && ((up >> sender(c)) & 1u)) {
-                                        v[k] = load_through(xsrc, place(c));
-                                        now |= 1u << k;
-                                    }
-                                }
-#pragma unroll
-                                for (int k = 0; k < kBatch; ++k) {
-                                    if (((now >> k) & 1u) && present(v[k])) {
-                                        *reinterpret_cast<float4 *>(reinterpret_cast<char *>(lds) + place(tid + (u0 + k) * 64 * KW)) = v[k];
-                                        missing &= ~(1u << (u0 + k));
-                                    }
-                                }
-                            }
-                            if (keys_now && key0.y == (unsigned)t && key0.w == (unsigned)t && key1.y == (unsigned)t &&
-                                key1.w == (unsigned)t) {
-                                want_keys = false;
-                                const u64 k0 = ((u64)key0.z << 32) | key0.x, k1 = ((u64)key1.z << 32) | key1.x;
-                                if (k0) top_insert<kTop>(top + (2 * ks / kTop) * kTop, k0);
-                                if (k1) top_insert<kTop>(top + ((2 * ks + 1) / kTop) * kTop, k1);
-                            }
-                        }
-                        // (wave 0 polls on until every member is up: the other waves read what it leaves)
-                        if (!__any(missing != 0u || want_keys) && (wave != 0 || up == 0xffffffffu)) break;
-                        RCOUNT(7, 1);
-                        __builtin_amdgcn_s_sleep(CLUSTER_POLL_SLEEP);
-                        if ((spins++ & 63u) == 0u) {              // (the clock is read at the first round that fails, then every 64th)
-                            const unsigned long long at = wall_clock64();
-                            if (since == 0ull) since = at;
-                            if (at - since >= clu.wait_ticks) {
-                                if (lane == 0) smisc[1] = 1;
-                                break;
-                            }
-                        }
-                    }
-                }
-                RSTAMP(10);
-                __syncthreads();      // the tile holds row t, `top` its largest entries
-                RSTAMP(11);
-                if (smisc[1]) break;  // (uniform: read behind the barrier)
-                if (tid == 0) smisc[3] = 0;           // (nobody is up for the next timestep yet)
-            }
-        }
-        if constexpr (CLUSTER && !CLUSTER_TAGGED) {
-            if (t + 1 < fmax) {
-                const int par = t & 1;
-                unsigned *const cflags = clu.flags + (size_t)cid * kMaxR;
-                // (1) this member's partial top lists behind the posterior row of its slot, then its flag (wave 0; the
-                // slices were drained before the barrier above)
-                const __amdgpu_buffer_rsrc_t xsrc =
-                    buffer_of(reinterpret_cast<const char *>(clu.xchg) + (size_t)(2 * cid + par) * xbytes, xbytes);
+                // (2) wave 0 waits until the other members say they have sent timestep t (bounded), the others for wave 0
                 if (wave == 0) {
-                    if (lane < kNI * kTop / 2) {
-                        const u64 k0 = top[2 * lane], k1 = top[2 * lane + 1];
-                        v4u x = {(unsigned)k0, (unsigned)(k0 >> 32), (unsigned)k1, (unsigned)(k1 >> 32)};
-                        if (local) __builtin_amdgcn_raw_buffer_store_b128(x, xsrc, (int)xrow + (member * kNI * kMaxTop + 2 * lane) * 8, 0, 0);
-                        else __builtin_amdgcn_raw_buffer_store_b128(x, xsrc, (int)xrow + (member * kNI * kMaxTop + 2 * lane) * 8, 0, 16);
-                    }
-                    if (!CLUSTER_LATE_DRAIN) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        if (lane == 0) raise_flag(cflags + member, (unsigned)t, local);
-                    }
-                }
-                if (CLUSTER_LATE_DRAIN) {
-                    // ONE wait for the acknowledgements of the slice stores and of the keys together (the slices were
-                    // stored before the barrier above and have been on their way since), then the flag
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    if (tid == 0) raise_flag(cflags + member, (unsigned)t, local);
-                }
-                RSTAMP(6);
-                // (2) wave 0 waits until the other members have published timestep t (one relaxed poll per member and
-                // round, lanes 0..R-1; bounded: a cluster that cannot complete gives up and reports it), the others for wave 0
-                if (!CLUSTER_ONE_POLLER || wave == 0) {
                     unsigned spins = 0;
                     unsigned long long since = 0ull;
-#if CLUSTER_FIRST_SLEEP > 0
-                    __builtin_amdgcn_s_sleep(CLUSTER_FIRST_SLEEP);
-#endif
                     for (;;) {
                         unsigned seen = 0xffffffffu;
                         if (lane < R && lane != member)
@@ -1138,32 +818,57 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                         }
                     }
                 }
-                if (CLUSTER_ONE_POLLER) __syncthreads();
+                __syncthreads();
                 RSTAMP(9);
-                // (3) their slices of row t -> the tile (every 16-byte piece except this member's own rows) and their
-                // partial top lists -> this workgroup's lists; all loads of a thread in flight together (eight slice pieces
-                // per round: one round up to 1536 states)
-                {
-                    const int own_lo = kRowGroup * rg_lo, own_hi = kRowGroup * rg_hi < S ? kRowGroup * rg_hi : S;
-                    const int pieces = (S - (own_hi - own_lo)) * G;
-                    auto place = [&](int c) {          // byte offset of piece c (tile and slot alike)
-                        int row = c / G;
-                        row = row < own_lo ? row : row + (own_hi - own_lo);
-                        return (row * kNI + 4 * (c % G)) * 4;
-                    };
-                    // keys: two per thread (R * 16 * kTop / 2 <= 512 threads)
-                    const int kpair = kNI * kTop / 2;
+                // (3) their slices of row t -> the tile (every 16-byte piece except this member's own rows), their partial
+                // top lists -> this workgroup's lists.  All loads of a thread in flight together (up to ten pieces: 7 at
+                // 1440 states and eight members); a piece that still reads absent (the hint overtook it), a key with
+                // another timestep's tag, is asked for again, bounded like the wait above
+                if (!smisc[1]) {
+                    const int kpair = kNI * kTop / 2;          // keys: two per thread (R * 16 * kTop / 2 <= 512 threads)
                     const int km = tid / kpair, ks = tid - km * kpair;
-                    const bool keyed = km < R && km != member;
-                    v4u keys = {0u, 0u, 0u, 0u};
-                    if (keyed) keys = __builtin_amdgcn_raw_buffer_load_b128(xsrc, (int)xrow + (km * kNI * kMaxTop + 2 * ks) * 8, 0, 16);
-                    constexpr int kRound = 8;
-                    for (int first = 0; first < pieces; first += kRound * 64 * KW) {
+                    bool want_keys = km < R && km != member;
+                    const bool keyed = want_keys;
+                    v4u key0 = {0u, 0u, 0u, 0u}, key1 = {0u, 0u, 0u, 0u};
+                    const int kat = (int)xrow + (km * kNI * kMaxTop + 2 * ks) * 16;
+                    constexpr int kRound = CLUSTER_ROUND;
+                    unsigned spins = 0;
+                    unsigned long long since = 0ull;
+                    bool gave_up = false;
+                    for (int first = 0; first < pieces && !gave_up; first += kRound * 64 * KW) {
                         float4 got[kRound];
+                        unsigned missing = 0u;
 #pragma unroll
-                        for (int u = 0; u < kRound; ++u) {
-                            const int c = first + tid + u * 64 * KW;
-                            if (c < pieces) got[u] = load_through(xsrc, place(c));
+                        for (int u = 0; u < kRound; ++u) missing |= (first + tid + u * 64 * KW < pieces ? 1u : 0u) << u;
+                        for (;;) {
+#pragma unroll
+                            for (int u = 0; u < kRound; ++u)
+                                if (missing >> u & 1u) got[u] = load_through(xsrc, place(first + tid + u * 64 * KW));
+                            if (want_keys) {
+                                key0 = __builtin_amdgcn_raw_buffer_load_b128(xsrc, kat, 0, 16);
+                                key1 = __builtin_amdgcn_raw_buffer_load_b128(xsrc, kat + 16, 0, 16);
+                            }
+#pragma unroll
+                            for (int u = 0; u < kRound; ++u) {
+                                const bool there = __float_as_uint(got[u].x) != kAbsentBits && __float_as_uint(got[u].y) != kAbsentBits &&
+                                                   __float_as_uint(got[u].z) != kAbsentBits && __float_as_uint(got[u].w) != kAbsentBits;
+                                if (there) missing &= ~(1u << u);
+                            }
+                            if (want_keys && key0.y == (unsigned)t && key0.w == (unsigned)t && key1.y == (unsigned)t &&
+                                key1.w == (unsigned)t)
+                                want_keys = false;
+                            if (!__any(missing != 0u || want_keys)) break;
+                            RCOUNT(7, 1);
+                            __builtin_amdgcn_s_sleep(2);
+                            if ((spins++ & 15u) == 0u) {
+                                const unsigned long long now = wall_clock64();
+                                if (since == 0ull) since = now;
+                                if (now - since >= clu.wait_ticks) {
+                                    if (lane == 0) smisc[1] = 1;
+                                    gave_up = true;
+                                    break;
+                                }
+                            }
                         }
 #pragma unroll
                         for (int u = 0; u < kRound; ++u) {
@@ -1171,10 +876,9 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                             if (c < pieces) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(lds) + place(c)) = got[u];
                         }
                     }
-                    if (keyed) {
-                        const u64 k0 = ((u64)keys.y << 32) | keys.x, k1 = ((u64)keys.w << 32) | keys.z;
-                        u64 *list = top + (2 * ks / kTop) * kTop;
-                        if (k0) top_insert<kTop>(list, k0);
+                    if (keyed && !gave_up) {
+                        const u64 k0 = ((u64)key0.z << 32) | key0.x, k1 = ((u64)key1.z << 32) | key1.x;
+                        if (k0) top_insert<kTop>(top + (2 * ks / kTop) * kTop, k0);
                         if (k1) top_insert<kTop>(top + ((2 * ks + 1) / kTop) * kTop, k1);
                     }
                 }

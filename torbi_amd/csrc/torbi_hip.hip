@@ -1235,15 +1235,12 @@ inline bool few_seeds(unsigned flags, bool clusters) {
 template <int KW, int MAXP, int KR, bool CLUSTER, int NI>
 hipError_t launch_resident_variant(const resident::Group &grp, const resident::Cluster &clu, int workgroups,
                                    const ResidentWorkspace &w, const float *init, int S, hipStream_t stream) {
-    // (cluster form: the LDS behind the tile holds the other members' slices until the workgroup barrier)
-    resident::Cluster with = clu;
-    with.staged = CLUSTER && CLUSTER_TAGGED && CLUSTER_EARLY ? resident::cluster_staged(S, KR + 1) : 0;
-    const size_t lds = resident::lds_bytes(S, KR + 1) + (size_t)with.staged * 64 * KW * 16;
+    const size_t lds = resident::lds_bytes(S, KR + 1);
     const void *fn = reinterpret_cast<const void *>(&resident::resident_forward_kernel<KW, MAXP, true, KR, CLUSTER, NI>);
     hipError_t e = ensure_dynamic_lds(fn, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((resident::resident_forward_kernel<KW, MAXP, true, KR, CLUSTER, NI>), dim3(workgroups), dim3(64 * KW), lds,
-                       stream, grp, with, w.tt, w.sorted, init, S, w.SpP);
+                       stream, grp, clu, w.tt, w.sorted, init, S, w.SpP);
     TORBI_NOTE_KERNEL("resident::resident_forward_kernel<%d, %d, true, %d, %s, %d, false>", KW, MAXP, KR, CLUSTER ? "true" : "false", NI);
     return hipGetLastError();
 }
@@ -1331,7 +1328,7 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
     const char *wait_env = getenv("TORBI_HIP_CLUSTER_WAIT_US");         // (read per launch: the tests switch it)
     const unsigned long long wait_ticks = wait_env ? 100ull * strtoull(wait_env, nullptr, 10) : resident::kClusterWaitTicks;
     // (flags [ctiles][kMaxR], control [16], failed [ctiles], where [ctiles][kMaxR]: all zeroed by order_tiles_kernel)
-    resident::Cluster clu{w.xchg, w.flags, control + 16 + std::max(cus / 2, 1), tiles, control, control + 16, R, 0, wait_ticks};
+    resident::Cluster clu{w.xchg, w.flags, control + 16 + std::max(cus / 2, 1), tiles, control, control + 16, R, wait_ticks};
     if (ev) (void)hipEventRecord(ev[0], s);
     for (int k = 0; k < n; ++k) {            // (order_items_kernel stamps the batches' route records)
         jobs.job[k].route_record = route_record(hb[k].workspace, hb[k].B, hb[k].T, S, cus);
@@ -1360,7 +1357,7 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
     const int nrg = (S + resident::pass_rows(S) - 1) / resident::pass_rows(S);
     const bool small = resident::tile_items(S) != resident::kNI;       // 8-item tiles (2048 < S <= 4096)
     if (R > 1) {
-        if (CLUSTER_TAGGED) {       // the slots this launch uses start out absent (resident_forward.hpp, cluster_slot_bytes)
+        {       // the slots this launch uses start out absent (resident_forward.hpp, cluster_slot_bytes)
             const size_t granules = (size_t)tiles * resident::kSlots * resident::cluster_slot_bytes(S) / 16;
             hipLaunchKernelGGL(resident::absent_kernel, dim3((unsigned)std::min<size_t>((granules + 255) / 256, 2048)), dim3(256),
                                0, s, reinterpret_cast<uint4 *>(w.xchg), granules);
