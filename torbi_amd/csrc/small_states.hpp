@@ -169,6 +169,9 @@ __global__ __launch_bounds__(64) void decode_kernel(const float *__restrict__ ob
 // trans[j][i] -- one conflict-free ds_read_b32 behind the v_readfirstlane of the step before.  A lone wavefront gains
 // nothing from this (its walk back is a dependent chain of ~300 cycles per step against ~10 through byte backpointers):
 // the launcher takes this kernel when the batch keeps every SIMD busy with several sequences (torbi_hip.hip, launch_small).
+#ifndef SMALL_ABL
+#define SMALL_ABL 0          // timing only (tools/small_abl_probe.py): 1 no walk back, 2 no history stores, 4 no LDS broadcast,
+#endif                       // 8 no observation loads
 template <int SP, int CH>
 __global__ __launch_bounds__(256) void decode_value_kernel(const float *__restrict__ obs, const int32_t *__restrict__ frames,
                                                            const float *__restrict__ trans, const float *__restrict__ init,
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(256) void decode_value_kernel(const float *__restri
     for (int t0 = 1; t0 < n; t0 += CH) {
         float nxt[CH];
 #pragma unroll
-        for (int k = 0; k < CH; ++k) nxt[k] = o[(size_t)min(t0 + CH + k, n - 1) * S];       // (clamped: never past the item)
+        for (int k = 0; k < CH; ++k) nxt[k] = (SMALL_ABL & 8) ? 0.25f * k : o[(size_t)min(t0 + CH + k, n - 1) * S];       // (clamped: never past the item)
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
             if (t0 + k < n) {                         // (wave-uniform)
@@ -214,7 +217,9 @@ __global__ __launch_bounds__(256) void decode_value_kernel(const float *__restri
                 float pv[SP];
 #pragma unroll
                 for (int i = 0; i < SP / 4; ++i) {
-                    const float4 v = shared_row[i];
+                    float4 v;
+                    if (SMALL_ABL & 4) v = make_float4(p, p + 1.f, p + 2.f, p + 3.f);
+                    else v = shared_row[i];
                     pv[4 * i] = v.x; pv[4 * i + 1] = v.y; pv[4 * i + 2] = v.z; pv[4 * i + 3] = v.w;
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -232,13 +237,14 @@ __global__ __launch_bounds__(256) void decode_value_kernel(const float *__restri
                 }
                 const float top = fmaxf(fmaxf(best[0], best[1]), fmaxf(best[2], best[3]));
                 p = live ? cur[k] + top : ninf;
-                if (live) h[(size_t)(t0 + k) * S + lane] = p;
+                if (live && !(SMALL_ABL & 2)) h[(size_t)(t0 + k) * S + lane] = p;
             }
         }
 #pragma unroll
         for (int k = 0; k < CH; ++k) cur[k] = nxt[k];
     }
     if (live) (((n - 1) & 1) ? post1 : post0)[(size_t)b * S + lane] = p;      // (where torbi_hip_read_posterior looks)
+    if (SMALL_ABL & 1) return;
 
     // first maximum of the last row
     float best = p;
