@@ -275,6 +275,8 @@ int torbi_hip_viterbi_decode_banded(const torbi_hip_batch *batches, int count, c
  *                        forward kernel's workgroup 0 (same unit both; DENSE: of the last timestep's launch) -- their ratio
  *                        x 100 MHz is the clock the kernel was delivered under its own load (measurement plumbing: bench.py
  *                        prices the vector ALU's ceiling at it)
+ *   RESIDENT / CLUSTER / BAND, one batch of at most 1024 sequences: stats_out[122], [123] = path steps of the backtrace and
+ *                        steps walked AGAIN where its speculative segments met (csrc/lazy_backtrace.hpp, chase_segment)
  *   BAND: stats_out[127] = members that gave up waiting (as CLUSTER)
  *   HELD: stats_out[127] = workgroups that ran out of polls (the launch could not be resident as a whole); the decode
  *                        was then redone by the repair kernel and its results are correct.  0 on any sane run.

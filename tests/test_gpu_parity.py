@@ -2017,3 +2017,43 @@ def test_value_only_form_of_the_wavefront_kernel(S, forward, monkeypatch):
             last = viterbi.read_posterior(ws, args[1], B, T, S).cpu().numpy()
             assert np.array_equal(last.view(np.uint32), post.view(np.uint32))
     monkeypatch.delenv('TORBI_HIP_SMALL_VALUE')
+
+
+@pytest.mark.parametrize('path', ['cluster', 'resident', 'band'])
+@pytest.mark.parametrize('segments', ['1', '3', '8', '16'])
+def test_backtrace_in_speculative_segments_is_the_whole_path(path, segments, forward, monkeypatch):
+    """Behind a time-resident or band forward launch, one batch of few sequences is walked back in K segments per sequence,
+    each from the first argmax of a posterior row, and joined from the end of the path (csrc/lazy_backtrace.hpp,
+    chase_segment / stitch_segments).  Asserted for K = 1 (whole paths), 3, 8, 16: the oracle's indices on ragged lengths
+    that include 1, 2, fewer steps than segments and the full length; on a coarse grid of values (every joint a tie);
+    with rows of -inf; and the counters of the joints in torbi_hip_scan_stats [122], [123]."""
+    if forward != 'auto':
+        pytest.skip('names its paths itself')
+    monkeypatch.setenv('TORBI_HIP_BACKTRACE_SEGMENTS', segments)
+    dev = torch.device('cuda:0')
+    B, T, S = 40, 61, 360
+    for variant in ('plain', 'ties', 'inf'):
+        obs, trans, init = synth.problem(B, T, S, seed=11)
+        if path == 'band':
+            trans = _banded(S, 9, 14, seed=5)
+        if variant == 'ties':
+            obs, trans, init = (np.where(np.isfinite(x), np.round(x * 2.0) / 2.0, x).astype(np.float32) for x in (obs, trans, init))
+        if variant == 'inf':
+            obs = obs.copy()
+            obs[:, 20:23, ::2] = -np.inf
+            obs[3, 30, :] = -np.inf
+        frames = np.full((B,), T, np.int32)
+        frames[:12] = [1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 33, 60]
+        want = oracle.decode(obs, frames, trans, init)
+        args = [torch.as_tensor(np.ascontiguousarray(x)).to(dev) for x in (obs, frames, trans, init)]
+        space = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+        prof = []
+        got = torbi_amd.decode(*args, path=path, workspace=space, _profile=prof)
+        assert viterbi.ROUTES[int(prof[3])] == path
+        np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f'{path} {segments} {variant}')
+        stats = viterbi.scan_stats(space, B, T, S).cpu()
+        if segments == '1':
+            assert int(stats[122]) == 0 and int(stats[123]) == 0
+        else:
+            assert int(stats[122]) == int((np.clip(frames, 1, T) - 1).sum())
+            assert int(stats[123]) <= int(stats[122])

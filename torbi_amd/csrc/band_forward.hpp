@@ -694,29 +694,25 @@ __global__ __launch_bounds__(256) void clear_exchange_kernel(ClearJobs jobs) {
 // by the history read, and the wider window is three times the bytes.)
 // ---------------------------------------------------------------------------------------
 template <int NQ>
-__global__ __launch_bounds__(64) void group_backtrace_band_kernel(Group grp, const float *__restrict__ trans, int S, int hl,
-                                                                  int hr) {
-    const Batch &bat = grp.batch[resident::batch_of_item(grp, blockIdx.x)];
-    const int b = (int)blockIdx.x - bat.item0, lane = threadIdx.x, T = bat.T;
-    const float *h = bat.hist + (size_t)b * T * S;
-    int32_t *o = bat.out + (size_t)b * T;
-    int f = bat.frames[b];
-    f = f < 1 ? 1 : (f > T ? T : f);
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    int j;
-    {
+struct BandWalker {
+    const float *__restrict__ h;          // [T][S] posterior rows of the item
+    const float *__restrict__ trans;
+    int S, hl, hr, lane;
+    // first argmax of posterior row t (the final state when t = frames - 1: viterbi.cpp:218)
+    __device__ __forceinline__ int first_state(int t) const {
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 last[NQ];
-        const float *row = h + (size_t)(f - 1) * S;
+        const float *row = h + (size_t)t * S;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int i = 4 * lane + 256 * q;
             last[q] = i < S ? *reinterpret_cast<const float4 *>(row + i) : zero;
         }
-        j = lazy::wave_first_argmax4<NQ>(last, lane, S);       // final state = first argmax of the last row (viterbi.cpp:218)
+        return lazy::wave_first_argmax4<NQ>(last, lane, S);
     }
-    for (int tt = f - 1 + lane; tt < T; tt += 64) o[tt] = j;    // viterbi.cpp:219-221
-    const float4 none = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    for (int tt = f - 1; tt >= 1; --tt) {
+    // the state at timestep tt - 1 of the path that is in state j at timestep tt: first argmax inside the band of row j
+    __device__ __forceinline__ int step(int j, int tt) const {
+        const float4 none = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         const int lo4 = max(0, j - hl) & ~3, hi = min(S, j + hr + 1);
         const float *tr = trans + (size_t)j * S, *hrow = h + (size_t)(tt - 1) * S;
         float4 cand[2];
@@ -746,9 +742,38 @@ __global__ __launch_bounds__(64) void group_backtrace_band_kernel(Group grp, con
             k = min(k, kq);
         }
         k = wavered::wave_min_i32(k);
-        j = m == -INFINITY ? 0 : k;          // (every candidate -inf: the reference's scan keeps prev-state 0)
-        if (lane == 0) o[tt - 1] = j;
+        return m == -INFINITY ? 0 : k;          // (every candidate -inf: the reference's scan keeps prev-state 0)
     }
+};
+
+template <int NQ>
+__global__ __launch_bounds__(64) void group_backtrace_band_kernel(Group grp, const float *__restrict__ trans, int S, int hl,
+                                                                  int hr) {
+    const Batch &bat = grp.batch[resident::batch_of_item(grp, blockIdx.x)];
+    const int b = (int)blockIdx.x - bat.item0;
+    const BandWalker<NQ> w{bat.hist + (size_t)b * bat.T * S, trans, S, hl, hr, (int)threadIdx.x};
+    lazy::walk_item(w, bat.frames[b], bat.out + (size_t)b * bat.T, bat.T, threadIdx.x);
+}
+
+// ... in K speculative segments per item (lazy_backtrace.hpp, chase_segment / stitch_segments): grid = items x K, then items
+template <int NQ>
+__global__ __launch_bounds__(64) void group_segment_band_kernel(Group grp, const float *__restrict__ trans, int S, int hl, int hr,
+                                                                int K, int32_t *__restrict__ arrive) {
+    const int item = (int)blockIdx.x / K, seg = (int)blockIdx.x - item * K;
+    const Batch &bat = grp.batch[resident::batch_of_item(grp, item)];
+    const int b = item - bat.item0;
+    const BandWalker<NQ> w{bat.hist + (size_t)b * bat.T * S, trans, S, hl, hr, (int)threadIdx.x};
+    lazy::chase_segment(w, bat.frames[b], bat.T, K, seg, bat.out + (size_t)b * bat.T, arrive + (size_t)item * K, threadIdx.x);
+}
+template <int NQ>
+__global__ __launch_bounds__(64) void group_stitch_band_kernel(Group grp, const float *__restrict__ trans, int S, int hl, int hr,
+                                                               int K, const int32_t *__restrict__ arrive) {
+    const int item = blockIdx.x;
+    const Batch &bat = grp.batch[resident::batch_of_item(grp, item)];
+    const int b = item - bat.item0;
+    const BandWalker<NQ> w{bat.hist + (size_t)b * bat.T * S, trans, S, hl, hr, (int)threadIdx.x};
+    lazy::stitch_segments(w, bat.frames[b], bat.T, K, bat.out + (size_t)b * bat.T, arrive + (size_t)item * K, threadIdx.x,
+                          grp.stats + 122);
 }
 
 // reach of a matrix: *left = max over finite entries of max(j - i, 0), *right = of max(i - j, 0); grid = S, block = 64;

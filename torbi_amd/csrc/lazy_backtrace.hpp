@@ -286,30 +286,29 @@ __device__ __forceinline__ void backtrace_sorted_item(const float *__restrict__ 
 // dependent loads (list chunk, then posteriors) instead of one -- and still the faster form from one 512-item batch (0.58
 // against 0.80 ms) to a launch group of eight (1.86 against 3.11 ms: 4096 paths move 11.8 GB through row staging).
 template <int NQ>
-__device__ __forceinline__ void backtrace_gather_item(const float *__restrict__ h, const float *__restrict__ rowmax,
-                                                      const float2 *__restrict__ sorted, int SpP, int shift, int f,
-                                                      int32_t *__restrict__ o, int T, int S, int lane) {
-    f = f < 1 ? 1 : (f > T ? T : f);
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    int j;
-    {
+struct GatherWalker {
+    const float *__restrict__ h;          // [T][S] posterior rows of the item
+    const float *__restrict__ rowmax;     // [T] their maxima
+    const float2 *__restrict__ sorted;
+    int SpP, shift, S, lane;
+    // first argmax of posterior row t (the final state when t = frames - 1: viterbi.cpp:218)
+    __device__ __forceinline__ int first_state(int t) const {
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 last[NQ];
-        const float *row = h + (size_t)(f - 1) * S;
+        const float *row = h + (size_t)t * S;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int i = 4 * lane + 256 * q;
             last[q] = i < S ? *reinterpret_cast<const float4 *>(row + i) : zero;
         }
-        j = wave_first_argmax4<NQ>(last, lane, S);       // final state = first argmax of the last posterior row
+        return wave_first_argmax4<NQ>(last, lane, S);
     }
-    for (int tt = f - 1 + lane; tt < T; tt += 64) o[tt] = j;
-    const int Sp = (S + 15) / 16 * 16;
-    float hmax_next = f >= 2 ? rowmax[f - 2] : 0.0f;
-    for (int tt = f - 1; tt >= 1; --tt) {
+    // the state at timestep tt - 1 of the path that is in state j at timestep tt
+    __device__ __forceinline__ int step(int j, int tt) const {
+        const int Sp = (S + 15) / 16 * 16;
         const float2 *row = sorted + (size_t)j * SpP;
         float2 ent = row[lane];
-        const float hmax = hmax_next;
-        if (tt >= 2) hmax_next = rowmax[tt - 2];             // (independent of the path: asked for a step ahead)
+        const float hmax = rowmax[tt - 1];                   // (independent of the path: in flight with the list chunk)
         const float *hrow = h + (size_t)(tt - 1) * S;
         float bv = -INFINITY;
         int bi = kSentinel;
@@ -331,9 +330,96 @@ __device__ __forceinline__ void backtrace_gather_item(const float *__restrict__ 
         }
         const int cand = (bv == best && bi != kSentinel) ? bi : kSentinel;
         const int win = wavered::wave_min_i32(cand);
-        j = best == -INFINITY ? 0 : win;
+        return best == -INFINITY ? 0 : win;
+    }
+};
+
+// final state, tail fill (viterbi.cpp:218-221) and the walk down the whole path: one wave per item
+template <class Walker>
+__device__ __forceinline__ void walk_item(const Walker &w, int f, int32_t *__restrict__ o, int T, int lane) {
+    f = f < 1 ? 1 : (f > T ? T : f);
+    int j = w.first_state(f - 1);
+    for (int tt = f - 1 + lane; tt < T; tt += 64) o[tt] = j;
+    for (int tt = f - 1; tt >= 1; --tt) {
+        j = w.step(j, tt);
         if (lane == 0) o[tt - 1] = j;
     }
+}
+
+// ---- the same walk in K SPECULATIVE SEGMENTS (single batches: a path per wave leaves the chip idle and pays two dependent
+// loads per step, 0.6 ms for 500 steps).  Backward walks from different states of a timestep merge with the decoded path
+// within a few steps (0-22 on the benchmark's rows and on posteriorgram-like rows under the pitch band), so segment s of an
+// item -- timesteps (lo, hi], lo = s L, hi = (s + 1) L, L = ceil((f - 1) / K) -- is walked by a wave of its own from the
+// first argmax of posterior row hi, all K at once (chase_segment), and one wave per item then checks the joints from the
+// end of the path (stitch_segments): where a segment's start is not the state the path really is in at hi, it walks on from
+// the true state until it meets what the segment left -- from there down the segment's walk IS the path -- or the segment's
+// end.  Every step is the same arithmetic; the result is the walk_item path, state for state.  `arrive[s]`: the state
+// segment s reached at timestep lo.
+template <class Walker>
+__device__ __forceinline__ void chase_segment(const Walker &w, int f, int T, int K, int s, int32_t *__restrict__ o,
+                                              int32_t *__restrict__ arrive, int lane) {
+    f = f < 1 ? 1 : (f > T ? T : f);
+    const int L = (f - 1 + K - 1) / K;
+    const int lo = min(s * L, f - 1), hi = min((s + 1) * L, f - 1);
+    const bool last = s == K - 1;                         // (hi = f - 1: the one segment whose start is known)
+    if (!last && lo >= hi) return;
+    int j = w.first_state(hi);
+    if (last) {
+        for (int tt = f - 1 + lane; tt < T; tt += 64) o[tt] = j;
+    } else if (lane == 0) {
+        o[hi] = j;
+    }
+    for (int tt = hi; tt > lo; --tt) {
+        j = w.step(j, tt);
+        if (lane == 0 && (tt - 1 > lo || s == 0)) o[tt - 1] = j;      // (o[lo] is the start of segment s - 1)
+    }
+    if (lane == 0) arrive[s] = j;
+}
+
+// (`stats`: null, or two counters -- steps walked, steps walked AGAIN at the joints: what the speculation cost)
+template <class Walker>
+__device__ __forceinline__ void stitch_segments(const Walker &w, int f, int T, int K, int32_t *__restrict__ o,
+                                                const int32_t *__restrict__ arrive, int lane, unsigned *stats = nullptr) {
+    f = f < 1 ? 1 : (f > T ? T : f);
+    const int L = (f - 1 + K - 1) / K;
+    int truth = arrive[K - 1];                            // the path's state at the last segment's lo
+    unsigned again = 0;
+    for (int s = K - 2; s >= 0; --s) {
+        const int lo = min(s * L, f - 1), hi = min((s + 1) * L, f - 1);
+        if (lo >= hi) continue;
+        if (o[hi] == truth) {                             // the segment started where the path is: all of it stands
+            truth = arrive[s];
+            continue;
+        }
+        int j = truth;
+        if (lane == 0) o[hi] = j;
+        bool met = false;
+        for (int tt = hi; tt > lo; --tt) {
+            j = w.step(j, tt);
+            ++again;
+            if (tt - 1 == lo) break;
+            if (o[tt - 1] == j) { met = true; break; }
+            if (lane == 0) o[tt - 1] = j;
+        }
+        if (met) {
+            truth = arrive[s];
+        } else {
+            truth = j;
+            if (s == 0 && lane == 0) o[0] = j;
+        }
+    }
+    if (stats && lane == 0) {
+        atomicAdd(stats, (unsigned)(f - 1));
+        atomicAdd(stats + 1, again);
+    }
+}
+
+template <int NQ>
+__device__ __forceinline__ void backtrace_gather_item(const float *__restrict__ h, const float *__restrict__ rowmax,
+                                                      const float2 *__restrict__ sorted, int SpP, int shift, int f,
+                                                      int32_t *__restrict__ o, int T, int S, int lane) {
+    const GatherWalker<NQ> w{h, rowmax, sorted, SpP, shift, S, lane};
+    walk_item(w, f, o, T, lane);
 }
 
 template <int NQ>

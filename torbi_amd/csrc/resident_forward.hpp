@@ -958,6 +958,29 @@ __global__ __launch_bounds__(64) void group_backtrace_gather_kernel(Group grp, c
                                     threadIdx.x);
 }
 
+// ... in K speculative segments per item (lazy_backtrace.hpp, chase_segment / stitch_segments): grid = items x K, then items
+template <int NQ>
+__global__ __launch_bounds__(64) void group_segment_gather_kernel(Group grp, const float2 *__restrict__ sorted, int SpP, int S,
+                                                                  int K, int32_t *__restrict__ arrive) {
+    const int item = (int)blockIdx.x / K, seg = (int)blockIdx.x - item * K;
+    const Batch &bat = grp.batch[batch_of_item(grp, item)];
+    const int b = item - bat.item0;
+    const lazy::GatherWalker<NQ> w{bat.hist + (size_t)b * bat.T * S, bat.rowmax + (size_t)b * bat.T, sorted, SpP,
+                                   tile_items(S) == kNI ? 6 : 5, S, (int)threadIdx.x};
+    lazy::chase_segment(w, bat.frames[b], bat.T, K, seg, bat.out + (size_t)b * bat.T, arrive + (size_t)item * K, threadIdx.x);
+}
+template <int NQ>
+__global__ __launch_bounds__(64) void group_stitch_gather_kernel(Group grp, const float2 *__restrict__ sorted, int SpP, int S,
+                                                                 int K, const int32_t *__restrict__ arrive) {
+    const int item = blockIdx.x;
+    const Batch &bat = grp.batch[batch_of_item(grp, item)];
+    const int b = item - bat.item0;
+    const lazy::GatherWalker<NQ> w{bat.hist + (size_t)b * bat.T * S, bat.rowmax + (size_t)b * bat.T, sorted, SpP,
+                                   tile_items(S) == kNI ? 6 : 5, S, (int)threadIdx.x};
+    lazy::stitch_segments(w, bat.frames[b], bat.T, K, bat.out + (size_t)b * bat.T, arrive + (size_t)item * K, threadIdx.x,
+                          grp.stats + 122);
+}
+
 template <int VEC>
 __global__ __launch_bounds__(64) void group_backtrace_kernel(Group grp, const float *__restrict__ trans, int S) {
     const Batch &bat = grp.batch[batch_of_item(grp, blockIdx.x)];

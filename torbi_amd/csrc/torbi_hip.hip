@@ -1287,6 +1287,16 @@ inline hipError_t launch_whole_tiles(const resident::Group &grp, const resident:
     return launch_resident_kernel<12, 11, false>(grp, clu, tiles, w, init, S, s, few);
 }
 
+// segments per path of the backtrace behind a time-resident forward launch: 8 while the launch holds few paths (a wave per
+// path leaves the chip idle and pays its steps' latency one after the other); 1 = whole paths, which a launch group's
+// thousands of paths are walked as (bound by the bytes they move).  TORBI_HIP_BACKTRACE_SEGMENTS overrides (1 = off).
+inline int backtrace_segments(int items) {
+    const char *e = getenv("TORBI_HIP_BACKTRACE_SEGMENTS");         // (read per launch: the tests switch it)
+    const int wanted = e ? atoi(e) : 8;
+    if (wanted <= 1 || items > 1024) return 1;
+    return std::max(2, std::min(wanted, 2048 / std::max(items, 1)));        // (items x K <= 2048 waves: 512 items -> 4)
+}
+
 // batches with B > 0 only; the preparation lives in the first batch's workspace
 hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const float *init, int S, int cus, hipStream_t s,
                         hipEvent_t *ev, int *launches, bool reuse, bool ascending = false, bool clusters = false,
@@ -1396,7 +1406,21 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
         const char *e = getenv("TORBI_HIP_BACKTRACE_GATHER");
         return !e || atoi(e) != 0;
     }();
-    if (S % 4 == 0 && backtrace_sorted_enabled() && gather) {
+    // few paths (one batch): every path in speculative segments, K waves per item, then one wave per item at the joints
+    // (lazy_backtrace.hpp, chase_segment); the forward launch is done with the tile map, which holds the segments' ends
+    const int K = backtrace_segments(items);
+    if (S % 4 == 0 && backtrace_sorted_enabled() && gather && K > 1) {
+        int32_t *const arrive = w.tile_map;
+#define TORBI_SEGMENTED(NQ_)                                                                                                      \
+        hipLaunchKernelGGL(resident::group_segment_gather_kernel<NQ_>, dim3(items * K), dim3(64), 0, s, grp, w.sorted, w.SpP, S, K, \
+                           arrive);                                                                                               \
+        hipLaunchKernelGGL(resident::group_stitch_gather_kernel<NQ_>, dim3(items), dim3(64), 0, s, grp, w.sorted, w.SpP, S, K, arrive)
+        if (S <= 512) { TORBI_SEGMENTED(2); }
+        else if (S <= 1536) { TORBI_SEGMENTED(6); }
+        else if (S <= 2048) { TORBI_SEGMENTED(8); }
+        else { TORBI_SEGMENTED(16); }
+#undef TORBI_SEGMENTED
+    } else if (S % 4 == 0 && backtrace_sorted_enabled() && gather) {
         if (S <= 512)
             hipLaunchKernelGGL(resident::group_backtrace_gather_kernel<2>, dim3(items), dim3(64), 0, s, grp, w.sorted, w.SpP, S);
         else if (S <= 1536)
@@ -1521,14 +1545,21 @@ hipError_t run_band(const HostBatch *hb, int n, const float *trans, const float 
     }
     if (launches) *launches = 1;
     if (ev) (void)hipEventRecord(ev[1], s);
-    if (S <= 512)
-        hipLaunchKernelGGL(band::group_backtrace_band_kernel<2>, dim3(items), dim3(64), 0, s, grp, trans, S, pl.hl, pl.hr);
-    else if (S <= 1536)
-        hipLaunchKernelGGL(band::group_backtrace_band_kernel<6>, dim3(items), dim3(64), 0, s, grp, trans, S, pl.hl, pl.hr);
-    else if (S <= 2048)
-        hipLaunchKernelGGL(band::group_backtrace_band_kernel<8>, dim3(items), dim3(64), 0, s, grp, trans, S, pl.hl, pl.hr);
-    else
-        hipLaunchKernelGGL(band::group_backtrace_band_kernel<16>, dim3(items), dim3(64), 0, s, grp, trans, S, pl.hl, pl.hr);
+    const int K = backtrace_segments(items);          // (few paths: speculative segments, as behind run_resident)
+    int32_t *const arrive = w.base.tile_map;
+#define TORBI_BAND_BACKTRACE(NQ_)                                                                                                  \
+    if (K > 1) {                                                                                                                   \
+        hipLaunchKernelGGL(band::group_segment_band_kernel<NQ_>, dim3(items * K), dim3(64), 0, s, grp, trans, S, pl.hl, pl.hr, K,   \
+                           arrive);                                                                                                \
+        hipLaunchKernelGGL(band::group_stitch_band_kernel<NQ_>, dim3(items), dim3(64), 0, s, grp, trans, S, pl.hl, pl.hr, K, arrive); \
+    } else {                                                                                                                       \
+        hipLaunchKernelGGL(band::group_backtrace_band_kernel<NQ_>, dim3(items), dim3(64), 0, s, grp, trans, S, pl.hl, pl.hr);       \
+    }
+    if (S <= 512) { TORBI_BAND_BACKTRACE(2) }
+    else if (S <= 1536) { TORBI_BAND_BACKTRACE(6) }
+    else if (S <= 2048) { TORBI_BAND_BACKTRACE(8) }
+    else { TORBI_BAND_BACKTRACE(16) }
+#undef TORBI_BAND_BACKTRACE
     if (ev) (void)hipEventRecord(ev[2], s);
     return hipGetLastError();
 }
