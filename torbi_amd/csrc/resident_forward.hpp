@@ -89,10 +89,10 @@ constexpr int kMaxTop = 4;               // list entries per item a member publi
 // The exchange is SELF-VALIDATING (round 5): a slot starts out as kAbsentBits in every word -- a NaN no fp32 addition of
 // the recurrence produces -- and a consumer takes a 16-byte piece of a posterior row when none of its four words is that
 // pattern any more; the partial top lists travel as {key low, timestep, key high, timestep}.  So a producer neither waits
-// for the acknowledgement of its slice stores nor publishes anything behind them: its flag is a HINT (raised without a
-// drain, it may overtake the data) that tells the one polling wave when loading is worth while, and a piece that is not
-// there yet is simply asked for again.  Two of the three dependent trips of a timestep (store acknowledgement, flag) are
-// gone from the critical path.  Four slots by timestep: row t goes to slot t % 4 and, behind the workgroup barrier of
+// for the acknowledgement of its slice stores nor publishes anything behind them, and a consumer asks for the pieces the
+// moment its own rows are in its tile: the load that finds them IS the hand-off, a piece that is not there yet is asked for
+// again after a pause.  Two of the three dependent trips of a timestep (store acknowledgement, flag) are gone from the
+// critical path.  Four slots by timestep: row t goes to slot t % 4 and, behind the workgroup barrier of
 // timestep t, every wave resets the slot row t - 2 went to -- which every member finished reading before it sent row t - 1,
 // which this member has taken -- two timesteps before the next use ((t + 2) % 4), with that timestep's observation loads
 // (issued behind the reset, awaited before any output exists: vmcnt counts in order) between the two.
@@ -109,7 +109,6 @@ struct Cluster {
     float *xchg;           // [tiles][kSlots] slots by timestep: the members' slices of the newest posterior rows
                            // [S4][16] floats, then their partial top lists [kMaxR][16 * kMaxTop] tagged 64-bit keys
                            // (every word kAbsentBits before the launch: absent_kernel)
-    unsigned *flags;       // [tiles][kMaxR] newest timestep each member has sent (a hint; zeroed before the launch)
     unsigned *where;       // [tiles][kMaxR] the XCD each member runs on, + 1 (zeroed before the launch)
     int tiles;             // tiles of the launch (the grid is padded to whole dispatch classes: 8 x ceil(tiles / 8) x R)
     unsigned *control;     // [0 .. 7] tickets drawn per dispatch class (zeroed before the launch); give-ups are counted
@@ -289,12 +288,6 @@ __device__ __forceinline__ float4 load_through(__amdgpu_buffer_rsrc_t buffer, in
     const v4u x = __builtin_amdgcn_raw_buffer_load_b128(buffer, offset, 0, 16);
     return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
 }
-// a member's flag: behind its drained payload.  One XCD: a plain store (the word stays in the L2 the pollers read);
-// else write-through
-__device__ __forceinline__ void raise_flag(unsigned *flag, unsigned value, bool local) {
-    if (local) *reinterpret_cast<volatile unsigned *>(flag) = value;
-    else __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void *base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
 }
@@ -306,13 +299,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void *base, un
 #ifndef RESIDENT_ABL
 #define RESIDENT_ABL 0
 #endif
-// Cluster form, waiting for the other members' flags: ONE polling wave per workgroup, the others wait at a barrier.  A
-// hand-off is paid in the consumer's own memory queue and every poll lengthens it: with all twelve waves polling, a
-// 512-item batch (R = 8) ran 17.5-18.1 us per timestep, with one 15.3; 256 items 18 -> 14 (tools/cluster_poll_probe.py,
-// profiles/r03_cluster_poll_probe.txt).  The pause between polls (64-cycle units) and a pause before the first poll
-// make no difference once one wave polls.
+// Cluster form: the pause (64-cycle units) between two attempts of a wave at slices that were not there yet
 #ifndef CLUSTER_POLL_SLEEP
-#define CLUSTER_POLL_SLEEP 1
+#define CLUSTER_POLL_SLEEP 4
 #endif
 #ifndef CLUSTER_ROUND
 #define CLUSTER_ROUND 8                // 16-byte pieces of the other members' slices a thread asks for at once
@@ -782,49 +771,25 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
         }
         if constexpr (CLUSTER) {
             if (t + 1 < fmax) {
-                unsigned *const cflags = clu.flags + (size_t)cid * kMaxR;
                 const __amdgpu_buffer_rsrc_t xsrc = buffer_of(
                     reinterpret_cast<const char *>(clu.xchg) + (size_t)(kSlots * cid + (t & (kSlots - 1))) * xbytes, xbytes);
-                // (1) this member's partial top lists, tagged with the timestep, behind the posterior row of the slot; then
-                // the hint that everything of timestep t has been SENT (no drain: it may arrive first)
-                if (wave == 0) {
-                    if (lane < kNI * kTop) {
-                        const u64 k = top[lane];
-                        v4u x = {(unsigned)k, (unsigned)t, (unsigned)(k >> 32), (unsigned)t};
-                        const int at = (int)xrow + (member * kNI * kMaxTop + lane) * 16;
-                        if (local) __builtin_amdgcn_raw_buffer_store_b128(x, xsrc, at, 0, 0);
-                        else __builtin_amdgcn_raw_buffer_store_b128(x, xsrc, at, 0, 16);
-                    }
-                    if (lane == 0) raise_flag(cflags + member, (unsigned)t, local);
+                // (1) this member's partial top lists, tagged with the timestep, behind the posterior row of the slot
+                if (wave == 0 && lane < kNI * kTop) {
+                    const u64 k = top[lane];
+                    v4u x = {(unsigned)k, (unsigned)t, (unsigned)(k >> 32), (unsigned)t};
+                    const int at = (int)xrow + (member * kNI * kMaxTop + lane) * 16;
+                    if (local) __builtin_amdgcn_raw_buffer_store_b128(x, xsrc, at, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(x, xsrc, at, 0, 16);
                 }
                 RSTAMP(6);
-                // (2) wave 0 waits until the other members say they have sent timestep t (bounded), the others for wave 0
-                if (wave == 0) {
-                    unsigned spins = 0;
-                    unsigned long long since = 0ull;
-                    for (;;) {
-                        unsigned seen = 0xffffffffu;
-                        if (lane < R && lane != member)
-                            seen = __hip_atomic_load(cflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (__all(seen >= (unsigned)t)) break;
-                        __builtin_amdgcn_s_sleep(CLUSTER_POLL_SLEEP);
-                        if ((spins++ & 255u) == 0u) {           // (the clock is read at the first failed poll, then every 256th)
-                            const unsigned long long now = wall_clock64();
-                            if (since == 0ull) since = now;
-                            if (now - since >= clu.wait_ticks) {
-                                if (lane == 0) smisc[1] = 1;
-                                break;
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
-                RSTAMP(9);
-                // (3) their slices of row t -> the tile (every 16-byte piece except this member's own rows), their partial
-                // top lists -> this workgroup's lists.  All loads of a thread in flight together (up to ten pieces: 7 at
-                // 1440 states and eight members); a piece that still reads absent (the hint overtook it), a key with
-                // another timestep's tag, is asked for again, bounded like the wait above
-                if (!smisc[1]) {
+                // (2) their slices of row t -> the tile (every 16-byte piece except this member's own rows), their partial
+                // top lists -> this workgroup's lists: asked for AT ONCE, all loads of a thread in flight together (eight
+                // pieces a round: 7 at 1440 states and eight members); a piece that still reads absent, a key with another
+                // timestep's tag, is asked for again after a pause -- the load that finds the data is the hand-off, there
+                // is no flag to wait for first (a hint flag per member, polled by one wave ahead of the loads, cost a
+                // dependent trip: 14.2 against 13.5 us per timestep at 512 x 1440, 26.3 against 22.0 at 128 x 4096).
+                // Bounded: a wave that has waited Cluster::wait_ticks gives up for its workgroup
+                {
                     const int kpair = kNI * kTop / 2;          // keys: two per thread (R * 16 * kTop / 2 <= 512 threads)
                     const int km = tid / kpair, ks = tid - km * kpair;
                     bool want_keys = km < R && km != member;
@@ -859,7 +824,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                                 want_keys = false;
                             if (!__any(missing != 0u || want_keys)) break;
                             RCOUNT(7, 1);
-                            __builtin_amdgcn_s_sleep(2);
+                            __builtin_amdgcn_s_sleep(CLUSTER_POLL_SLEEP);
                             if ((spins++ & 15u) == 0u) {
                                 const unsigned long long now = wall_clock64();
                                 if (since == 0ull) since = now;

@@ -1338,7 +1338,7 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
     const char *wait_env = getenv("TORBI_HIP_CLUSTER_WAIT_US");         // (read per launch: the tests switch it)
     const unsigned long long wait_ticks = wait_env ? 100ull * strtoull(wait_env, nullptr, 10) : resident::kClusterWaitTicks;
     // (flags [ctiles][kMaxR], control [16], failed [ctiles], where [ctiles][kMaxR]: all zeroed by order_tiles_kernel)
-    resident::Cluster clu{w.xchg, w.flags, control + 16 + std::max(cus / 2, 1), tiles, control, control + 16, R, wait_ticks};
+    resident::Cluster clu{w.xchg, control + 16 + std::max(cus / 2, 1), tiles, control, control + 16, R, wait_ticks};
     if (ev) (void)hipEventRecord(ev[0], s);
     for (int k = 0; k < n; ++k) {            // (order_items_kernel stamps the batches' route records)
         jobs.job[k].route_record = route_record(hb[k].workspace, hb[k].B, hb[k].T, S, cus);
