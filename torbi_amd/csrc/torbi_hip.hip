@@ -1274,11 +1274,18 @@ inline hipError_t launch_repair(const resident::Group &grp, const resident::Clus
     return small ? launch_repair_variant<1, 8>(grp, clu, tiles, w, init, S, s) : launch_repair_variant<1, 16>(grp, clu, tiles, w, init, S, s);
 }
 
+inline bool cluster_eight_waves() {             // TORBI_HIP_CLUSTER_KW8=0: the twelve-wave instances everywhere (experiments)
+    const char *e = getenv("TORBI_HIP_CLUSTER_KW8");
+    return !e || atoi(e) != 0;
+}
+
 // every workgroup owns a whole tile (resident_forward_kernel without clusters)
 inline hipError_t launch_whole_tiles(const resident::Group &grp, const resident::Cluster &clu, int tiles,
                                      const ResidentWorkspace &w, const float *init, int S, hipStream_t s, bool few) {
     const int nrg = (S + resident::pass_rows(S) - 1) / resident::pass_rows(S);
     if (resident::tile_items(S) != resident::kNI) {       // 8-item tiles (2048 < S <= 4096)
+        // (eight waves x 16 passes with 256 registers each measured slower than twelve x 8-11 at 168: 197 against 183 us per
+        // timestep at 4096 states with a third of the units busy, equal on a full chip)
         if (nrg <= 96) return launch_resident_kernel<12, 8, false, 8>(grp, clu, tiles, w, init, S, s, few);
         return launch_resident_kernel<12, 11, false, 8>(grp, clu, tiles, w, init, S, s, few);
     }
@@ -1375,7 +1382,14 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
         const int passes = ((nrg + R - 1) / R + 11) / 12;       // row groups of the largest share over 12 waves
         // (eight dispatch classes of R x ceil(tiles / 8) workgroups each: resident_forward.hpp, struct Cluster)
         const int grid = 8 * ((tiles + 7) / 8) * R;
-        if (small) {
+        const int share = (nrg + R - 1) / R;                    // row groups of the largest share
+        if (small && share <= 16 && cluster_eight_waves()) {
+            // 8-item tiles, at most 16 row groups a member: EIGHT waves (256 registers each: the twelve-wave instances of
+            // the 8-item tile spill 20-80 registers at 168, and every scratch reload waits for the write-through stores
+            // ahead of it); 128 x 4096 (16 tiles x 16 members, 8 row groups each) kept four of twelve waves idle anyway
+            if (share <= 8) e = launch_resident_kernel<8, 1, true, 8>(grp, clu, grid, w, init, S, s, few);
+            else e = launch_resident_kernel<8, 2, true, 8>(grp, clu, grid, w, init, S, s, few);
+        } else if (small) {
             if (passes <= 1) e = launch_resident_kernel<12, 1, true, 8>(grp, clu, grid, w, init, S, s, few);
             else if (passes <= 2) e = launch_resident_kernel<12, 2, true, 8>(grp, clu, grid, w, init, S, s, few);
             else if (passes <= 4) e = launch_resident_kernel<12, 4, true, 8>(grp, clu, grid, w, init, S, s, few);
