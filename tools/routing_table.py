@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 BATCHES = (1, 3, 4, 8, 16, 17, 512, 2049)
-STATES = (64, 256, 1440, 4096)
+STATES = (256, 1440, 4096)          # (up to 192 states AUTO answers `small` whatever the batch)
 PATHS = ('auto', 'dense', 'pruned', 'resident', 'cluster', 'held')
 
 

@@ -538,4 +538,58 @@ __global__ __launch_bounds__(64) void backtrace_ranged_kernel(const float *__res
     }
 }
 
+// ---- whole transition rows in speculative segments (chase_segment / stitch_segments above): the backtrace behind the
+// value-only workgroup kernel of small_states.hpp (65 .. 256 states: a step reads 2 x 4 S bytes and is bound by their
+// latency, not by bytes -- at 1440 states the row walks of the dense route gained 3 % and keep whole paths).  S % 4 == 0,
+// 16-byte aligned matrix, S <= 256 NQ.
+template <int NQ>
+struct RowWalker {
+    const float *__restrict__ h;          // [T][S] posterior rows of the item
+    const float *__restrict__ trans;
+    int S, lane;
+    __device__ __forceinline__ int first_state(int t) const {
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 last[NQ];
+        const float *row = h + (size_t)t * S;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = 4 * lane + 256 * q;
+            last[q] = i < S ? *reinterpret_cast<const float4 *>(row + i) : zero;
+        }
+        return wave_first_argmax4<NQ>(last, lane, S);
+    }
+    __device__ __forceinline__ int step(int j, int tt) const {
+        const float *tr = trans + (size_t)j * S, *hrow = h + (size_t)(tt - 1) * S;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 cand[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = 4 * lane + 256 * q;
+            const float4 t4 = i < S ? *reinterpret_cast<const float4 *>(tr + i) : zero;
+            const float4 p4 = i < S ? *reinterpret_cast<const float4 *>(hrow + i) : zero;
+            cand[q] = make_float4(p4.x + t4.x, p4.y + t4.y, p4.z + t4.z, p4.w + t4.w);
+        }
+        return wave_first_argmax4<NQ>(cand, lane, S);
+    }
+};
+
+// grid = B x K
+template <int NQ>
+__global__ __launch_bounds__(64) void segment_rows_kernel(const float *__restrict__ hist, const float *__restrict__ trans,
+                                                          const int32_t *__restrict__ frames, int32_t *__restrict__ out, int B,
+                                                          int T, int S, int K, int32_t *__restrict__ arrive) {
+    const int b = (int)blockIdx.x / K, seg = (int)blockIdx.x - b * K;
+    const RowWalker<NQ> w{hist + (size_t)b * T * S, trans, S, (int)threadIdx.x};
+    chase_segment(w, frames[b], T, K, seg, out + (size_t)b * T, arrive + (size_t)b * K, threadIdx.x);
+}
+// grid = B
+template <int NQ>
+__global__ __launch_bounds__(64) void stitch_rows_kernel(const float *__restrict__ hist, const float *__restrict__ trans,
+                                                         const int32_t *__restrict__ frames, int32_t *__restrict__ out, int B,
+                                                         int T, int S, int K, const int32_t *__restrict__ arrive) {
+    const int b = blockIdx.x;
+    const RowWalker<NQ> w{hist + (size_t)b * T * S, trans, S, (int)threadIdx.x};
+    stitch_segments(w, frames[b], T, K, out + (size_t)b * T, arrive + (size_t)b * K, threadIdx.x);
+}
+
 }  // namespace lazy

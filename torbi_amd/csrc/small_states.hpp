@@ -493,4 +493,93 @@ __global__ __launch_bounds__(64 * PQ * PQ) void block_decode_kernel(
     }
 }
 
+// ---- 65 .. 256 states, MANY sequences: the workgroup kernel value-only ----------------------------------------------
+// block_decode_kernel spends 4.3 vector instructions per cell on (value, index) pairs.  Here a cell is add, add, 1/2 max3:
+// the forward pass keeps no backpointers, it stores the posterior rows (fp32: hist[b][t][:], where the byte plane would
+// lie) and the backtrace is a launch of its own -- lazy_backtrace.hpp recomputes the first argmax of
+// fl(hist[t-1][i] + trans[j][i]) for the state on the path (viterbi.cpp:81-100), in speculative segments for a batch of few
+// paths.  Same decomposition as above: wave (nb, pq) keeps next-states [64 nb, 64 nb + 64) x prev-states [pq L, pq L + L)
+// of the matrix in registers; the pieces of a row meet through the LDS as VALUES (max is exact and order independent).
+// A lone sequence gains nothing (a launch and ~1 us per path step against ~10 cycles through byte backpointers): the
+// launcher takes this form for batches (torbi_hip.hip, launch_block).
+template <int PQ, int L>
+__global__ __launch_bounds__(64 * PQ * PQ) void block_value_kernel(
+    const float *__restrict__ obs, const int32_t *__restrict__ frames, const float *__restrict__ trans,
+    const float *__restrict__ init, float *__restrict__ hist, float *__restrict__ post0, float *__restrict__ post1,
+    int32_t *__restrict__ route_record, int route, int B, int T, int S, int NB) {
+    __shared__ float4 rows[2][kBlockMaxS / 4];            // posterior rows t-1 / t (entries >= S: -inf)
+    __shared__ float upper_best[PQ - 1][kBlockMaxS];      // what the pieces pq >= 1 of the prev-states offer
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = wave % NB, pq = wave / NB;
+    const int j = nb * 64 + lane;
+    const bool live = j < S;
+    const bool writer = pq == 0;
+    const int lo = pq * L;
+    if (b == 0 && tid == 0) *route_record = route;
+    int n = __builtin_amdgcn_readfirstlane(frames[b]);
+    n = n < 1 ? 1 : (n > T ? T : n);
+    const float ninf = -__builtin_huge_valf();
+
+    float row[L];                                          // trans[j][lo + e]
+#pragma unroll
+    for (int e = 0; e < L; ++e) row[e] = trans[(size_t)min(j, S - 1) * S + min(lo + e, S - 1)];   // (clamped addresses:
+    asm volatile("" ::: "memory");                         //  every load unconditional and in flight before the first use)
+#pragma unroll
+    for (int e = 0; e < L; ++e) row[e] = fminf(row[e], (live && lo + e < S) ? -ninf : ninf);          // the padding: -inf
+    const float *o = obs + (size_t)b * T * S + min(j, S - 1);
+    float *h = hist + (size_t)b * T * S;
+    float p = o[0] + init[min(j, S - 1)];
+    p = live ? p : ninf;
+    if (writer) {
+        reinterpret_cast<float *>(rows[0])[j] = p;
+        if (live) h[j] = p;
+    }
+    float cur[4] = {0.f, 0.f, 0.f, 0.f};
+    if (writer) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cur[k] = o[(size_t)min(1 + k, n - 1) * S];
+    }
+    __syncthreads();
+
+    for (int t0 = 1; t0 < n; t0 += 4) {
+        float nxt[4] = {0.f, 0.f, 0.f, 0.f};
+        if (writer) {                                       // (the observation rows of the next four timesteps)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nxt[k] = o[(size_t)min(t0 + 4 + k, n - 1) * S];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (t0 + r < n) {                               // (uniform over the workgroup)
+                const float4 *src = rows[(t0 + r - 1) & 1] + lo / 4;
+                float best[4] = {ninf, ninf, ninf, ninf};
+#pragma unroll
+                for (int e = 0; e < L; e += 8) {            // (L = 48 or 64: whole groups of eight prev-states)
+                    const float4 v0 = src[e / 4], v1 = src[e / 4 + 1];
+                    best[0] = fmaxf(fmaxf(best[0], v0.x + row[e]), v1.x + row[e + 4]);
+                    best[1] = fmaxf(fmaxf(best[1], v0.y + row[e + 1]), v1.y + row[e + 5]);
+                    best[2] = fmaxf(fmaxf(best[2], v0.z + row[e + 2]), v1.z + row[e + 6]);
+                    best[3] = fmaxf(fmaxf(best[3], v0.w + row[e + 3]), v1.w + row[e + 7]);
+                }
+                float top = fmaxf(fmaxf(best[0], best[1]), fmaxf(best[2], best[3]));
+                if (!writer && live) upper_best[pq - 1][j] = top;
+                __syncthreads();
+                if (writer) {
+                    if (live) {
+#pragma unroll
+                        for (int u = 0; u < PQ - 1; ++u) top = fmaxf(top, upper_best[u][j]);
+                    }
+                    p = live ? cur[r] + top : ninf;
+                    reinterpret_cast<float *>(rows[(t0 + r) & 1])[j] = p;
+                    if (live) h[(size_t)(t0 + r) * S + j] = p;
+                }
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+    }
+    if (writer && live) (((n - 1) & 1) ? post1 : post0)[(size_t)b * S + j] = p;
+}
+
 }  // namespace small

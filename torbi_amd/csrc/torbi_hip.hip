@@ -558,7 +558,14 @@ inline bool held_auto(int B, int S) {
 // half the compute units a workgroup, tiles split over clusters of workgroups for smaller batches of >= 17 items --
 // else the sorted-row scan / held-matrix kernel for a handful of sequences, else the dense (max,+) GEMM, else generic.
 inline bool small_block_auto(int B, int S, int cus) {
-    return small::block_supported(S) && (long long)B * S * S <= (3ll << 16) * cus;
+    // (value-only since round 5: ahead of the time-resident kernels at every batch size up to 192 states -- 8192 x 200 x 128
+    // 2.0 against 4.0 ms, 8192 x 100 x 192 2.8 against 3.0 -- and up to ~3000 sequences at 256: 2048 x 200 x 256 1.6 against
+    // 2.3 ms, 4096 x 200 x 256 3.2 against 2.9.  TORBI_HIP_SMALL_BLOCK_LIMIT: cells per compute unit, in units of 65536)
+    static const long long limit = [] {
+        const char *e = getenv("TORBI_HIP_SMALL_BLOCK_LIMIT");
+        return e ? atoll(e) : 12ll;
+    }();
+    return small::block_supported(S) && (S <= 192 || (long long)B * S * S <= (limit << 16) * cus);
 }
 inline Route route_for(int path, int B, int S, int cus, bool allow_held = true) {
     if (path == TORBI_HIP_FORWARD_BAND) path = TORBI_HIP_FORWARD_AUTO;     // (a band is known to torbi_hip_viterbi_decode_banded only)
@@ -606,6 +613,7 @@ struct Workspace {
     unsigned *control;  // [64] its control words ([1]: workgroups that gave up waiting)
     int32_t *maps;      // [B][chunks][S] chunk maps of the parallel chase (B <= 16, S <= 4096, T >= 129), else null
     int32_t *entries;   // [B][chunks]    the path's state at every chunk boundary
+    int32_t *arrive;    // [B][8] ends of the backtrace's speculative segments (65 .. 256 states, B <= 1024), else null
     size_t bytes;
 };
 
@@ -632,6 +640,11 @@ inline Workspace carve(void *base, int B, int T, int S) {
         w.bytes += align_up(sizeof(int32_t) * (size_t)B * chunks * S, 256);
         w.entries = reinterpret_cast<int32_t *>(p + w.bytes);
         w.bytes += align_up(sizeof(int32_t) * (size_t)B * chunks, 256);
+    }
+    w.arrive = nullptr;
+    if (small::block_supported(S) && B <= 1024) {
+        w.arrive = reinterpret_cast<int32_t *>(p + w.bytes);
+        w.bytes += align_up(sizeof(int32_t) * (size_t)B * 8, 256);
     }
     return w;
 }
@@ -1038,10 +1051,53 @@ hipError_t launch_block_as(const float *obs, const int32_t *frames, const float 
                        reinterpret_cast<uint32_t *>(w.trellis), w.post[0], w.post[1], record, (int)ROUTE_SMALL, B, T, S, NB);
     return hipGetLastError();
 }
+// value-only form of the workgroup kernel + backtrace launches of their own (small_states.hpp, block_value_kernel): faster
+// from ONE sequence up (1 x 500 x 256: 0.49 against 1.05 ms -- the forward pass at 4.3 instructions per cell was the whole
+// decode, and a lone path is walked back in eight speculative segments); TORBI_HIP_SMALL_VALUE=0 brings the byte
+// backpointers back (experiments, and matrices that are not 16-byte aligned walk whole paths)
+inline bool block_value_form(int B, int S, int cus) {
+    if (const char *e = getenv("TORBI_HIP_SMALL_VALUE")) return atoi(e) != 0;
+    return true;
+}
+inline int backtrace_segments(int items);
+hipError_t launch_backtrace_on(const float *hist, const float *trans, const int32_t *frames, int32_t *out,
+                               int B, int T, int S, hipStream_t stream, const int32_t *ranges, const int32_t *widest);
+template <int PQ, int L>
+hipError_t launch_block_value_as(const float *obs, const int32_t *frames, const float *trans, const float *init,
+                                 const Workspace &w, int32_t *record, int B, int T, int S, hipStream_t stream) {
+    const int NB = (S + 63) / 64;
+    TORBI_NOTE_KERNEL("small::block_value_kernel<%d, %d>", PQ, L);
+    hipLaunchKernelGGL((small::block_value_kernel<PQ, L>), dim3(B), dim3(64 * NB * PQ), 0, stream, obs, frames, trans, init,
+                       reinterpret_cast<float *>(w.trellis), w.post[0], w.post[1], record, (int)ROUTE_SMALL, B, T, S, NB);
+    return hipGetLastError();
+}
 hipError_t launch_block(const float *obs, const int32_t *frames, const float *trans, const float *init, const Workspace &w,
-                        int32_t *out, int32_t *record, int B, int T, int S, hipStream_t stream, int *launches) {
-    if (launches) *launches += 1;
+                        int32_t *out, int32_t *record, int B, int T, int S, hipStream_t stream, int *launches, int cus) {
     const bool narrow = small::block_row_registers(S) == 48;
+    if (block_value_form(B, S, cus)) {
+        if (launches) *launches += 2;
+        hipError_t e;
+        switch (small::block_splits(S)) {
+            case 2: e = narrow ? launch_block_value_as<2, 48>(obs, frames, trans, init, w, record, B, T, S, stream)
+                               : launch_block_value_as<2, 64>(obs, frames, trans, init, w, record, B, T, S, stream); break;
+            case 3: e = narrow ? launch_block_value_as<3, 48>(obs, frames, trans, init, w, record, B, T, S, stream)
+                               : launch_block_value_as<3, 64>(obs, frames, trans, init, w, record, B, T, S, stream); break;
+            default: e = launch_block_value_as<4, 64>(obs, frames, trans, init, w, record, B, T, S, stream);
+        }
+        if (e != hipSuccess) return e;
+        const float *hist = reinterpret_cast<const float *>(w.trellis);
+        const bool vec = (S % 4 == 0) && ((reinterpret_cast<uintptr_t>(trans) & 15) == 0);
+        const int K = (vec && w.arrive) ? std::min(backtrace_segments(B), 8) : 1;
+        if (K > 1) {      // few paths: speculative segments (lazy_backtrace.hpp, chase_segment)
+            hipLaunchKernelGGL(lazy::segment_rows_kernel<1>, dim3(B * K), dim3(64), 0, stream, hist, trans, frames, out, B, T, S, K,
+                               w.arrive);
+            hipLaunchKernelGGL(lazy::stitch_rows_kernel<1>, dim3(B), dim3(64), 0, stream, hist, trans, frames, out, B, T, S, K,
+                               w.arrive);
+            return hipGetLastError();
+        }
+        return launch_backtrace_on(hist, trans, frames, out, B, T, S, stream, nullptr, nullptr);
+    }
+    if (launches) *launches += 1;
     switch (small::block_splits(S)) {
         case 2: return narrow ? launch_block_as<2, 48>(obs, frames, trans, init, w, out, record, B, T, S, stream)
                               : launch_block_as<2, 64>(obs, frames, trans, init, w, out, record, B, T, S, stream);
@@ -1623,7 +1679,7 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
         const Workspace w = carve(workspace, B, T, S);
         int32_t *const record = route_record(workspace, B, T, S, cus);
         e = small::supported(S) ? launch_small(obs, frames, trans, init, w, out, record, B, T, S, s, launches, cus)
-                                : launch_block(obs, frames, trans, init, w, out, record, B, T, S, s, launches);
+                                : launch_block(obs, frames, trans, init, w, out, record, B, T, S, s, launches, cus);
         if (ev) (void)hipEventRecord(ev[1], s);
         if (ev) (void)hipEventRecord(ev[2], s);
         return e;
