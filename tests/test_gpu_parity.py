@@ -279,7 +279,7 @@ def test_one_wavefront_per_sequence_up_to_64_states(S):
     np.testing.assert_array_equal(gpu_decode(obs, frames, trans, init), oracle.decode(obs, frames, trans, init))
 
 
-@pytest.mark.parametrize('form', ['value', 'backpointers'])
+@pytest.mark.parametrize('form', ['value', 'pairs', 'backpointers'])
 @pytest.mark.parametrize('S', [65, 80, 81, 100, 128, 129, 160, 161, 192, 193, 224, 225, 255, 256])
 def test_one_workgroup_per_sequence_up_to_256_states(S, form, monkeypatch):
     """small_states.hpp, block_value_kernel (the default: posterior rows kept, the backtrace a launch of its own -- in
@@ -290,6 +290,7 @@ def test_one_workgroup_per_sequence_up_to_256_states(S, form, monkeypatch):
     posterior rows."""
     if form == 'backpointers':
         monkeypatch.setenv('TORBI_HIP_SMALL_VALUE', '0')
+    monkeypatch.setenv('TORBI_HIP_BLOCK_PAIRS', '1' if form == 'pairs' else '0')       # (two sequences per workgroup)
     dev = torch.device('cuda:0')
     rng = np.random.default_rng(S)
     for B, T in [(1, 1), (3, 2), (5, 5), (9, 67), (3, 130), (2, 261)]:

@@ -502,24 +502,40 @@ __global__ __launch_bounds__(64 * PQ * PQ) void block_decode_kernel(
 // of the matrix in registers; the pieces of a row meet through the LDS as VALUES (max is exact and order independent).
 // A lone sequence gains nothing (a launch and ~1 us per path step against ~10 cycles through byte backpointers): the
 // launcher takes this form for batches (torbi_hip.hip, launch_block).
-template <int PQ, int L>
+// NSEQ = 2: a workgroup decodes TWO sequences against the one copy of the matrix in its registers -- the two barriers and
+// the merge of a timestep, which nothing overlaps when a 16-wave workgroup has a compute unit to itself, are shared by two
+// independent recurrences; taken when the compute units are full without it (torbi_hip.hip, launch_block_value_as).
+template <int PQ, int L, int NSEQ>
 __global__ __launch_bounds__(64 * PQ * PQ) void block_value_kernel(
     const float *__restrict__ obs, const int32_t *__restrict__ frames, const float *__restrict__ trans,
     const float *__restrict__ init, float *__restrict__ hist, float *__restrict__ post0, float *__restrict__ post1,
     int32_t *__restrict__ route_record, int route, int B, int T, int S, int NB) {
-    __shared__ float4 rows[2][kBlockMaxS / 4];            // posterior rows t-1 / t (entries >= S: -inf)
-    __shared__ float upper_best[PQ - 1][kBlockMaxS];      // what the pieces pq >= 1 of the prev-states offer
-    const int b = blockIdx.x;
+    __shared__ float4 rows[2][NSEQ][kBlockMaxS / 4];      // posterior rows t-1 / t (entries >= S: -inf)
+    __shared__ float upper_best[NSEQ][PQ - 1][kBlockMaxS];   // what the pieces pq >= 1 of the prev-states offer
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = wave % NB, pq = wave / NB;
     const int j = nb * 64 + lane;
     const bool live = j < S;
     const bool writer = pq == 0;
     const int lo = pq * L;
-    if (b == 0 && tid == 0) *route_record = route;
-    int n = __builtin_amdgcn_readfirstlane(frames[b]);
-    n = n < 1 ? 1 : (n > T ? T : n);
+    if (blockIdx.x == 0 && tid == 0) *route_record = route;
     const float ninf = -__builtin_huge_valf();
+    int n[NSEQ], nmax = 0;                                  // (0 past the batch: never active, nothing written)
+    const float *o[NSEQ];
+    float *h[NSEQ];
+#pragma unroll
+    for (int q = 0; q < NSEQ; ++q) {
+        const int b = blockIdx.x * NSEQ + q;
+        n[q] = 0;
+        if (b < B) {
+            n[q] = __builtin_amdgcn_readfirstlane(frames[b]);
+            n[q] = n[q] < 1 ? 1 : (n[q] > T ? T : n[q]);
+        }
+        nmax = max(nmax, n[q]);
+        const int bb = b < B ? b : B - 1;
+        o[q] = obs + (size_t)bb * T * S + min(j, S - 1);
+        h[q] = hist + (size_t)bb * T * S;
+    }
 
     float row[L];                                          // trans[j][lo + e]
 #pragma unroll
@@ -527,59 +543,77 @@ __global__ __launch_bounds__(64 * PQ * PQ) void block_value_kernel(
     asm volatile("" ::: "memory");                         //  every load unconditional and in flight before the first use)
 #pragma unroll
     for (int e = 0; e < L; ++e) row[e] = fminf(row[e], (live && lo + e < S) ? -ninf : ninf);          // the padding: -inf
-    const float *o = obs + (size_t)b * T * S + min(j, S - 1);
-    float *h = hist + (size_t)b * T * S;
-    float p = o[0] + init[min(j, S - 1)];
-    p = live ? p : ninf;
-    if (writer) {
-        reinterpret_cast<float *>(rows[0])[j] = p;
-        if (live) h[j] = p;
-    }
-    float cur[4] = {0.f, 0.f, 0.f, 0.f};
-    if (writer) {
+    float p[NSEQ], cur[NSEQ][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) cur[k] = o[(size_t)min(1 + k, n - 1) * S];
+    for (int q = 0; q < NSEQ; ++q) {
+        p[q] = o[q][0] + init[min(j, S - 1)];
+        p[q] = live ? p[q] : ninf;
+        if (writer) {
+            reinterpret_cast<float *>(rows[0][q])[j] = p[q];
+            if (live && n[q]) h[q][j] = p[q];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cur[q][k] = writer ? o[q][(size_t)min(1 + k, max(n[q], 1) - 1) * S] : 0.f;
     }
     __syncthreads();
 
-    for (int t0 = 1; t0 < n; t0 += 4) {
-        float nxt[4] = {0.f, 0.f, 0.f, 0.f};
-        if (writer) {                                       // (the observation rows of the next four timesteps)
+    for (int t0 = 1; t0 < nmax; t0 += 4) {
+        float nxt[NSEQ][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) nxt[k] = o[(size_t)min(t0 + 4 + k, n - 1) * S];
-        }
+        for (int q = 0; q < NSEQ; ++q)                      // (the observation rows of the next four timesteps)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nxt[q][k] = writer ? o[q][(size_t)min(t0 + 4 + k, max(n[q], 1) - 1) * S] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (t0 + r < n) {                               // (uniform over the workgroup)
-                const float4 *src = rows[(t0 + r - 1) & 1] + lo / 4;
-                float best[4] = {ninf, ninf, ninf, ninf};
+            if (t0 + r < nmax) {                            // (uniform over the workgroup)
+                float top[NSEQ];
 #pragma unroll
-                for (int e = 0; e < L; e += 8) {            // (L = 48 or 64: whole groups of eight prev-states)
-                    const float4 v0 = src[e / 4], v1 = src[e / 4 + 1];
-                    best[0] = fmaxf(fmaxf(best[0], v0.x + row[e]), v1.x + row[e + 4]);
-                    best[1] = fmaxf(fmaxf(best[1], v0.y + row[e + 1]), v1.y + row[e + 5]);
-                    best[2] = fmaxf(fmaxf(best[2], v0.z + row[e + 2]), v1.z + row[e + 6]);
-                    best[3] = fmaxf(fmaxf(best[3], v0.w + row[e + 3]), v1.w + row[e + 7]);
+                for (int q = 0; q < NSEQ; ++q) {
+                    top[q] = ninf;
+                    if (t0 + r < n[q]) {                    // (uniform over the workgroup)
+                        const float4 *src = rows[(t0 + r - 1) & 1][q] + lo / 4;
+                        float best[4] = {ninf, ninf, ninf, ninf};
+#pragma unroll
+                        for (int e = 0; e < L; e += 8) {    // (L = 48 or 64: whole groups of eight prev-states)
+                            const float4 v0 = src[e / 4], v1 = src[e / 4 + 1];
+                            best[0] = fmaxf(fmaxf(best[0], v0.x + row[e]), v1.x + row[e + 4]);
+                            best[1] = fmaxf(fmaxf(best[1], v0.y + row[e + 1]), v1.y + row[e + 5]);
+                            best[2] = fmaxf(fmaxf(best[2], v0.z + row[e + 2]), v1.z + row[e + 6]);
+                            best[3] = fmaxf(fmaxf(best[3], v0.w + row[e + 3]), v1.w + row[e + 7]);
+                        }
+                        top[q] = fmaxf(fmaxf(best[0], best[1]), fmaxf(best[2], best[3]));
+                        if (!writer && live) upper_best[q][pq - 1][j] = top[q];
+                    }
                 }
-                float top = fmaxf(fmaxf(best[0], best[1]), fmaxf(best[2], best[3]));
-                if (!writer && live) upper_best[pq - 1][j] = top;
                 __syncthreads();
                 if (writer) {
-                    if (live) {
 #pragma unroll
-                        for (int u = 0; u < PQ - 1; ++u) top = fmaxf(top, upper_best[u][j]);
+                    for (int q = 0; q < NSEQ; ++q) {
+                        if (t0 + r < n[q]) {
+                            float best = top[q];
+                            if (live) {
+#pragma unroll
+                                for (int u = 0; u < PQ - 1; ++u) best = fmaxf(best, upper_best[q][u][j]);
+                            }
+                            p[q] = live ? cur[q][r] + best : ninf;
+                            reinterpret_cast<float *>(rows[(t0 + r) & 1][q])[j] = p[q];
+                            if (live) h[q][(size_t)(t0 + r) * S + j] = p[q];
+                        }
                     }
-                    p = live ? cur[r] + top : ninf;
-                    reinterpret_cast<float *>(rows[(t0 + r) & 1])[j] = p;
-                    if (live) h[(size_t)(t0 + r) * S + j] = p;
                 }
                 __syncthreads();
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+        for (int q = 0; q < NSEQ; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cur[q][k] = nxt[q][k];
     }
-    if (writer && live) (((n - 1) & 1) ? post1 : post0)[(size_t)b * S + j] = p;
+#pragma unroll
+    for (int q = 0; q < NSEQ; ++q) {
+        const int b = blockIdx.x * NSEQ + q;
+        if (writer && live && n[q]) (((n[q] - 1) & 1) ? post1 : post0)[(size_t)b * S + j] = p[q];
+    }
 }
 
 }  // namespace small

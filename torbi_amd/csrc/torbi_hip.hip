@@ -1064,11 +1064,22 @@ hipError_t launch_backtrace_on(const float *hist, const float *trans, const int3
                                int B, int T, int S, hipStream_t stream, const int32_t *ranges, const int32_t *widest);
 template <int PQ, int L>
 hipError_t launch_block_value_as(const float *obs, const int32_t *frames, const float *trans, const float *init,
-                                 const Workspace &w, int32_t *record, int B, int T, int S, hipStream_t stream) {
+                                 const Workspace &w, int32_t *record, int B, int T, int S, hipStream_t stream, int cus) {
     const int NB = (S + 63) / 64;
-    TORBI_NOTE_KERNEL("small::block_value_kernel<%d, %d>", PQ, L);
-    hipLaunchKernelGGL((small::block_value_kernel<PQ, L>), dim3(B), dim3(64 * NB * PQ), 0, stream, obs, frames, trans, init,
-                       reinterpret_cast<float *>(w.trellis), w.post[0], w.post[1], record, (int)ROUTE_SMALL, B, T, S, NB);
+    // two sequences per workgroup once the compute units are full without it: a 9- or 16-wave workgroup has a unit to
+    // itself (512 x 500 x 256: 1.07 -> 1.03 ms, 2048 x 200 x 192: 1.33 -> 1.19), several 4-wave workgroups share one and
+    // overlap anyway (512 x 500 x 128: 0.44 -> 0.64, but 4096 x 200 x 128: 0.95 -> 0.89).  TORBI_HIP_BLOCK_PAIRS=0 / 1 overrides
+    const char *env = getenv("TORBI_HIP_BLOCK_PAIRS");
+    const bool pairs = env ? atoi(env) != 0 : B > cus * (NB * PQ >= 9 ? 1 : 8);
+    TORBI_NOTE_KERNEL("small::block_value_kernel<%d, %d, %d>", PQ, L, pairs ? 2 : 1);
+    if (pairs)
+        hipLaunchKernelGGL((small::block_value_kernel<PQ, L, 2>), dim3((B + 1) / 2), dim3(64 * NB * PQ), 0, stream, obs, frames,
+                           trans, init, reinterpret_cast<float *>(w.trellis), w.post[0], w.post[1], record, (int)ROUTE_SMALL, B,
+                           T, S, NB);
+    else
+        hipLaunchKernelGGL((small::block_value_kernel<PQ, L, 1>), dim3(B), dim3(64 * NB * PQ), 0, stream, obs, frames, trans,
+                           init, reinterpret_cast<float *>(w.trellis), w.post[0], w.post[1], record, (int)ROUTE_SMALL, B, T, S,
+                           NB);
     return hipGetLastError();
 }
 hipError_t launch_block(const float *obs, const int32_t *frames, const float *trans, const float *init, const Workspace &w,
@@ -1078,11 +1089,11 @@ hipError_t launch_block(const float *obs, const int32_t *frames, const float *tr
         if (launches) *launches += 2;
         hipError_t e;
         switch (small::block_splits(S)) {
-            case 2: e = narrow ? launch_block_value_as<2, 48>(obs, frames, trans, init, w, record, B, T, S, stream)
-                               : launch_block_value_as<2, 64>(obs, frames, trans, init, w, record, B, T, S, stream); break;
-            case 3: e = narrow ? launch_block_value_as<3, 48>(obs, frames, trans, init, w, record, B, T, S, stream)
-                               : launch_block_value_as<3, 64>(obs, frames, trans, init, w, record, B, T, S, stream); break;
-            default: e = launch_block_value_as<4, 64>(obs, frames, trans, init, w, record, B, T, S, stream);
+            case 2: e = narrow ? launch_block_value_as<2, 48>(obs, frames, trans, init, w, record, B, T, S, stream, cus)
+                               : launch_block_value_as<2, 64>(obs, frames, trans, init, w, record, B, T, S, stream, cus); break;
+            case 3: e = narrow ? launch_block_value_as<3, 48>(obs, frames, trans, init, w, record, B, T, S, stream, cus)
+                               : launch_block_value_as<3, 64>(obs, frames, trans, init, w, record, B, T, S, stream, cus); break;
+            default: e = launch_block_value_as<4, 64>(obs, frames, trans, init, w, record, B, T, S, stream, cus);
         }
         if (e != hipSuccess) return e;
         const float *hist = reinterpret_cast<const float *>(w.trellis);
