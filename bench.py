@@ -706,8 +706,9 @@ class Bench:
         record('c2_per_timestep_kernels', sec, T, S, 'the same with one launch per timestep (what AUTO took before round 3)',
                {'us_per_timestep': sec / max(T - 1, 1) * 1e6})
         # state counts below the reference's pitch bins (a 3-state toy like BASELINE configs[0], 40 classes, 256 bins):
-        # one wavefront / workgroup per sequence, recurrence and walk back in ONE launch (csrc/small_states.hpp)
-        for Bs, Ss in ((1, 3), (512, 40), (512, 256), (4096, 64)):
+        # one wavefront / workgroup per sequence, the matrix in registers (csrc/small_states.hpp): up to 64 states recurrence
+        # and walk back in ONE launch; 65 .. 256 states a value-only forward launch + the backtrace in speculative segments
+        for Bs, Ss in ((1, 3), (512, 40), (512, 256), (4096, 64), (512, 128)):
             os_ = v.fill_synthetic((Bs, T, Ss), synth.STREAM_OBSERVATION, seed=7, device=dev)
             ts_ = v.fill_synthetic((Ss, Ss), synth.STREAM_TRANSITION, seed=7, device=dev)
             is_ = v.fill_synthetic((Ss,), synth.STREAM_INITIAL, seed=7, device=dev)
@@ -719,8 +720,9 @@ class Bench:
             if Bs * T <= 512 * 500:       # (the per-timestep kernels beside it; not for the large batch: seconds)
                 sec_steps, _ = self.timed_decodes(lambda: self.torbi_amd.decode(os_, fs_, ts_, is_, path='dense'), 2)
                 extra['one_launch_per_timestep_ms'] = sec_steps * 1e3
-            record(f'small_states_{Bs}x{T}x{Ss}', sec, Bs * T, Ss, 'up to 256 states: the whole decode in one launch, the matrix '
-                                                                   'in registers; beside it the per-timestep kernels (DENSE named)',
+            record(f'small_states_{Bs}x{T}x{Ss}', sec, Bs * T, Ss, 'up to 256 states: a wavefront / workgroup per sequence, the '
+                                                                   'matrix in registers (`launches` says how many kernels the decode '
+                                                                   'took); beside it the per-timestep kernels (DENSE named)',
                    extra)
             del os_, ts_, is_, fs_
         # BASELINE configs[4]: 4096 states, 2000 frames, batch 128
