@@ -279,17 +279,14 @@ def test_one_wavefront_per_sequence_up_to_64_states(S):
     np.testing.assert_array_equal(gpu_decode(obs, frames, trans, init), oracle.decode(obs, frames, trans, init))
 
 
-@pytest.mark.parametrize('form', ['value', 'pairs', 'backpointers'])
+@pytest.mark.parametrize('form', ['value', 'pairs'])
 @pytest.mark.parametrize('S', [65, 80, 81, 100, 128, 129, 160, 161, 192, 193, 224, 225, 255, 256])
 def test_one_workgroup_per_sequence_up_to_256_states(S, form, monkeypatch):
-    """small_states.hpp, block_value_kernel (the default: posterior rows kept, the backtrace a launch of its own -- in
-    speculative segments where the matrix is 16-byte aligned and S % 4 == 0, whole paths otherwise) and block_decode_kernel
-    (TORBI_HIP_SMALL_VALUE=0: byte backpointers, one launch): the matrix in the registers of one compute unit, the
-    prev-states in one or two ranges, four running maxima per lane.  Ties everywhere (coarse grid), -inf rows / columns /
-    observations, lengths around the 4-timestep backpointer words and the 64-timestep chunks of the walk back, the final
-    posterior rows."""
-    if form == 'backpointers':
-        monkeypatch.setenv('TORBI_HIP_SMALL_VALUE', '0')
+    """small_states.hpp, block_value_kernel: the matrix in the registers of one compute unit, the prev-states in one or
+    two ranges, four running maxima per lane, posterior rows kept; the backtrace a launch pair of its own -- in speculative
+    segments where the matrix is 16-byte aligned and S % 4 == 0, whole paths otherwise.  One sequence per workgroup and two
+    (`pairs`).  Ties everywhere (coarse grid), -inf rows / columns / observations, ragged lengths around the 4-timestep
+    observation prefetch, the final posterior rows."""
     monkeypatch.setenv('TORBI_HIP_BLOCK_PAIRS', '1' if form == 'pairs' else '0')       # (two sequences per workgroup)
     dev = torch.device('cuda:0')
     rng = np.random.default_rng(S)
@@ -310,9 +307,8 @@ def test_one_workgroup_per_sequence_up_to_256_states(S, form, monkeypatch):
                                torch.tensor(init, device=dev), workspace=ws, _profile=profile)
         np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f'{B} x {T} x {S}')
         if viterbi.forward_path(B, S) == 'small':
-            assert viterbi.ROUTES[int(profile[3])] == 'small' and profile[2] == (1 if form == 'backpointers' else 2)
-            assert viterbi.last_forward_kernel().startswith(
-                'small::block_decode_kernel<' if form == 'backpointers' else 'small::block_value_kernel<')
+            assert viterbi.ROUTES[int(profile[3])] == 'small' and profile[2] == 2
+            assert viterbi.last_forward_kernel().startswith('small::block_value_kernel<')
         back = viterbi.read_posterior(ws, torch.tensor(frames), B, T, S).cpu().numpy()
         assert np.array_equal(back.view(np.uint32), post.view(np.uint32)), (B, T, S)
     B, T = 21, 150

@@ -280,228 +280,28 @@ __global__ __launch_bounds__(256) void decode_value_kernel(const float *__restri
     }
 }
 
-// ---- 65 .. 256 states: one WORKGROUP per sequence --------------------------------------------------------------------
+// ---- 65 .. 256 states: one WORKGROUP per sequence (or per two), value-only ---------------------------------------------
 // The matrix still fits the registers of one compute unit (256 x 256 x 4 B = half of its vector register file): wave
 // (nb, pq) of NB x PQ owns next-states [64 nb, 64 nb + 64) x prev-states [pq L, pq L + L), L <= 64 -- lane j keeps that
-// piece of row j in L registers for the whole launch, and with at most ~110 registers a lane the 4 .. 16 waves of a
-// workgroup hide each other's latencies.  A timestep: the previous posterior row is broadcast from the LDS (one
-// ds_read_b128 per four prev-states), four interleaved running maxima per lane keep the dependent chain short, the PQ
-// pieces of a row meet through the LDS, the waves with pq = 0 add the observation, write the new row and pack the byte
-// backpointers.  Ties: every merge compares (value, prev-state) pairs -- higher value, else lower index -- which is the
-// reference's strict '>' scan from prev-state 0 (viterbi.cpp:94-100).  The walk back reads 64 timesteps of backpointers
-// into the LDS at a time.
+// piece of row j in L registers for the whole launch, and with ~100-115 registers a lane the 4 .. 16 waves of a workgroup
+// hide each other's latencies.  A timestep: the previous posterior row is broadcast from the LDS (one ds_read_b128 per four
+// prev-states), four interleaved running maxima per lane keep the dependent chain short, the PQ pieces of a row meet
+// through the LDS, the waves with pq = 0 add the observation and write the new row.
+// (Rounds 4-5 carried a byte-backpointer form beside it -- add / compare / max / select with (value, index) merges, 4.3
+// instructions per cell, the walk back in the same launch: 2.17 against 1.02 ms at 512 x 500 x 256, 1.05 against 0.49 for ONE
+// sequence; removed.)
 constexpr int kBlockMaxS = 256;
 __host__ __device__ inline int block_splits(int S) { return (S + 63) / 64; }                          // PQ (= NB)
 __host__ __device__ inline int block_row_registers(int S) {                                           // L
     return (S + block_splits(S) - 1) / block_splits(S) <= 48 ? 48 : 64;
 }
 inline bool block_supported(int S) { return S > kMaxS && S <= kBlockMaxS; }
-// dwords of the backpointer plane per item: [ceil((T-1)/4)][S]
-__host__ __device__ inline size_t block_plane_dwords(int T, int S) { return (size_t)((T - 1 + 3) / 4) * S; }
 
-// Four prev-states lo + 4 K .. lo + 4 K + 3 against the four running maxima of a lane: add, compare, max, select -- written
-// out so that it stays four vector instructions per cell with no candidate kept in a register (left to itself the compiler
-// reduces the values first and recovers the indices afterwards from ~100 saved candidates per lane).  Running maximum c
-// remembers K of its prev-state lo + 4 K + c (an inline constant); the compares land in four scalar pairs, eight
-// instructions ahead of the selects that read them.
-template <int K>
-__device__ __forceinline__ void four_cells(const float4 pv, const float *row, float (&best)[4], uint32_t (&arg)[4]) {
-    float c0, c1, c2, c3;
-    unsigned long long m0, m1, m2, m3;
-    asm volatile(
-        "v_add_f32 %0, %16, %20\n\tv_add_f32 %1, %17, %21\n\tv_add_f32 %2, %18, %22\n\tv_add_f32 %3, %19, %23\n\t"
-        "v_cmp_ngt_f32 %4, %0, %8\n\tv_cmp_ngt_f32 %5, %1, %9\n\tv_cmp_ngt_f32 %6, %2, %10\n\tv_cmp_ngt_f32 %7, %3, %11\n\t"
-        "v_max_f32 %8, %8, %0\n\tv_max_f32 %9, %9, %1\n\tv_max_f32 %10, %10, %2\n\tv_max_f32 %11, %11, %3\n\t"
-        "v_cndmask_b32 %12, %24, %12, %4\n\tv_cndmask_b32 %13, %24, %13, %5\n\t"
-        "v_cndmask_b32 %14, %24, %14, %6\n\tv_cndmask_b32 %15, %24, %15, %7"
-        : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "+v"(best[0]), "+v"(best[1]),
-          "+v"(best[2]), "+v"(best[3]), "+v"(arg[0]), "+v"(arg[1]), "+v"(arg[2]), "+v"(arg[3])
-        : "v"(pv.x), "v"(pv.y), "v"(pv.z), "v"(pv.w), "v"(row[0]), "v"(row[1]), "v"(row[2]), "v"(row[3]), "n"(K));
-}
-
-// L prev-states in groups of 4 G: the broadcasts of group g + 1 are issued before group g is added up (the compiler moves
-// nothing across the blocks above, so the order written here is the order that runs)
-template <int Base, int L, int G, int... Is>
-__device__ __forceinline__ void one_group(const float4 (&pv)[G], const float (&row)[L], float (&best)[4], uint32_t (&arg)[4],
-                                          std::integer_sequence<int, Is...>) {
-    (four_cells<Base + Is>(pv[Is], &row[4 * (Base + Is)], best, arg), ...);
-}
-template <int L, int G, int Gi = 0>
-__device__ __forceinline__ void every_cell(const float4 *src, const float (&row)[L], float4 (&pv)[G], float (&best)[4],
-                                           uint32_t (&arg)[4]) {
-    constexpr int NG = L / (4 * G);
-    float4 next[G];
-    if constexpr (Gi + 1 < NG) {
-#pragma unroll
-        for (int i = 0; i < G; ++i) next[i] = src[(Gi + 1) * G + i];
-    }
-    one_group<Gi * G>(pv, row, best, arg, std::make_integer_sequence<int, G>{});
-    if constexpr (Gi + 1 < NG) every_cell<L, G, Gi + 1>(src, row, next, best, arg);
-}
-template <int L, int G>
-__device__ __forceinline__ void every_cell(const float4 *src, const float (&row)[L], float (&best)[4], uint32_t (&arg)[4]) {
-    static_assert(L % (4 * G) == 0, "whole groups");
-    float4 first[G];
-#pragma unroll
-    for (int i = 0; i < G; ++i) first[i] = src[i];
-    every_cell<L, G, 0>(src, row, first, best, arg);
-}
-
-template <int PQ, int L>
-__global__ __launch_bounds__(64 * PQ * PQ) void block_decode_kernel(
-    const float *__restrict__ obs, const int32_t *__restrict__ frames, const float *__restrict__ trans,
-    const float *__restrict__ init, int32_t *__restrict__ out, uint32_t *__restrict__ plane, float *__restrict__ post0,
-    float *__restrict__ post1, int32_t *__restrict__ route_record, int route, int B, int T, int S, int NB) {
-    __shared__ float4 rows[2][kBlockMaxS / 4];            // posterior rows t-1 / t (entries >= S: -inf)
-    __shared__ float upper_best[PQ - 1][kBlockMaxS];      // what the pieces pq >= 1 of the prev-states offer
-    __shared__ uint32_t upper_arg[PQ - 1][kBlockMaxS];
-    __shared__ uint32_t steps[16 * kBlockMaxS];           // the walk back: 16 backpointer words (64 timesteps) x S
-    __shared__ int shared_idx;
-    const int b = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nb = wave % NB, pq = wave / NB;
-    const int j = nb * 64 + lane;
-    const bool live = j < S;
-    const bool writer = pq == 0;
-    const int lo = pq * L;
-    if (b == 0 && tid == 0) *route_record = route;
-    int n = __builtin_amdgcn_readfirstlane(frames[b]);
-    n = n < 1 ? 1 : (n > T ? T : n);
-    const float ninf = -__builtin_huge_valf();
-
-    float row[L];                                          // trans[j][lo + e]
-#pragma unroll
-    for (int e = 0; e < L; ++e) row[e] = trans[(size_t)min(j, S - 1) * S + min(lo + e, S - 1)];   // (clamped addresses:
-    asm volatile("" ::: "memory");                         //  every load unconditional and in flight before the first use)
-#pragma unroll
-    for (int e = 0; e < L; ++e) row[e] = fminf(row[e], (live && lo + e < S) ? -ninf : ninf);          // the padding: -inf
-    const float *o = obs + (size_t)b * T * S + min(j, S - 1);
-    uint32_t *pl = plane + (size_t)b * block_plane_dwords(T, S);
-    float p = o[0] + init[min(j, S - 1)];
-    p = live ? p : ninf;
-    if (writer) reinterpret_cast<float *>(rows[0])[j] = p;
-    float cur[4] = {0.f, 0.f, 0.f, 0.f};
-    if (writer) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) cur[k] = o[(size_t)min(1 + k, n - 1) * S];
-    }
-    __syncthreads();
-
-    for (int t0 = 1; t0 < n; t0 += 4) {
-        float nxt[4] = {0.f, 0.f, 0.f, 0.f};
-        if (writer) {                                       // (the observation rows of the next four timesteps)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) nxt[k] = o[(size_t)min(t0 + 4 + k, n - 1) * S];
-        }
-        uint32_t packed = 0u;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (t0 + r < n) {                               // (uniform over the workgroup)
-                const float4 *src = rows[(t0 + r - 1) & 1] + lo / 4;
-                float best[4] = {ninf, ninf, ninf, ninf};   // (a running maximum that is never exceeded keeps index 0 of its
-                uint32_t arg[4] = {0u, 0u, 0u, 0u};         // own: the reference's zero default, viterbi.cpp:201-203)
-                every_cell<L, (PQ == 4 ? 2 : 4)>(src, row, best, arg);     // (16 waves: 128 registers a lane)
-                float top = best[0];
-                uint32_t at = 4u * arg[0];
-#pragma unroll
-                for (int c = 1; c < 4; ++c) {               // (value, index) pairs: higher value, else lower prev-state
-                    const uint32_t mine = 4u * arg[c] + (uint32_t)c;
-                    const bool better = best[c] > top || (best[c] == top && mine < at);
-                    top = better ? best[c] : top;
-                    at = better ? mine : at;
-                }
-                at += (uint32_t)lo;
-                if (!writer && live) {
-                    upper_best[pq - 1][j] = top;
-                    upper_arg[pq - 1][j] = at;
-                }
-                __syncthreads();
-                if (writer && live) {                       // the later pieces' prev-states are all larger: strict '>'
-#pragma unroll
-                    for (int u = 0; u < PQ - 1; ++u) {
-                        const float other = upper_best[u][j];
-                        const bool better = other > top;
-                        at = better ? upper_arg[u][j] : at;
-                        top = better ? other : top;
-                    }
-                }
-                if (writer) {
-                    p = live ? cur[r] + top : ninf;
-                    reinterpret_cast<float *>(rows[(t0 + r) & 1])[j] = p;
-                    packed |= at << (8 * r);
-                }
-                __syncthreads();
-            }
-        }
-        if (writer && live) pl[(size_t)((t0 - 1) / 4) * S + j] = packed;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
-    }
-    if (writer && live) (((n - 1) & 1) ? post1 : post0)[(size_t)b * S + j] = p;
-
-    // first maximum of the last row (wave 0: four entries per lane, then (value, index) pairs across the lanes)
-    if (wave == 0) {
-        const float *last = reinterpret_cast<const float *>(rows[(n - 1) & 1]);
-        float top = ninf;
-        int at = 0x7fffffff;
-#pragma unroll
-        for (int k = 0; k < kBlockMaxS / 64; ++k) {
-            const int i = lane + 64 * k;
-            const float v = i < S ? last[i] : ninf;
-            if (i < S && (at == 0x7fffffff || v > top)) { top = v; at = i; }
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const float v = __shfl_xor(top, d, 64);
-            const int i = __shfl_xor(at, d, 64);
-            const bool better = i != 0x7fffffff && (at == 0x7fffffff || v > top || (v == top && i < at));
-            top = better ? v : top;
-            at = better ? i : at;
-        }
-        if (lane == 0) shared_idx = at;
-    }
-    __threadfence_block();                                  // the plane stores of this workgroup, read back below
-    __syncthreads();
-    int idx = shared_idx;
-    int32_t *ob = out + (size_t)b * T;
-    for (int t = n - 1 + tid; t < T; t += blockDim.x) ob[t] = idx;
-    if (n < 2) return;
-
-    const int groups = (n - 1 + 3) / 4;
-    for (int c = (groups - 1) / 16; c >= 0; --c) {
-        const int have = min(16, groups - 16 * c);
-        for (int e = tid; e < have * S; e += blockDim.x) steps[e] = pl[(size_t)16 * c * S + e];
-        __syncthreads();
-        if (wave == 0) {
-            int32_t mine = 0;
-            for (int g = have - 1; g >= 0; --g) {
-#pragma unroll
-                for (int r = 3; r >= 0; --r) {
-                    const int t = 4 * (16 * c + g) + 1 + r;
-                    if (t <= n - 1) {
-                        idx = (int)((steps[g * S + idx] >> (8 * r)) & 255u);
-                        mine = lane == 4 * g + r ? idx : mine;
-                    }
-                }
-            }
-            const int pos = 64 * c + lane;
-            if (pos <= n - 2) ob[pos] = mine;
-            if (lane == 0) shared_idx = idx;
-        }
-        __syncthreads();
-        idx = shared_idx;
-    }
-}
-
-// ---- 65 .. 256 states, MANY sequences: the workgroup kernel value-only ----------------------------------------------
-// block_decode_kernel spends 4.3 vector instructions per cell on (value, index) pairs.  Here a cell is add, add, 1/2 max3:
-// the forward pass keeps no backpointers, it stores the posterior rows (fp32: hist[b][t][:], where the byte plane would
-// lie) and the backtrace is a launch of its own -- lazy_backtrace.hpp recomputes the first argmax of
-// fl(hist[t-1][i] + trans[j][i]) for the state on the path (viterbi.cpp:81-100), in speculative segments for a batch of few
-// paths.  Same decomposition as above: wave (nb, pq) keeps next-states [64 nb, 64 nb + 64) x prev-states [pq L, pq L + L)
-// of the matrix in registers; the pieces of a row meet through the LDS as VALUES (max is exact and order independent).
-// A lone sequence gains nothing (a launch and ~1 us per path step against ~10 cycles through byte backpointers): the
-// launcher takes this form for batches (torbi_hip.hip, launch_block).
+// A cell is add, add, 1/2 max3: the forward pass keeps no backpointers, it stores the posterior rows (fp32: hist[b][t][:],
+// where the generic route's trellis would lie) and the backtrace is a launch of its own -- lazy_backtrace.hpp recomputes
+// the first argmax of fl(hist[t-1][i] + trans[j][i]) for the state on the path (viterbi.cpp:81-100), in speculative
+// segments for a batch of few paths.  The pieces of a row meet through the LDS as VALUES (max is exact and order
+// independent).
 // NSEQ = 2: a workgroup decodes TWO sequences against the one copy of the matrix in its registers -- the two barriers and
 // the merge of a timestep, which nothing overlaps when a 16-wave workgroup has a compute unit to itself, are shared by two
 // independent recurrences; taken when the compute units are full without it (torbi_hip.hip, launch_block_value_as).

@@ -1042,23 +1042,7 @@ hipError_t launch_small(const float *obs, const int32_t *frames, const float *tr
     }
 }
 
-template <int PQ, int L>
-hipError_t launch_block_as(const float *obs, const int32_t *frames, const float *trans, const float *init, const Workspace &w,
-                           int32_t *out, int32_t *record, int B, int T, int S, hipStream_t stream) {
-    const int NB = (S + 63) / 64;
-    TORBI_NOTE_KERNEL("small::block_decode_kernel<%d, %d>", PQ, L);
-    hipLaunchKernelGGL((small::block_decode_kernel<PQ, L>), dim3(B), dim3(64 * NB * PQ), 0, stream, obs, frames, trans, init, out,
-                       reinterpret_cast<uint32_t *>(w.trellis), w.post[0], w.post[1], record, (int)ROUTE_SMALL, B, T, S, NB);
-    return hipGetLastError();
-}
-// value-only form of the workgroup kernel + backtrace launches of their own (small_states.hpp, block_value_kernel): faster
-// from ONE sequence up (1 x 500 x 256: 0.49 against 1.05 ms -- the forward pass at 4.3 instructions per cell was the whole
-// decode, and a lone path is walked back in eight speculative segments); TORBI_HIP_SMALL_VALUE=0 brings the byte
-// backpointers back (experiments, and matrices that are not 16-byte aligned walk whole paths)
-inline bool block_value_form(int B, int S, int cus) {
-    if (const char *e = getenv("TORBI_HIP_SMALL_VALUE")) return atoi(e) != 0;
-    return true;
-}
+// 65 .. 256 states: the value-only workgroup kernel + backtrace launches of their own (small_states.hpp, block_value_kernel)
 inline int backtrace_segments(int items);
 hipError_t launch_backtrace_on(const float *hist, const float *trans, const int32_t *frames, int32_t *out,
                                int B, int T, int S, hipStream_t stream, const int32_t *ranges, const int32_t *widest);
@@ -1085,37 +1069,26 @@ hipError_t launch_block_value_as(const float *obs, const int32_t *frames, const 
 hipError_t launch_block(const float *obs, const int32_t *frames, const float *trans, const float *init, const Workspace &w,
                         int32_t *out, int32_t *record, int B, int T, int S, hipStream_t stream, int *launches, int cus) {
     const bool narrow = small::block_row_registers(S) == 48;
-    if (block_value_form(B, S, cus)) {
-        if (launches) *launches += 2;
-        hipError_t e;
-        switch (small::block_splits(S)) {
-            case 2: e = narrow ? launch_block_value_as<2, 48>(obs, frames, trans, init, w, record, B, T, S, stream, cus)
-                               : launch_block_value_as<2, 64>(obs, frames, trans, init, w, record, B, T, S, stream, cus); break;
-            case 3: e = narrow ? launch_block_value_as<3, 48>(obs, frames, trans, init, w, record, B, T, S, stream, cus)
-                               : launch_block_value_as<3, 64>(obs, frames, trans, init, w, record, B, T, S, stream, cus); break;
-            default: e = launch_block_value_as<4, 64>(obs, frames, trans, init, w, record, B, T, S, stream, cus);
-        }
-        if (e != hipSuccess) return e;
-        const float *hist = reinterpret_cast<const float *>(w.trellis);
-        const bool vec = (S % 4 == 0) && ((reinterpret_cast<uintptr_t>(trans) & 15) == 0);
-        const int K = (vec && w.arrive) ? std::min(backtrace_segments(B), 8) : 1;
-        if (K > 1) {      // few paths: speculative segments (lazy_backtrace.hpp, chase_segment)
-            hipLaunchKernelGGL(lazy::segment_rows_kernel<1>, dim3(B * K), dim3(64), 0, stream, hist, trans, frames, out, B, T, S, K,
-                               w.arrive);
-            hipLaunchKernelGGL(lazy::stitch_rows_kernel<1>, dim3(B), dim3(64), 0, stream, hist, trans, frames, out, B, T, S, K,
-                               w.arrive);
-            return hipGetLastError();
-        }
-        return launch_backtrace_on(hist, trans, frames, out, B, T, S, stream, nullptr, nullptr);
-    }
-    if (launches) *launches += 1;
+    if (launches) *launches += 2;
+    hipError_t e;
     switch (small::block_splits(S)) {
-        case 2: return narrow ? launch_block_as<2, 48>(obs, frames, trans, init, w, out, record, B, T, S, stream)
-                              : launch_block_as<2, 64>(obs, frames, trans, init, w, out, record, B, T, S, stream);
-        case 3: return narrow ? launch_block_as<3, 48>(obs, frames, trans, init, w, out, record, B, T, S, stream)
-                              : launch_block_as<3, 64>(obs, frames, trans, init, w, out, record, B, T, S, stream);
-        default: return launch_block_as<4, 64>(obs, frames, trans, init, w, out, record, B, T, S, stream);
+        case 2: e = narrow ? launch_block_value_as<2, 48>(obs, frames, trans, init, w, record, B, T, S, stream, cus)
+                           : launch_block_value_as<2, 64>(obs, frames, trans, init, w, record, B, T, S, stream, cus); break;
+        case 3: e = narrow ? launch_block_value_as<3, 48>(obs, frames, trans, init, w, record, B, T, S, stream, cus)
+                           : launch_block_value_as<3, 64>(obs, frames, trans, init, w, record, B, T, S, stream, cus); break;
+        default: e = launch_block_value_as<4, 64>(obs, frames, trans, init, w, record, B, T, S, stream, cus);
     }
+    if (e != hipSuccess) return e;
+    const float *hist = reinterpret_cast<const float *>(w.trellis);
+    const bool vec = (S % 4 == 0) && ((reinterpret_cast<uintptr_t>(trans) & 15) == 0);
+    const int K = (vec && w.arrive) ? std::min(backtrace_segments(B), 8) : 1;
+    if (K > 1) {      // few paths: speculative segments (lazy_backtrace.hpp, chase_segment)
+        hipLaunchKernelGGL(lazy::segment_rows_kernel<1>, dim3(B * K), dim3(64), 0, stream, hist, trans, frames, out, B, T, S, K,
+                           w.arrive);
+        hipLaunchKernelGGL(lazy::stitch_rows_kernel<1>, dim3(B), dim3(64), 0, stream, hist, trans, frames, out, B, T, S, K, w.arrive);
+        return hipGetLastError();
+    }
+    return launch_backtrace_on(hist, trans, frames, out, B, T, S, stream, nullptr, nullptr);
 }
 
 // ---- dense path -----------------------------------------------------------------------
