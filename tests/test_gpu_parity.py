@@ -344,10 +344,14 @@ def test_forward_path_selection(forward):
                                              'auto': 'held'}.get(forward, 'generic')   # AUTO: held matrix up to 3 items
     assert viterbi.forward_path(16, 1440, path='held') == 'held' and viterbi.forward_path(17, 1440, path='held') == 'cluster'
     assert viterbi.forward_path(1, 4096, path='auto') == 'held' and viterbi.forward_path(1, 4100, path='auto') == 'generic'
-    assert viterbi.forward_path(16, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'dense': 'generic'}.get(forward, 'rows')
+    assert viterbi.forward_path(12, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'dense': 'generic'}.get(forward, 'rows')
+    # (AUTO up to 16 items: the sorted-row scan while items x states <= 12 x 1440, one tile split over sixteen members beyond)
+    assert viterbi.forward_path(16, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'dense': 'generic',
+                                              'auto': 'cluster'}.get(forward, 'rows')
     assert viterbi.forward_path(2, 4096) == {'dense': 'generic', 'resident': 'resident', 'cluster': 'cluster',
                                              'auto': 'held'}.get(forward, 'rows')
-    assert viterbi.forward_path(9, 4096) == {'dense': 'generic', 'resident': 'resident', 'cluster': 'cluster'}.get(forward, 'rows')
+    assert viterbi.forward_path(9, 4096) == {'dense': 'generic', 'resident': 'resident', 'cluster': 'cluster',
+                                             'auto': 'cluster'}.get(forward, 'rows')
     # up to 64 states: one wavefront per sequence whatever the batch (a named path that covers the shape keeps it; one that
     # does not falls back as AUTO would; DENSE named below 32 items or 64 states: the generic kernels)
     assert viterbi.forward_path(4, 40) == ('generic' if forward == 'dense' else 'small')
@@ -371,7 +375,8 @@ def test_forward_path_selection(forward):
     assert viterbi.forward_path(3 * cus, 1440, path='auto') == 'cluster'
     assert viterbi.forward_path(2 * cus, 1440, path='auto') == 'cluster'
     assert viterbi.forward_path(17, 1440, path='auto') == 'cluster'
-    assert viterbi.forward_path(16, 1440, path='auto') == 'rows'
+    assert viterbi.forward_path(16, 1440, path='auto') == 'cluster' and viterbi.forward_path(12, 1440, path='auto') == 'rows'
+    assert viterbi.forward_path(16, 512, path='auto') == 'rows' and viterbi.forward_path(12, 2048, path='auto') == 'cluster'
     assert viterbi.forward_path(128, 4096, path='auto') == 'cluster'              # 8-item tiles: 16 tiles x 16 members
     assert viterbi.forward_path(128, 4100, path='auto') == 'dense' and viterbi.forward_path(40, 40, path='auto') == 'small'
     assert viterbi.forward_path(2 * cus, 1440, path='pruned') == 'cluster'       # (its per-timestep tile kernel is gone)

@@ -594,6 +594,12 @@ inline Route route_for(int path, int B, int S, int cus, bool allow_held = true) 
     if (held::supported(B, S, cus) &&
         (path == TORBI_HIP_FORWARD_HELD || (path == TORBI_HIP_FORWARD_AUTO && allow_held && held_auto(B, S))))
         return ROUTE_HELD;
+    // up to 16 items the sorted-row scan's time grows with items x states, the cluster form's (one tile, sixteen members)
+    // does not: 12 x 1440 rows 5.1 / cluster 5.3 ms per 500 frames, 16 x 1440 6.1 / 5.3, 12 x 2048 4.6 / 4.2 per 300,
+    // 12 x 4096 8.7 / 4.8 per 200, 16 x 4096 10.9 / 4.8 -- but 16 x 512 2.4 / 3.6 (tools/few_items_probe.py)
+    if (path == TORBI_HIP_FORWARD_AUTO && fits && (long long)B * S > 12ll * 1440 &&
+        cluster_members(tiles_of(B, S), S, cus) > 1)
+        return ROUTE_CLUSTER;
     if ((path == TORBI_HIP_FORWARD_PRUNED && rowscan::supported(B, S)) ||
         (path != TORBI_HIP_FORWARD_DENSE && rowscan::profitable(B, S)))
         return ROUTE_ROWS;
