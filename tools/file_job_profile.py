@@ -20,6 +20,20 @@ try:
         f = os.path.join(folder, f'in{k}.pt'); torch.save(torch.roll(block, k, dims=0)[:n].clone(), f)
         ins.append(f); outs.append(os.path.join(folder, f'out{k}.pt'))
     tf = os.path.join(folder, 'transition.pt'); torch.save(torch.rand(S, S, generator=gen).softmax(-1), tf)
+    if os.environ.get('PREREAD'):          # every input file read once by plain Python before the first job (is the cold
+        t0 = time.perf_counter()           # job slow because the FILES are new, or because the process is?)
+        n = 0
+        for f in ins:
+            with open(f, 'rb') as fh:
+                n += len(fh.read())
+        print(f'pre-read {n / 1e9:.1f} GB in {time.perf_counter() - t0:.2f} s', flush=True)
+    if os.environ.get('PREPIN'):           # ... or because the pinned memory is?
+        t0 = time.perf_counter()
+        warm = [torch.empty(int(2.8e9), dtype=torch.uint8).pin_memory() for _ in range(4)]
+        for w in warm:
+            w.zero_()
+        del warm
+        print(f'pinned and touched 4 x 2.8 GB in {time.perf_counter() - t0:.2f} s', flush=True)
     for attempt in range(2):
         torch.cuda.synchronize()
         prof = cProfile.Profile()
