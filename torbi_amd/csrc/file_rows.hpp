@@ -12,6 +12,9 @@
 #include <cerrno>
 #include <cstring>
 #include <stdint.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 #include <fcntl.h>
@@ -82,6 +85,7 @@ struct HeadJob {
     std::atomic<int> next{0};
     std::atomic<int> failed{0};
     std::atomic<int> error{0};
+    std::atomic<long long> open_ns{0}, read_ns{0};      // (TORBI_FILE_TIMINGS: summed over the threads)
 };
 
 inline void head_work(HeadJob *job) {
@@ -89,7 +93,10 @@ inline void head_work(HeadJob *job) {
         const int k = job->next.fetch_add(1, std::memory_order_relaxed);
         if (k >= job->n) return;
         job->lengths[k] = 0;
+        const auto t_open = std::chrono::steady_clock::now();
         const int fd = open(job->paths[k], O_RDONLY | O_CLOEXEC);
+        const auto t_read = std::chrono::steady_clock::now();
+        job->open_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(t_read - t_open).count();
         job->fds[k] = fd;
         int err = 0;
         if (fd < 0) {
@@ -105,6 +112,7 @@ inline void head_work(HeadJob *job) {
                 have += (int)got;
             }
             job->lengths[k] = have;
+            job->read_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_read).count();
         }
         if (err) {
             int expected = 0;
@@ -121,11 +129,18 @@ inline int open_heads(const char *const *paths, int n, int threads, int head_byt
     job.paths = paths; job.fds = fds_out; job.heads = heads_out; job.lengths = lengths_out; job.head_bytes = head_bytes; job.n = n;
     if (threads > n) threads = n;
     if (threads < 1) threads = 1;
+    const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> pool;
     pool.reserve((size_t)threads - 1);
     for (int t = 1; t < threads; ++t) pool.emplace_back(head_work, &job);
+    const auto t1 = std::chrono::steady_clock::now();
     head_work(&job);
     for (auto &t : pool) t.join();
+    if (getenv("TORBI_FILE_TIMINGS")) {
+        const auto ms = [](auto d) { return std::chrono::duration_cast<std::chrono::microseconds>(d).count() / 1000.0; };
+        fprintf(stderr, "    open_heads: %d threads started in %.1f ms, all done after %.1f ms; open() %.1f ms, pread() %.1f ms summed\n",
+                threads, ms(t1 - t0), ms(std::chrono::steady_clock::now() - t0), job.open_ns.load() / 1e6, job.read_ns.load() / 1e6);
+    }
     if (error_out) *error_out = job.error.load();
     const int failed = job.failed.load();
     return failed ? -failed : 0;
