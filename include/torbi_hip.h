@@ -75,18 +75,22 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
 
 /*
  * Forward-recurrence paths (all give identical indices):
- *   SMALL     2 <= S <= 256: ONE launch per decode, the matrix in registers for the whole of it, byte backpointers, the
- *             walk back in the same launch (small_states.hpp).  Up to 64 states one wavefront per sequence: lane j keeps row
- *             j of the matrix, a timestep is the previous row broadcast through the LDS and S x (add, compare, max, select).
- *             65 .. 256 states one workgroup of ceil(S / 64)^2 waves per sequence: wave (nb, pq) keeps next-states
- *             64 nb .. x a quarter / third / half of the prev-states, the pieces of a row meet through the LDS.  AUTO's
- *             choice up to 64 states, and up to 256 while B S^2 <= 3 * 2^16 per compute unit (larger batches: RESIDENT /
- *             CLUSTER, whose pruning then wins).  No path name: a named path that covers the shape runs instead.
+ *   SMALL     2 <= S <= 256: the matrix in registers for the whole decode (small_states.hpp).  Up to 64 states one
+ *             wavefront per sequence, ONE launch: lane j keeps row j of the matrix, a timestep is the previous row broadcast
+ *             through the LDS and S x (add, compare, max, select), byte backpointers walked back by the same wavefront
+ *             (many sequences: a value-only form, the first argmax recomputed along the path).  65 .. 256 states one
+ *             workgroup of ceil(S / 64)^2 waves per sequence (or per two), value-only: wave (nb, pq) keeps next-states
+ *             64 nb .. x a quarter / third / half of the prev-states, the pieces of a row meet through the LDS, posterior
+ *             rows go to the history and the backtrace is a launch pair of its own (speculative segments, joined
+ *             exactly).  AUTO's choice up to 192 states, and up to 256 while B S^2 <= 12 * 2^16 per compute unit (larger
+ *             batches: RESIDENT / CLUSTER, whose pruning then wins).  No path name: a named path that covers the shape
+ *             runs instead.
  *   GENERIC   S = 1, S > 4096 with B < 32, or DENSE named for a batch below 32 items (any S): trellis kernels shaped like
  *             the reference's, one launch per timestep
  *   ROWS      B <= 16, 64 <= S <= 4096: the pruned recurrence with one wave per (item, next-state), 64 list
  *             entries per wave step (small_batch_forward.hpp); one launch per timestep.  AUTO takes it for
- *             B >= 6 or S > 2048 (below that both it and GENERIC are bound by the gap between launches)
+ *             6 .. 16 items while B S <= 12 * 1440 (beyond that one tile split over sixteen workgroups -- CLUSTER -- is
+ *             faster; below six items both it and GENERIC are bound by the gap between launches)
  *   DENSE     value-only (max,+) GEMM, every (prev, next) cell evaluated, one launch per timestep
  *   (PRUNED)  the exact pruned recurrence -- sorted transition rows + per-item top posteriors bound the cells that can
  *             still win, the rest are never touched -- is what ROWS, RESIDENT and CLUSTER run.  Its one-launch-per-timestep
@@ -97,8 +101,8 @@ size_t torbi_hip_workspace_bytes(int B, int T, int S);
  *             One tile per compute unit: the path for many items in flight -- several batches through
  *             torbi_hip_viterbi_decode_batches, or one batch of more than 8 * compute-units items.
  *   CLUSTER   the same kernel with each tile split over R <= 16 workgroups that scan 1/R of the next-states each and
- *             exchange their slices of every new posterior row inside the launch (write-through stores, one flag per
- *             member and timestep): the path for launches that fill at most half the compute units.  Named for a launch
+ *             exchange their slices of every new posterior row inside the launch (self-validating 16-byte pieces: no
+ *             flag, no store drain; resident_forward.hpp): the path for launches that fill at most half the compute units.  Named for a launch
  *             that fills more, it is RESIDENT.
  *   HELD      B <= 16, S <= 4096: the reference's scan with the time loop inside ONE launch: ceil(S / 8) workgroups
  *             hold 8 rows of the matrix each in registers for the whole launch and pass the posterior rows to each
