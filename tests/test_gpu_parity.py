@@ -2066,3 +2066,31 @@ def test_backtrace_in_speculative_segments_is_the_whole_path(path, segments, for
         else:
             assert int(stats[122]) == int((np.clip(frames, 1, T) - 1).sum())
             assert int(stats[123]) <= int(stats[122])
+
+
+def test_cluster_exchange_survives_the_one_nan_it_uses_as_absent(forward, monkeypatch):
+    """The cluster form's exchange marks a slice that has not arrived with one NaN bit pattern (resident_forward.hpp,
+    kAbsentBits).  NaNs are out of contract -- but an observation that carries exactly that pattern must not hang the
+    call: the members that wait for the poisoned row give up within the wait budget, the tile is decoded again by the
+    repair launch, every other sequence still equals the oracle's."""
+    if forward != 'auto':
+        pytest.skip('names its path itself')
+    import time
+    monkeypatch.setenv('TORBI_HIP_CLUSTER_WAIT_US', '3000')
+    dev = torch.device('cuda:0')
+    B, T, S = 48, 12, 1440
+    obs, trans, init = synth.problem(B, T, S, seed=21)
+    frames = np.full((B,), T, np.int32)
+    want = oracle.decode(obs, frames, trans, init)
+    poisoned = obs.copy()
+    poisoned.view(np.uint32)[5, 6, 700] = 0x7fd5a5a5            # item 5 (tile 0), timestep 6
+    args = [torch.as_tensor(np.ascontiguousarray(x)).to(dev) for x in (poisoned, frames, trans, init)]
+    space = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = torbi_amd.decode(*args, path='cluster', workspace=space).cpu().numpy()
+    assert time.perf_counter() - t0 < 5.0
+    stats = viterbi.scan_stats(space, B, T, S).cpu()
+    assert int(stats[127]) > 0                                  # somebody gave up, the repair launch ran
+    clean = [b for b in range(B) if b != 5]
+    np.testing.assert_array_equal(got[clean], want[clean])

@@ -9,13 +9,13 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 1440
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 trans = viterbi.fill_synthetic((S, S), synth.STREAM_TRANSITION, device=dev)
 init = viterbi.fill_synthetic((S,), synth.STREAM_INITIAL, device=dev)
-for B in (4,5,6,8,12,16,17,24):
+for B in (2,3,4,5,6,8,12,16,17,24):
     obs = viterbi.fill_synthetic((B, T, S), synth.STREAM_OBSERVATION, device=dev)
     frames = torch.full((B,), T, dtype=torch.int32, device=dev)
     ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
     line=f'B={B}:'
     ref=None
-    for path in ('auto','cluster','dense'):
+    for path in ('auto','cluster','dense','pruned'):
         got=torbi_amd.decode(obs, frames, trans, init, workspace=ws, path=path)
         ref = got if ref is None else ref
         ts=[]
