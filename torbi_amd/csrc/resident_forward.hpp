@@ -804,7 +804,10 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                         float4 got[kRound];
                         unsigned missing = 0u;
 #pragma unroll
-                        for (int u = 0; u < kRound; ++u) missing |= (first + tid + u * 64 * KW < pieces ? 1u : 0u) << u;
+                        for (int u = 0; u < kRound; ++u) {
+                            missing |= (first + tid + u * 64 * KW < pieces ? 1u : 0u) << u;
+                            got[u] = make_float4(0.f, 0.f, 0.f, 0.f);       // (a piece that is never asked for counts as there)
+                        }
                         for (;;) {
 #pragma unroll
                             for (int u = 0; u < kRound; ++u)
