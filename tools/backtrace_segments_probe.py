@@ -11,7 +11,7 @@ from torbi_amd import viterbi, synth
 dev = torch.device('cuda:0')
 import math
 for (B, T, S, path) in [(512, 500, 1440, 'cluster'), (64, 500, 1440, 'cluster'), (512, 500, 1440, 'band'), (512, 500, 1440, 'band-peaked'),
-                        (512, 500, 1440, 'band-smooth'), (128, 300, 4096, 'cluster')]:
+                        (512, 500, 1440, 'band-smooth'), (512, 500, 1440, 'band-mixed'), (128, 300, 4096, 'cluster')]:
     init = viterbi.fill_synthetic((S,), synth.STREAM_INITIAL, device=dev)
     obs = viterbi.fill_synthetic((B, T, S), synth.STREAM_OBSERVATION, device=dev)
     kind, path = path, path.split('-')[0]
@@ -23,6 +23,9 @@ for (B, T, S, path) in [(512, 500, 1440, 'cluster'), (64, 500, 1440, 'cluster'),
         else:
             centre = (S / 2 + torch.cumsum(torch.randn((B, T, 1), device=dev, generator=gen) * 12.0, dim=1)).remainder(S).long()
         logits -= ((torch.arange(S, device=dev)[None, None, :] - centre).abs().float() / 12.0) ** 2
+        if kind.endswith('mixed'):      # stretches of 50 frames without a peak (unvoiced), 50 with one
+            flat = ((torch.arange(T, device=dev) // 50) %% 2 == 1)[None, :, None]
+            logits = torch.where(flat, torch.randn((B, T, S), device=dev, generator=gen) * 0.3, logits)
         obs = torch.log_softmax(logits, dim=-1).clamp_(min=math.log(torch.finfo(torch.float32).tiny))
     if path == 'band':
         x = torch.arange(S, device=dev, dtype=torch.float32)
