@@ -82,8 +82,8 @@ struct Plan {
 struct Exchange {
     char *xchg[resident::kMaxBatches];   // per batch: [tiles] x { [2 parities][16 items][2 halves][S / 4] granules of 16 bytes,
                                          // [16] the members' XCDs + 1 (256 bytes) }
-    int tiles;                           // tiles of the group
-    unsigned *control;                   // [0 .. 7] tickets drawn per dispatch class (zeroed before the launch)
+    int tile0, tiles;                    // this launch decodes tiles [tile0, tiles) of the group's tile map (tile0 % 8 == 0)
+    unsigned *control;                   // [0 .. 7] tickets drawn per dispatch class IN THIS LAUNCH (zeroed before it)
     unsigned *failed;                    // [tiles of the group] set by a member that gave up waiting (zeroed before the launch)
     unsigned long long wait_ticks;       // budget of one wait (100 MHz ticks)
 };
@@ -91,12 +91,16 @@ struct Exchange {
 __host__ __device__ inline size_t xchg_tile_bytes(int S) { return (size_t)2 * kNI * (size_t)S * 8 + 256; }
 __host__ __device__ inline size_t xchg_bytes(int B, int S) { return (size_t)((B + kNI - 1) / kNI) * xchg_tile_bytes(S); }
 
-// The plan for `tiles` tiles on `cus` compute units, or false when the band kernel does not cover the shape.
+// The plan for `tiles` tiles on `cus` compute units, or false when the band kernel does not cover the shape.  A dispatch
+// class (workgroups b, b + 8, ...) runs on ONE XCD and holds R x ceil(tiles / 8) members, all of which must be resident at
+// once (they wait for each other inside the launch): the plan takes the largest R that fits the XCD's cus / 8 units; when
+// even the smallest R the LDS allows does not, the caller decodes tiles_per_launch(pl, cus) tiles per launch.
+inline int tiles_per_launch(const Plan &pl, int cus) { return pl.R == 1 ? 1 << 30 : 8 * ((cus / 8) / pl.R); }
 inline bool make_plan(int S, int hl, int hr, int tiles, int cus, Plan &pl) {
     if (S < 64 || S % 4 != 0 || hl < 0 || hr < 0 || hl >= S || hr >= S || tiles < 1) return false;
     if (hl + hr + 4 > kMaxWindow) return false;
     const int Dq = (hl + hr + 1 + 3) / 4;
-    const int want = std::max(1, std::min(kMaxR, cus / tiles));
+    const int want = std::max(1, std::min(kMaxR, (cus / 8) / ((tiles + 7) / 8)));
     int best = 0;
     Plan found{};
     for (int R = 1; R <= kMaxR; ++R) {
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
         __syncthreads();
         const int ticket = __builtin_amdgcn_readfirstlane(smisc[0]);
         member = ticket % R;
-        cid = (ticket / R) * 8 + cls;
+        cid = ex.tile0 + (ticket / R) * 8 + cls;
         if (cid >= ex.tiles) return;            // (the grid is padded to whole classes)
     }
     const int code = grp.tile_map[cid];

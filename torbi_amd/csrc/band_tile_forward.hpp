@@ -1,0 +1,316 @@
+// band_tile_forward.hpp -- the band recurrence of band_forward.hpp with ONE workgroup per 16-item tile: every next-state
+// of the tile in one workgroup, the time loop inside the launch, no hand-off between workgroups at all.
+//
+// Where band_forward.hpp splits a tile over R workgroups so that each member's slab of the band fits its LDS (and pays for
+// it with halo granules, tickets, bounded waits and three barriers per timestep), a launch group that has a tile for
+// every compute unit needs no split: the workgroup keeps the tile's whole window of the previous posterior row in the LDS
+//     W   [4 item groups][S + 4 Dq - 1 rows][4 items]                         103.5 KB at 1440 states, reach 87
+// and STREAMS the band.  The band is packed once per launch, diagonal-major in the order the lanes read it,
+//     tpack [64-next block][dquad q][16 groups of four next-states][4 diagonals][4 next]     1 KiB per (block, dquad)
+// (1.0 MB at 1440 states, reach 87: it stays in every XCD's 4 MB L2, where the 32 workgroups of the XCD read the same
+// bytes), and a wave copies the KiB of its next dquads by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write)
+// into a ring of four 1 KiB stages of its own -- three dquads ahead, so that a stage has ~2 dquads (500 - 1 500 cycles) to
+// land -- and reads it back with the same ds_read_b128 broadcasts as the split kernel reads its slab: per dquad and lane
+// 4 x 16 B of band + 4 x 16 B of window for 64 cells (64 v_add_f32 + 32 v_max3_f32); 16 B per compute unit and clock
+// from the L2 at the vector ALU's rate.  The issuing wave is the only reader of its ring: its own s_waitcnt vmcnt(2)
+// (exactly two younger copies are in flight at every dquad) is the whole synchronisation.
+//
+// A lane owns 4 next-states x 4 items (as in the split kernel) for ALL diagonals of a 64-next block, so the waves share no
+// outputs: no merge buffer, no atomics.  A wave scans its blocks one after the other (wave w: blocks w, w + waves), keeps
+// the finished values in registers, and the timestep ends with
+//     observations of row t + 1 asked for, history stores, barrier (every wave is done with the window),
+//     own rows -> window, barrier
+// -- two barriers per timestep of ~27 us, nothing else between workgroups or waves.  Arithmetic and results are those of
+// band_forward.hpp (viterbi.cpp:81-104 over the band: -inf candidates never win the strict '>').
+#pragma once
+
+#include "band_forward.hpp"
+
+namespace band {
+
+constexpr int kTileWaves = 12;           // at most (three per SIMD: 168 registers a lane; eight waves: 256)
+constexpr int kTileBlocks = 3;           // 64-next blocks per wave, at most
+constexpr int kTileSlots = 24;           // waves x blocks per wave, at most
+constexpr int kRing = 4;                 // stages of the band ring per wave, 1 KiB each
+
+struct TilePlan {
+    int S, hl, hr;
+    int Dq, Dq4;             // dquads of the band; rounded up to whole turns of the ring (the tail is never evaluated)
+    int n_jg, nblk;          // groups of four next-states, 64-next blocks
+    int waves, bpw;          // waves per workgroup; blocks per wave
+    int w_rows, ig_stride;   // rows of the window (row w holds state w - hl); floats between the item groups' windows
+    int w_off, ring_off, misc_off, lds_bytes;
+};
+
+__host__ __device__ inline size_t tile_pack_bytes(int nblk, int Dq4) { return (size_t)nblk * Dq4 * 1024; }
+// what a workspace sets aside for the packed band of any reach the plan accepts
+inline size_t tile_pack_bytes_max(int S) {
+    if (S % 4 != 0 || S > 64 * kTileSlots) return 0;
+    return tile_pack_bytes((S / 4 + 15) / 16, kMaxWindow / 4);
+}
+
+// `waves_wanted`: 0, or 8 / 12 for shapes of more than 8 blocks (experiments)
+inline bool make_tile_plan(int S, int hl, int hr, TilePlan &p, int waves_wanted = 0) {
+    if (S < 64 || S % 4 != 0 || hl < 0 || hr < 0 || hl >= S || hr >= S) return false;
+    if (hl + hr + 4 > kMaxWindow) return false;
+    p.S = S; p.hl = hl; p.hr = hr;
+    p.Dq = (hl + hr + 1 + 3) / 4;
+    p.Dq4 = (p.Dq + 3) / 4 * 4;
+    p.n_jg = S / 4;
+    p.nblk = (p.n_jg + 15) / 16;
+    if (p.nblk > kTileSlots) return false;
+    p.waves = p.nblk <= 4 ? 4 : p.nblk <= 8 ? 8 : kTileWaves;
+    if (p.nblk > 8 && (waves_wanted == 8 || waves_wanted == 12)) p.waves = waves_wanted;
+    p.bpw = (p.nblk + p.waves - 1) / p.waves;
+    if (p.bpw > (p.waves == 12 ? 2 : 3)) return false;
+    p.w_rows = S + 4 * p.Dq - 1;
+    p.ig_stride = 4 * p.w_rows;
+    while (p.ig_stride % 64 != 4) p.ig_stride += 4;
+    p.w_off = 0;
+    p.ring_off = p.w_off + 4 * p.ig_stride * 4;
+    p.misc_off = p.ring_off + p.waves * kRing * 1024;
+    p.lds_bytes = p.misc_off + 256;
+    return p.lds_bytes <= kLdsBytes;
+}
+
+// the band, packed: grid = nblk * Dq4, block = 64 (lane = group of four next-states x diagonal of the dquad)
+__global__ __launch_bounds__(64) void pack_band_kernel(const float *__restrict__ trans, float *__restrict__ tpack, int S, int hl,
+                                                       int hr, int Dq, int Dq4) {
+    const int blk = (int)blockIdx.x / Dq4, q = (int)blockIdx.x - blk * Dq4, lane = threadIdx.x;
+    const int jgl = lane >> 2, dd = 4 * q + (lane & 3);
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = 4 * (16 * blk + jgl) + k, i = j + dd - hl;
+        const bool in = q < Dq && j < S && i >= 0 && i < S && dd <= hl + hr;
+        v[k] = in ? trans[(size_t)j * S + i] : -INFINITY;
+    }
+    reinterpret_cast<float4 *>(tpack)[(size_t)blockIdx.x * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+#ifndef BAND_TILE_ABL
+#define BAND_TILE_ABL 0       // build-time ablations (timing only, results wrong): 1 no band copies (the ring keeps what it has),
+                              // 2 no history stores, 4 no observation loads, 8 no barriers, 16 no dquads
+#endif
+
+// 1 KiB, global -> LDS: lane l's 16 bytes from `base + voff` to LDS byte address `dst + 16 l` (dst wave-uniform, through M0)
+__device__ __forceinline__ void glds16s(const char *base, unsigned voff, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(base), "s"(dst)
+                 : "memory");
+}
+
+#ifdef BAND_STAMP
+#define TSTAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); bacc[i] += now_ - blast; blast = now_; }
+#else
+#define TSTAMP(i)
+#endif
+
+// grid = tiles of the group, block = 64 * pl.waves, dynamic LDS = pl.lds_bytes
+template <int BPW, int NW>
+__global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan pl, const float *__restrict__ tpack,
+                                                                    const float *__restrict__ initial) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float *const wq = reinterpret_cast<float *>(lds + pl.w_off);
+    int *const sframes = reinterpret_cast<int *>(lds + pl.misc_off);                                 // [16] frames per item (0 past the batch)
+    unsigned long long *const sbase = reinterpret_cast<unsigned long long *>(lds + pl.misc_off + 64);  // [16] element offset of the item
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nthreads = 64 * pl.waves;
+    const unsigned long long clock_0 = clock64(), wall_0 = wall_clock64();      // (stats[120], [121]: the clock under this load)
+    const int S = pl.S, hl = pl.hl, Dq = pl.Dq, Dq4 = pl.Dq4, n_jg = pl.n_jg;
+
+    const int code = grp.tile_map[blockIdx.x];
+    const int bk = code >> 20, tile = code & 0xfffff;
+    const Batch &bat = grp.batch[bk];
+    const float *__restrict__ obs = bat.obs;
+    float *__restrict__ hist = bat.hist;
+    const int B = bat.B, T = bat.T;
+    const int b0 = tile * kNI;
+
+    if (tid < kNI) {
+        int f = 0;
+        const int item = bat.order[b0 + tid < B ? b0 + tid : B - 1];
+        if (b0 + tid < B) {
+            f = bat.frames[item];
+            f = f < 1 ? 1 : (f > T ? T : f);
+        }
+        sframes[tid] = f;
+        sbase[tid] = (unsigned long long)item * (unsigned long long)T * (unsigned long long)S;
+    }
+    // rows outside the matrix stay 0: their band entries are -inf
+    for (int e = tid; e < 4 * pl.ig_stride; e += nthreads) wq[e] = 0.0f;
+    __syncthreads();
+    int fmax = 0;
+#pragma unroll
+    for (int it = 0; it < kNI; ++it) fmax = max(fmax, sframes[it]);
+
+    // ---- the lane: 4 next-states (group jg) x 4 items (group ig) of each of the wave's blocks ----------------------------
+    const int ig = lane & 3, jgl = lane >> 2;
+    int jg[BPW];
+    bool rowok[BPW];
+    unsigned goff[BPW];                    // byte offset of the block's first dquad in the packed band
+    int nb = 0;
+#pragma unroll
+    for (int u = 0; u < BPW; ++u) {
+        const int blk = wave + u * pl.waves;
+        const bool has = blk < pl.nblk;
+        nb += has ? 1 : 0;
+        const int raw = 16 * blk + jgl;
+        rowok[u] = has && raw < n_jg;
+        jg[u] = raw < n_jg ? raw : n_jg - 1;
+        goff[u] = (unsigned)(has ? blk : 0) * (unsigned)Dq4 * 1024u;
+    }
+    nb = __builtin_amdgcn_readfirstlane(nb);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
+    const unsigned ring_m0 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)pl.ring_off + (unsigned)wave * (kRing * 1024u));
+    const char *const ring_lane = lds + pl.ring_off + wave * (kRing * 1024) + jgl * 64;
+    const char *const tp_bytes = reinterpret_cast<const char *>(tpack);
+    const unsigned voff = (unsigned)lane * 16u;
+
+    // the band ring: copies are issued in the order the dquads are evaluated, three ahead, for ever
+    unsigned d_off = __builtin_amdgcn_readfirstlane(goff[0]);
+    int d_q = 0, d_u = 0;
+    auto copy_next = [&](unsigned stage) {
+        if (!(BAND_TILE_ABL & 1)) glds16s(tp_bytes + d_off, voff, ring_m0 + stage * 1024u);
+        ++d_q;
+        d_off += 1024u;
+        if (d_q == Dq4) {
+            d_q = 0;
+            d_u = d_u + 1 == nb ? 0 : d_u + 1;
+            unsigned o = goff[0];
+#pragma unroll
+            for (int u = 1; u < BPW; ++u) o = d_u == u ? goff[u] : o;
+            d_off = __builtin_amdgcn_readfirstlane(o);
+        }
+    };
+    auto landed = [&]() {          // all but the two youngest copies have landed
+        if (!(BAND_TILE_ABL & 1)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    };
+    auto barrier = [&]() {         // (not __syncthreads(): its fence would wait for the copies in flight)
+        if (!(BAND_TILE_ABL & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    // post'[j] = obs[t][j] + max (viterbi.cpp:102); row 0 = obs[b][0][:] + initial (viterbi.cpp:72-76)
+    float4 ob[BPW][4] = {};         // observations of the row being finished: [block][item] x 4 next-states
+    float v[BPW][16];               // the finished rows: [block][4 next + item]
+    // (the items' offsets and lengths are read from the LDS where they are used: twelve registers less across the scans)
+    auto ask = [&](int t) {
+        const int tr = t < fmax ? t : fmax - 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float *row = obs + sbase[4 * ig + c] + (size_t)tr * S;
+#pragma unroll
+            for (int u = 0; u < BPW; ++u)
+                if (!(BAND_TILE_ABL & 4) && u < nb) ob[u][c] = *reinterpret_cast<const float4 *>(row + 4 * jg[u]);
+        }
+    };
+    auto finish = [&](int u, const float (&acc)[16]) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            v[u][0 + c] = ob[u][c].x + acc[0 + c];
+            v[u][4 + c] = ob[u][c].y + acc[4 + c];
+            v[u][8 + c] = ob[u][c].z + acc[8 + c];
+            v[u][12 + c] = ob[u][c].w + acc[12 + c];
+        }
+    };
+    auto close_timestep = [&](int t) {
+        ask(t + 1);
+        if (!(BAND_TILE_ABL & 2)) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float *row = hist + sbase[4 * ig + c] + (size_t)t * S;
+                const bool live = t < sframes[4 * ig + c];
+#pragma unroll
+                for (int u = 0; u < BPW; ++u)
+                    if (rowok[u] && live)
+                        *reinterpret_cast<float4 *>(row + 4 * jg[u]) = make_float4(v[u][c], v[u][4 + c], v[u][8 + c], v[u][12 + c]);
+            }
+        }
+        if (t + 1 >= fmax) return;
+        barrier();                      // every wave is done with the window of row t - 1
+#pragma unroll
+        for (int u = 0; u < BPW; ++u)
+            if (rowok[u]) {
+                float *at = wq + ig * pl.ig_stride + 4 * (hl + 4 * jg[u]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    *reinterpret_cast<float4 *>(at + 4 * k) = make_float4(v[u][4 * k], v[u][4 * k + 1], v[u][4 * k + 2], v[u][4 * k + 3]);
+            }
+        barrier();                      // the window holds row t
+    };
+
+    if (nb > 0) {
+        ask(0);
+#pragma unroll
+        for (int u = 0; u < BPW; ++u) {
+            float first[16];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float x = initial[4 * jg[u] + k];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) first[4 * k + c] = x;
+            }
+            finish(u, first);
+        }
+        if (fmax > 1)
+            for (int r = 0; r < kRing - 1; ++r) copy_next((unsigned)r);
+    }
+    close_timestep(0);
+
+#ifdef BAND_STAMP
+    unsigned long long bacc[kPhases] = {};
+    unsigned long long blast = __builtin_readcyclecounter();
+#endif
+    for (int t = 1; t < fmax; ++t) {
+#pragma unroll
+        for (int u = 0; u < BPW; ++u) {
+            if (u >= nb) continue;
+            float acc[16];
+            float4 w[8], tt[4];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = -INFINITY;
+            const char *const w0 = lds + pl.w_off + (ig * pl.ig_stride + 16 * jg[u]) * 4;
+            landed();                   // the block's first stage
+#pragma unroll
+            for (int d = 0; d < 4; ++d) tt[d] = lds_f4(ring_lane + 16 * d);
+#pragma unroll
+            for (int m = 0; m < 7; ++m) w[m] = lds_f4(w0 + 16 * m);
+            TSTAMP(0);
+            for (int q = 0; q < Dq4; q += 4) {
+                const char *const wp = w0 + (size_t)q * 64;
+                copy_next(3u);
+                landed();
+                if (!(BAND_TILE_ABL & 16)) dquad<0>(acc, w, tt, ring_lane + 1024, wp + 64);
+                copy_next(0u);
+                landed();
+                if (q + 1 < Dq && !(BAND_TILE_ABL & 16)) dquad<1>(acc, w, tt, ring_lane + 2048, wp + 128);
+                copy_next(1u);
+                landed();
+                if (q + 2 < Dq && !(BAND_TILE_ABL & 16)) dquad<0>(acc, w, tt, ring_lane + 3072, wp + 192);
+                copy_next(2u);
+                landed();
+                if (q + 3 < Dq && !(BAND_TILE_ABL & 16)) dquad<1>(acc, w, tt, ring_lane, wp + 256);
+            }
+            TSTAMP(1);
+            finish(u, acc);
+        }
+        TSTAMP(2);
+        close_timestep(t);
+        TSTAMP(3);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (no copy may land in an LDS that is no longer this workgroup's)
+#ifdef BAND_STAMP
+    if (lane == 0 && blockIdx.x < 1024)
+        for (int i = 0; i < kPhases; ++i) g_phase[((size_t)blockIdx.x * kMaxWaves + wave) * kPhases + i] = bacc[i];
+#endif
+    if (blockIdx.x == 0 && tid == 0) {
+        grp.stats[120] = (unsigned)((clock64() - clock_0) >> 4);
+        grp.stats[121] = (unsigned)((wall_clock64() - wall_0) >> 4);
+    }
+}
+
+}  // namespace band

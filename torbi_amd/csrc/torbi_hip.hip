@@ -35,6 +35,7 @@
 #include "held_matrix_forward.hpp"
 #include "small_states.hpp"
 #include "band_forward.hpp"
+#include "band_tile_forward.hpp"
 
 namespace {
 
@@ -738,9 +739,11 @@ struct BandWorkspace {
     ResidentWorkspace base;
     char *xchg;
     size_t xchg_bytes;
-    unsigned *words;      // [0] tickets, [16 ..] failed[kMaxGroupTiles]
+    unsigned *words;      // [16 ..] failed[kMaxGroupTiles], behind them [8] tickets per launch of the group
+    float *tpack;         // whole tiles (band_tile_forward.hpp): the band as the lanes read it
     size_t bytes;
 };
+constexpr size_t kBandWords = 16 + 2 * (size_t)kMaxGroupTiles + 64;
 inline BandWorkspace carve_band(void *base, int B, int T, int S, int cus) {
     BandWorkspace w;
     void *const kept = g_preparation;
@@ -751,7 +754,9 @@ inline BandWorkspace carve_band(void *base, int B, int T, int S, int cus) {
     w.xchg_bytes = align_up(band::xchg_bytes(B, S), 256);
     w.xchg = p;
     w.words = reinterpret_cast<unsigned *>(p + w.xchg_bytes);
-    w.bytes = w.base.bytes + w.xchg_bytes + sizeof(unsigned) * (kMaxGroupTiles + 64);
+    const size_t word_bytes = align_up(sizeof(unsigned) * kBandWords, 256);
+    w.tpack = reinterpret_cast<float *>(p + w.xchg_bytes + word_bytes);
+    w.bytes = w.base.bytes + w.xchg_bytes + word_bytes + align_up(band::tile_pack_bytes_max(S), 256);
     return w;
 }
 
@@ -1521,8 +1526,35 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
 inline int band_tiles(int B) { return (B + band::kNI - 1) / band::kNI; }
 
 // batches with B > 0 only; tile map, statistics, tickets and give-up flags live in the first batch's workspace
-hipError_t run_band(const HostBatch *hb, int n, const float *trans, const float *init, int S, const band::Plan &pl, int cus,
+// What the band route does with a launch group: whole tiles (band_tile_forward.hpp: one workgroup per tile, once the group
+// has a tile for at least every other compute unit) or tiles split over R members (band_forward.hpp), `cap` tiles per
+// launch -- every member of a launch resident at once, because they wait for each other inside it.
+struct BandChoice {
+    band::Plan pl;          // split form (pl.R members per tile); whole tiles: S, hl, hr and R = 1 only
+    band::TilePlan tile;
+    bool whole;
+    int cap;                // tiles per launch (split form)
+};
+inline bool choose_band(int S, int hl, int hr, int tiles, int cus, BandChoice &c) {
+    c = BandChoice{};
+    if (tiles < 1) return false;
+    const char *force = getenv("TORBI_HIP_BAND_FORM");            // experiments: "tile" / "split"
+    const char *tw = getenv("TORBI_HIP_TILE_WAVES");              // experiments: 8 / 12 waves per workgroup
+    const bool tile_ok = band::make_tile_plan(S, hl, hr, c.tile, tw ? atoi(tw) : 0) && !(force && force[0] == 's');
+    if (tile_ok && (2 * tiles >= cus || (force && force[0] == 't'))) {
+        c.whole = true;
+        c.pl.S = S; c.pl.hl = hl; c.pl.hr = hr; c.pl.R = 1;
+        c.cap = tiles;
+        return true;
+    }
+    if (!band::make_plan(S, hl, hr, tiles, cus, c.pl)) return false;
+    c.cap = std::min(band::tiles_per_launch(c.pl, cus), kMaxGroupTiles);
+    return c.cap >= 1;
+}
+
+hipError_t run_band(const HostBatch *hb, int n, const float *trans, const float *init, int S, const BandChoice &choice, int cus,
                     hipStream_t s, hipEvent_t *ev, int *launches, bool ascending) {
+    const band::Plan &pl = choice.pl;
     resident::Group grp{};
     resident::OrderJobs jobs{};
     band::Exchange ex{};
@@ -1563,14 +1595,16 @@ hipError_t run_band(const HostBatch *hb, int n, const float *trans, const float 
     jobs.tiles = tiles;
     jobs.tile_map = w.base.tile_map;
     jobs.ni = band::kNI;
-    ex.control = w.words;
+    const int nlaunch = choice.whole ? 1 : (tiles + choice.cap - 1) / choice.cap;
     ex.failed = w.words + 16;
-    ex.tiles = tiles;
+    unsigned *const tickets = w.words + 16 + kMaxGroupTiles;        // [8] per launch
     const char *wait_env = getenv("TORBI_HIP_CLUSTER_WAIT_US");         // (read per launch: the tests switch it)
     ex.wait_ticks = wait_env ? 100ull * strtoull(wait_env, nullptr, 10) : resident::kClusterWaitTicks;
     clear.words = w.words;
-    clear.nwords = 16 + tiles;
+    clear.nwords = 16 + kMaxGroupTiles + 8 * nlaunch;
     clear.n = n;
+    if (choice.whole)
+        for (int k = 0; k < n; ++k) clear.bytes[k] = 0;
     if (ev) (void)hipEventRecord(ev[0], s);
     hipLaunchKernelGGL(resident::order_items_kernel, dim3((widest + 255) / 256, n), dim3(256), 0, s, jobs);
     for (int k = 0; k < n; ++k) {            // batches too large for the all-pairs ranking: counting sort over the lengths
@@ -1584,26 +1618,55 @@ hipError_t run_band(const HostBatch *hb, int n, const float *trans, const float 
         hipLaunchKernelGGL(resident::order_large_place_kernel, dim3((jb.B + 255) / 256), dim3(256), 0, s, jb);
     }
     hipLaunchKernelGGL(resident::order_tiles_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, jobs);
-    {
-        const size_t blocks = std::max<size_t>(1, std::min<size_t>(2048, (most / 16 + 255) / 256));
-        hipLaunchKernelGGL(band::clear_exchange_kernel, dim3((unsigned)blocks, n), dim3(256), 0, s, clear);
-    }
-    if (ev) (void)hipEventRecord(ev[3], s);
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&band::band_forward_kernel), (size_t)pl.lds_bytes);
-    if (e != hipSuccess) return e;
-    TORBI_NOTE_KERNEL("band::band_forward_kernel");
-    // (R > 1: eight dispatch classes of R x ceil(tiles / 8) workgroups each -- band_forward.hpp, membership)
-    const int grid = pl.R > 1 ? 8 * ((tiles + 7) / 8) * pl.R : tiles;
-    hipLaunchKernelGGL(band::band_forward_kernel, dim3(grid), dim3(64 * pl.waves), (size_t)pl.lds_bytes, s, grp, ex, pl,
-                       trans, init);
-    if (pl.R > 1) {          // does nothing unless a member gave up waiting (band_forward.hpp)
-        const size_t lds = 32 * (size_t)S;
-        e = ensure_dynamic_lds(reinterpret_cast<const void *>(&band::band_repair_kernel), lds);
+    hipError_t e;
+    if (choice.whole) {
+        // whole tiles: the band packed in the lanes' reading order (1 MB at 1440 states, reach 87: ~10 us), then ONE launch
+        const band::TilePlan &tp = choice.tile;
+        hipLaunchKernelGGL(band::pack_band_kernel, dim3(tp.nblk * tp.Dq4), dim3(64), 0, s, trans, w.tpack, S, tp.hl, tp.hr, tp.Dq,
+                           tp.Dq4);
+        if (ev) (void)hipEventRecord(ev[3], s);
+#define TORBI_BAND_TILE(BPW_, NW_)                                                                                                \
+        {                                                                                                                         \
+            e = ensure_dynamic_lds(reinterpret_cast<const void *>(&band::band_tile_kernel<BPW_, NW_>), (size_t)tp.lds_bytes);     \
+            if (e != hipSuccess) return e;                                                                                        \
+            TORBI_NOTE_KERNEL("band::band_tile_kernel<" #BPW_ ", " #NW_ ">");                                                     \
+            hipLaunchKernelGGL((band::band_tile_kernel<BPW_, NW_>), dim3(tiles), dim3(64 * tp.waves), (size_t)tp.lds_bytes, s,    \
+                               grp, tp, w.tpack, init);                                                                          \
+        }
+        if (tp.bpw == 1) TORBI_BAND_TILE(1, 12)
+        else if (tp.waves == 12) TORBI_BAND_TILE(2, 12)
+        else if (tp.bpw == 2) TORBI_BAND_TILE(2, 8)
+        else TORBI_BAND_TILE(3, 8)
+#undef TORBI_BAND_TILE
+    } else {
+        {
+            const size_t blocks = std::max<size_t>(1, std::min<size_t>(2048, (most / 16 + 255) / 256));
+            hipLaunchKernelGGL(band::clear_exchange_kernel, dim3((unsigned)blocks, n), dim3(256), 0, s, clear);
+        }
+        if (ev) (void)hipEventRecord(ev[3], s);
+        e = ensure_dynamic_lds(reinterpret_cast<const void *>(&band::band_forward_kernel), (size_t)pl.lds_bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(band::band_repair_kernel, dim3(tiles), dim3(1024), lds, s, grp, ex.failed, trans, init, S, pl.hl,
-                           pl.hr);
+        TORBI_NOTE_KERNEL("band::band_forward_kernel");
+        // (R > 1: eight dispatch classes of R x ceil(tiles / 8) workgroups each -- band_forward.hpp, membership; a launch
+        // never holds more members than one XCD has units for its class: choose_band)
+        for (int l = 0; l < nlaunch; ++l) {
+            ex.tile0 = l * choice.cap;
+            ex.tiles = std::min(tiles, ex.tile0 + choice.cap);
+            ex.control = tickets + 8 * l;
+            const int here = ex.tiles - ex.tile0;
+            const int grid = pl.R > 1 ? 8 * ((here + 7) / 8) * pl.R : here;
+            hipLaunchKernelGGL(band::band_forward_kernel, dim3(grid), dim3(64 * pl.waves), (size_t)pl.lds_bytes, s, grp, ex, pl,
+                               trans, init);
+        }
+        if (pl.R > 1) {          // does nothing unless a member gave up waiting (band_forward.hpp)
+            const size_t lds = 32 * (size_t)S;
+            e = ensure_dynamic_lds(reinterpret_cast<const void *>(&band::band_repair_kernel), lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(band::band_repair_kernel, dim3(tiles), dim3(1024), lds, s, grp, ex.failed, trans, init, S, pl.hl,
+                               pl.hr);
+        }
     }
-    if (launches) *launches = 1;
+    if (launches) *launches = nlaunch;
     if (ev) (void)hipEventRecord(ev[1], s);
     const int K = backtrace_segments(items);          // (few paths: speculative segments, as behind run_resident)
     int32_t *const arrive = w.base.tile_map;
@@ -1626,7 +1689,7 @@ hipError_t run_band(const HostBatch *hb, int n, const float *trans, const float 
 
 // AUTO takes the band kernel for a promised band when its plan covers the group -- except for shapes a wavefront or a
 // workgroup decodes alone (small_states.hpp) and for the handful of sequences of the held-matrix kernel
-inline bool band_plan_for(const HostBatch *hb, int n, int S, int hl, int hr, int cus, int path, band::Plan &pl) {
+inline bool band_plan_for(const HostBatch *hb, int n, int S, int hl, int hr, int cus, int path, BandChoice &pl) {
     if (path != TORBI_HIP_FORWARD_AUTO && path != TORBI_HIP_FORWARD_BAND) return false;
     if (!band_shape(S)) return false;
     int tiles = 0;
@@ -1637,7 +1700,7 @@ inline bool band_plan_for(const HostBatch *hb, int n, int S, int hl, int hr, int
         if (small::supported(S) || small_block_auto((int)std::min(items, 1ll << 30), S, cus)) return false;
         if (n == 1 && held::supported(hb[0].B, S, cus) && held_auto(hb[0].B, S)) return false;
     }
-    return band::make_plan(S, hl, hr, tiles, cus, pl);
+    return choose_band(S, hl, hr, tiles, cus, pl);
 }
 
 // one decode on `s`; optional events bracket the forward and backtrace phases (ev[3]: end of the preparation)
@@ -1926,9 +1989,9 @@ int torbi_hip_band_reach(const float *transition, int S, int device, void *strea
 
 int torbi_hip_band_members(int items, int S, int reach_left, int reach_right, int device) {
     if (items < 1 || S < 1 || reach_left < 0 || reach_right < 0) return TORBI_HIP_EINVAL;
-    band::Plan pl;
-    if (!band_shape(S) || !band::make_plan(S, reach_left, reach_right, band_tiles(items), cu_count(device), pl)) return 0;
-    return pl.R;
+    BandChoice c;
+    if (!band_shape(S) || !choose_band(S, reach_left, reach_right, band_tiles(items), cu_count(device), c)) return 0;
+    return c.pl.R;
 }
 
 int torbi_hip_viterbi_decode_banded(const torbi_hip_batch *batches, int count, const float *transition, const float *initial,
@@ -1949,7 +2012,7 @@ int torbi_hip_viterbi_decode_banded(const torbi_hip_batch *batches, int count, c
         if (b.B == 0) continue;
         hb[n++] = HostBatch{b.observation, b.batch_frames, b.indices_out, b.workspace, b.B, b.T};
     }
-    band::Plan pl;
+    BandChoice pl;
     const int path = requested_path(flags);
     bool vec = (reinterpret_cast<uintptr_t>(transition) & 15) == 0;       // (16-byte reads of matrix rows and observation rows)
     for (int k = 0; k < n; ++k) vec = vec && (reinterpret_cast<uintptr_t>(hb[k].obs) & 15) == 0;
