@@ -13,59 +13,25 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
-    config.addinivalue_line('markers', 'slow: repeats coverage the default GPU run already has (a forced forward path that '
-                                       'routes the case exactly as AUTO does, a second pass through a host path); run with '
-                                       '--runslow or TORBI_RUN_SLOW=1')
+    config.addinivalue_line('markers', 'slow: repeats coverage the default run already has (a second pass through a host '
+                                       'path); run with --runslow or TORBI_RUN_SLOW=1')
 
 
 def pytest_addoption(parser):
     parser.addoption('--runslow', action='store_true', default=False, help='also run the tests marked slow')
 
 
-# tests/test_gpu_parity.py runs every test under five forward paths (autouse fixture `forward`).  Where a forced path
-# launches exactly the kernels AUTO launches for every shape of the test, the repetition adds run time and no coverage:
-#   PATH_BLIND     tests that never reach a forward kernel choice (elementwise kernels, synthetic fill, library load):
-#                  only the 'auto' instance stays in the default run
-#   SAME_AS_AUTO   test -> forced paths that route every one of its shapes as AUTO does (fresh tensors, 256 compute units:
-#                  batches of 17..2047 items over 64..4096 states with a matrix that is not a narrow band are 'cluster'
-#                  under AUTO, and 'pruned' names the same form for them since its per-timestep tile kernel was removed;
-#                  DESIGN.md section 4)
-# Every route keeps oracle-comparing tests in the default run: cluster / held / rows / generic through 'auto' (and through
-# 'cluster' / 'pruned' wherever a test has small batches), resident and dense through their forced instances.
-PATH_BLIND = {'test_extension_is_loaded_and_sees_the_gpu', 'test_fused_epsilon_clamp_is_bit_identical_to_the_torch_ops',
-              'test_fused_log_and_epsilon_clamp_is_bit_identical_to_the_torch_ops',
-              'test_fill_synthetic_matches_numpy_definition', 'test_uniform_transition_entry_equals_materialised_matrix',
-              'test_the_default_call_on_probabilities_is_one_pass_with_the_reference_s_values',
-              'test_uniform_entry_at_every_state_count_it_takes', 'test_every_state_count_up_to_256'}
-LARGE_BATCHES_ONLY = {'cluster', 'pruned'}
-SAME_AS_AUTO = {'test_minus_inf_observations_on_the_large_batch_paths': LARGE_BATCHES_ONLY,
-                'test_pruned_path_adversarial_inputs': LARGE_BATCHES_ONLY,
-                'test_headline_shape_properties': LARGE_BATCHES_ONLY,
-                'test_large_state_shape_properties': LARGE_BATCHES_ONLY,
-                'test_inference_mode_is_supported': LARGE_BATCHES_ONLY,
-                'test_dense_path_edge_shapes': LARGE_BATCHES_ONLY,
-                # up to 256 states every named path but DENSE falls back to (or, from 64 states, repeats other tests' coverage
-                # of) what AUTO runs: the auto and dense instances stay
-                'test_one_wavefront_per_sequence_up_to_64_states': {'pruned', 'resident', 'cluster'},
-                'test_one_workgroup_per_sequence_up_to_256_states': {'pruned', 'resident', 'cluster'}}
-
-
 def pytest_collection_modifyitems(config, items):
     run_slow = config.getoption('--runslow') or os.environ.get('TORBI_RUN_SLOW') == '1'
     skip = pytest.mark.skip(reason='slow: repeats default-run coverage (--runslow / TORBI_RUN_SLOW=1 runs it)')
     for item in items:
-        callspec = getattr(item, 'callspec', None)
-        forward = callspec.params.get('forward') if callspec is not None else None
-        name = getattr(item, 'originalname', None) or item.name.split('[')[0]
-        if forward is not None and ((name in PATH_BLIND and forward != 'auto') or forward in SAME_AS_AUTO.get(name, ())):
-            item.add_marker(pytest.mark.slow)
         if not run_slow and item.get_closest_marker('slow') is not None:
             item.add_marker(skip)
 
 
 class CachedOracle:
-    """The oracle with its answers remembered by input CONTENT: tests/test_gpu_parity.py runs every test under five forward
-    paths, and the checker's answer for one seeded input does not depend on which HIP kernel is being checked.  The C
+    """The oracle with its answers remembered by input CONTENT: tests/test_gpu_parity.py runs its path-sensitive tests under
+    five forward paths, and the checker's answer for one seeded input does not depend on which HIP kernel is being checked.  The C
     restatement runs once per distinct input instead of five times (it is most of the suite's run time on a busy host).
     Everything else of the `oracle` package passes through."""
 

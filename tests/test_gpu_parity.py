@@ -18,17 +18,30 @@ oracle = CachedOracle(oracle)        # (one run of the checker per distinct inpu
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=['auto', 'dense', 'pruned', 'resident', 'cluster'])
+@pytest.fixture
 def forward(request):
-    """Every test runs under five forward paths: the automatic choice; the dense (max,+) GEMM forced; 'pruned' (the
-    sorted-row scan for batches of up to 16 items -- above that it names the time-resident forms, see conftest.py for
-    what that makes redundant); the time-resident kernel forced wherever it is supported (64 <= S <= 4096, ANY batch
-    size) with whole 16-item tiles per workgroup; and its cluster form (the next-states of a tile split over up to 16
-    workgroups that exchange their slices of every posterior row inside the launch).  Instances that launch exactly the
-    kernels another instance launches are marked slow (tests/conftest.py)."""
-    viterbi.set_forward_path(request.param)
-    yield request.param
+    """The forward path a path-sensitive test runs under (set process-wide for the test, 'auto' again behind it).  Tests
+    marked `@all_paths` run under five: the automatic choice; the dense (max,+) GEMM forced; 'pruned' (the sorted-row scan
+    for batches of up to 16 items -- above that it names the time-resident forms); the time-resident kernel forced
+    wherever it is supported (64 <= S <= 4096, ANY batch size) with whole 16-item tiles per workgroup; and its cluster form
+    (the next-states of a tile split over up to 16 workgroups that exchange their slices of every posterior row inside the
+    launch).  `@paths(...)` names fewer where a forced path launches exactly the kernels AUTO launches for every shape of
+    the test (fresh tensors, 256 compute units: batches of 17..2047 items over 64..4096 states with a matrix that is not a
+    narrow band are 'cluster' under AUTO, and 'pruned' names the same form for them).  A test without
+    either mark names its paths itself or never reaches a forward kernel choice: it runs once, under AUTO."""
+    name = getattr(request, 'param', 'auto')
+    viterbi.set_forward_path(name)
+    yield name
     viterbi.set_forward_path('auto')
+
+
+def paths(*names):
+    def mark(fn):
+        return pytest.mark.usefixtures('forward')(pytest.mark.parametrize('forward', list(names), indirect=True)(fn))
+    return mark
+
+
+all_paths = paths('auto', 'dense', 'pruned', 'resident', 'cluster')
 
 
 def gpu_decode(obs, frames, trans, init):
@@ -47,12 +60,14 @@ def test_extension_is_loaded_and_sees_the_gpu():
     assert 'gfx950' in torch.cuda.get_device_properties(0).gcnArchName
 
 
+@all_paths
 @pytest.mark.parametrize('name', SMALL_NAMES)
 def test_golden_small(golden, name):
     obs, frames, trans, init, want = golden.small_case(name)
     assert np.array_equal(gpu_decode(obs, frames, trans, init), want)
 
 
+@all_paths
 @pytest.mark.parametrize('name', LARGE_NAMES)
 def test_golden_large(golden, name):
     obs, frames, trans, init, want = golden.large_case(name)
@@ -67,6 +82,7 @@ def test_golden_large(golden, name):
                                    (512, 3, 100), (128, 5, 4096), (70, 40, 360), (600, 4, 97),
                                    (17, 7, 256), (31, 5, 1440), (24, 6, 1442), (16, 9, 1440), (200, 3, 40),
                                    (256, 4, 360), (300, 3, 1440), (272, 5, 132), (260, 3, 1443)])
+@all_paths
 @pytest.mark.parametrize('ties', [False, True])
 def test_random_shapes_against_oracle(shape, ties):
     B, T, S = shape
@@ -79,6 +95,7 @@ def test_random_shapes_against_oracle(shape, ties):
     assert np.array_equal(gpu_decode(obs, frames, trans, init), want)
 
 
+@all_paths
 @pytest.mark.parametrize('kind', ['banded', 'diagonal', 'blocks', 'dead_rows', 'dead_everything'])
 @pytest.mark.parametrize('shape', [(64, 25, 360), (40, 12, 1440), (96, 9, 131)])
 def test_dense_path_skips_minus_inf_blocks_exactly(kind, shape):
@@ -109,13 +126,11 @@ def test_dense_path_skips_minus_inf_blocks_exactly(kind, shape):
 
 
 @pytest.mark.parametrize('width', [1, 7, 254, 255, 256, 257, 300])
-def test_dense_route_backtrace_reads_the_band_only(width, forward):
+def test_dense_route_backtrace_reads_the_band_only(width):
     """On the dense route the backtrace of a banded matrix reads a row's finite range only (a window of up to 512
     prev-states, lazy::backtrace_ranged_kernel); a matrix with a wider row goes through the whole-row kernel -- decided on
     the device.  Half widths that put the widest row below, on and above the window, rows cut off by the matrix edge, a
     row without any finite entry, ties inside the band."""
-    if forward != 'auto':
-        pytest.skip('names its path itself')
     B, T, S = 40, 7, 1440
     obs, trans, init = synth.problem(B, T, S, seed=width)
     obs = np.round(obs * 2) / 2
@@ -166,12 +181,10 @@ def test_uniform_transition_entry_equals_materialised_matrix(shape, kind):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
-def test_uniform_entry_at_every_state_count_it_takes(forward):
+def test_uniform_entry_at_every_state_count_it_takes():
     """Multiples of 4 up to 516 and the edges of every template instance up to 4096 (a wave owns ceil(S / 256) float4 per
     row): a ragged 3 x 19 batch, scores as they are and as probabilities, against the oracle on the materialised matrix."""
     import math
-    if forward != 'auto':
-        pytest.skip('no forward path involved')
     dev = torch.device('cuda:0')
     B, T = 3, 19
     frames = np.array([19, 1, 10], np.int32)
@@ -232,6 +245,7 @@ def test_the_default_call_on_probabilities_is_one_pass_with_the_reference_s_valu
     assert torch.equal(again, got)
 
 
+@paths('auto', 'dense', 'resident')
 @pytest.mark.parametrize('shape', [(64, 1, 64), (33, 2, 100), (32, 3, 8192), (48, 4, 6148)])
 def test_dense_path_edge_shapes(shape):
     """T = 1 (no recurrence step), T = 2, and panels too long for the chunk-list walk (S > 6144)."""
@@ -242,6 +256,7 @@ def test_dense_path_edge_shapes(shape):
     assert np.array_equal(gpu_decode(obs, frames, trans, init), want)
 
 
+@paths('auto', 'dense')
 @pytest.mark.parametrize('S', [2, 3, 4, 5, 8, 9, 16, 17, 31, 32, 33, 63, 64])
 def test_one_wavefront_per_sequence_up_to_64_states(S):
     """small_states.hpp: recurrence, byte backpointers and backtrace in one launch.  Lengths around the 4-timestep
@@ -279,6 +294,7 @@ def test_one_wavefront_per_sequence_up_to_64_states(S):
     np.testing.assert_array_equal(gpu_decode(obs, frames, trans, init), oracle.decode(obs, frames, trans, init))
 
 
+@paths('auto', 'dense')
 @pytest.mark.parametrize('form', ['value', 'pairs'])
 @pytest.mark.parametrize('S', [65, 80, 81, 100, 128, 129, 160, 161, 192, 193, 224, 225, 255, 256])
 def test_one_workgroup_per_sequence_up_to_256_states(S, form, monkeypatch):
@@ -317,11 +333,9 @@ def test_one_workgroup_per_sequence_up_to_256_states(S, form, monkeypatch):
     np.testing.assert_array_equal(gpu_decode(obs, frames, trans, init), oracle.decode(obs, frames, trans, init))
 
 
-def test_every_state_count_up_to_256(forward):
+def test_every_state_count_up_to_256():
     """Every S in 2..256 once (each template instance of small_states.hpp at its edges: padded state counts, the pieces
     of the prev-states, workgroups of 4 / 9 / 16 waves), a ragged 5 x 23 batch of coarse-grid scores with -inf entries."""
-    if forward != 'auto':
-        pytest.skip('the one-launch kernels are what AUTO runs')
     dev = torch.device('cuda:0')
     rng = np.random.default_rng(256)
     B, T = 5, 23
@@ -338,6 +352,7 @@ def test_every_state_count_up_to_256(forward):
         np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f'S = {S}')
 
 
+@all_paths
 def test_forward_path_selection(forward):
     assert viterbi.forward_path(4, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'pruned': 'rows'}.get(forward, 'generic')
     assert viterbi.forward_path(3, 1440) == {'resident': 'resident', 'cluster': 'cluster', 'pruned': 'rows',
@@ -390,14 +405,12 @@ def test_forward_path_selection(forward):
                                    (16, 6, 1440), (3, 5, 2048), (7, 11, 1027), (1, 300, 360), (2, 5, 2052), (3, 4, 3072),
                                    (2, 7, 3100), (1, 6, 4096), (16, 3, 4096)])
 @pytest.mark.parametrize('kind', ['random', 'ties', 'minus_inf'])
-def test_held_matrix_kernel_equals_the_oracle(shape, kind, forward):
+def test_held_matrix_kernel_equals_the_oracle(shape, kind):
     """The one-launch forward pass for a handful of sequences (csrc/held_matrix_forward.hpp: the matrix in registers
     across the chip, posterior rows exchanged as {value, timestep} words): ragged lengths, heavy ties (the first
     maximum must win through the (value, index) folds), -inf transitions and whole -inf observation rows, every
     prev-states-per-thread variant (S <= 512, 1024, 1536, 2048 with 8 rows per workgroup; <= 3072, 4096 with 16) and state
     counts that leave threads and rows idle."""
-    if forward != 'auto':
-        pytest.skip('names its path itself')
     B, T, S = shape
     obs, trans, init = synth.problem(B, T, S, seed=S + B)
     rng = np.random.default_rng(B * 1000 + S)
@@ -429,12 +442,10 @@ def test_held_matrix_kernel_equals_the_oracle(shape, kind, forward):
 
 @pytest.mark.parametrize('path', ['dense', 'held'])
 @pytest.mark.parametrize('T', [129, 160, 161, 257, 500])
-def test_parallel_chase_of_long_sequences(T, path, forward):
+def test_parallel_chase_of_long_sequences(T, path):
     """The backpointer chase of a handful of long sequences runs as three short launches (chunk maps for every state,
     boundary states, chunk interiors; torbi_hip.hip chase_*_kernel) from 129 frames on: lengths on and next to every
     chunk boundary, length 1 and 2, under the per-timestep trellis kernels and the held-matrix kernel."""
-    if forward != 'auto':
-        pytest.skip('names its paths itself')
     B, S = 12, 96
     obs, trans, init = synth.problem(B, T, S, seed=T)
     frames = np.array([T, 1, 2, 31, 32, 33, 64, 65, T - 1, 96, 97, (T // 32) * 32], dtype=np.int32)
@@ -446,11 +457,9 @@ def test_parallel_chase_of_long_sequences(T, path, forward):
 
 
 @pytest.mark.parametrize('shape', [(2, 3000, 360), (1, 1500, 1440), (3, 700, 2050)])
-def test_held_matrix_kernel_over_many_timesteps(shape, forward):
+def test_held_matrix_kernel_over_many_timesteps(shape):
     """Thousands of hand-offs in one launch (two parities of {value, timestep} words, every workgroup waiting for all the
     others every timestep): ragged lengths, AUTO's own choice of the path, indices against the oracle."""
-    if forward != 'auto':
-        pytest.skip('once is enough')
     B, T, S = shape
     obs, trans, init = synth.problem(B, T, S, seed=T)
     frames = np.clip(synth.lengths(B, T // 2, T, seed=1), 1, T).astype(np.int32)
@@ -465,13 +474,11 @@ def test_held_matrix_kernel_over_many_timesteps(shape, forward):
 
 
 @pytest.mark.parametrize('shape', [(1, 40, 1440), (3, 25, 360), (2, 6, 4096), (5, 9, 130)])
-def test_held_launch_that_cannot_complete_is_repaired(shape, forward, monkeypatch):
+def test_held_launch_that_cannot_complete_is_repaired(shape, monkeypatch):
     """A held-matrix launch needs all its workgroups resident at once; when they are not (several such launches from
     different streams on a full device) its polls run out, the workgroups go on without waiting and `repair_kernel` decodes
     the sequences again.  Forced here with a poll limit of 0: every wait gives up at once (counted in the statistics),
     the indices and the final posterior rows are still the oracle's; without the limit nothing gives up."""
-    if forward != 'auto':
-        pytest.skip('names its path itself')
     B, T, S = shape
     obs, trans, init = synth.problem(B, T, S, seed=77)
     frames = np.clip(synth.lengths(B, 1, T, seed=5), 1, T).astype(np.int32)
@@ -494,14 +501,12 @@ def test_held_launch_that_cannot_complete_is_repaired(shape, forward, monkeypatc
 
 
 @pytest.mark.parametrize('shape', [(40, 12, 360), (17, 9, 1440), (130, 7, 724), (20, 6, 2052)])
-def test_cluster_that_gives_up_waiting_is_repaired(shape, forward, monkeypatch):
+def test_cluster_that_gives_up_waiting_is_repaired(shape, monkeypatch):
     """A cluster launch whose members cannot all arrive in time (a device shared with work that holds the compute units)
     used to return incomplete histories (round-3 advisor).  Now a member that gives up flags its tile and the launch
     behind the cluster launch decodes the flagged tiles again, whole.  Forced with a wait budget of 0 (every poll that
     fails gives up): indices and final posterior rows are the oracle's, the give-ups are counted; without the limit
     nothing gives up."""
-    if forward != 'auto':
-        pytest.skip('names its path itself')
     B, T, S = shape
     obs, trans, init = synth.problem(B, T, S, seed=31)
     frames = np.clip(synth.lengths(B, 1, T, seed=6), 1, T).astype(np.int32)
@@ -523,14 +528,12 @@ def test_cluster_that_gives_up_waiting_is_repaired(shape, forward, monkeypatch):
         assert (int(stats[127]) > 0) == gave_up, (limit, int(stats[127]))
 
 
-def test_a_single_sequence_beside_a_busy_stream_keeps_away_from_the_held_kernel(forward):
+def test_a_single_sequence_beside_a_busy_stream_keeps_away_from_the_held_kernel():
     """Round-3 review item 5: the held-matrix kernel needs all its workgroups resident at once.  A B = 1 AUTO decode
     issued while a full-chip time-resident launch group occupies ANOTHER stream must not sit out a wait budget and the
     slow repair: AUTO sees the other stream's work in flight (the library marks the end of every decode with an event)
     and takes the per-timestep kernels, which queue behind it.  Asserted: oracle equality, no give-ups, wall time of the
     pair <= the launch group alone + 5 ms; and once the device is idle again the same call is back on the held kernel."""
-    if forward != 'auto':
-        pytest.skip('AUTO routing is the subject')
     import time
     dev = torch.device('cuda:0')
     S, T = 1440, 200
@@ -583,13 +586,11 @@ def test_a_single_sequence_beside_a_busy_stream_keeps_away_from_the_held_kernel(
     assert viterbi.ROUTES[int(prof[3])] == 'held'
 
 
-def test_concurrent_held_launches_from_several_streams(forward):
+def test_concurrent_held_launches_from_several_streams():
     """Six host threads, six streams, one 4096-state sequence each on the held-matrix kernel -- 256 workgroups of 1024
     threads per launch, one per compute unit, so the launches cannot all be resident together.  Whatever the dispatcher
     does (one after the other, or interleaved until polls run out and the repair kernel steps in), every result is the
     oracle's."""
-    if forward != 'auto':
-        pytest.skip('names its path itself')
     import threading
     dev = torch.device('cuda:0')
     T, S, n = 24, 4096, 6
@@ -625,12 +626,10 @@ def test_concurrent_held_launches_from_several_streams(forward):
         np.testing.assert_array_equal(results[k], jobs[k][2], err_msg=f'stream {k}')
 
 
-def test_auto_looks_at_the_transition_once_per_tensor_version(forward):
+def test_auto_looks_at_the_transition_once_per_tensor_version():
     """The Python layer's look at the transition decides where ONE batch of more than 16 items goes: the band kernel for a
     matrix that is -inf outside a band it covers (csrc/band_forward.hpp; dense + -inf skipping until round 4), clusters
     otherwise (16- and 8-item tiles alike) -- once per tensor version."""
-    if forward != 'auto':
-        pytest.skip('path forced')
     dev = torch.device('cuda:0')
     B, T, S = 64, 6, 360
     obs, trans, init = synth.problem(B, T, S, seed=3)
@@ -659,6 +658,7 @@ def test_auto_looks_at_the_transition_once_per_tensor_version(forward):
 @pytest.mark.parametrize('kind', ['flat', 'nearly_flat', 'peaked', 'anti', 'two_level'])
 @pytest.mark.parametrize('shape', [(32, 12, 64), (33, 9, 132), (48, 6, 1444), (40, 5, 2048), (64, 10, 360),
                                    (36, 4, 2052), (32, 3, 4096), (256, 4, 724), (270, 3, 1440)])
+@paths('auto', 'dense', 'resident')
 def test_pruned_path_adversarial_inputs(kind, shape):
     """Inputs chosen against the pruning bound: rows without spread (nothing can be pruned: the scan runs to
     the end of every list), posteriors with a few dominant peaks (the explicit seeds carry the maximum),
@@ -686,6 +686,7 @@ def test_pruned_path_adversarial_inputs(kind, shape):
     np.testing.assert_array_equal(gpu_decode(obs, frames, trans, init), want)
 
 
+@all_paths
 @pytest.mark.parametrize('seed', [11, 12, 13])
 def test_randomised_shapes_lengths_and_structures(seed):
     """A slice of tools/stress.py (1200 cases x 3 paths clean on the box): random batch/state counts around the
@@ -716,6 +717,7 @@ def test_randomised_shapes_lengths_and_structures(seed):
                                       err_msg=f'B={B} T={T} S={S} kind={kind}')
 
 
+@all_paths
 @pytest.mark.parametrize('B', [2, 40])
 def test_out_of_range_lengths_are_clamped(B):
     """batch_frames outside [1, T] is clamped on the device (the reference reads out of bounds
@@ -729,6 +731,7 @@ def test_out_of_range_lengths_are_clamped(B):
     assert np.array_equal(gpu_decode(obs, frames, trans, init), want)
 
 
+@all_paths
 def test_non_contiguous_inputs_are_accepted():
     """the reference calls .contiguous() inside the op (viterbi.cu:325-328)"""
     dev = torch.device('cuda:0')
@@ -743,6 +746,7 @@ def test_non_contiguous_inputs_are_accepted():
     assert np.array_equal(got, want)
 
 
+@all_paths
 @pytest.mark.parametrize('B', [48, 12])
 def test_preparation_reuse_follows_the_transition_and_the_shape(B):
     """decode(workspace=..., reuse_preparation=True) skips the per-transition preparation only when the
@@ -776,6 +780,7 @@ def test_preparation_reuse_follows_the_transition_and_the_shape(B):
                                            got.data_ptr(), ws.data_ptr(), ws.numel(), B, T, S, 0, None, 4) == -1
 
 
+@all_paths
 def test_calls_without_a_workspace_keep_the_preparation_with_the_matrix():
     """decode() / decode_batches() allocate their scratch per call like the reference's operator (viterbi.cu:331-336); the
     time-resident routes' per-transition preparation then lives with the transition tensor (include/torbi_hip.h,
@@ -840,6 +845,7 @@ def test_calls_without_a_workspace_keep_the_preparation_with_the_matrix():
     np.testing.assert_array_equal(out.cpu().numpy(), want3)
 
 
+@all_paths
 def test_decode_pipeline_equals_serial_decodes():
     """torbi_amd.DecodePipeline: consecutive batches on alternating streams, private scratch."""
     dev = torch.device('cuda:0')
@@ -904,6 +910,7 @@ def test_fused_log_and_epsilon_clamp_is_bit_identical_to_the_torch_ops():
     assert torch.equal(a.cpu(), b.cpu())
 
 
+@all_paths
 def test_posterior_rows_match_oracle_bitwise():
     B, T, S = 5, 23, 300
     obs, trans, init = synth.problem(B, T, S, seed=77)
@@ -917,13 +924,11 @@ def test_posterior_rows_match_oracle_bitwise():
     assert np.array_equal(got.view(np.uint32), post.view(np.uint32))
 
 
-def test_posterior_and_statistics_follow_the_route_the_decode_took(forward):
+def test_posterior_and_statistics_follow_the_route_the_decode_took():
     """torbi_hip_read_posterior / torbi_hip_scan_stats look at the route RECORD the last decode left in the workspace,
     not at what the batch's own shape and flags would choose: a 5-item batch decoded inside a time-resident launch
     group (its own route would be the generic kernels, whose posterior rows live elsewhere) reads back the oracle's
     posterior rows bit for bit, and the group's scan statistics are found without naming a path."""
-    if forward != 'auto':
-        pytest.skip('names its paths itself')
     dev = torch.device('cuda:0')
     S = 300
     _, trans, init = synth.problem(1, 1, S, seed=78)
@@ -949,12 +954,10 @@ def test_posterior_and_statistics_follow_the_route_the_decode_took(forward):
             assert int(stats[64]) > 0 and int(stats[127]) == 0       # wave passes counted, no cluster gave up waiting
 
 
-def test_one_seed_per_item_after_shallow_scans_gives_the_same_indices(forward):
+def test_one_seed_per_item_after_shallow_scans_gives_the_same_indices():
     """TORBI_HIP_FEW_SEEDS: once an earlier time-resident launch with a matrix has reported shallow scans, later launches
     keep ONE explicit candidate per item instead of three (a third of the seed gathers' traffic, same speed on flat rows).
     The flag must not show in the results: flat and peaked rows, whole tiles and clusters, against the oracle."""
-    if forward != 'auto':
-        pytest.skip('names its paths itself')
     dev = torch.device('cuda:0')
     S, T = 360, 14
     obs, trans, init = synth.problem(300, T, S, seed=31)
@@ -978,11 +981,9 @@ def test_one_seed_per_item_after_shallow_scans_gives_the_same_indices(forward):
     torbi_amd.reset_path_state()
 
 
-def test_timing_scope_covers_the_decode_on_the_device(forward):
+def test_timing_scope_covers_the_decode_on_the_device():
     """torbi_amd.timer (the stand-in for torchutil.time as torbi/core.py:200 uses it): from_probabilities accumulates
     under 'torbi'; with `device=` the scope is bracketed by HIP events and reports device time."""
-    if forward != 'auto':
-        pytest.skip('once is enough')
     dev = torch.device('cuda:0')
     probs = torch.rand(40, 30, 96, generator=torch.Generator().manual_seed(0)).softmax(-1)
     trans = torch.rand(96, 96, generator=torch.Generator().manual_seed(1)).softmax(-1)
@@ -1018,6 +1019,7 @@ def path_score(obs, trans, init, idx, frames):
     return score
 
 
+@paths('auto', 'dense', 'resident')
 def test_headline_shape_properties():
     """B=512, T=500, S=1440 (BASELINE config 3): too large for the oracle, so
     (1) the first 4 items equal the committed reference output (items are independent),
@@ -1048,6 +1050,7 @@ def test_headline_shape_properties():
     assert torch.equal(idx2, idx[sub])
 
 
+@paths('auto', 'dense', 'resident')
 def test_large_state_shape_properties():
     """B=128, T=2000, S=4096 (BASELINE config 5, the large-S stress): the first 2 items equal the
     committed reference output; every decoded path re-scores to its item's final posterior
@@ -1072,6 +1075,7 @@ def test_large_state_shape_properties():
     assert bool((idx[5, 1233:] == idx[5, 1233]).all()) and bool((idx[77] == idx[77, 0]).all())
 
 
+@all_paths
 def test_dispatcher_registration_matches_reference_call_site():
     """reference torbi/viterbi.py:53: torch.ops.torbi.viterbi_decode(observation, batch_frames,
     transition, initial) -- the same call reaches the HIP decode after torch_op.register()."""
@@ -1090,6 +1094,7 @@ def test_dispatcher_registration_matches_reference_call_site():
            torch.tensor(trans, device=dev), torch.tensor(init, device=dev))
 
 
+@all_paths
 def test_ragged_batch_equals_oracle_decodes_of_every_file():
     """collate-style padded batch (reference collate.py:24-33) == the ORACLE's decode of each sequence alone
     (core.py:449-457 keeps the first `frames` indices of every row)."""
@@ -1105,6 +1110,7 @@ def test_ragged_batch_equals_oracle_decodes_of_every_file():
         assert (got[b, n - 1:] == got[b, n - 1]).all()
 
 
+@all_paths
 def test_reference_toy_tests_on_gpu_and_host_tensors():
     """reference tests/test_core.py:7-46, both forms."""
     observation = torch.tensor([[0.25, 0.5, 0.25], [0.25, 0.25, 0.5], [0.33, 0.33, 0.33]]).unsqueeze(dim=0)
@@ -1124,6 +1130,7 @@ def test_reference_toy_tests_on_gpu_and_host_tensors():
         initial=initial).tolist() == [[1, 2, 2]]
 
 
+@all_paths
 def test_from_probabilities_equals_decode_of_same_device_preprocessing():
     """pin the defaults and the epsilon round trip with this device's ops."""
     import math
@@ -1155,6 +1162,7 @@ def _oracle_for_file(observation, transition_probs, states):
     return oracle.decode(x, [x.shape[1]], trans, init, num_threads=min(oracle.max_threads(), max(1, states // 16)))[0]
 
 
+@all_paths
 def test_files_round_trip(tmp_path):
     """from_files_to_files / from_file_to_file write, per file, the oracle's decode of that file alone
     (reference core.py:310-368, 211-307)."""
@@ -1199,6 +1207,7 @@ def _device_problem(B, T, S, seed, dev, ragged=True):
     return obs, frames.astype(np.int32), trans, init
 
 
+@all_paths
 @pytest.mark.parametrize('S', [64, 130, 360, 1440, 1442, 2048, 2052, 4096])
 def test_decode_batches_equals_oracle_per_batch(S):
     """A group of batches with different sizes and lengths (a many-file job, reference torbi/core.py:417-457)
@@ -1218,11 +1227,9 @@ def test_decode_batches_equals_oracle_per_batch(S):
         np.testing.assert_array_equal(got[k].cpu().numpy(), want[k], err_msg=f'batch {k} {shapes[k]}')
 
 
-def test_decode_batches_auto_goes_resident_when_the_group_fills_the_chip(forward):
+def test_decode_batches_auto_goes_resident_when_the_group_fills_the_chip():
     """AUTO counts the 16-item tiles of the whole group: 8 batches of 272 items are 136 tiles >= half the compute
     units -> one time-resident launch (phase record: route 3, 8 batches); two of them are decoded one by one."""
-    if forward != 'auto':
-        pytest.skip("names path='auto' itself: once is enough")
     dev = torch.device('cuda:0')
     S, T, B = 360, 12, 272
     _, trans, init = synth.problem(1, 1, S, seed=5)
@@ -1260,6 +1267,7 @@ def test_decode_batches_auto_goes_resident_when_the_group_fills_the_chip(forward
     np.testing.assert_array_equal(got[2].cpu().numpy(), ref)
 
 
+@paths('auto', 'dense', 'resident')
 @pytest.mark.parametrize('B', [40, 270])
 @pytest.mark.parametrize('S', [360, 1440, 4096])
 @pytest.mark.parametrize('kind', ['some', 'rows', 'all'])
@@ -1284,6 +1292,7 @@ def test_minus_inf_observations_on_the_large_batch_paths(B, S, kind):
     np.testing.assert_array_equal(gpu_decode(obs, frames, trans, init), want)
 
 
+@all_paths
 def test_headline_batch_against_the_oracle_on_random_items(forward):
     """B=512, T=500, S=1440 (BASELINE config 3): 64 randomly chosen items of the full batch against the oracle
     (lowest-index ties included: the path-score property of test_headline_shape_properties accepts any optimal
@@ -1308,6 +1317,7 @@ def test_headline_batch_against_the_oracle_on_random_items(forward):
 _HEADLINE_ORACLE = {}
 
 
+@paths('auto', 'dense', 'resident')
 def test_inference_mode_is_supported():
     """Tensors created under torch.inference_mode() have no version counter; decode / from_probabilities must
     not depend on one (the reference works there)."""
@@ -1333,6 +1343,7 @@ def test_inference_mode_is_supported():
     assert torch.equal(inside.cpu(), outside.cpu())
 
 
+@all_paths
 def test_concurrent_host_threads_on_separate_streams():
     """SURVEY 8(b) threading: two host threads, each with its own stream (and its own device when there are
     two), decode a banded and a dense matrix at the same time, each naming its forward path in the call.
@@ -1375,6 +1386,7 @@ def test_concurrent_host_threads_on_separate_streams():
     assert not errors, errors
 
 
+@all_paths
 def test_host_threads_share_one_kept_preparation():
     """Four host threads, each on its own stream, call decode() WITHOUT a workspace on the SAME transition tensor at the same
     time: one of them fills the preparation kept with the tensor (torbi_amd/viterbi.py::_Preparation), the others wait for
@@ -1439,6 +1451,7 @@ def _write_api_files(tmp_path, tag):
     return ins, outs, tf
 
 
+@all_paths
 def test_from_files_to_files_equals_the_reference_outputs(tmp_path, monkeypatch):
     """the files the reference's from_files_to_files wrote (real torbi Python, CPU operator, batch
     size 3: three batches) for seven ragged inputs -- same shapes, dtypes and indices here."""
@@ -1452,6 +1465,7 @@ def test_from_files_to_files_equals_the_reference_outputs(tmp_path, monkeypatch)
         np.testing.assert_array_equal(got.numpy(), want, err_msg=f'file {k}')
 
 
+@all_paths
 def test_chunked_from_files_to_files_equals_the_reference_outputs(tmp_path, monkeypatch):
     """chunked decoding (reference torbi/chunk.py with MIN_CHUNK_SIZE = 8): files are cut at
     the same frames, decoded as extra batch rows and joined; outputs equal the reference's."""
@@ -1466,6 +1480,7 @@ def test_chunked_from_files_to_files_equals_the_reference_outputs(tmp_path, monk
         np.testing.assert_array_equal(got.numpy(), want, err_msg=f'file {k}')
 
 
+@all_paths
 def test_from_probabilities_equals_the_reference_outputs():
     """reference from_probabilities (CPU) on probability and log-probability inputs, with given
     and with default transition / initial (the epsilon round trip runs on different devices: SURVEY 0.5 -- these
@@ -1500,13 +1515,10 @@ def _ragged_job(tmp_path, count, S, seed, shortest=100, longest=900):
     return lengths, ins, outs, tf
 
 
-def test_many_file_job_every_file_equals_the_oracle(tmp_path, forward, monkeypatch):
+def test_many_file_job_every_file_equals_the_oracle(tmp_path, monkeypatch):
     """BASELINE configs[3] scaled down fivefold in time: 2100 sequences of 20..180 frames over 256 states, batches of 512
     in file order (five batches -> one launch group) and again length-bucketed: EVERY output file equals the oracle's
     decode of that file alone."""
-    if forward != 'auto':
-        pytest.skip('once is enough (15 s of host work): AUTO decodes the five batches as one time-resident launch '
-                    'group; the per-timestep paths see ragged batches in the other tests')
     S, count = 256, 2100
     lengths, ins, outs, tf = _ragged_job(tmp_path, count, S, seed=4, shortest=20, longest=180)
     torbi_amd.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, gpu=0)
@@ -1537,12 +1549,10 @@ def test_many_file_job_every_file_equals_the_oracle(tmp_path, forward, monkeypat
 
 
 @pytest.mark.parametrize('count', [600, pytest.param(2100, marks=pytest.mark.slow)])
-def test_many_file_job_through_the_reference_loader(tmp_path, forward, monkeypatch, count):
+def test_many_file_job_through_the_reference_loader(tmp_path, monkeypatch, count):
     """The same ragged job with the reference's host path (torch.load + collate in a DataLoader, saves on the calling
     thread) instead of the direct file reader (torbi_amd/fastio.py) and the saver threads: identical output files.
     600 files (two batches) in the default run; the 2 100-file job is the slow instance (the loader delivers 1.5 GB/s)."""
-    if forward != 'auto':
-        pytest.skip('host path: once is enough')
     S = 256
     lengths, ins, outs, tf = _ragged_job(tmp_path, count, S, seed=4, shortest=20, longest=180)
     torbi_amd.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, gpu=0)
@@ -1558,15 +1568,13 @@ def test_many_file_job_through_the_reference_loader(tmp_path, forward, monkeypat
             assert np.array_equal(got.numpy(), _oracle_for_file(torch.load(ins[k]), trans, S)), f'file {k}'
 
 
-def test_many_file_job_with_the_default_uniform_transition(tmp_path, forward):
+def test_many_file_job_with_the_default_uniform_transition(tmp_path):
     """from_files_to_files(log_probs=True, transition_file=None, gpu=0): the reference's default model (core.py:175-180)
     takes the uniform-transition entry, which decodes on the staging side's preparation stream -- the consumer's copy of
     the indices has to be ordered behind it (round-3 review: the last batch of a job, drained right behind its
     host-to-device copy, was saved unwritten).  1 100 ragged files = 3 batches of 512; every output equals the oracle's
     decode of that file with the materialised matrix."""
     import math
-    if forward != 'auto':
-        pytest.skip('the uniform entry has one kernel: once is enough')
     S, count = 256, 1100
     lengths, ins, outs, _ = _ragged_job(tmp_path, count, S, seed=11, shortest=20, longest=180)
     tiny = torch.finfo(torch.float32).tiny
@@ -1586,12 +1594,10 @@ def test_many_file_job_with_the_default_uniform_transition(tmp_path, forward):
             f.unlink()
 
 
-def test_many_file_job_frees_its_scratch_unless_asked_to_keep_it(tmp_path, forward, monkeypatch):
+def test_many_file_job_frees_its_scratch_unless_asked_to_keep_it(tmp_path, monkeypatch):
     """Round-3 advisor: the launch-group pipeline (2 x GROUP_SIZE workspaces) and the staging slabs used to stay allocated
     for the life of the process.  By default a job now frees them when it ends; KEEP_JOB_MEMORY keeps them for the next
     job and release_job_memory() drops them."""
-    if forward != 'auto':
-        pytest.skip('host-side memory management: once is enough')
     from torbi_amd import core, slabs
     dev = torch.device('cuda', 0)
     S = 256
@@ -1612,12 +1618,10 @@ def test_many_file_job_frees_its_scratch_unless_asked_to_keep_it(tmp_path, forwa
     assert not core._job_pipelines and slabs.pool(dev).held_bytes() == 0
 
 
-def test_many_file_job_at_1440_states(tmp_path, forward):
+def test_many_file_job_at_1440_states(tmp_path):
     """BASELINE configs[3] at its own state count, 560 sequences (two batches: 512 + 48): in-order and
     length-bucketed batching write identical files, and 40 randomly chosen files equal the oracle's decode of
     that file alone (about 1 s of host time each)."""
-    if forward != 'auto':
-        pytest.skip('a launch group of two batches under AUTO; the forced paths see ragged batches in the other tests')
     S, count = 1440, 560
     lengths, ins, outs, tf = _ragged_job(tmp_path, count, S, seed=9)
     torbi_amd.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, gpu=0)
@@ -1632,6 +1636,7 @@ def test_many_file_job_at_1440_states(tmp_path, forward):
         assert np.array_equal(torch.load(outs[k]).numpy(), want), f'file {k} ({lengths[k]} frames)'
 
 
+@all_paths
 def test_grouped_decode_pipeline_equals_the_oracle():
     """DecodePipeline(group=3): batches are collected and decoded three per launch group; a different model, a
     different state count, wait() on a batch that is still being collected, and synchronize() all flush what has
@@ -1660,12 +1665,10 @@ def test_grouped_decode_pipeline_equals_the_oracle():
 
 
 @pytest.mark.parametrize('B', [8200, 1000])
-def test_time_resident_tile_orders_do_not_change_results(B, forward):
+def test_time_resident_tile_orders_do_not_change_results(B):
     """The time-resident kernel forms its 16-item tiles from items ranked by length and ranks the tiles across the
     launch group (longest or shortest first); batches above 8192 items keep their order.  None of it may show in
     the indices: ragged lengths, partial last tile, both orders, against the oracle."""
-    if forward != 'auto':
-        pytest.skip('names its path itself: once is enough')
     dev = torch.device('cuda:0')
     T, S = 7, 64
     obs, trans, init = synth.problem(B, T, S, seed=B)
@@ -1681,11 +1684,9 @@ def test_time_resident_tile_orders_do_not_change_results(B, forward):
         np.testing.assert_array_equal(got[1].cpu().numpy(), want_small)
 
 
-def test_command_line_decodes_files_like_the_reference_cli(tmp_path, forward):
+def test_command_line_decodes_files_like_the_reference_cli(tmp_path):
     """`python -m torbi_amd --input_files ... --output_files ... --transition_file ... --log_probs --gpu 0`
     (the reference's flags, torbi/__main__.py:16-49) writes the oracle's decode of every file."""
-    if forward != 'auto':
-        pytest.skip('a child process: the fixture does not reach it')
     import subprocess
     import sys
     S = 48
@@ -1709,13 +1710,11 @@ def test_command_line_decodes_files_like_the_reference_cli(tmp_path, forward):
         assert np.array_equal(got.numpy(), _oracle_for_file(torch.load(fin), torch.load(tf), S))
 
 
-def test_auto_leaves_the_time_resident_kernel_when_nothing_is_pruned(forward):
+def test_auto_leaves_the_time_resident_kernel_when_nothing_is_pruned():
     """Transitions that fall with the prev-state exactly as fast as the posteriors rise make every candidate of a row
     nearly equal: the pruning bound never bites and the time-resident kernel walks every list to its end.  The scan
     statistics of the first AUTO launch group say so (torbi_hip_scan_stats), and later groups with the same matrix
     go to the dense kernel; with the benchmark's inputs the groups stay time-resident.  Same indices either way."""
-    if forward != 'auto':
-        pytest.skip('path forced')
     dev = torch.device('cuda:0')
     S, T, B, n = 360, 10, 272, 8
     noise_obs, noise_trans, init = synth.problem(B * n, T, S, seed=2)
@@ -1766,14 +1765,17 @@ def _decode_band(obs, frames, trans, init, want_route='band'):
                                   (48, 9, 3072, 30, 30), (70, 6, 132, 8, 8), (260, 4, 1444, 86, 88), (24, 10, 512, 100, 100),
                                   (1, 30, 1440, 87, 87), (530, 3, 64, 3, 3), (31, 7, 2048, 120, 0), (96, 5, 768, 0, 150)])
 @pytest.mark.parametrize('ties', [False, True])
-def test_band_kernel_matches_the_oracle(case, ties, forward):
+@pytest.mark.parametrize('form', ['split', 'tile'])
+def test_band_kernel_matches_the_oracle(case, ties, form, monkeypatch):
     """torbi_hip_viterbi_decode_banded on matrices that are -inf outside a band (viterbi.cpp:81-104 with -inf candidates never
     winning the strict '>'): one tile and many, ragged lengths, 1 .. 16 members per tile, asymmetric and one-sided bands, a
     band of the diagonal alone, a next-state nothing leads to, coarse grids (many exactly equal candidates: lowest index
-    wins), states the members' shares do not divide evenly."""
-    if forward != 'auto':
-        pytest.skip('names its path itself')
+    wins), states the members' shares do not divide evenly.  Both forms of the kernel: tiles split over members
+    (csrc/band_forward.hpp) and whole tiles with the band streamed from the L2 (csrc/band_tile_forward.hpp; what launch
+    groups of at least half a tile per compute unit run, here forced on small groups)."""
     B, T, S, left, right = case
+    whole = form == 'tile' and S % 4 == 0 and 64 <= S <= 1536
+    monkeypatch.setenv('TORBI_HIP_BAND_FORM', form)
     obs, _, init = synth.problem(B, T, S, seed=B + S)
     trans = _banded(S, left, right, seed=S)
     if ties:
@@ -1783,15 +1785,17 @@ def test_band_kernel_matches_the_oracle(case, ties, forward):
     frames[0] = T
     want = oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())
     np.testing.assert_array_equal(_decode_band(obs, frames, trans, init), want)
+    assert ('band_tile_kernel' in viterbi.last_forward_kernel()) == whole, viterbi.last_forward_kernel()
 
 
 @pytest.mark.parametrize('width', [1, 7, 44, 87, 88, 89, 93, 122, 123, 254, 300])
-def test_band_width_sweep_at_1440_states(width, forward):
+@pytest.mark.parametrize('form', ['split', 'tile'])
+def test_band_width_sweep_at_1440_states(width, form, monkeypatch):
     """Half widths from the diagonal alone over the reference's pitch model (reach 87 either way, torbi/evaluate/core.py:24-33)
-    to the widest band 1440 states allow (reach 121: eleven members of 132 next-states), and bands the kernel does not cover
-    (the call then is torbi_hip_viterbi_decode_batches); a dead row; ties."""
-    if forward != 'auto':
-        pytest.skip('names its path itself')
+    to the widest band 1440 states allow (split form: reach 121, eleven members of 132 next-states; whole tiles: any reach up
+    to 254, the backtrace's window), and bands the kernel does not cover (the call then is
+    torbi_hip_viterbi_decode_batches); a dead row; ties."""
+    monkeypatch.setenv('TORBI_HIP_BAND_FORM', form)
     B, T, S = 40, 7, 1440
     obs, trans, init = synth.problem(B, T, S, seed=width)
     obs = np.round(obs * 2) / 2
@@ -1804,17 +1808,15 @@ def test_band_width_sweep_at_1440_states(width, forward):
     want = oracle.decode(obs.astype(np.float32), frames, trans, init)
     reach = width - 1
     covered = torbi_amd._lib.load().torbi_hip_band_members(B, S, reach, reach, 0) > 0
-    assert covered == (reach <= 121)
+    assert covered == (reach <= (254 if form == 'tile' else 121))
     got = _decode_band(obs.astype(np.float32), frames, trans, init, want_route='band' if covered else None)
     np.testing.assert_array_equal(got, want)
 
 
-def test_auto_takes_the_band_kernel_for_the_pitch_transition(forward):
+def test_auto_takes_the_band_kernel_for_the_pitch_transition():
     """The reference's own evaluation workload (torbi/evaluate/core.py:24-33): peaked posteriorgram-like rows, the triangular
     pitch band, ragged 512 x 500 x 1440 -- AUTO routes it to the band kernel (one batch and a launch group), the first 64
     items equal the oracle's, and every named path agrees on all of them."""
-    if forward != 'auto':
-        pytest.skip('AUTO routing is the subject')
     import math
     dev = torch.device('cuda:0')
     B, T, S = 512, 500, 1440
@@ -1849,13 +1851,86 @@ def test_auto_takes_the_band_kernel_for_the_pitch_transition(forward):
     del stats
 
 
+def _peaked_pitch_problem(B, T, S, seed):
+    """Posteriorgram-like rows and the reference's triangular pitch band (torbi/evaluate/core.py:24-33), on the device."""
+    import math
+    dev = torch.device('cuda:0')
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    logits = torch.randn((B, T, S), device=dev, generator=gen) * 2.0
+    centre = torch.randint(0, S, (B, T, 1), device=dev, generator=gen)
+    logits -= ((torch.arange(S, device=dev)[None, None, :] - centre).abs().float() / 12.0) ** 2
+    peaked = torch.log_softmax(logits, dim=-1).clamp_(min=math.log(torch.finfo(torch.float32).tiny))
+    band_np = synth.banded_transition(S, 87.2)
+    init_np = np.full((S,), math.log(1.0 / S), np.float32)
+    return peaked, band_np, init_np
+
+
+@pytest.mark.parametrize('waves', [None, '8'])
+def test_band_launch_group_runs_whole_tiles(waves, monkeypatch):
+    """A launch group with a tile for at least every other compute unit runs the band kernel's WHOLE-TILE form
+    (csrc/band_tile_forward.hpp: one workgroup per 16-item tile, the band streamed from the L2, no hand-off between
+    workgroups) under AUTO: eight ragged batches of the reference's pitch workload (torbi/evaluate/core.py:24-33), sizes that
+    leave partial tiles.  Every batch equals the dense kernel's decode of it (another kernel, every cell), 48 items spread
+    over the batches equal the oracle's, nothing gave up, and the group took ONE forward launch.  Also with eight waves
+    per workgroup (three blocks per wave: the instance wide bands run)."""
+    if waves:
+        monkeypatch.setenv('TORBI_HIP_TILE_WAVES', waves)
+    dev = torch.device('cuda:0')
+    T, S = 40, 1440
+    sizes = [512, 512, 300, 512, 100, 17, 512, 129]
+    peaked, band_np, init_np = _peaked_pitch_problem(512, T, S, seed=23)
+    band, init = torch.from_numpy(band_np).to(dev), torch.from_numpy(init_np).to(dev)
+    obs_list, frame_list, frames_np = [], [], []
+    for k, B in enumerate(sizes):
+        f = np.clip(synth.lengths(B, 1, T, seed=40 + k), 1, T).astype(np.int32)
+        f[0] = T
+        frames_np.append(f)
+        obs_list.append(torch.roll(peaked, k, dims=0)[:B].contiguous())
+        frame_list.append(torch.from_numpy(f).to(dev))
+    assert sum((B + 15) // 16 for B in sizes) >= 128
+    prof = []
+    got = viterbi.decode_batches(obs_list, frame_list, band, init, _profile=prof)
+    torch.cuda.synchronize()
+    assert viterbi.ROUTES[int(prof[3])] == 'band' and int(prof[2]) == 1
+    assert 'band_tile_kernel<2, 12>' in viterbi.last_forward_kernel() or (waves and 'band_tile_kernel<3, 8>' in viterbi.last_forward_kernel())
+    for k, B in enumerate(sizes):
+        dense = torbi_amd.decode(obs_list[k], frame_list[k], band, init, path='dense')
+        np.testing.assert_array_equal(got[k].cpu().numpy(), dense.cpu().numpy(), err_msg=f'batch {k}')
+        pick = np.random.default_rng(k).choice(B, size=6, replace=False)
+        want = oracle.decode(obs_list[k][pick].cpu().numpy(), frames_np[k][pick], band_np, init_np, num_threads=oracle.max_threads())
+        np.testing.assert_array_equal(got[k].cpu().numpy()[pick], want, err_msg=f'batch {k}')
+
+
+def test_band_launch_never_holds_more_members_than_are_resident():
+    """Round-5 advisor: the members of a tile wait for each other INSIDE a launch, so a launch must not hold more members
+    than the chip has units for (a dispatch class of R x ceil(tiles / 8) workgroups runs on one XCD: cus / 8 units).  600
+    sequences with reach 88 need nine members per tile: 38 tiles x 9 = 342 workgroups used to be launched at once -- the
+    late ones spun for their wait budget and the repair launch decoded their tiles again.  Now the group is decoded 24 tiles
+    per launch (two launches), nothing gives up, and the result is the dense kernel's."""
+    dev = torch.device('cuda:0')
+    B, T, S, reach = 600, 500, 1440, 88
+    peaked, _, init_np = _peaked_pitch_problem(B, T, S, seed=5)
+    idx = np.arange(S)
+    trans_np = np.where(np.abs(idx[:, None] - idx[None, :]) <= reach, synth.scores(synth.STREAM_TRANSITION, (S, S), seed=3), -np.inf)
+    trans = torch.from_numpy(trans_np.astype(np.float32)).to(dev)
+    init = torch.from_numpy(init_np).to(dev)
+    frames = torch.full((B,), T, dtype=torch.int32, device=dev)
+    space = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+    assert torbi_amd._lib.load().torbi_hip_band_members(B, S, reach, reach, 0) == 9
+    prof = []
+    got = torbi_amd.decode(peaked, frames, trans, init, workspace=space, path='band', _profile=prof)
+    torch.cuda.synchronize()
+    assert viterbi.ROUTES[int(prof[3])] == 'band' and int(prof[2]) == 2
+    assert int(viterbi.scan_stats(space, B, T, S).cpu()[127]) == 0
+    assert prof[0] < 60.0, f'forward took {prof[0]:.1f} ms: members waiting for units?'
+    np.testing.assert_array_equal(got.cpu().numpy(), torbi_amd.decode(peaked, frames, trans, init, path='dense').cpu().numpy())
+
+
 @pytest.mark.parametrize('shape', [(40, 12, 360, 10), (17, 9, 1440, 87), (130, 7, 724, 30)])
-def test_band_launch_that_gives_up_waiting_is_repaired(shape, forward, monkeypatch):
+def test_band_launch_that_gives_up_waiting_is_repaired(shape, monkeypatch):
     """The members of a tile wait for each other's halo rows inside the launch; every wait is bounded.  With a budget of 0
     every failed poll gives up: the members flag their tile and band_repair_kernel decodes it again without hand-offs --
     indices and final posterior rows are the oracle's, the give-ups are counted; without the limit nothing gives up."""
-    if forward != 'auto':
-        pytest.skip('names its path itself')
     B, T, S, reach = shape
     obs, _, init = synth.problem(B, T, S, seed=41)
     trans = _banded(S, reach, reach, seed=7)
@@ -1880,11 +1955,9 @@ def test_band_launch_that_gives_up_waiting_is_repaired(shape, forward, monkeypat
         assert (int(stats[127]) > 0) == gave_up, (limit, int(stats[127]))
 
 
-def test_band_entry_point_falls_back_and_validates(forward):
+def test_band_entry_point_falls_back_and_validates():
     """torbi_hip_viterbi_decode_banded through ctypes: a band it does not cover, a path other than AUTO / BAND and a
     misaligned matrix all decode as torbi_hip_viterbi_decode_batches would (same indices); negative reaches are EINVAL."""
-    if forward != 'auto':
-        pytest.skip('names its path itself')
     import ctypes
     from torbi_amd import _lib
     lib = _lib.load()
@@ -1922,13 +1995,11 @@ def test_band_entry_point_falls_back_and_validates(forward):
     assert (left.value, right.value) == (4, 31)
 
 
-def test_generic_route_takes_more_items_than_one_grid_dimension_holds(forward):
+def test_generic_route_takes_more_items_than_one_grid_dimension_holds():
     """The per-timestep trellis kernels index the item by gridDim.y (at most 65535): a batch of 70 000 sequences over ONE
     state (AUTO: generic -- nothing else covers S == 1) and over 8 states with DENSE named (generic below 64 states) used to
     fail with hipErrorInvalidConfiguration once the 64 x 64 tile kernel was gone (round-4 advisor); now a timestep is
     launched in slices.  One state: every index is 0; eight states: the oracle's on a sample, every row within range."""
-    if forward != 'auto':
-        pytest.skip('names its path itself')
     dev = torch.device('cuda:0')
     B, T = 70000, 3
     for S, path in ((1, 'auto'), (8, 'dense')):
@@ -1944,15 +2015,13 @@ def test_generic_route_takes_more_items_than_one_grid_dimension_holds(forward):
         assert got.min() >= 0 and got.max() < S
 
 
-def test_auto_gates_follow_the_data_not_the_first_call(forward):
+def test_auto_gates_follow_the_data_not_the_first_call():
     """AUTO's data-dependent gates (torbi_amd/viterbi.py: scan depth of the time-resident kernel against the dense kernel) used
     to be measured once per matrix: peaked batches first, flat ones later left the matrix on clusters through a 3-4x cliff,
     the reverse on the dense kernel for ever (round-4 review).  Now every time-resident launch AUTO chose leaves a sample,
     the depth is a mean that leans on the newest one, and a matrix the gates keep on the dense kernel is looked at again every
     third call.  Peaked batches, then flat ones, then peaked ones with ONE transition tensor: the route changes within three
     calls each time, and every call's indices are the oracle's."""
-    if forward != 'auto':
-        pytest.skip('AUTO routing is the subject')
     dev = torch.device('cuda:0')
     B, T, S = 256, 10, 1440
     _, trans, init = synth.problem(1, 1, S, seed=3)
@@ -1996,13 +2065,11 @@ def test_auto_gates_follow_the_data_not_the_first_call(forward):
 
 
 @pytest.mark.parametrize('S', [2, 3, 5, 17, 31, 32, 33, 40, 63, 64])
-def test_value_only_form_of_the_wavefront_kernel(S, forward, monkeypatch):
+def test_value_only_form_of_the_wavefront_kernel(S, monkeypatch):
     """small::decode_value_kernel (csrc/small_states.hpp): no backpointers, the posterior rows kept and the first argmax
     recomputed along the decoded path from the matrix in the LDS -- AUTO's choice from 32 padded states and 512 sequences
     up, forced here for every state count: ties on a coarse grid, -inf entries, a state nobody can come from, ragged
     lengths incl. 1, more sequences than one workgroup holds; and the byte-backpointer form forced on the same inputs."""
-    if forward != 'auto':
-        pytest.skip('names its kernel itself')
     dev = torch.device('cuda:0')
     rng = np.random.default_rng(S)
     for B, T in [(1, 1), (5, 5), (70, 67), (6, 130), (530, 19)]:
@@ -2030,14 +2097,12 @@ def test_value_only_form_of_the_wavefront_kernel(S, forward, monkeypatch):
 
 @pytest.mark.parametrize('path', ['cluster', 'resident', 'band'])
 @pytest.mark.parametrize('segments', ['1', '3', '8', '16'])
-def test_backtrace_in_speculative_segments_is_the_whole_path(path, segments, forward, monkeypatch):
+def test_backtrace_in_speculative_segments_is_the_whole_path(path, segments, monkeypatch):
     """Behind a time-resident or band forward launch, one batch of few sequences is walked back in K segments per sequence,
     each from the first argmax of a posterior row, and joined from the end of the path (csrc/lazy_backtrace.hpp,
     chase_segment / stitch_segments).  Asserted for K = 1 (whole paths), 3, 8, 16: the oracle's indices on ragged lengths
     that include 1, 2, fewer steps than segments and the full length; on a coarse grid of values (every joint a tie);
     with rows of -inf; and the counters of the joints in torbi_hip_scan_stats [122], [123]."""
-    if forward != 'auto':
-        pytest.skip('names its paths itself')
     monkeypatch.setenv('TORBI_HIP_BACKTRACE_SEGMENTS', segments)
     dev = torch.device('cuda:0')
     B, T, S = 40, 61, 360
@@ -2068,13 +2133,11 @@ def test_backtrace_in_speculative_segments_is_the_whole_path(path, segments, for
             assert int(stats[123]) <= int(stats[122])
 
 
-def test_cluster_exchange_survives_the_one_nan_it_uses_as_absent(forward, monkeypatch):
+def test_cluster_exchange_survives_the_one_nan_it_uses_as_absent(monkeypatch):
     """The cluster form's exchange marks a slice that has not arrived with one NaN bit pattern (resident_forward.hpp,
     kAbsentBits).  NaNs are out of contract -- but an observation that carries exactly that pattern must not hang the
     call: the members that wait for the poisoned row give up within the wait budget, the tile is decoded again by the
     repair launch, every other sequence still equals the oracle's."""
-    if forward != 'auto':
-        pytest.skip('names its path itself')
     import time
     monkeypatch.setenv('TORBI_HIP_CLUSTER_WAIT_US', '3000')
     dev = torch.device('cuda:0')

@@ -59,18 +59,22 @@ inline bool make_tile_plan(int S, int hl, int hr, TilePlan &p, int waves_wanted 
     p.n_jg = S / 4;
     p.nblk = (p.n_jg + 15) / 16;
     if (p.nblk > kTileSlots) return false;
-    p.waves = p.nblk <= 4 ? 4 : p.nblk <= 8 ? 8 : kTileWaves;
-    if (p.nblk > 8 && (waves_wanted == 8 || waves_wanted == 12)) p.waves = waves_wanted;
-    p.bpw = (p.nblk + p.waves - 1) / p.waves;
-    if (p.bpw > (p.waves == 12 ? 2 : 3)) return false;
     p.w_rows = S + 4 * p.Dq - 1;
     p.ig_stride = 4 * p.w_rows;
     while (p.ig_stride % 64 != 4) p.ig_stride += 4;
     p.w_off = 0;
     p.ring_off = p.w_off + 4 * p.ig_stride * 4;
-    p.misc_off = p.ring_off + p.waves * kRing * 1024;
-    p.lds_bytes = p.misc_off + 256;
-    return p.lds_bytes <= kLdsBytes;
+    // twelve waves (three per SIMD) where the rings fit beside the window, else eight (wide bands)
+    for (int waves = p.nblk <= 4 ? 4 : p.nblk <= 8 ? 8 : kTileWaves; waves >= 4; waves -= 4) {
+        if (p.nblk > 8 && (waves_wanted == 8 || waves_wanted == 12) && waves > waves_wanted) continue;
+        p.waves = waves;
+        p.bpw = (p.nblk + waves - 1) / waves;
+        if (p.bpw > (waves == 12 ? 2 : 3)) return false;
+        p.misc_off = p.ring_off + waves * kRing * 1024;
+        p.lds_bytes = p.misc_off + 256;
+        if (p.lds_bytes <= kLdsBytes) return true;
+    }
+    return false;
 }
 
 // the band, packed: grid = nblk * Dq4, block = 64 (lane = group of four next-states x diagonal of the dquad)
@@ -152,7 +156,6 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
     const int ig = lane & 3, jgl = lane >> 2;
     int jg[BPW];
     bool rowok[BPW];
-    unsigned goff[BPW];                    // byte offset of the block's first dquad in the packed band
     int nb = 0;
 #pragma unroll
     for (int u = 0; u < BPW; ++u) {
@@ -162,7 +165,6 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
         const int raw = 16 * blk + jgl;
         rowok[u] = has && raw < n_jg;
         jg[u] = raw < n_jg ? raw : n_jg - 1;
-        goff[u] = (unsigned)(has ? blk : 0) * (unsigned)Dq4 * 1024u;
     }
     nb = __builtin_amdgcn_readfirstlane(nb);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
@@ -172,7 +174,8 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
     const unsigned voff = (unsigned)lane * 16u;
 
     // the band ring: copies are issued in the order the dquads are evaluated, three ahead, for ever
-    unsigned d_off = __builtin_amdgcn_readfirstlane(goff[0]);
+    const unsigned blk_bytes = (unsigned)Dq4 * 1024u;            // a block's dquads in the packed band
+    unsigned d_off = (unsigned)wave * blk_bytes;
     int d_q = 0, d_u = 0;
     auto copy_next = [&](unsigned stage) {
         if (!(BAND_TILE_ABL & 1)) glds16s(tp_bytes + d_off, voff, ring_m0 + stage * 1024u);
@@ -181,10 +184,7 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
         if (d_q == Dq4) {
             d_q = 0;
             d_u = d_u + 1 == nb ? 0 : d_u + 1;
-            unsigned o = goff[0];
-#pragma unroll
-            for (int u = 1; u < BPW; ++u) o = d_u == u ? goff[u] : o;
-            d_off = __builtin_amdgcn_readfirstlane(o);
+            d_off = (unsigned)(wave + d_u * pl.waves) * blk_bytes;
         }
     };
     auto landed = [&]() {          // all but the two youngest copies have landed
@@ -194,42 +194,48 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
         if (!(BAND_TILE_ABL & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
 
-    // post'[j] = obs[t][j] + max (viterbi.cpp:102); row 0 = obs[b][0][:] + initial (viterbi.cpp:72-76)
-    float4 ob[BPW][4] = {};         // observations of the row being finished: [block][item] x 4 next-states
-    float v[BPW][16];               // the finished rows: [block][4 next + item]
+    // post'[j] = obs[t][j] + max (viterbi.cpp:102); row 0 = obs[b][0][:] + initial (viterbi.cpp:72-76).
+    // A block's observations of row t are asked for, and its history row t - 1 is stored, in the MIDDLE of the block's scan
+    // of timestep t, each wave of a SIMD at another dquad (the row is still in the window: nobody writes the window during
+    // the scans).  A workgroup moves 2 x 92 KB per timestep, which the compute unit's memory pipe takes 2 - 3 us to issue:
+    // at the end of the timestep -- every wave at once, nothing else running -- that was 10 % of the launch.  Here the
+    // wave that has just issued them waits at its next `landed()` (the counter is in order) while the SIMD's other two
+    // waves keep the vector ALU busy.
+    float4 ob[4] = {};              // observations of the block being scanned: [item] x 4 next-states
+    float v[BPW][16];               // the finished rows of this timestep: [block][4 next + item]
     // (the items' offsets and lengths are read from the LDS where they are used: twelve registers less across the scans)
-    auto ask = [&](int t) {
-        const int tr = t < fmax ? t : fmax - 1;
+    auto ask = [&](int j4, int t) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float *row = obs + sbase[4 * ig + c] + (size_t)tr * S;
+        for (int c = 0; c < 4; ++c)
+            if (!(BAND_TILE_ABL & 4)) ob[c] = *reinterpret_cast<const float4 *>(obs + sbase[4 * ig + c] + (size_t)t * S + j4);
+    };
+    auto store_row = [&](int j4, bool ok, int t, const float (&x)[16]) {
+        if (BAND_TILE_ABL & 2) return;
 #pragma unroll
-            for (int u = 0; u < BPW; ++u)
-                if (!(BAND_TILE_ABL & 4) && u < nb) ob[u][c] = *reinterpret_cast<const float4 *>(row + 4 * jg[u]);
+        for (int c = 0; c < 4; ++c)
+            if (ok && t < sframes[4 * ig + c])
+                *reinterpret_cast<float4 *>(hist + sbase[4 * ig + c] + (size_t)t * S + j4) = make_float4(x[c], x[4 + c], x[8 + c], x[12 + c]);
+    };
+    auto store_from_window = [&](int j4, bool ok, int t) {         // row t of the lane's 4 next-states x 4 items, as the window holds it
+        float x[16];
+        const float *at = wq + ig * pl.ig_stride + 4 * (hl + j4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 r = *reinterpret_cast<const float4 *>(at + 4 * k);
+            x[4 * k] = r.x; x[4 * k + 1] = r.y; x[4 * k + 2] = r.z; x[4 * k + 3] = r.w;
         }
+        store_row(j4, ok, t, x);
     };
     auto finish = [&](int u, const float (&acc)[16]) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            v[u][0 + c] = ob[u][c].x + acc[0 + c];
-            v[u][4 + c] = ob[u][c].y + acc[4 + c];
-            v[u][8 + c] = ob[u][c].z + acc[8 + c];
-            v[u][12 + c] = ob[u][c].w + acc[12 + c];
+            v[u][0 + c] = ob[c].x + acc[0 + c];
+            v[u][4 + c] = ob[c].y + acc[4 + c];
+            v[u][8 + c] = ob[c].z + acc[8 + c];
+            v[u][12 + c] = ob[c].w + acc[12 + c];
         }
     };
     auto close_timestep = [&](int t) {
-        ask(t + 1);
-        if (!(BAND_TILE_ABL & 2)) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float *row = hist + sbase[4 * ig + c] + (size_t)t * S;
-                const bool live = t < sframes[4 * ig + c];
-#pragma unroll
-                for (int u = 0; u < BPW; ++u)
-                    if (rowok[u] && live)
-                        *reinterpret_cast<float4 *>(row + 4 * jg[u]) = make_float4(v[u][c], v[u][4 + c], v[u][8 + c], v[u][12 + c]);
-            }
-        }
         if (t + 1 >= fmax) return;
         barrier();                      // every wave is done with the window of row t - 1
 #pragma unroll
@@ -243,24 +249,27 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
         barrier();                      // the window holds row t
     };
 
-    if (nb > 0) {
-        ask(0);
 #pragma unroll
-        for (int u = 0; u < BPW; ++u) {
-            float first[16];
+    for (int u = 0; u < BPW; ++u) {
+        if (u >= nb) continue;
+        ask(4 * jg[u], 0);
+        float first[16];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float x = initial[4 * jg[u] + k];
+        for (int k = 0; k < 4; ++k) {
+            const float x = initial[4 * jg[u] + k];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) first[4 * k + c] = x;
-            }
-            finish(u, first);
+            for (int c = 0; c < 4; ++c) first[4 * k + c] = x;
         }
-        if (fmax > 1)
-            for (int r = 0; r < kRing - 1; ++r) copy_next((unsigned)r);
+        finish(u, first);
     }
+    if (nb > 0 && fmax > 1)
+        for (int r = 0; r < kRing - 1; ++r) copy_next((unsigned)r);
     close_timestep(0);
 
+    // where in a block's scan this wave talks to the memory: the waves of a SIMD (w, w + 4, w + 8) a third of the scan apart
+    const int nq = Dq4 / 4;
+    const int q_ask = 4 * (((wave >> 2) % 3) * nq / 3);
+    const int q_store = 4 * min(nq - 1, q_ask / 4 + (nq + 5) / 6);
 #ifdef BAND_STAMP
     unsigned long long bacc[kPhases] = {};
     unsigned long long blast = __builtin_readcyclecounter();
@@ -282,6 +291,8 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
             TSTAMP(0);
             for (int q = 0; q < Dq4; q += 4) {
                 const char *const wp = w0 + (size_t)q * 64;
+                if (q == q_ask) ask(4 * jg[u], t);
+                if (q == q_store) store_from_window(4 * jg[u], rowok[u], t - 1);
                 copy_next(3u);
                 landed();
                 if (!(BAND_TILE_ABL & 16)) dquad<0>(acc, w, tt, ring_lane + 1024, wp + 64);
@@ -302,6 +313,10 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
         close_timestep(t);
         TSTAMP(3);
     }
+    // the last row never reaches the window: from the registers
+#pragma unroll
+    for (int u = 0; u < BPW; ++u)
+        if (u < nb) store_row(4 * jg[u], rowok[u], fmax - 1, v[u]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (no copy may land in an LDS that is no longer this workgroup's)
 #ifdef BAND_STAMP
     if (lane == 0 && blockIdx.x < 1024)
