@@ -126,9 +126,15 @@ def profiled_traffic(kernel_name, batches):
             if squeeze(kernel) == squeeze(kernel_name) and 'FETCH_SIZE' in counters and 'WRITE_SIZE' in counters:
                 nbytes = (2.0 * counters['FETCH_SIZE']['mean_per_dispatch']
                           + counters['WRITE_SIZE']['mean_per_dispatch']) * 1024.0 * batches / taken_with
+                mean = lambda c: counters[c]['mean_per_dispatch'] if c in counters else None
                 return nbytes, {'file': f'profiles/{name}', 'kernel': kernel, 'taken_at_commit': meta.get('git'),
+                                'command': meta.get('command'),
                                 'batches_per_launch_when_taken': int(taken_with),
-                                'dispatches': counters['FETCH_SIZE'].get('dispatches')}
+                                'dispatches': counters['FETCH_SIZE'].get('dispatches'),
+                                # the same passes' shader counters, per dispatch of `taken_with` batches (None: not collected)
+                                'counters': {c: mean(c) for c in ('SQ_INSTS_VALU', 'SQ_LDS_IDX_ACTIVE', 'SQ_LDS_BANK_CONFLICT',
+                                                                  'SQ_BUSY_CYCLES', 'SQ_WAVE_CYCLES')},
+                                'executed_cells_per_launch_when_taken': meta.get('executed_cells_per_launch')}
     return None, {'file': None, 'running_kernel': kernel_name,
                   'reason': 'no committed PMC summary was taken on this kernel instance'}
 
@@ -438,28 +444,38 @@ class Bench:
             passes = covered * math.ceil(B / ni) * math.ceil(S / rows_per_pass) * (T - 1)
             cells = passes * blocks * 16.0 * rows_per_pass * ni
             clock = measured or 2.4e9
+            # per-cell costs from the committed PMC summary of THIS kernel instance (profiled_traffic matched it by name):
+            # vector instructions per examined cell and lane, and the LDS's bank-conflict factor; None when no summary matches
+            pmc = (provenance or {}).get('counters') or {}
+            scale = covered / float((provenance or {}).get('batches_per_launch_when_taken') or covered)
+            pmc_cells = (provenance or {}).get('executed_cells_per_launch_when_taken')
+            pmc_cells = pmc_cells * scale if pmc_cells else cells          # (the same seeded inputs: the same cells)
+            instr = pmc['SQ_INSTS_VALU'] * scale * 64.0 / pmc_cells if pmc.get('SQ_INSTS_VALU') and pmc_cells else None
+            conflict = (1.0 + pmc['SQ_LDS_BANK_CONFLICT'] / (pmc['SQ_LDS_IDX_ACTIVE'] - pmc['SQ_LDS_BANK_CONFLICT'])
+                        if pmc.get('SQ_LDS_IDX_ACTIVE') and pmc.get('SQ_LDS_BANK_CONFLICT') is not None
+                        and pmc['SQ_LDS_IDX_ACTIVE'] > pmc['SQ_LDS_BANK_CONFLICT'] else None)
             executed = {
                 'clock_hz_measured': measured,
                 'list_blocks_per_wave_pass': blocks, 'row_blocks': math.ceil(S / 16),
                 'cells_per_launch': cells, 'cells_per_s': cells / kernel_s,
                 'fraction_of_all_cells': cells / cells_per_launch if cells_per_launch else None,
                 # issue model of the scan: per entry pair and lane 4 quad broadcasts + 8 adds + 4 max3 = 16 instructions
-                # for 8 cells, ~40 issue cycles (tools/ubench2: v_max3_f32 / DPP moves ~4, v_add_f32 2 cycles per wave
-                # instruction); + bound test, list loads, epilogue: 2.5 instructions per cell measured (SQ_INSTS_VALU of
-                # profiles/r03_pmc.json / executed cells)
-                'valu_instr_per_cell': 2.5,
-                'per_cell_costs': 'MODELLED, not live: constants from profiles/r03_pmc.json (2.5 VALU instructions per cell, 1.43 '
-                                  'LDS conflict factor); list_blocks_per_wave_pass and the clock (shader-clock over wall-clock ticks '
-                                  'of the kernel\'s workgroup 0) are measured in this run',
-                'valu_busy_frac': cells * 2.5 * 2.5 / 64.0 / (256 * 4 * clock * kernel_s),
-                # one ds_read_b128 per 4 cells and lane = 4 LDS cycles per wave instruction x 1.43 (bank conflicts left by
-                # the arrangement pass: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.30)
-                'lds_busy_frac': cells / 256.0 * 4.0 * 1.43 / (256 * clock * kernel_s),
+                # for 8 cells (tools/ubench2: v_max3_f32 / DPP moves ~4, v_add_f32 2 cycles per wave instruction: 2.5 on
+                # average); + bound test, list loads, epilogue
+                'valu_instr_per_cell': instr,
+                'lds_conflict_factor': conflict,
+                'per_cell_costs': ('SQ_INSTS_VALU x 64 lanes / examined cells and SQ_LDS_IDX_ACTIVE / (SQ_LDS_IDX_ACTIVE - '
+                                   'SQ_LDS_BANK_CONFLICT) of the committed PMC summary named in roofline.traffic_source (taken on '
+                                   'this kernel instance); list_blocks_per_wave_pass and the clock are measured in this run')
+                if instr else 'None: no committed PMC summary was taken on the running kernel instance',
+                'valu_busy_frac': cells * instr * 2.5 / 64.0 / (256 * 4 * clock * kernel_s) if instr else None,
+                # one ds_read_b128 per 4 cells and lane = 4 LDS cycles per wave instruction x the conflict factor
+                'lds_busy_frac': cells / 256.0 * 4.0 * conflict / (256 * clock * kernel_s) if conflict else None,
                 'statistics_gave_up': int(stats[127]),
                 'note': 'list blocks per wave pass live from torbi_hip_scan_stats (every 16th timestep sampled) x 16 '
                         'entries x 256 (row, item) pairs; the busy fractions price those cells with the per-cell costs '
-                        'stated here at the measured clock -- both pipes are more than half busy and do not overlap fully: that, '
-                        'not HBM, is what binds this kernel'}
+                        'stated here at the measured clock (2.5 issue cycles per vector instruction on average) -- both pipes '
+                        'are more than half busy and do not overlap fully: that, not HBM, is what binds this kernel'}
         del spaces
         result['config'] = {
             'workload': (f'{S} states, {T} frames, batch={B} per GPU, fp32, dense transition'
@@ -510,6 +526,42 @@ class Bench:
                 result['secondary']['serial'] = dict(result['single_call'], note='= single_call (kept under its old name)')
         if rank == 0 and size == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(last_obs, trans, init, indices)
+        # every BASELINE config and the structured-transition routes, compact, INSIDE the part of the line the driver keeps
+        sec_, one = result.get('secondary') or {}, result.get('single_call')
+
+        def compact(rec, roof_timesteps_per_s, **more):
+            if not rec or rec.get('value') is None:
+                return None
+            found = {'value': rec['value'], 'ms_per_decode': rec.get('ms_per_decode'),
+                     'frac': rec['value'] / roof_timesteps_per_s, 'kernel': rec.get('kernel'),
+                     'forward_path': rec.get('forward_path')}
+            found.update(more)
+            return found
+        roof = lambda S_: HBM_PEAK_GBS * 1e9 / algorithmic_bytes_per_timestep(S_)
+        band_exec = lambda rec: {'frac_of_alu_ceiling_at_measured_clock':
+                                 ((rec or {}).get('executed') or {}).get('forward_frac_of_ceiling_at_measured_clock')}
+        configs = {
+            'c2': compact(sec_.get('c2'), roof(S)),
+            'c3_launch_group': {'value': value / size, 'ms_per_decode': elapsed / args.steps * 1e3,
+                                'frac': result['hbm_roofline_frac_whole_job'], 'kernel': running, 'forward_path': route},
+            'c3_single_call': compact(one, roof(S)),
+            'c3_every_cell': compact(sec_.get('every_cell'), roof(S),
+                                     frac_of_alu_ceiling_at_measured_clock=(sec_.get('every_cell') or {}).get('frac_of_ceiling_at_measured_clock')),
+            'c3_peaked_dense': compact(sec_.get('peaked_dense_transition'), roof(S)),
+            'c4_decode_only': compact(sec_.get('c4_40000_files'), roof(S)),
+            'c5': compact(sec_.get('c5'), roof(4096)),
+            'band_single': compact(sec_.get('peaked_banded'), roof(S), **band_exec(sec_.get('peaked_banded'))),
+            'band_group': compact(sec_.get('peaked_banded_launch_group'), roof(S),
+                                  **band_exec(sec_.get('peaked_banded_launch_group'))),
+            'uniform': compact(sec_.get('uniform'), HBM_PEAK_GBS * 1e9 / (4 * S + 4)),
+        }
+        result['roofline']['configs'] = {k: c for k, c in configs.items() if c}
+        result['roofline']['configs_note'] = ('value in timesteps/s; frac = value x algorithmic bytes per timestep (8 S + 8; uniform: '
+                                              '4 S + 4) / 8 TB/s; c2 / c3_* / c5 = BASELINE configs[1], [2], [4] (c3_launch_group = the '
+                                              'headline value, c3_single_call = ONE decode of ONE batch, c3_every_cell = the dense '
+                                              'kernel forced, c3_peaked_dense = posteriorgram-like rows); band_* = the reference\'s pitch '
+                                              'transition (torbi/evaluate/core.py:24-33) on peaked rows; the long notes are under '
+                                              '"secondary"')
         return result
 
     # ---- the literal BASELINE config: ONE decode call on ONE batch -------------------------------------
@@ -624,7 +676,7 @@ class Bench:
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(obs, frames, trans, init, workspace=ws, path='dense'), 2)
         dense_clock = v.delivered_clock_hz(v.scan_stats(ws, B, T, S))
         record('every_cell', sec, B * T, S, 'headline batch, dense (max,+) GEMM forced: every (prev, next) cell evaluated',
-               {'valu_frac_at_1p5_instr_per_cell': 1.5 * B * T * S * S / sec / VALU_LANE_OPS,
+               {'forward_path': 'dense', 'kernel': v.last_forward_kernel(), 'valu_frac_at_1p5_instr_per_cell': 1.5 * B * T * S * S / sec / VALU_LANE_OPS,
                 'clock_hz_measured': dense_clock, 'cells_per_s': B * T * S * S / sec,
                 'ceiling_cells_per_s_at_measured_clock': valu_ceiling(dense_clock),
                 'frac_of_ceiling_at_measured_clock': B * T * S * S / sec / valu_ceiling(dense_clock)})
@@ -672,7 +724,7 @@ class Bench:
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(peaked, frames, trans, init, workspace=ws), 3, warmup=4)
         self.torbi_amd.decode(peaked, frames, trans, init, workspace=ws, _profile=prof)
         record('peaked_dense_transition', sec, B * T, S, 'the same peaked rows with the dense random transition (AUTO)',
-               {'forward_path': ROUTES[int(prof[3])]})
+               {'forward_path': ROUTES[int(prof[3])], 'kernel': v.last_forward_kernel()})
         # the same workload as a launch group of 8 batches (what from_files_to_files sees): AUTO's choice for the group
         spaces = [torch.empty(v.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev) for _ in range(8)]
         prof = []
@@ -680,8 +732,12 @@ class Bench:
         sec, _ = self.timed_decodes(lambda: v.decode_batches([peaked] * 8, [frames] * 8, band, init, workspaces=spaces), 2)
         record('peaked_banded_launch_group', sec, 8 * B * T, S,
                'eight batches of the peaked rows + banded pitch transition in one call',
-               {'forward_path': ROUTES[int(prof[3])], 'forward_ms': prof[0], 'backtrace_ms': prof[1],
-                'executed': executed(sec, 8 * B * T, prof[0], spaces[0])})
+               {'forward_path': ROUTES[int(prof[3])], 'kernel': v.last_forward_kernel(), 'forward_ms': prof[0],
+                'backtrace_ms': prof[1], 'us_per_timestep_forward': (prof[0] - prof[4]) * 1e3 / max(T - 1, 1),
+                'members_per_tile': int(self.torbi_amd._lib.load().torbi_hip_band_members(8 * B, S, *v.band_reach(band, band, S),
+                                                                                         dev.index or 0)),
+                'executed': executed(sec, 8 * B * T, prof[0], spaces[0]),
+                'statistics_gave_up': int(v.scan_stats(spaces[0], B, T, S).cpu()[127])})
         sec, _ = self.timed_decodes(lambda: v.decode_batches([peaked] * 8, [frames] * 8, band, init, workspaces=spaces,
                                                              path='resident'), 2)
         record('peaked_banded_launch_group_resident', sec, 8 * B * T, S, 'the same, time-resident kernel forced')
@@ -690,6 +746,7 @@ class Bench:
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode_uniform(obs, frames, c, init), 3)
         out['uniform'] = {'value': B * T / sec, 'unit': 'timesteps/s', 'ms_per_decode': sec * 1e3,
                           'roofline_frac': B * T * (4 * S + 4) / sec / (HBM_PEAK_GBS * 1e9),
+                          'forward_path': 'uniform', 'kernel': 'uniform::uniform_rows_kernel',
                           'note': 'uniform transition (reference default, transition=None): O(S) per timestep, '
                                   'HBM-bound on the 4S observation bytes'}
         del ws
@@ -701,7 +758,7 @@ class Bench:
         record('c2', sec, T, S, f'BASELINE configs[1]: {S} states, {T} frames, batch=1 (latency bound): ONE launch, the '
                                 'matrix held in registers across the chip, posterior rows handed from workgroup to '
                                 'workgroup as {value, timestep} words',
-               {'us_per_timestep': sec / max(T - 1, 1) * 1e6, 'forward_path': ROUTES[int(prof[3])]})
+               {'us_per_timestep': sec / max(T - 1, 1) * 1e6, 'forward_path': ROUTES[int(prof[3])], 'kernel': v.last_forward_kernel()})
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(o1, f1, trans, init, path='dense'), 3)
         record('c2_per_timestep_kernels', sec, T, S, 'the same with one launch per timestep (what AUTO took before round 3)',
                {'us_per_timestep': sec / max(T - 1, 1) * 1e6})
@@ -738,7 +795,7 @@ class Bench:
             sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(o5, f5, t5, i5, workspace=w5), 2)
             record('c5', sec, B5 * T5, S5, 'BASELINE configs[4]: 4096 states, 2000 frames, batch=128 (AUTO: ONE time-resident '
                                            'launch, 16 tiles of 8 items x 16 workgroups each)',
-                   {'forward_path': ROUTES[int(prof[3])]})
+                   {'forward_path': ROUTES[int(prof[3])], 'kernel': v.last_forward_kernel()})
             # the same shape as a launch group (a many-file job at 4096 states): four batches in one time-resident launch
             T5g, n5 = 500, 4
             spaces5 = [torch.empty(v.workspace_bytes(B5, T5g, S5), dtype=torch.uint8, device=dev) for _ in range(n5)]

@@ -11,6 +11,7 @@ cd $R
 # one warm-up launch group and one timed launch group of 8 batches on one stream, then the three profiled groups
 # (PROFILE_CMD / PROFILE_OUT: another command under the same passes, e.g. "python3 tools/small_states_probe.py 512x500x64")
 CMD=${PROFILE_CMD:-"python3 bench.py --steps 8 --warmup 8 --no-cpu-baseline --no-secondary --no-single-call --pipeline 1"}
+export PROFILE_CMD="$CMD"
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/trace -o x --output-format csv -- $CMD > $OUT/bench_under_trace.json 2> $OUT/trace.err
 # FETCH_SIZE and WRITE_SIZE do not fit one pass ("exceeds the capabilities of the hardware", after which rocprofv3
 # hangs): one pass each, and every pass under its own timeout
