@@ -29,8 +29,14 @@
  *   - backpointer = LOWEST index attaining the maximum; final state = lowest index attaining
  *     the maximum of the last posterior row; every output position t >= batch_frames[b]-1
  *     holds that final state
- *   - decoded indices are bit-identical to the reference CPU operator for inputs without
- *     NaN (-inf is allowed).  batch_frames[b] outside [1, T] is clamped on the device
+ *   - decoded indices are bit-identical to the reference CPU operator, -inf, +inf and NaN
+ *     inputs included: the reference is deterministic there (a NaN candidate at prev-state 0
+ *     is never replaced and a NaN candidate elsewhere never wins, viterbi.cpp:94-100; the
+ *     final state is ATen's argmax, the first NaN of the last row, :218), the fast kernels
+ *     are not, so every decode looks for NaN / +inf in what it reads and produces and an
+ *     item that met one is decoded again on the device in the reference's own order of
+ *     evaluation (csrc/nonfinite.hpp: no host involvement, nothing to pay on finite inputs
+ *     beyond two small launches).  batch_frames[b] outside [1, T] is clamped on the device
  *     (the reference reads out of bounds for 0, viterbi.cpp:153).
  */
 #ifndef TORBI_HIP_H
@@ -43,7 +49,7 @@
 extern "C" {
 #endif
 
-#define TORBI_HIP_ABI_VERSION 14
+#define TORBI_HIP_ABI_VERSION 15
 
 #define TORBI_HIP_OK 0
 #define TORBI_HIP_EINVAL (-1)      /* null pointer / non-positive dimension            */

@@ -1995,6 +1995,170 @@ def test_band_entry_point_falls_back_and_validates():
     assert (left.value, right.value) == (4, 31)
 
 
+# ---- NaN and +inf inputs (csrc/nonfinite.hpp): the reference's results on every route ----------------------------------------
+
+def _poison(kind, obs, trans, init, frames):
+    """The NaN cases of tests/test_oracle.py (where the oracle is checked against the reference operator itself), placed
+    where the shape allows; 'inf': +inf observations that meet -inf transitions as NaN candidates at prev-state 0 (they
+    stay, viterbi.cpp:94-100) and elsewhere (they lose)."""
+    B, T, S = obs.shape
+    nan = np.float32('nan')
+    obs, trans, init = obs.copy(), trans.copy(), init.copy()
+    b1, b2 = min(1, B - 1), min(2, B - 1)
+    if kind == 'observation':
+        obs[0, min(3, T - 1), 5 % S] = nan
+    elif kind == 'matrix':
+        trans[7 % S, 0] = nan
+        trans[9 % S, 11 % S] = nan
+    elif kind == 'initial':
+        init[0] = nan
+    elif kind == 'final_row':
+        obs[b1, frames[b1] - 1, 17 % S] = nan
+        obs[b2, 0, :] = nan
+    elif kind == 'inf':
+        obs[0, min(2, T - 1), 0] = np.inf
+        obs[b1, min(4, T - 1), 3 % S] = np.inf
+        trans[6 % S, 0] = -np.inf
+        trans[5 % S, 3 % S] = -np.inf
+    return obs, trans, init
+
+
+NONFINITE_ROUTES = [  # (B, T, S, path, environment, route expected)
+    (3, 12, 40, 'auto', {}, 'small'),                                   # one wavefront per sequence, backpointers
+    (600, 9, 40, 'auto', {'TORBI_HIP_SMALL_VALUE': '1'}, 'small'),       # ... value-only
+    (9, 10, 200, 'auto', {}, 'small'),                                   # one workgroup per sequence
+    (2, 14, 1440, 'auto', {}, 'held'),
+    (4, 9, 1440, 'auto', {}, 'generic'),
+    (8, 9, 300, 'auto', {}, 'rows'),
+    (40, 10, 360, 'auto', {}, 'cluster'),
+    (40, 10, 360, 'resident', {}, 'resident'),
+    (64, 8, 360, 'dense', {}, 'dense'),
+]
+
+
+@pytest.mark.parametrize('kind', ['observation', 'matrix', 'initial', 'final_row', 'inf', 'clean'])
+@pytest.mark.parametrize('shape', NONFINITE_ROUTES, ids=lambda s: f'{s[0]}x{s[1]}x{s[2]}-{s[3]}')
+def test_nan_and_inf_inputs_decode_as_the_reference_operator(shape, kind, monkeypatch):
+    """The reference is deterministic on NaN (viterbi.cpp:94-100 never replaces a NaN candidate at prev-state 0 and never lets
+    one win elsewhere; :218 ATen's argmax takes the first NaN of the final row) and +inf meets -inf as NaN; the oracle
+    restates exactly that and is pinned against the reference operator on these cases (tests/test_oracle.py).  Every route
+    of the HIP path must give the same indices: its kernels raise an alarm when they produce a NaN / +inf posterior value
+    (or find one in the matrix / the observations), and the items that read one are decoded again exactly as the reference
+    does it (csrc/nonfinite.hpp).  'clean': the same shapes without any, through the same launches."""
+    B, T, S, path, env, route = shape
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    obs, trans, init = synth.problem(B, T, S, seed=3000 + B + S)
+    frames = np.clip(synth.lengths(B, 2, T, seed=9), 2, T).astype(np.int32)
+    frames[0] = T
+    if kind != 'clean':
+        obs, trans, init = _poison(kind, obs, trans, init, frames)
+    want = oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())
+    dev = torch.device('cuda:0')
+    args = [torch.as_tensor(np.ascontiguousarray(x)).to(dev) for x in (obs, frames, trans, init)]
+    prof = []
+    got = torbi_amd.decode(*args, path=path, _profile=prof)
+    assert viterbi.ROUTES[int(prof[3])] == route
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('kind', ['observation', 'matrix', 'initial', 'final_row', 'inf'])
+@pytest.mark.parametrize('form', ['split', 'tile'])
+def test_nan_and_inf_inputs_on_the_band_kernels(kind, form, monkeypatch):
+    """... and a banded matrix through both forms of the band kernel, as one batch and as a launch group of two batches of which
+    only the second reads a NaN."""
+    monkeypatch.setenv('TORBI_HIP_BAND_FORM', form)
+    B, T, S, reach = 40, 10, 360, 10
+    obs, _, init = synth.problem(B, T, S, seed=77)
+    trans = _banded(S, reach, reach, seed=5)
+    frames = np.clip(synth.lengths(B, 2, T, seed=4), 2, T).astype(np.int32)
+    frames[0] = T
+    clean = oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())
+    bad_obs, bad_trans, bad_init = _poison(kind, obs, trans, init, frames)
+    if kind in ('matrix', 'inf'):
+        bad_trans = np.where(np.isneginf(trans), -np.inf, bad_trans).astype(np.float32)      # (the band stays a band)
+    want = oracle.decode(bad_obs, frames, bad_trans, bad_init, num_threads=oracle.max_threads())
+    dev = torch.device('cuda:0')
+    to = lambda x: torch.as_tensor(np.ascontiguousarray(x)).to(dev)
+    prof = []
+    got = torbi_amd.decode(to(bad_obs), to(frames), to(bad_trans), to(bad_init), path='band', _profile=prof)
+    assert viterbi.ROUTES[int(prof[3])] == 'band'
+    assert ('band_tile_kernel' in viterbi.last_forward_kernel()) == (form == 'tile')
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    if kind in ('observation', 'final_row'):       # a group: the matrix is shared, only the second batch reads a NaN
+        both = viterbi.decode_batches([to(obs), to(bad_obs)], [to(frames), to(frames)], to(trans), to(init), path='band')
+        np.testing.assert_array_equal(both[0].cpu().numpy(), clean)
+        np.testing.assert_array_equal(both[1].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('kind', ['observation', 'initial', 'final_row', 'first'])
+@pytest.mark.parametrize('probabilities', [False, True])
+def test_nan_inputs_on_the_uniform_transition_entry(kind, probabilities):
+    """The reference's default call (transition=None: every entry log(1 / S), torbi/core.py:175-180) through
+    torbi_hip_viterbi_decode_uniform[_probabilities]: an item that reads a NaN is decoded again inside the same launch in the
+    reference's order of evaluation (csrc/uniform_decode.hpp, faithful_uniform_item) -- against the oracle on the materialised
+    matrix."""
+    import math
+    B, T, S = 5, 11, 300
+    rng = np.random.default_rng(12)
+    probs = rng.random((B, T, S)).astype(np.float32) + 1e-3
+    probs /= probs.sum(axis=-1, keepdims=True)
+    init_p = (rng.random(S).astype(np.float32) + 1e-3)
+    init_p /= init_p.sum()
+    frames = np.array([T, T - 3, T, 2, T], np.int32)
+    nan = np.float32('nan')
+    if kind == 'observation':
+        probs[0, 4, 7] = nan
+    elif kind == 'initial':
+        init_p[0] = nan
+    elif kind == 'final_row':
+        probs[1, frames[1] - 1, 17] = nan
+        probs[2, 0, :] = nan
+    else:
+        probs[4, 3, 0] = nan                   # prev-state 0 of a middle row: the NaN stays for the rest of the item
+    dev = torch.device('cuda:0')
+    c = float(torch.tensor(math.log(1.0 / S), dtype=torch.float32))
+    tiny = torch.finfo(torch.float32).tiny
+    scores = torch.log(torch.exp(torch.log(torch.from_numpy(probs).to(dev))) + tiny)       # core.py:189-197, on this device
+    init = torch.log(torch.from_numpy(init_p)).to(dev)
+    want = oracle.decode(scores.cpu().numpy(), frames, np.full((S, S), c, np.float32), init.cpu().numpy(),
+                         num_threads=oracle.max_threads())
+    f = torch.from_numpy(frames).to(dev)
+    if probabilities:
+        got = torbi_amd.decode_uniform(torch.from_numpy(probs).to(dev), f, c, init, probabilities=True)
+    else:
+        got = torbi_amd.decode_uniform(scores, f, c, init)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_a_stale_band_promise_is_caught_on_the_device():
+    """Round-5 advisor: torbi_amd.decode keeps the band of a matrix with the tensor's notes, keyed on its version counter; an edit
+    that does not bump the counter (`.data`, memory shared with numpy, another library's kernel) leaves a stale promise, and the
+    band kernels never read outside the promised band.  The launch that looks at the matrix for NaN (csrc/nonfinite.hpp) also
+    checks the promise: a finite entry outside the band raises the alarm and every item is decoded again on the WHOLE matrix.
+    Here the entry point is called with reach 9 for a matrix whose band was widened to 40 behind its back."""
+    import ctypes
+    from torbi_amd import _lib
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    B, T, S = 48, 6, 360
+    obs, _, init = synth.problem(B, T, S, seed=2)
+    frames = np.full((B,), T, np.int32)
+    o, f, i = (torch.as_tensor(x).to(dev) for x in (obs, frames, init))
+    ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+    out = torch.empty((B, T), dtype=torch.int32, device=dev)
+    one = (_lib.Batch * 1)(_lib.Batch(o.data_ptr(), f.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B, T))
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    phases = (ctypes.c_float * 6)()
+    for reach in (9, 40):
+        trans = _banded(S, reach, reach, seed=3)
+        matrix = torch.as_tensor(trans).to(dev)
+        out.zero_()
+        rc = lib.torbi_hip_viterbi_decode_banded(one, 1, matrix.data_ptr(), i.data_ptr(), S, 9, 9, 0, stream, viterbi._path_flag('band'), phases)
+        assert rc == 0 and viterbi.ROUTES[int(phases[3])] == 'band'
+        np.testing.assert_array_equal(out.cpu().numpy(), oracle.decode(obs, frames, trans, init), err_msg=f'true reach {reach}')
+
+
 def test_generic_route_takes_more_items_than_one_grid_dimension_holds():
     """The per-timestep trellis kernels index the item by gridDim.y (at most 65535): a batch of 70 000 sequences over ONE
     state (AUTO: generic -- nothing else covers S == 1) and over 8 states with DENSE named (generic below 64 states) used to
@@ -2057,9 +2221,9 @@ def test_auto_gates_follow_the_data_not_the_first_call():
     for _ in range(2):
         assert calls_until('peaked', 'cluster', 1) == 1                 # shallow scans: stays
     assert calls_until('flat', 'dense', 3) is not None                  # flat rows: the dense kernel within three calls
-    assert calls_until('flat', 'cluster', 3) is not None                # ... which is looked at again every third call
-    assert calls_until('flat', 'dense', 2) is not None                  # ... and found as deep as before
-    assert calls_until('peaked', 'cluster', 3) is not None              # peaked rows again: back on clusters within three calls
+    assert calls_until('flat', 'cluster', 3) is not None                # ... which is looked at again after three calls
+    assert calls_until('flat', 'dense', 2) is not None                  # ... and found as deep as before (the next look: six calls on)
+    assert calls_until('peaked', 'cluster', 6) is not None              # peaked rows again: back on clusters with that look
     assert calls_until('peaked', 'cluster', 1) == 1
     torbi_amd.reset_path_state()
 

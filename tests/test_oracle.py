@@ -95,10 +95,10 @@ def test_oracle_equals_reference_operator_on_fresh_inputs(seed):
 
 
 @pytest.mark.skipif(not oracle.ref_available(), reason='oracle/_ref not built (no /root/reference)')
-@pytest.mark.parametrize('seed', range(4))
+@pytest.mark.parametrize('seed', range(5))
 def test_oracle_follows_the_reference_operator_on_nan_inputs(seed):
-    """NaN is outside the contract of the HIP path (include/torbi_hip.h), but the ORACLE restates the reference also
-    there: a NaN candidate at prev-state 0 is never replaced (viterbi.cpp:94-100 starts its running maximum there),
+    """NaN and +inf inputs (the HIP path decodes such items again as the reference does: csrc/nonfinite.hpp): the ORACLE
+    restates the reference also there: a NaN candidate at prev-state 0 is never replaced (viterbi.cpp:94-100 starts its running maximum there),
     later NaN candidates never win, and the final state is ATen's argmax, which takes the first NaN of a row
     (viterbi.cpp:218).  Checked against the reference operator itself."""
     if _torbi_namespace_taken():
@@ -114,9 +114,14 @@ def test_oracle_follows_the_reference_operator_on_nan_inputs(seed):
         trans[9, 11] = nan
     elif seed == 2:
         init[0] = nan                           # the first posterior's first entry
-    else:
+    elif seed == 3:
         obs[1, T - 1, 17] = nan                 # NaN in the final row: argmax takes it
         obs[2, 0, :] = nan
+    else:
+        obs[0, 2, 0] = np.inf                   # +inf meets -inf: NaN candidates at prev-state 0 (they stay) and 3 (they lose)
+        obs[1, 4, 3] = np.inf
+        trans[6, 0] = -np.inf
+        trans[5, 3] = -np.inf
     frames = np.array([T, T, T - 2], np.int32)
     want = oracle.ref_decode(obs, frames, trans, init, num_threads=2).numpy()
     for mode in (0, 1):

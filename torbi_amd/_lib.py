@@ -16,7 +16,7 @@ SOURCE = os.path.join(_HERE, 'csrc', 'torbi_hip.hip')
 INCLUDE = os.path.join(ROOT, 'include')
 # TORBI_HIP_LIBRARY: an alternative build of the library (tools/variants_probe.py: -D experiments)
 LIBRARY = os.environ.get('TORBI_HIP_LIBRARY') or os.path.join(_HERE, 'libtorbi_hip.so')
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 # every symbol include/torbi_hip.h declares: name -> (restype, argtypes)
 _c = ctypes

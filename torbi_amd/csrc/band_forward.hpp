@@ -410,8 +410,10 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
     // (measured: sending behind the barrier that opens the next timestep, so that the stores issue under its first dquads,
     // is 2 % slower -- the granules leave later); `fetch`: the observations of row t + 2 (behind the halo granules of the timestep: a wave's loads return in
     // order, and a granule asked for behind a first-touch HBM read would wait for it)
+    bool odd = false;                  // a NaN / +inf posterior value was produced (nonfinite.hpp)
     auto settle = [&](const float4 &best) {
         const float4 v = make_float4(ob.x + best.x, ob.y + best.y, ob.z + best.z, ob.w + best.w);
+        odd = odd || nonfinite::odd4(v);
         fw_at[0] = v.x;
         fw_at[4] = v.y;
         fw_at[8] = v.z;
@@ -594,6 +596,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
         ex.failed[cid] = 1u;
         atomicAdd(&grp.stats[127], 1u);
     }
+    nonfinite::raise(odd && fin_row, bat.alarm, grp.serial);
     if (blockIdx.x == 0 && tid == 0) {
         grp.stats[120] = (unsigned)((clock64() - clock_0) >> 4);
         grp.stats[121] = (unsigned)((wall_clock64() - wall_0) >> 4);
@@ -613,6 +616,7 @@ __global__ __launch_bounds__(1024) void band_repair_kernel(Group grp, const unsi
     const int code = grp.tile_map[blockIdx.x];
     const Batch &bat = grp.batch[code >> 20];
     const int B = bat.B, T = bat.T, b0 = (code & 0xfffff) * kNI;
+    bool odd = false;
     if (tid < kNI) {
         int f = 0;
         const int item = bat.order[b0 + tid < B ? b0 + tid : B - 1];
@@ -637,6 +641,7 @@ __global__ __launch_bounds__(1024) void band_repair_kernel(Group grp, const unsi
             float v[4];
             for (int bb = 0; bb < 4; ++bb) {
                 v[bb] = bat.obs[at[bb] + j] + initial[j];
+                odd = odd || nonfinite::odd(v[bb]);
                 if (len[bb] > 0) bat.hist[at[bb] + j] = v[bb];
             }
             rows[j] = make_float4(v[0], v[1], v[2], v[3]);
@@ -660,6 +665,7 @@ __global__ __launch_bounds__(1024) void band_repair_kernel(Group grp, const unsi
                 float v[4];
                 for (int bb = 0; bb < 4; ++bb) {
                     v[bb] = bat.obs[at[bb] + (size_t)t * S + j] + best[bb];
+                    odd = odd || nonfinite::odd(v[bb]);
                     if (t < len[bb]) bat.hist[at[bb] + (size_t)t * S + j] = v[bb];
                 }
                 nxt[j] = make_float4(v[0], v[1], v[2], v[3]);
@@ -667,6 +673,7 @@ __global__ __launch_bounds__(1024) void band_repair_kernel(Group grp, const unsi
             __syncthreads();
         }
     }
+    nonfinite::raise(odd, bat.alarm, grp.serial);
 }
 
 // zero the exchange buffers of a launch (tags of an earlier decode must not be taken for this one's) and its control words

@@ -226,6 +226,7 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
         }
         store_row(j4, ok, t, x);
     };
+    bool odd = false;               // a NaN / +inf posterior value was produced (nonfinite.hpp)
     auto finish = [&](int u, const float (&acc)[16]) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -234,6 +235,8 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
             v[u][8 + c] = ob[c].z + acc[8 + c];
             v[u][12 + c] = ob[c].w + acc[12 + c];
         }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) odd = odd || (rowok[u] && nonfinite::odd(v[u][e]));
     };
     auto close_timestep = [&](int t) {
         if (t + 1 >= fmax) return;
@@ -318,6 +321,7 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
     for (int u = 0; u < BPW; ++u)
         if (u < nb) store_row(4 * jg[u], rowok[u], fmax - 1, v[u]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (no copy may land in an LDS that is no longer this workgroup's)
+    nonfinite::raise(odd, bat.alarm, grp.serial);
 #ifdef BAND_STAMP
     if (lane == 0 && blockIdx.x < 1024)
         for (int i = 0; i < kPhases; ++i) g_phase[((size_t)blockIdx.x * kMaxWaves + wave) * kPhases + i] = bacc[i];

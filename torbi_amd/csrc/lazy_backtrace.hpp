@@ -126,7 +126,8 @@ __device__ __forceinline__ float lane_max(const float4 (&v)[NQ], int lane, int S
 template <int NQ>
 __device__ __forceinline__ int wave_first_argmax4(const float4 (&v)[NQ], int lane, int S) {
     const float m = wavered::wave_reduce_f32(lane_max<NQ>(v, lane, S), wavered::MaxOp());
-    return wavered::wave_min_i32(lane_first_equal<NQ>(v, m, lane, S));
+    const int k = wavered::wave_min_i32(lane_first_equal<NQ>(v, m, lane, S));
+    return k < S ? k : 0;          // (a row of NaNs equals nothing: stay inside the matrix -- nonfinite.hpp decodes the item again)
 }
 
 // Register-resident form for S % 4 == 0 and S <= 256*NQ: the posterior row of the NEXT path step
@@ -334,14 +335,19 @@ struct GatherWalker {
     }
 };
 
+// (A row of NaNs has no first argmax: the walkers then answer kSentinel.  Such an item is decoded again behind this launch
+// (nonfinite.hpp); here the state only has to stay inside the matrix.)
+template <class Walker>
+__device__ __forceinline__ int inside(const Walker &w, int j) { return (unsigned)j < (unsigned)w.S ? j : 0; }
+
 // final state, tail fill (viterbi.cpp:218-221) and the walk down the whole path: one wave per item
 template <class Walker>
 __device__ __forceinline__ void walk_item(const Walker &w, int f, int32_t *__restrict__ o, int T, int lane) {
     f = f < 1 ? 1 : (f > T ? T : f);
-    int j = w.first_state(f - 1);
+    int j = inside(w, w.first_state(f - 1));
     for (int tt = f - 1 + lane; tt < T; tt += 64) o[tt] = j;
     for (int tt = f - 1; tt >= 1; --tt) {
-        j = w.step(j, tt);
+        j = inside(w, w.step(j, tt));
         if (lane == 0) o[tt - 1] = j;
     }
 }
@@ -363,14 +369,14 @@ __device__ __forceinline__ void chase_segment(const Walker &w, int f, int T, int
     const int lo = min(s * L, f - 1), hi = min((s + 1) * L, f - 1);
     const bool last = s == K - 1;                         // (hi = f - 1: the one segment whose start is known)
     if (!last && lo >= hi) return;
-    int j = w.first_state(hi);
+    int j = inside(w, w.first_state(hi));
     if (last) {
         for (int tt = f - 1 + lane; tt < T; tt += 64) o[tt] = j;
     } else if (lane == 0) {
         o[hi] = j;
     }
     for (int tt = hi; tt > lo; --tt) {
-        j = w.step(j, tt);
+        j = inside(w, w.step(j, tt));
         if (lane == 0 && (tt - 1 > lo || s == 0)) o[tt - 1] = j;      // (o[lo] is the start of segment s - 1)
     }
     if (lane == 0) arrive[s] = j;
@@ -395,7 +401,7 @@ __device__ __forceinline__ void stitch_segments(const Walker &w, int f, int T, i
         if (lane == 0) o[hi] = j;
         bool met = false;
         for (int tt = hi; tt > lo; --tt) {
-            j = w.step(j, tt);
+            j = inside(w, w.step(j, tt));
             ++again;
             if (tt - 1 == lo) break;
             if (o[tt - 1] == j) { met = true; break; }
@@ -533,7 +539,8 @@ __global__ __launch_bounds__(64) void backtrace_ranged_kernel(const float *__res
             k = min(k, kq);
         }
         k = wavered::wave_min_i32(k);
-        j = m == -INFINITY ? 0 : k;                             // (every candidate -inf: the reference's scan keeps prev-state 0)
+        j = (m == -INFINITY || k >= S) ? 0 : k;                 // (every candidate -inf: the reference's scan keeps prev-state 0;
+                                                                // a window of NaNs: inside the matrix, nonfinite.hpp decodes the item again)
         if (lane == 0) o[tt - 1] = j;
     }
 }

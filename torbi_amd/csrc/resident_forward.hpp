@@ -25,6 +25,7 @@
 
 #include "pruned_forward.hpp"
 #include "lazy_backtrace.hpp"
+#include "nonfinite.hpp"
 
 namespace resident {
 
@@ -59,6 +60,7 @@ struct Batch {
     int B, T;
     int tile0;               // first workgroup of this batch in the launch
     int item0;               // first item of this batch in the launch-wide item numbering (backtrace grid)
+    int32_t *alarm;          // raised (= Group::serial) by a kernel that produced a NaN / +inf posterior value (nonfinite.hpp)
 };
 
 struct Group {
@@ -68,6 +70,7 @@ struct Group {
     unsigned *stats;           // [128] scan statistics: [0] list blocks walked, [64] wave passes counted (sampled)
     const unsigned *only;      // null, or [tiles]: workgroup w decodes its tile only where only[w] != 0 -- the repair launch
                                // behind a cluster launch (Cluster::failed): tiles whose cluster gave up waiting, whole again
+    int serial;                // of this decode: what an alarm is raised with
 };
 
 // CLUSTER form: R workgroups (a cluster) share one 16-item tile.  Every member keeps the WHOLE posterior tile in its
@@ -410,6 +413,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
     float *__restrict__ hist = bat.hist;
     const int B = bat.B, T = bat.T;
     const int b0 = (code & 0xfffff) * kNI;
+    bool odd = false;                  // a NaN / +inf posterior value was produced (nonfinite.hpp)
 
     if (tid < kNI) {
         int f = 0;
@@ -435,6 +439,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
         float *dst = hist + (size_t)b * T * S;
         for (int i = tid; i < S; i += 64 * KW) {
             const float v = src[i] + initial[i];
+            odd = odd || nonfinite::odd(v);
             lds[i * kNI + item] = v;
             if (valid) dst[i] = v;
             top_insert<kTop>(top + item * kTop, top_key(v, i));
@@ -700,6 +705,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                     if (dummy[it] == 12345.678f) best[it] = 0.f;
 #endif
                     const float o = ob[it] + best[it];                     // post'[j] = obs[t,j] + max
+                    odd = odd || nonfinite::odd(o);
                     pend[p][it] = o;
                     if (jv && live[it] && !(RESIDENT_ABL & 8)) hist[((size_t)ib[it] * T + t) * S + jr] = o;
                     const u64 key = top_key(o, jr);
@@ -869,6 +875,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
         atomicAdd(&grp.stats[0], stat_blocks);
         atomicAdd(&grp.stats[64], stat_passes);
     }
+    nonfinite::raise(odd, bat.alarm, grp.serial);
     if (!REPAIR && blockIdx.x == 0 && tid == 0) {
         grp.stats[120] = (unsigned)((clock64() - clock_0) >> 4);         // (in units of 16 ticks: a launch may run for seconds)
         grp.stats[121] = (unsigned)((wall_clock64() - wall_0) >> 4);

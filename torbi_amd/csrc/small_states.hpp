@@ -16,6 +16,7 @@
 #include <utility>
 
 #include "wave_reduce.hpp"
+#include "nonfinite.hpp"
 
 namespace small {
 
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const float *__restrict__ ob
                                                     const float *__restrict__ trans, const float *__restrict__ init,
                                                     int32_t *__restrict__ out, uint32_t *__restrict__ plane,
                                                     float *__restrict__ post0, float *__restrict__ post1,
-                                                    int32_t *__restrict__ route_record, int route, int B, int T, int S) {
+                                                    int32_t *__restrict__ route_record, int route, int B, int T, int S, int serial) {
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
     if (b == 0 && lane == 0) *route_record = route;
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const float *__restrict__ ob
     uint32_t *pl = plane + (size_t)b * plane_dwords(T, S);
     float p = o[0] + init[min(lane, S - 1)];
     p = live ? p : ninf;
+    bool odd = nonfinite::odd(p);                    // a NaN / +inf posterior value was produced (nonfinite.hpp)
 
     float cur[CH];
 #pragma unroll
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const float *__restrict__ ob
                         arg = better ? argc[c] : arg;
                     }
                     p = live ? cur[k] + best : ninf;
+                    odd = odd || nonfinite::odd(p);
                     packed |= arg << (8 * r);
                 }
             }
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const float *__restrict__ ob
         for (int k = 0; k < CH; ++k) cur[k] = nxt[k];
     }
     if (live) (((n - 1) & 1) ? post1 : post0)[(size_t)b * S + lane] = p;      // (where torbi_hip_read_posterior looks)
+    nonfinite::raise(odd, route_record + nonfinite::kAlarmWord, serial);
 
     // first maximum of the last row
     float best = p;
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void decode_value_kernel(const float *__restri
                                                            const float *__restrict__ trans, const float *__restrict__ init,
                                                            int32_t *__restrict__ out, float *__restrict__ hist,
                                                            float *__restrict__ post0, float *__restrict__ post1,
-                                                           int32_t *__restrict__ route_record, int route, int B, int T, int S) {
+                                                           int32_t *__restrict__ route_record, int route, int B, int T, int S, int serial) {
     __shared__ float matrix[kMaxS * kMaxS];           // trans[j][i] at j * SP + i (the padding is never read)
     __shared__ float4 shared_rows[4][SP / 4];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -199,6 +203,7 @@ __global__ __launch_bounds__(256) void decode_value_kernel(const float *__restri
     float *h = hist + (size_t)b * T * S;
     float p = o[0] + init[min(lane, S - 1)];
     p = live ? p : ninf;
+    bool odd = nonfinite::odd(p);                    // a NaN / +inf posterior value was produced (nonfinite.hpp)
     if (live) h[lane] = p;
     float4 *const shared_row = shared_rows[wave];
 
@@ -237,6 +242,7 @@ __global__ __launch_bounds__(256) void decode_value_kernel(const float *__restri
                 }
                 const float top = fmaxf(fmaxf(best[0], best[1]), fmaxf(best[2], best[3]));
                 p = live ? cur[k] + top : ninf;
+                odd = odd || nonfinite::odd(p);
                 if (live && !(SMALL_ABL & 2)) h[(size_t)(t0 + k) * S + lane] = p;
             }
         }
@@ -244,6 +250,7 @@ __global__ __launch_bounds__(256) void decode_value_kernel(const float *__restri
         for (int k = 0; k < CH; ++k) cur[k] = nxt[k];
     }
     if (live) (((n - 1) & 1) ? post1 : post0)[(size_t)b * S + lane] = p;      // (where torbi_hip_read_posterior looks)
+    nonfinite::raise(odd, route_record + nonfinite::kAlarmWord, serial);
     if (SMALL_ABL & 1) return;
 
     // first maximum of the last row
@@ -309,7 +316,7 @@ template <int PQ, int L, int NSEQ>
 __global__ __launch_bounds__(64 * PQ * PQ) void block_value_kernel(
     const float *__restrict__ obs, const int32_t *__restrict__ frames, const float *__restrict__ trans,
     const float *__restrict__ init, float *__restrict__ hist, float *__restrict__ post0, float *__restrict__ post1,
-    int32_t *__restrict__ route_record, int route, int B, int T, int S, int NB) {
+    int32_t *__restrict__ route_record, int route, int B, int T, int S, int NB, int serial) {
     __shared__ float4 rows[2][NSEQ][kBlockMaxS / 4];      // posterior rows t-1 / t (entries >= S: -inf)
     __shared__ float upper_best[NSEQ][PQ - 1][kBlockMaxS];   // what the pieces pq >= 1 of the prev-states offer
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -344,10 +351,12 @@ __global__ __launch_bounds__(64 * PQ * PQ) void block_value_kernel(
 #pragma unroll
     for (int e = 0; e < L; ++e) row[e] = fminf(row[e], (live && lo + e < S) ? -ninf : ninf);          // the padding: -inf
     float p[NSEQ], cur[NSEQ][4];
+    bool odd = false;                                      // a NaN / +inf posterior value was produced (nonfinite.hpp)
 #pragma unroll
     for (int q = 0; q < NSEQ; ++q) {
         p[q] = o[q][0] + init[min(j, S - 1)];
         p[q] = live ? p[q] : ninf;
+        odd = odd || (n[q] && nonfinite::odd(p[q]));
         if (writer) {
             reinterpret_cast<float *>(rows[0][q])[j] = p[q];
             if (live && n[q]) h[q][j] = p[q];
@@ -396,6 +405,7 @@ __global__ __launch_bounds__(64 * PQ * PQ) void block_value_kernel(
                                 for (int u = 0; u < PQ - 1; ++u) best = fmaxf(best, upper_best[q][u][j]);
                             }
                             p[q] = live ? cur[q][r] + best : ninf;
+                            odd = odd || nonfinite::odd(p[q]);
                             reinterpret_cast<float *>(rows[(t0 + r) & 1][q])[j] = p[q];
                             if (live) h[q][(size_t)(t0 + r) * S + j] = p[q];
                         }
@@ -414,6 +424,7 @@ __global__ __launch_bounds__(64 * PQ * PQ) void block_value_kernel(
         const int b = blockIdx.x * NSEQ + q;
         if (writer && live && n[q]) (((n[q] - 1) & 1) ? post1 : post0)[(size_t)b * S + j] = p[q];
     }
+    nonfinite::raise(odd, route_record + nonfinite::kAlarmWord, serial);
 }
 
 }  // namespace small

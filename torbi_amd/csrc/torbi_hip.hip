@@ -683,6 +683,17 @@ struct ResidentWorkspace {
 thread_local void *g_preparation = nullptr;
 thread_local size_t g_preparation_bytes = 0;
 thread_local bool g_preparation_valid = false;      // holds this matrix's preparation (the caller's promise, or filled by this call)
+
+// the serial number of the decode this host thread is launching: what its kernels raise their NaN / +inf alarms with
+// (nonfinite.hpp; never 0, never repeated within a process: no alarm word has to be cleared between decodes)
+static std::atomic<unsigned> g_serial_counter{(unsigned)(std::chrono::steady_clock::now().time_since_epoch().count() * 2654435761u)};
+thread_local int t_serial = 0;          // of the decode this host thread is launching
+inline int new_serial() {
+    unsigned v;
+    do { v = ++g_serial_counter; } while (v == 0u);
+    t_serial = (int)v;
+    return t_serial;
+}
 inline size_t preparation_bytes(int S) {
     const int Sp = (S + 15) / 16 * 16;
     return align_up(sizeof(float2) * (size_t)S * (Sp + pruned::kPad), 256) + align_up(sizeof(float) * (size_t)S * S, 256) +
@@ -850,11 +861,14 @@ inline size_t layout_bytes(int B, int T, int S, int cus) {
 // (a Route), written on the stream by that decode and read ON THE DEVICE by torbi_hip_read_posterior /
 // torbi_hip_scan_stats -- a batch decoded inside a launch group takes the group's route, not the one its own shape
 // and flags would give it.
-inline size_t need_bytes(int B, int T, int S, int cus) { return layout_bytes(B, T, S, cus) + 256; }
+// ... and behind the record the two posterior rows per item of nonfinite::repair_kernel (NaN / +inf inputs: nonfinite.hpp)
+inline size_t nonfinite_rows_bytes(int B, int S) { return align_up(sizeof(float) * 2 * (size_t)B * S, 256); }
+inline size_t need_bytes(int B, int T, int S, int cus) { return layout_bytes(B, T, S, cus) + 256 + nonfinite_rows_bytes(B, S); }
 inline int32_t *route_record(const void *workspace, int B, int T, int S, int cus) {
     return reinterpret_cast<int32_t *>(static_cast<char *>(const_cast<void *>(workspace)) + layout_bytes(B, T, S, cus));
 }
 __global__ void stamp_route_kernel(int32_t *record, int route) { *record = route; }
+__global__ void fill_pair_kernel(int32_t *pair, int a, int b) { pair[0] = a; pair[1] = b; }
 inline hipError_t stamp_route(void *workspace, int B, int T, int S, int cus, Route route, hipStream_t s) {
     // (a one-thread kernel: hipMemsetD32Async costs ~0.17 ms per call on this stack)
     hipLaunchKernelGGL(stamp_route_kernel, dim3(1), dim3(1), 0, s, route_record(workspace, B, T, S, cus), (int)route);
@@ -1028,12 +1042,12 @@ hipError_t launch_small_as(const float *obs, const int32_t *frames, const float 
     if (value_form) {
         TORBI_NOTE_KERNEL("small::decode_value_kernel<%d, %d>", SP, CH);
         hipLaunchKernelGGL((small::decode_value_kernel<SP, CH>), dim3((B + 3) / 4), dim3(256), 0, stream, obs, frames, trans, init,
-                           out, reinterpret_cast<float *>(w.trellis), w.post[0], w.post[1], record, (int)ROUTE_SMALL, B, T, S);
+                           out, reinterpret_cast<float *>(w.trellis), w.post[0], w.post[1], record, (int)ROUTE_SMALL, B, T, S, t_serial);
         return hipGetLastError();
     }
     TORBI_NOTE_KERNEL("small::decode_kernel<%d, %d>", SP, CH);
     hipLaunchKernelGGL((small::decode_kernel<SP, CH>), dim3(B), dim3(64), 0, stream, obs, frames, trans, init, out,
-                       reinterpret_cast<uint32_t *>(w.trellis), w.post[0], w.post[1], record, (int)ROUTE_SMALL, B, T, S);
+                       reinterpret_cast<uint32_t *>(w.trellis), w.post[0], w.post[1], record, (int)ROUTE_SMALL, B, T, S, t_serial);
     return hipGetLastError();
 }
 hipError_t launch_small(const float *obs, const int32_t *frames, const float *trans, const float *init, const Workspace &w,
@@ -1070,11 +1084,11 @@ hipError_t launch_block_value_as(const float *obs, const int32_t *frames, const 
     if (pairs)
         hipLaunchKernelGGL((small::block_value_kernel<PQ, L, 2>), dim3((B + 1) / 2), dim3(64 * NB * PQ), 0, stream, obs, frames,
                            trans, init, reinterpret_cast<float *>(w.trellis), w.post[0], w.post[1], record, (int)ROUTE_SMALL, B,
-                           T, S, NB);
+                           T, S, NB, t_serial);
     else
         hipLaunchKernelGGL((small::block_value_kernel<PQ, L, 1>), dim3(B), dim3(64 * NB * PQ), 0, stream, obs, frames, trans,
                            init, reinterpret_cast<float *>(w.trellis), w.post[0], w.post[1], record, (int)ROUTE_SMALL, B, T, S,
-                           NB);
+                           NB, t_serial);
     return hipGetLastError();
 }
 hipError_t launch_block(const float *obs, const int32_t *frames, const float *trans, const float *init, const Workspace &w,
@@ -1356,6 +1370,48 @@ inline int backtrace_segments(int items) {
 }
 
 // batches with B > 0 only; the preparation lives in the first batch's workspace
+// ---- NaN / +inf inputs (nonfinite.hpp): alarms raised with the decode's serial number, a repair launch behind the decode ----
+// Ahead of a decode's forward launches: the matrix and the initial vector; the observations too for the routes whose
+// forward kernels do not look at what they produce (a launch per timestep: generic, held, rows, dense).
+inline hipError_t nonfinite_begin(const HostBatch *hb, int n, const float *trans, const float *init, int S, int cus, hipStream_t s,
+                                  bool scan_observations, int reach_left = -1, int reach_right = -1) {
+    const int serial = new_serial();
+    nonfinite::Records recs{};
+    recs.n = n;
+    for (int k = 0; k < n; ++k) recs.record[k] = route_record(hb[k].workspace, hb[k].B, hb[k].T, S, cus);
+    const size_t cells = (size_t)S * S;
+    hipLaunchKernelGGL(nonfinite::matrix_kernel, dim3((unsigned)std::max<size_t>(1, std::min<size_t>(1024, (cells + 2047) / 2048))),
+                       dim3(256), 0, s, trans, init, S, recs, serial, reach_left, reach_right);
+    if (scan_observations)
+        for (int k = 0; k < n; ++k) {
+            const size_t count = (size_t)hb[k].B * hb[k].T * S;
+            hipLaunchKernelGGL(nonfinite::observation_kernel,
+                               dim3((unsigned)std::max<size_t>(1, std::min<size_t>(2048, (count + 4095) / 4096))), dim3(256), 0, s,
+                               hb[k].obs, count, recs.record[k], serial);
+        }
+    return hipGetLastError();
+}
+// Behind the decode's backtrace: does nothing unless an alarm carries this decode's serial number.
+inline hipError_t nonfinite_end(const HostBatch *hb, int n, const float *trans, const float *init, int S, int cus, hipStream_t s) {
+    nonfinite::RepairJobs jobs{};
+    jobs.n = n;
+    int items = 0;
+    for (int k = 0; k < n; ++k) {
+        jobs.obs[k] = hb[k].obs;
+        jobs.frames[k] = hb[k].frames;
+        jobs.out[k] = hb[k].out;
+        jobs.trellis[k] = static_cast<int32_t *>(hb[k].workspace);
+        jobs.record[k] = route_record(hb[k].workspace, hb[k].B, hb[k].T, S, cus);
+        jobs.rows[k] = reinterpret_cast<float *>(reinterpret_cast<char *>(jobs.record[k]) + 256);
+        jobs.B[k] = hb[k].B;
+        jobs.T[k] = hb[k].T;
+        jobs.item0[k] = items;
+        items += hb[k].B;
+    }
+    hipLaunchKernelGGL(nonfinite::repair_kernel, dim3(items), dim3(256), 0, s, jobs, trans, init, S, t_serial);
+    return hipGetLastError();
+}
+
 hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const float *init, int S, int cus, hipStream_t s,
                         hipEvent_t *ev, int *launches, bool reuse, bool ascending = false, bool clusters = false,
                         bool few = false) {
@@ -1363,10 +1419,16 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
     resident::OrderJobs jobs{};
     jobs.ascending = ascending ? 1 : 0;
     grp.n = n;
+    {
+        const hipError_t ne = nonfinite_begin(hb, n, trans, init, S, cus, s, false);
+        if (ne != hipSuccess) return ne;
+    }
+    grp.serial = t_serial;
     int tiles = 0, items = 0, widest = 0;
     for (int k = 0; k < n; ++k) {
         resident::Batch &b = grp.batch[k];
         const ResidentWorkspace wk = carve_resident(hb[k].workspace, hb[k].B, hb[k].T, S, cus);
+        b.alarm = route_record(hb[k].workspace, hb[k].B, hb[k].T, S, cus) + nonfinite::kAlarmWord;
         b.obs = hb[k].obs;
         b.frames = hb[k].frames;
         b.out = hb[k].out;
@@ -1517,6 +1579,10 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
         hipLaunchKernelGGL(resident::group_backtrace_prefetch_kernel<16>, dim3(items), dim3(64), 0, s, grp, trans, S);
     else
         hipLaunchKernelGGL(resident::group_backtrace_kernel<1>, dim3(items), dim3(64), 0, s, grp, trans, S);
+    {
+        const hipError_t ne = nonfinite_end(hb, n, trans, init, S, cus, s);
+        if (ne != hipSuccess) return ne;
+    }
     if (ev) (void)hipEventRecord(ev[2], s);
     return hipGetLastError();
 }
@@ -1561,11 +1627,17 @@ hipError_t run_band(const HostBatch *hb, int n, const float *trans, const float 
     band::ClearJobs clear{};
     jobs.ascending = ascending ? 1 : 0;
     grp.n = n;
+    {
+        const hipError_t ne = nonfinite_begin(hb, n, trans, init, S, cus, s, false, pl.hl, pl.hr);     // (and the band's promise)
+        if (ne != hipSuccess) return ne;
+    }
+    grp.serial = t_serial;
     int tiles = 0, items = 0, widest = 0;
     size_t most = 0;
     for (int k = 0; k < n; ++k) {
         resident::Batch &b = grp.batch[k];
         const BandWorkspace wk = carve_band(hb[k].workspace, hb[k].B, hb[k].T, S, cus);
+        b.alarm = route_record(hb[k].workspace, hb[k].B, hb[k].T, S, cus) + nonfinite::kAlarmWord;
         b.obs = hb[k].obs;
         b.frames = hb[k].frames;
         b.out = hb[k].out;
@@ -1683,6 +1755,10 @@ hipError_t run_band(const HostBatch *hb, int n, const float *trans, const float 
     else if (S <= 2048) { TORBI_BAND_BACKTRACE(8) }
     else { TORBI_BAND_BACKTRACE(16) }
 #undef TORBI_BAND_BACKTRACE
+    {
+        const hipError_t ne = nonfinite_end(hb, n, trans, init, S, cus, s);
+        if (ne != hipSuccess) return ne;
+    }
     if (ev) (void)hipEventRecord(ev[2], s);
     return hipGetLastError();
 }
@@ -1726,6 +1802,11 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
     if (g_preparation) reuse = false;       // (the promise was about the caller's buffer; this route prepares in the workspace)
     if (ev) (void)hipEventRecord(ev[0], s);
     if (ev) (void)hipEventRecord(ev[3], s);
+    // NaN / +inf inputs (nonfinite.hpp): the small-state kernels look at the values they produce; the routes below get
+    // their observations looked at by a launch of its own (they launch a kernel per timestep anyway)
+    const HostBatch alone{obs, frames, out, workspace, B, T};
+    e = nonfinite_begin(&alone, 1, trans, init, S, cus, s, route != ROUTE_SMALL);
+    if (e != hipSuccess) return e;
     if (route == ROUTE_SMALL) {             // one launch: recurrence, backtrace and the route record
         // (the byte plane lies where the generic path's trellis does and is never larger: small_states.hpp)
         // (and so does the value-only form's fp32 history: the trellis region itself)
@@ -1734,6 +1815,7 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
         e = small::supported(S) ? launch_small(obs, frames, trans, init, w, out, record, B, T, S, s, launches, cus)
                                 : launch_block(obs, frames, trans, init, w, out, record, B, T, S, s, launches, cus);
         if (ev) (void)hipEventRecord(ev[1], s);
+        if (e == hipSuccess) e = nonfinite_end(&alone, 1, trans, init, S, cus, s);
         if (ev) (void)hipEventRecord(ev[2], s);
         return e;
     }
@@ -1776,6 +1858,7 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
         if (ev) (void)hipEventRecord(ev[1], s);
         if (e == hipSuccess) e = launch_finalize(frames, w, out, B, T, S, s);
     }
+    if (e == hipSuccess) e = nonfinite_end(&alone, 1, trans, init, S, cus, s);
     if (ev) (void)hipEventRecord(ev[2], s);
     return e;
 }
@@ -1969,18 +2052,20 @@ int torbi_hip_band_reach(const float *transition, int S, int device, void *strea
     DeviceGuard guard(device);
     if (guard.err != hipSuccess) return (int)guard.err;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    int32_t *dev = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&dev), 2 * sizeof(int32_t));
+    // eight bytes of device scratch per host thread and device, kept for the life of the thread: hipMalloc / hipFree per call
+    // synchronise the whole device (round-5 advisor) and stall other streams' decodes
+    thread_local int32_t *scratch[kMaxDevices] = {};
+    if (device < 0 || device >= kMaxDevices) return TORBI_HIP_EINVAL;
+    hipError_t e = hipSuccess;
+    if (!scratch[device]) e = hipMalloc(reinterpret_cast<void **>(&scratch[device]), 2 * sizeof(int32_t));
     if (e != hipSuccess) return (int)e;
+    int32_t *const dev = scratch[device];
     int32_t host[2] = {-1, -1};
-    e = hipMemsetAsync(dev, 0xff, 2 * sizeof(int32_t), s);           // (-1, -1: what a matrix without a finite entry leaves)
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(band::band_reach_kernel, dim3(S), dim3(64), 0, s, transition, dev, S);
-        e = hipGetLastError();
-    }
+    hipLaunchKernelGGL(fill_pair_kernel, dim3(1), dim3(1), 0, s, dev, -1, -1);     // (-1, -1: what a matrix without a finite entry leaves)
+    hipLaunchKernelGGL(band::band_reach_kernel, dim3(S), dim3(64), 0, s, transition, dev, S);
+    e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(dev);
     if (e != hipSuccess) return (int)e;
     *reach_left_out = host[0];
     *reach_right_out = host[1];

@@ -16,6 +16,7 @@
 #include <math.h>
 
 #include "wave_reduce.hpp"
+#include "nonfinite.hpp"
 
 namespace uniform {
 
@@ -44,6 +45,72 @@ constexpr int kNone = 0x7fffffff;
 // precedes the decode is gone.  (Out of place like upstream's torch.log: the caller's tensor is not written.)
 __device__ __forceinline__ float score_of_probability(float p) { return logf(expf(logf(p)) + 1.17549435e-38f); }
 
+
+// An item that reads a NaN or +inf: the reference's own order of evaluation (viterbi.cpp:94-100: the running maximum of a row
+// starts at prev-state 0 and is replaced on a strict '>': a NaN candidate at prev-state 0 is never replaced, a NaN anywhere
+// else never wins; :218: ATen's argmax takes the FIRST NaN of the final row), with the constant matrix.  One workgroup, a
+// few barriers per timestep: slow, identical to the reference operator.  Every thread of the workgroup calls it.
+template <bool PROBS>
+__device__ inline void faithful_uniform_item(const float *__restrict__ o, int f, const float *__restrict__ initial, float c,
+                                             int32_t *__restrict__ res, int T, int S, float *red_v, int *red_k, int *flag) {
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    auto value = [&](int t, int i) { const float x = o[(size_t)t * S + i]; return PROBS ? score_of_probability(x) : x; };
+    // post_t[i] = t == 0 ? obs[0][i] + initial[i] : obs[t][i] + m
+    auto post = [&](int t, int i, float m) { return t == 0 ? value(0, i) + initial[i] : value(t, i) + m; };
+    float m = 0.f;
+    for (int t = 1; t < f; ++t) {
+        // candidates of timestep t: fl(post_{t-1}[i] + c); largest non-NaN one and its first index
+        float best = -INFINITY;
+        for (int i = tid; i < S; i += nt) best = __builtin_fmaxf(best, post(t - 1, i, m) + c);
+        best = wave_reduce_f32(best, MaxOp());
+        if (lane == 0) red_v[wave] = best;
+        __syncthreads();
+        best = red_v[0];
+        for (int w = 1; w < nw; ++w) best = __builtin_fmaxf(best, red_v[w]);
+        int k = kNone;
+        for (int i = tid; i < S; i += nt)
+            if (post(t - 1, i, m) + c == best) { k = i; break; }
+        k = wave_min_i32(k);
+        if (lane == 0) red_k[wave] = k;
+        __syncthreads();
+        k = red_k[0];
+        for (int w = 1; w < nw; ++w) k = min(k, red_k[w]);
+        const float first = post(t - 1, 0, m) + c;
+        if (first != first) { best = first; k = 0; }             // the NaN at prev-state 0 stays
+        if (k == kNone) k = 0;                                    // (every other candidate NaN: the first one stands)
+        if (tid == 0) res[t - 1] = k;                             // the backpointer of EVERY next state (viterbi.cpp:153-157)
+        m = best;
+        __syncthreads();
+    }
+    // final state: the first NaN of the last posterior row, else its first maximum (viterbi.cpp:218-221)
+    int nan_at = kNone;
+    float best = -INFINITY;
+    for (int i = tid; i < S; i += nt) {
+        const float p = post(f - 1, i, m);
+        if (p != p) nan_at = min(nan_at, i);
+        best = __builtin_fmaxf(best, p);
+    }
+    nan_at = wave_min_i32(nan_at);
+    best = wave_reduce_f32(best, MaxOp());
+    if (lane == 0) { red_k[wave] = nan_at; red_v[wave] = best; }
+    __syncthreads();
+    nan_at = red_k[0];
+    best = red_v[0];
+    for (int w = 1; w < nw; ++w) { nan_at = min(nan_at, red_k[w]); best = __builtin_fmaxf(best, red_v[w]); }
+    __syncthreads();
+    int k = kNone;
+    for (int i = tid; i < S; i += nt)
+        if (post(f - 1, i, m) == best) { k = i; break; }
+    k = wave_min_i32(k);
+    if (lane == 0) red_k[wave] = k;
+    __syncthreads();
+    k = red_k[0];
+    for (int w = 1; w < nw; ++w) k = min(k, red_k[w]);
+    k = nan_at != kNone ? nan_at : (k == kNone ? 0 : k);
+    for (int tt = f - 1 + tid; tt < T; tt += nt) res[tt] = k;
+    (void)flag;
+}
+
 // NW: waves per workgroup (4; 8 or 16 for a handful of sequences, whose only parallelism is the rows in flight per item:
 // 1 x 500 x 1440 0.148 ms with 4 waves)
 template <int NQW, int R, bool PROBS = false, int NW = 4>
@@ -52,6 +119,9 @@ __global__ __launch_bounds__(64 * NW) void uniform_rows_kernel(const float *__re
                                                            int32_t *__restrict__ out, int B, int T, int S) {
     constexpr int CH = NW * R;
     __shared__ float rowmax[2][CH];
+    __shared__ float red_v[NW];
+    __shared__ int red_k[NW];
+    bool odd = false;                  // a NaN / +inf among the item's inputs (nonfinite.hpp): decoded again below
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -75,6 +145,7 @@ __global__ __launch_bounds__(64 * NW) void uniform_rows_kernel(const float *__re
                 if constexpr (PROBS)
                     v = make_float4(score_of_probability(v.x), score_of_probability(v.y), score_of_probability(v.z),
                                     score_of_probability(v.w));
+                odd = odd || (t < f && i < S && nonfinite::odd4(v));
                 dst[r][q] = v;
             }
         }
@@ -85,6 +156,7 @@ __global__ __launch_bounds__(64 * NW) void uniform_rows_kernel(const float *__re
         for (int q = 0; q < NQW; ++q) {
             const int i = 4 * lane + 256 * q;
             const float4 a = *reinterpret_cast<const float4 *>(initial + (i < S ? i : 0));
+            odd = odd || (i < S && nonfinite::odd4(a));
             cur[0][q] = make_float4(cur[0][q].x + a.x, cur[0][q].y + a.y, cur[0][q].z + a.z, cur[0][q].w + a.w);
         }
     }
@@ -156,6 +228,8 @@ __global__ __launch_bounds__(64 * NW) void uniform_rows_kernel(const float *__re
 #pragma unroll
             for (int q = 0; q < NQW; ++q) cur[r][q] = nxt[r][q];
     }
+    odd = odd || nonfinite::odd(c);
+    if (__syncthreads_or(odd)) faithful_uniform_item<PROBS>(o, f, initial, c, res, T, S, red_v, red_k, nullptr);
 }
 
 }  // namespace uniform

@@ -4,6 +4,7 @@
 implementation through the C ABI (include/torbi_hip.h) instead of
 `torch.ops.torbi.viterbi_decode` (reference torbi/csrc/ops.cpp:17).
 """
+import threading
 import ctypes
 import os
 from typing import Optional
@@ -124,18 +125,21 @@ ONE_SEED_DEPTH = 1.25
 # kernel -- which leaves no statistics -- every DENSE_PROBE_EVERY-th call takes the time-resident kernel anyway to look again.
 # Peaked batches followed by flat ones (or the reverse) with ONE matrix change route within three calls.
 DEPTH_NEWEST_WEIGHT = 0.75
-DENSE_PROBE_EVERY = 3
+DENSE_PROBE_EVERY = 3           # ... the first look again; the interval doubles while the looks keep saying "losing"
+DENSE_PROBE_AT_MOST = 48        # (flat data for good: one call in 48 pays for the look, not one in three)
+_depth_lock = threading.Lock()  # host threads that share one transition tensor share its record
 
 
 def _depth_record(transition: torch.Tensor, states: int):
     """[scan depth of time-resident launches with this matrix in list blocks per wave pass, on the scale of a three-seed
-    launch (None until known), pending sample (pinned stats, event, seeds per item of that launch) or None, 3 (unused),
-    the pinned buffer kept for the samples, consecutive calls the gates sent to the dense kernel], kept with the tensor's
-    notes (torbi_amd/state.py)."""
+    launch (None until known), pending sample (pinned stats, event, seeds per item of that launch) or None, calls between
+    two looks while the gates keep the matrix on the dense kernel, the pinned buffer kept for the samples, consecutive calls
+    the gates sent to the dense kernel], kept with the tensor's notes (torbi_amd/state.py); read and written under
+    `_depth_lock`."""
     kept = state.notes(transition)
     if kept is None:
         return None
-    return kept.setdefault(('depth', states), [None, None, 3, None, 0])
+    return kept.setdefault(('depth', states), [None, None, DENSE_PROBE_EVERY, None, 0])
 
 
 def _known_depth(transition: torch.Tensor, states: int):
@@ -143,13 +147,15 @@ def _known_depth(transition: torch.Tensor, states: int):
     known = _depth_record(transition, states)
     if known is None:
         return None
-    if known[1] is not None and known[1][1].query():
-        stats, _, seeds = known[1]
-        known[1] = None
-        if int(stats[64:120].sum()) > 0:
-            sample = critical_blocks(stats) / (ONE_SEED_DEPTH if seeds == 1 else 1.0)
-            known[0] = sample if known[0] is None else DEPTH_NEWEST_WEIGHT * sample + (1.0 - DEPTH_NEWEST_WEIGHT) * known[0]
-    return known[0]
+    with _depth_lock:
+        pending = known[1]
+        if pending is not None and pending[1].query():
+            stats, _, seeds = pending
+            if int(stats[64:120].sum()) > 0:
+                sample = critical_blocks(stats) / (ONE_SEED_DEPTH if seeds == 1 else 1.0)
+                known[0] = sample if known[0] is None else DEPTH_NEWEST_WEIGHT * sample + (1.0 - DEPTH_NEWEST_WEIGHT) * known[0]
+            known[1] = None             # (only now may another thread start a copy into the pinned buffer)
+        return known[0]
 
 
 def _resident_is_losing(transition: torch.Tensor, states: int, single: bool = False) -> bool:
@@ -162,10 +168,15 @@ def _resident_is_losing(transition: torch.Tensor, states: int, single: bool = Fa
     losing = depth is not None and depth > (SINGLE_BATCH_GATE if single else RESIDENT_GATE) * states / 16.0
     known = _depth_record(transition, states)
     if known is not None:
-        known[4] = known[4] + 1 if losing else 0
-        if known[4] >= DENSE_PROBE_EVERY:
-            known[4] = 0
-            return False
+        with _depth_lock:
+            if not losing:
+                known[4], known[2] = 0, DENSE_PROBE_EVERY
+            else:
+                known[4] += 1
+                if known[4] >= known[2]:            # look again; the next look twice as far away while this keeps happening
+                    known[4] = 0
+                    known[2] = min(2 * known[2], DENSE_PROBE_AT_MOST)
+                    return False
     return losing
 
 
@@ -202,14 +213,17 @@ def _watch_resident(transition, workspace, batch, frames, states, seeds=3) -> No
     host memory (asynchronously; folded in by a later call, never waited for) -- unless the previous sample is still on its
     way.  `seeds`: what the launch kept per item."""
     known = _depth_record(transition, states)
-    if known is None or known[1] is not None:
+    if known is None:
         return
-    if known[3] is None:
-        known[3] = torch.empty((128,), dtype=torch.int32, pin_memory=True)
-    known[3].copy_(scan_stats(workspace, batch, frames, states, path='resident'), non_blocking=True)
-    done = torch.cuda.Event()
-    done.record(torch.cuda.current_stream(workspace.device))
-    known[1] = (known[3], done, seeds)
+    with _depth_lock:
+        if known[1] is not None:
+            return
+        if known[3] is None:
+            known[3] = torch.empty((128,), dtype=torch.int32, pin_memory=True)
+        known[3].copy_(scan_stats(workspace, batch, frames, states, path='resident'), non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(workspace.device))
+        known[1] = (known[3], done, seeds)
 
 
 def band_reach(trans: torch.Tensor, original: torch.Tensor, states: int):
