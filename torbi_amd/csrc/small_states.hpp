@@ -47,6 +47,11 @@ __global__ __launch_bounds__(64) void decode_kernel(const float *__restrict__ ob
 #pragma unroll
     for (int i = 0; i < SP; ++i) row[i] = trans[(size_t)min(lane, S - 1) * S + min(i, S - 1)];   // (clamped addresses:
     asm volatile("" ::: "memory");                   //  every load unconditional and in flight before the first use)
+    bool odd_matrix = false;                         // the matrix / initial vector hold a NaN or +inf (nonfinite.hpp: this
+#pragma unroll                                       // route looks itself, its launches are too short for a launch that does)
+    for (int i = 0; i < SP; ++i) odd_matrix = odd_matrix || nonfinite::odd(row[i]);
+    odd_matrix = odd_matrix || nonfinite::odd(init[min(lane, S - 1)]);
+    nonfinite::raise(odd_matrix, route_record + nonfinite::kMatrixWord, serial);
 #pragma unroll
     for (int i = 0; i < SP; ++i) row[i] = fminf(row[i], (live && i < S) ? -ninf : ninf);             // the padding: -inf
     const float *o = obs + (size_t)b * T * S + min(lane, S - 1);
@@ -187,7 +192,14 @@ __global__ __launch_bounds__(256) void decode_value_kernel(const float *__restri
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (blockIdx.x == 0 && tid == 0) *route_record = route;
-    for (int e = tid; e < S * S; e += 256) matrix[(e / S) * SP + e % S] = trans[e];
+    bool odd_matrix = false;                          // (nonfinite.hpp: this route looks at the matrix itself)
+    for (int e = tid; e < S * S; e += 256) {
+        const float x = trans[e];
+        odd_matrix = odd_matrix || nonfinite::odd(x);
+        matrix[(e / S) * SP + e % S] = x;
+    }
+    for (int i = tid; i < S; i += 256) odd_matrix = odd_matrix || nonfinite::odd(init[i]);
+    nonfinite::raise(odd_matrix, route_record + nonfinite::kMatrixWord, serial);
     __syncthreads();
     const int b = blockIdx.x * 4 + wave;
     if (b >= B) return;                               // (behind the only workgroup barrier)
@@ -348,6 +360,10 @@ __global__ __launch_bounds__(64 * PQ * PQ) void block_value_kernel(
 #pragma unroll
     for (int e = 0; e < L; ++e) row[e] = trans[(size_t)min(j, S - 1) * S + min(lo + e, S - 1)];   // (clamped addresses:
     asm volatile("" ::: "memory");                         //  every load unconditional and in flight before the first use)
+    bool odd_matrix = nonfinite::odd(init[min(j, S - 1)]);     // (nonfinite.hpp: this route looks at the matrix itself)
+#pragma unroll
+    for (int e = 0; e < L; ++e) odd_matrix = odd_matrix || nonfinite::odd(row[e]);
+    nonfinite::raise(odd_matrix, route_record + nonfinite::kMatrixWord, serial);
 #pragma unroll
     for (int e = 0; e < L; ++e) row[e] = fminf(row[e], (live && lo + e < S) ? -ninf : ninf);          // the padding: -inf
     float p[NSEQ], cur[NSEQ][4];

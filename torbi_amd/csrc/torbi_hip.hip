@@ -1374,8 +1374,9 @@ inline int backtrace_segments(int items) {
 // Ahead of a decode's forward launches: the matrix and the initial vector; the observations too for the routes whose
 // forward kernels do not look at what they produce (a launch per timestep: generic, held, rows, dense).
 inline hipError_t nonfinite_begin(const HostBatch *hb, int n, const float *trans, const float *init, int S, int cus, hipStream_t s,
-                                  bool scan_observations, int reach_left = -1, int reach_right = -1) {
+                                  bool scan_observations, int reach_left = -1, int reach_right = -1, bool scan_matrix = true) {
     const int serial = new_serial();
+    if (!scan_matrix) return hipSuccess;            // (the small-state kernels hold the whole matrix: they look themselves)
     nonfinite::Records recs{};
     recs.n = n;
     for (int k = 0; k < n; ++k) recs.record[k] = route_record(hb[k].workspace, hb[k].B, hb[k].T, S, cus);
@@ -1805,7 +1806,7 @@ hipError_t run_decode(const float *obs, const int32_t *frames, const float *tran
     // NaN / +inf inputs (nonfinite.hpp): the small-state kernels look at the values they produce; the routes below get
     // their observations looked at by a launch of its own (they launch a kernel per timestep anyway)
     const HostBatch alone{obs, frames, out, workspace, B, T};
-    e = nonfinite_begin(&alone, 1, trans, init, S, cus, s, route != ROUTE_SMALL);
+    e = nonfinite_begin(&alone, 1, trans, init, S, cus, s, route != ROUTE_SMALL, -1, -1, route != ROUTE_SMALL);
     if (e != hipSuccess) return e;
     if (route == ROUTE_SMALL) {             // one launch: recurrence, backtrace and the route record
         // (the byte plane lies where the generic path's trellis does and is never larger: small_states.hpp)
@@ -2196,6 +2197,8 @@ int decode_uniform_as(const float *observation, const int32_t *batch_frames, flo
         else                                                                                             \
             hipLaunchKernelGGL((uniform::uniform_rows_kernel<NQW_, R_, PROBS>), dim3(B), dim3(256), 0, s, \
                                observation, batch_frames, initial, log_transition, indices_out, B, T, S); \
+        hipLaunchKernelGGL((uniform::uniform_repair_kernel<PROBS>), dim3(B), dim3(256), 0, s, observation, batch_frames, \
+                           initial, log_transition, indices_out, B, T, S);     /* (items that read a NaN / +inf) */ \
         mark_decode_end(device, s);                                                                      \
         return (int)hipGetLastError();                                                                   \
     }

@@ -26,6 +26,7 @@ using wavered::MaxOp;
 
 
 constexpr int kNone = 0x7fffffff;
+constexpr int kFlagged = -2;          // in out[b][0]: the item read a NaN / +inf (uniform_repair_kernel decodes it again)
 
 // ---- the reductions OFF the dependent chain ----------------------------------------------------------------------------
 // (Rounds 1-3 ran the recurrence as written above: one workgroup-wide (max, first index) reduction and one barrier per
@@ -52,7 +53,7 @@ __device__ __forceinline__ float score_of_probability(float p) { return logf(exp
 // few barriers per timestep: slow, identical to the reference operator.  Every thread of the workgroup calls it.
 template <bool PROBS>
 __device__ inline void faithful_uniform_item(const float *__restrict__ o, int f, const float *__restrict__ initial, float c,
-                                             int32_t *__restrict__ res, int T, int S, float *red_v, int *red_k, int *flag) {
+                                             int32_t *__restrict__ res, int T, int S, float *red_v, int *red_k) {
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
     auto value = [&](int t, int i) { const float x = o[(size_t)t * S + i]; return PROBS ? score_of_probability(x) : x; };
     // post_t[i] = t == 0 ? obs[0][i] + initial[i] : obs[t][i] + m
@@ -108,7 +109,6 @@ __device__ inline void faithful_uniform_item(const float *__restrict__ o, int f,
     for (int w = 1; w < nw; ++w) k = min(k, red_k[w]);
     k = nan_at != kNone ? nan_at : (k == kNone ? 0 : k);
     for (int tt = f - 1 + tid; tt < T; tt += nt) res[tt] = k;
-    (void)flag;
 }
 
 // NW: waves per workgroup (4; 8 or 16 for a handful of sequences, whose only parallelism is the rows in flight per item:
@@ -119,8 +119,6 @@ __global__ __launch_bounds__(64 * NW) void uniform_rows_kernel(const float *__re
                                                            int32_t *__restrict__ out, int B, int T, int S) {
     constexpr int CH = NW * R;
     __shared__ float rowmax[2][CH];
-    __shared__ float red_v[NW];
-    __shared__ int red_k[NW];
     bool odd = false;                  // a NaN / +inf among the item's inputs (nonfinite.hpp): decoded again below
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -145,7 +143,6 @@ __global__ __launch_bounds__(64 * NW) void uniform_rows_kernel(const float *__re
                 if constexpr (PROBS)
                     v = make_float4(score_of_probability(v.x), score_of_probability(v.y), score_of_probability(v.z),
                                     score_of_probability(v.w));
-                odd = odd || (t < f && i < S && nonfinite::odd4(v));
                 dst[r][q] = v;
             }
         }
@@ -167,11 +164,15 @@ __global__ __launch_bounds__(64 * NW) void uniform_rows_kernel(const float *__re
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float lm = ninf;
+            const bool inside = t0 + R * wave + r < f;         // (rows at or past the item's length are not its input)
 #pragma unroll
             for (int q = 0; q < NQW; ++q)
-                if (4 * lane + 256 * q < S)
+                if (4 * lane + 256 * q < S) {
+                    // (looked at HERE, where the row is consumed anyway: in the load it would wait for the load)
+                    odd = odd || (inside && nonfinite::odd4(cur[r][q]));
                     lm = __builtin_fmaxf(__builtin_fmaxf(lm, __builtin_fmaxf(cur[r][q].x, cur[r][q].y)),
                                          __builtin_fmaxf(cur[r][q].z, cur[r][q].w));
+                }
             const float wm = wave_reduce_f32(lm, MaxOp());
             if (lane == 0) rowmax[parity][R * wave + r] = wm;
         }
@@ -228,8 +229,26 @@ __global__ __launch_bounds__(64 * NW) void uniform_rows_kernel(const float *__re
 #pragma unroll
             for (int q = 0; q < NQW; ++q) cur[r][q] = nxt[r][q];
     }
+    // an item that read a NaN / +inf says so in its first output position; uniform_repair_kernel, queued behind this launch,
+    // decodes it again (in here the reference-order path costs the streaming kernel a third of its occupancy)
     odd = odd || nonfinite::odd(c);
-    if (__syncthreads_or(odd)) faithful_uniform_item<PROBS>(o, f, initial, c, res, T, S, red_v, red_k, nullptr);
+    if (__syncthreads_or(odd) && tid == 0) res[0] = kFlagged;
+}
+
+// grid = B, block = 256: items uniform_rows_kernel flagged, again in the reference's order of evaluation
+template <bool PROBS>
+__global__ __launch_bounds__(256) void uniform_repair_kernel(const float *__restrict__ obs, const int32_t *__restrict__ frames,
+                                                             const float *__restrict__ initial, float c,
+                                                             int32_t *__restrict__ out, int B, int T, int S) {
+    __shared__ float red_v[4];
+    __shared__ int red_k[4];
+    const int b = blockIdx.x;
+    int32_t *res = out + (size_t)b * T;
+    if (res[0] != kFlagged) return;
+    int f = frames[b];
+    f = f < 1 ? 1 : (f > T ? T : f);
+    __syncthreads();                         // (every thread has read the flag before thread 0 overwrites it)
+    faithful_uniform_item<PROBS>(obs + (size_t)b * T * S, f, initial, c, res, T, S, red_v, red_k);
 }
 
 }  // namespace uniform
