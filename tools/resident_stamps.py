@@ -49,11 +49,18 @@ for i, name in enumerate(names):
     v = acc[:, :, i].mean() / steps
     print(f'{name:38s} {v:9.0f} ticks/step  {100 * v * steps / tot:5.1f} %')
 if PATH == 'cluster':
-    for i, name in zip((8, 9, 10, 11), ('drain of the slice stores', 'wait for the other members\' flags', 'slices -> tile, top lists',
-                                        'barrier E (tile complete)')):
+    # (round 5's exchange: self-validating 16-byte pieces, no store drain, no flag -- the load that finds a piece is the hand-off)
+    for i, name in zip((8, 10, 11), ('own row slices -> the other members (stores issued)',
+                                     'the others\' slices + keys: asked for, awaited, -> tile / top lists', 'barrier E (tile complete)')):
         v = acc[:, :, i].mean() / steps
-        print(f'{name:38s} {v:9.0f} ticks/step  (cluster; not in the percentages above)')
-blocks = acc[:, :, 7].mean() / steps
-print(f'extra list blocks per wave and timestep: {blocks:.1f} over {np.ceil(90 / KW):.0f} passes -> '
-      f'{16 * (1 + blocks / (90 / KW)):.0f} entries per row group on average')
+        print(f'{name:38s} {v:9.0f} ticks/step  (min / max over waves {acc[:, :, i].min() / steps:.0f} / {acc[:, :, i].max() / steps:.0f}; cluster, not in the percentages above)')
+    print(f'polls that found a piece or key missing, per wave and timestep: {acc[:, :, 9].mean() / steps:.2f} '
+          f'(0 = every first look succeeded)')
+    per_wg = acc[:, :, 3].max(axis=1) / steps
+    print(f'slowest wave\'s scan per workgroup: mean {per_wg.mean():.0f} ticks, max {per_wg.max():.0f}; '
+          f'mean wave {acc[:, :, 3].mean() / steps:.0f} (ticks = shader cycles)')
+if PATH != 'cluster':
+    blocks = acc[:, :, 7].mean() / steps
+    print(f'extra list blocks per wave and timestep: {blocks:.1f} over {np.ceil(90 / KW):.0f} passes -> '
+          f'{16 * (1 + blocks / (90 / KW)):.0f} entries per row group on average')
 print('scan ticks per wave: min/mean/max over waves', acc[:, :, 3].min() / steps, acc[:, :, 3].mean() / steps, acc[:, :, 3].max() / steps)

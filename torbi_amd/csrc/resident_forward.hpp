@@ -120,6 +120,8 @@ struct Cluster {
                            // tile's history is incomplete and the launch that follows decodes it again, whole
     int R;
     unsigned long long wait_ticks;     // how long a member waits for the others' flags (100 MHz ticks; 0: not at all)
+    int spread;            // 1 (R % 8 == 0): member m of EVERY tile runs on XCD m / (R / 8) -- the rows' sorted lists, which the
+                           // members of all tiles walk, stay in that XCD's L2; the exchange then crosses XCDs (write-through)
 };
 // Cluster::wait_ticks, default (ticks of the 100 MHz wall clock): a quarter of a second -- members that have not been
 // dispatched yet because another stream's launch holds the compute units arrive within tens of milliseconds; a cluster
@@ -378,8 +380,14 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
         }
         __syncthreads();
         const int ticket = __builtin_amdgcn_readfirstlane(smisc[0]);
-        member = ticket % R;
-        cid = (ticket / R) * 8 + cls;
+        if (clu.spread) {
+            const int per = R / 8;           // members of a tile per XCD
+            member = cls * per + ticket % per;
+            cid = ticket / per;
+        } else {
+            member = ticket % R;
+            cid = (ticket / R) * 8 + cls;
+        }
         if (cid >= clu.tiles) return;        // (the grid is padded to whole classes)
         // where do the R members run?  Each says so (write-through), all read all R answers (bounded wait; a cluster that
         // cannot complete in time exchanges write-through and gives up at its first hand-off as before)
@@ -832,7 +840,7 @@ __global__ __launch_bounds__(64 * KW) void resident_forward_kernel(Group grp, Cl
                                 key1.w == (unsigned)t)
                                 want_keys = false;
                             if (!__any(missing != 0u || want_keys)) break;
-                            RCOUNT(7, 1);
+                            RCOUNT(9, 1);
                             __builtin_amdgcn_s_sleep(CLUSTER_POLL_SLEEP);
                             if ((spins++ & 15u) == 0u) {
                                 const unsigned long long now = wall_clock64();

@@ -1369,7 +1369,6 @@ inline int backtrace_segments(int items) {
     return std::max(2, std::min(wanted, 2048 / std::max(items, 1)));        // (items x K <= 2048 waves: 512 items -> 4)
 }
 
-// batches with B > 0 only; the preparation lives in the first batch's workspace
 // ---- NaN / +inf inputs (nonfinite.hpp): alarms raised with the decode's serial number, a repair launch behind the decode ----
 // Ahead of a decode's forward launches: the matrix and the initial vector; the observations too for the routes whose
 // forward kernels do not look at what they produce (a launch per timestep: generic, held, rows, dense).
@@ -1413,6 +1412,7 @@ inline hipError_t nonfinite_end(const HostBatch *hb, int n, const float *trans, 
     return hipGetLastError();
 }
 
+// batches with B > 0 only; the preparation lives in the first batch's workspace
 hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const float *init, int S, int cus, hipStream_t s,
                         hipEvent_t *ev, int *launches, bool reuse, bool ascending = false, bool clusters = false,
                         bool few = false) {
@@ -1459,7 +1459,14 @@ hipError_t run_resident(const HostBatch *hb, int n, const float *trans, const fl
     const char *wait_env = getenv("TORBI_HIP_CLUSTER_WAIT_US");         // (read per launch: the tests switch it)
     const unsigned long long wait_ticks = wait_env ? 100ull * strtoull(wait_env, nullptr, 10) : resident::kClusterWaitTicks;
     // (flags [ctiles][kMaxR], control [16], failed [ctiles], where [ctiles][kMaxR]: all zeroed by order_tiles_kernel)
-    resident::Cluster clu{w.xchg, control + 16 + std::max(cus / 2, 1), tiles, control, control + 16, R, wait_ticks};
+    // Above 2048 states (8-item tiles) the sorted lists are what the launch fetches -- 134 MB at 4096 states, far beyond an
+    // XCD's 4 MB L2, walked by every tile: 232 GB per 128 x 2000 x 4096 decode against 8.4 GB algorithmic
+    // (profiles/r06_c5_pmc.json).  Member m of EVERY tile on one XCD keeps that member's rows' lists in its L2; the exchange
+    // then crosses XCDs (write-through), which costs less than it saves there: 19.8 -> 17.3 us per timestep at 128 items,
+    // 34.3 -> 30.6 at 256; up to 2048 states it loses 1-3 % (profiles/r06_c5_spread.txt).  TORBI_HIP_CLUSTER_SPREAD=0|1 overrides.
+    const char *spread_env = getenv("TORBI_HIP_CLUSTER_SPREAD");
+    const int spread = (R % 8 == 0 && (spread_env ? atoi(spread_env) != 0 : resident::tile_items(S) == 8)) ? 1 : 0;
+    resident::Cluster clu{w.xchg, control + 16 + std::max(cus / 2, 1), tiles, control, control + 16, R, wait_ticks, spread};
     if (ev) (void)hipEventRecord(ev[0], s);
     for (int k = 0; k < n; ++k) {            // (order_items_kernel stamps the batches' route records)
         jobs.job[k].route_record = route_record(hb[k].workspace, hb[k].B, hb[k].T, S, cus);
