@@ -256,8 +256,12 @@ int torbi_hip_viterbi_decode_batches_prepared(const torbi_hip_batch *batches, in
  * + window + merge buffer within the 160 KB LDS (at 1440 states: reach_left + reach_right <= 175 with 8 members per tile,
  * up to 16 members for fewer than 16 tiles), each reach at most a member's share of the states, reach_left + reach_right <= 508.
  *
+ * (ABI 15) torbi_hip_band_members answers 1 where the band kernel runs WHOLE tiles: one workgroup per 16-item tile, the band
+ * streamed from the L2 (S % 4 == 0, 64 <= S <= 1536), for `items` that give at least every other compute unit a tile.
+ *
  * torbi_hip_viterbi_decode_banded: torbi_hip_viterbi_decode_batches for a matrix whose band the caller states -- a
- * PROMISE: finite entries outside it are ignored, the decoded indices then differ from the reference's.  Same arguments,
+ * PROMISE, verified on the device (ABI 15): an entry outside the band that is not -inf is noticed by the launch that looks
+ * at the matrix, and every item is then decoded again on the whole matrix (slow, identical to the reference).  Same arguments,
  * same workspaces (torbi_hip_workspace_bytes covers the route), same phase_ms (phase_ms[3] = 8 when the band kernel ran).
  * `transition` and the observations must be 16-byte aligned for the band kernel.  The band kernel runs for TORBI_HIP_FORWARD_AUTO and
  * TORBI_HIP_FORWARD_BAND when its plan covers the group -- under AUTO except for shapes SMALL decodes and for the handful
@@ -270,6 +274,25 @@ int torbi_hip_band_members(int items, int S, int reach_left, int reach_right, in
 int torbi_hip_viterbi_decode_banded(const torbi_hip_batch *batches, int count, const float *transition, const float *initial,
                                     int S, int reach_left, int reach_right, int device, void *stream, unsigned flags,
                                     float *phase_ms);
+
+/*
+ * (ABI 15) A band with ONE CONSTANT outside it.  The reference's evaluation does not decode with log(p) but with
+ * log(p + tiny) (torbi/evaluate/core.py:97-103 -> torbi/core.py:341-347): its pitch matrix holds log(tiny) = -87.34 outside the
+ * band, not -inf, and candidates from out there do win on rows whose posteriors fall that far.  Every such candidate is
+ * fl(post[i] + c), so the best of them is fl(M + c), M the largest posterior outside the band (rounding is monotone): the
+ * whole-tile band kernel keeps every row's maximum and where it is attained, and decides every output exactly
+ * (csrc/band_tile_forward.hpp; what it cannot decide -- in-band entries BELOW the constant where the row's maximum stands --
+ * is decoded again in the reference's order).  The `_over` entry points are the banded ones with `background` = that constant
+ * (-inf: identical to them): torbi_hip_band_reach_over takes the matrix's corner entry transition[0][S - 1] for it (bit for
+ * bit) and answers the reach over every other value; torbi_hip_band_members_over is 1 or 0 for a finite background (whole tiles
+ * only: launch groups with a tile for at least every other compute unit).
+ */
+int torbi_hip_band_reach_over(const float *transition, int S, int device, void *stream, int *reach_left_out, int *reach_right_out,
+                              float *background_out);
+int torbi_hip_band_members_over(int items, int S, int reach_left, int reach_right, float background, int device);
+int torbi_hip_viterbi_decode_banded_over(const torbi_hip_batch *batches, int count, const float *transition, const float *initial,
+                                         int S, int reach_left, int reach_right, float background, int device, void *stream,
+                                         unsigned flags, float *phase_ms);
 
 /*
  * Scan statistics for adaptive path selection (torbi_amd/viterbi.py uses them): copies 128 uint32 to `stats_out`

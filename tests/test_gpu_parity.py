@@ -1901,6 +1901,109 @@ def test_band_launch_group_runs_whole_tiles(waves, monkeypatch):
         np.testing.assert_array_equal(got[k].cpu().numpy()[pick], want, err_msg=f'batch {k}')
 
 
+@pytest.mark.parametrize('case', [(300, 9, 360, 10, 3, -3.0), (300, 7, 360, 22, 22, -40.0), (272, 8, 1440, 87, 87, -87.33654),
+                                  (260, 6, 1024, 5, 60, -1.0), (300, 9, 360, 10, 10, 2.5)])
+@pytest.mark.parametrize('rows', ['random', 'peaked', 'ties'])
+def test_band_with_a_constant_outside_matches_the_oracle(case, rows, monkeypatch):
+    """The reference's evaluation decodes with log(p + tiny) (torbi/evaluate/core.py:97-103 -> torbi/core.py:341-347): ONE
+    constant outside the band, not -inf.  The whole-tile band kernel decides every output exactly from the band and the row's
+    maximum (csrc/band_tile_forward.hpp): background values from "never matters" (-87.3 under random rows) to "wins almost
+    everywhere" (-1, +2.5: above the in-band entries), peaked rows whose tails sit far below the peak (candidates from outside
+    the band win wherever the peak is out of reach), coarse grids (ties between a candidate inside and one outside the band:
+    lowest index wins), ragged lengths, a next-state nothing inside the band leads to.  AUTO finds band and constant itself."""
+    monkeypatch.setenv('TORBI_HIP_BAND_FORM', 'tile')
+    B, T, S, left, right, c = case
+    obs, trans, init = synth.problem(B, T, S, seed=B + S)
+    idx = np.arange(S)
+    d = idx[None, :] - idx[:, None]
+    inside = (d >= -left) & (d <= right)
+    if rows == 'peaked':
+        centre = synth.lengths(B * T, 0, S - 1, seed=5).reshape(B, T, 1)
+        obs = (-np.abs(idx[None, None, :] - centre) * 1.5 + obs * 0.25).clip(min=-87.0).astype(np.float32)
+    if rows == 'ties':
+        obs, trans, init = np.round(obs * 2) / 2, np.round(trans * 2) / 2, np.round(init)
+    trans = np.where(inside, trans, np.float32(c)).astype(np.float32)
+    trans[S // 3, max(0, S // 3 - left):S // 3 + right + 1] = -np.inf        # (inside the band only: the constant stays outside)
+    frames = np.clip(synth.lengths(B, 1, T, seed=3), 1, T).astype(np.int32)
+    frames[0] = T
+    want = oracle.decode(obs.astype(np.float32), frames, trans, init, num_threads=oracle.max_threads())
+    dev = torch.device('cuda:0')
+    args = [torch.as_tensor(np.ascontiguousarray(x)).to(dev) for x in (obs.astype(np.float32), frames, trans, init)]
+    assert viterbi.band_over(args[2], args[2], S) == (left, right, pytest.approx(c))
+    prof = []
+    got = torbi_amd.decode(*args, _profile=prof)
+    assert viterbi.ROUTES[int(prof[3])] == 'band' and 'band_tile_kernel' in viterbi.last_forward_kernel()
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_the_reference_evaluation_matrix_runs_on_the_band_kernel():
+    """torbi.evaluate calls from_files_to_files(transition_file=<pitch matrix>, log_probs=True) (torbi/evaluate/core.py:97-103):
+    the matrix the operator sees is log(p + tiny) -- log(tiny) outside the band (torbi/core.py:341-347).  A launch group of four
+    ragged batches of posteriorgram-like rows under AUTO: the whole-tile band kernel, every batch equal to the dense kernel's
+    decode (every cell of the matrix), 24 items equal to the oracle's; rows with network-like tails (nothing outside the band
+    ever wins) and rows clamped at log(tiny) (candidates from outside the band win wherever the last peak is out of reach)."""
+    import math
+    dev = torch.device('cuda:0')
+    T, S = 40, 1440
+    tiny = torch.finfo(torch.float32).tiny
+    x = np.arange(S)
+    tri = np.clip(87.2 - np.abs(x[:, None] - x[None, :]), 0, None).astype(np.float32)
+    probs = torch.from_numpy(tri / tri.sum(axis=1, keepdims=True)).to(dev)
+    band = torch.log(probs + tiny)
+    band_np = band.cpu().numpy()
+    left, right, c = viterbi.band_over(band, band, S)
+    assert (left, right) == (87, 87) and c == pytest.approx(math.log(tiny)) and viterbi.band_reach(band, band, S) is None
+    init_np = np.full((S,), math.log(1.0 / S), np.float32)
+    init = torch.from_numpy(init_np).to(dev)
+    peaked, _, _ = _peaked_pitch_problem(512, T, S, seed=31)                 # tails clamped at log(tiny)
+    soft = torch.log_softmax(peaked.clamp(min=-30.0), dim=-1)               # tails like a network's softmax
+    for name, rows in (('clamped', peaked), ('soft', soft)):
+        sizes = [512, 512, 512, 500]
+        obs_list, frame_list, frames_np = [], [], []
+        for k, B in enumerate(sizes):
+            f = np.clip(synth.lengths(B, 1, T, seed=60 + k), 1, T).astype(np.int32)
+            f[0] = T
+            frames_np.append(f)
+            obs_list.append(torch.roll(rows, 3 * k, dims=0)[:B].contiguous())
+            frame_list.append(torch.from_numpy(f).to(dev))
+        prof = []
+        got = viterbi.decode_batches(obs_list, frame_list, band, init, _profile=prof)
+        torch.cuda.synchronize()
+        assert viterbi.ROUTES[int(prof[3])] == 'band' and 'band_tile_kernel' in viterbi.last_forward_kernel(), name
+        for k, B in enumerate(sizes):
+            dense = torbi_amd.decode(obs_list[k], frame_list[k], band, init, path='dense')
+            np.testing.assert_array_equal(got[k].cpu().numpy(), dense.cpu().numpy(), err_msg=f'{name} batch {k}')
+            pick = np.random.default_rng(k).choice(B, size=6, replace=False)
+            want = oracle.decode(obs_list[k][pick].cpu().numpy(), frames_np[k][pick], band_np, init_np, num_threads=oracle.max_threads())
+            np.testing.assert_array_equal(got[k].cpu().numpy()[pick], want, err_msg=f'{name} batch {k}')
+        space = torch.empty(viterbi.workspace_bytes(512, T, S), dtype=torch.uint8, device=dev)
+        del space
+
+
+def test_band_constant_that_the_tests_cannot_decide_is_decoded_in_the_reference_order():
+    """In-band entries BELOW the constant outside the band, exactly where a row's maximum stands: the candidates from outside can
+    win although the maximum itself is in reach, and the kernel's two tests decide nothing -- the batch raises its alarm and is
+    decoded again in the reference's order (csrc/nonfinite.hpp).  Indices equal the oracle's."""
+    B, T, S, reach, c = 264, 6, 360, 12, -2.0
+    obs, trans, init = synth.problem(B, T, S, seed=91)
+    idx = np.arange(S)
+    inside = np.abs(idx[None, :] - idx[:, None]) <= reach
+    trans = np.where(inside, trans - 12.0, np.float32(c)).astype(np.float32)       # the band far BELOW the constant
+    frames = np.full((B,), T, np.int32)
+    want = oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())
+    dev = torch.device('cuda:0')
+    args = [torch.as_tensor(np.ascontiguousarray(x)).to(dev) for x in (obs, frames, trans, init)]
+    import os
+    os.environ['TORBI_HIP_BAND_FORM'] = 'tile'
+    try:
+        prof = []
+        got = torbi_amd.decode(*args, _profile=prof)
+    finally:
+        del os.environ['TORBI_HIP_BAND_FORM']
+    assert viterbi.ROUTES[int(prof[3])] == 'band'
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
 def test_band_launch_never_holds_more_members_than_are_resident():
     """Round-5 advisor: the members of a tile wait for each other INSIDE a launch, so a launch must not hold more members
     than the chip has units for (a dispatch class of R x ceil(tiles / 8) workgroups runs on one XCD: cus / 8 units).  600

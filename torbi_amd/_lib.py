@@ -48,6 +48,12 @@ SYMBOLS = {
     'torbi_hip_viterbi_decode_banded': (_c.c_int, [
         _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint,
         _c.POINTER(_c.c_float)]),
+    'torbi_hip_band_reach_over': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.POINTER(_c.c_int),
+                                             _c.POINTER(_c.c_int), _c.POINTER(_c.c_float)]),
+    'torbi_hip_band_members_over': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_int]),
+    'torbi_hip_viterbi_decode_banded_over': (_c.c_int, [
+        _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_int, _c.c_void_p, _c.c_uint,
+        _c.POINTER(_c.c_float)]),
     'torbi_hip_preparation_bytes': (_c.c_size_t, [_c.c_int]),
     'torbi_hip_viterbi_decode_batches_prepared': (_c.c_int, [
         _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint,

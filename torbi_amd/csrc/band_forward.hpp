@@ -709,6 +709,8 @@ struct BandWalker {
     const float *__restrict__ h;          // [T][S] posterior rows of the item
     const float *__restrict__ trans;
     int S, hl, hr, lane;
+    float bg;                             // every entry outside the band (-inf, or the constant of band_tile_forward.hpp)
+    const float *__restrict__ rowmax;     // [T] largest entry of every posterior row of the item (read when bg is finite)
     // first argmax of posterior row t (the final state when t = frames - 1: viterbi.cpp:218)
     __device__ __forceinline__ int first_state(int t) const {
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -742,6 +744,12 @@ struct BandWalker {
             __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(cand[0].x, cand[0].y), __builtin_fmaxf(cand[0].z, cand[0].w)),
                             __builtin_fmaxf(__builtin_fmaxf(cand[1].x, cand[1].y), __builtin_fmaxf(cand[1].z, cand[1].w))),
             wavered::MaxOp());
+        // a constant outside the band: no candidate out there exceeds fl(row maximum + constant) (rounding is monotone); where
+        // that reaches the band's best, the first argmax is taken over the whole matrix row (the constant is IN the matrix)
+        if (bg != -INFINITY && rowmax[tt - 1] + bg >= m) {
+            const lazy::RowWalker<NQ> whole{h, trans, S, lane};
+            return whole.step(j, tt);
+        }
         int k = lazy::kSentinel;
 #pragma unroll
         for (int q = 1; q >= 0; --q) {
@@ -759,42 +767,47 @@ struct BandWalker {
 
 template <int NQ>
 __global__ __launch_bounds__(64) void group_backtrace_band_kernel(Group grp, const float *__restrict__ trans, int S, int hl,
-                                                                  int hr) {
+                                                                  int hr, float bg) {
     const Batch &bat = grp.batch[resident::batch_of_item(grp, blockIdx.x)];
     const int b = (int)blockIdx.x - bat.item0;
-    const BandWalker<NQ> w{bat.hist + (size_t)b * bat.T * S, trans, S, hl, hr, (int)threadIdx.x};
+    const BandWalker<NQ> w{bat.hist + (size_t)b * bat.T * S, trans, S, hl, hr, (int)threadIdx.x, bg, bat.rowmax + (size_t)b * bat.T};
     lazy::walk_item(w, bat.frames[b], bat.out + (size_t)b * bat.T, bat.T, threadIdx.x);
 }
 
 // ... in K speculative segments per item (lazy_backtrace.hpp, chase_segment / stitch_segments): grid = items x K, then items
 template <int NQ>
 __global__ __launch_bounds__(64) void group_segment_band_kernel(Group grp, const float *__restrict__ trans, int S, int hl, int hr,
-                                                                int K, int32_t *__restrict__ arrive) {
+                                                                int K, int32_t *__restrict__ arrive, float bg) {
     const int item = (int)blockIdx.x / K, seg = (int)blockIdx.x - item * K;
     const Batch &bat = grp.batch[resident::batch_of_item(grp, item)];
     const int b = item - bat.item0;
-    const BandWalker<NQ> w{bat.hist + (size_t)b * bat.T * S, trans, S, hl, hr, (int)threadIdx.x};
+    const BandWalker<NQ> w{bat.hist + (size_t)b * bat.T * S, trans, S, hl, hr, (int)threadIdx.x, bg, bat.rowmax + (size_t)b * bat.T};
     lazy::chase_segment(w, bat.frames[b], bat.T, K, seg, bat.out + (size_t)b * bat.T, arrive + (size_t)item * K, threadIdx.x);
 }
 template <int NQ>
 __global__ __launch_bounds__(64) void group_stitch_band_kernel(Group grp, const float *__restrict__ trans, int S, int hl, int hr,
-                                                               int K, const int32_t *__restrict__ arrive) {
+                                                               int K, const int32_t *__restrict__ arrive, float bg) {
     const int item = blockIdx.x;
     const Batch &bat = grp.batch[resident::batch_of_item(grp, item)];
     const int b = item - bat.item0;
-    const BandWalker<NQ> w{bat.hist + (size_t)b * bat.T * S, trans, S, hl, hr, (int)threadIdx.x};
+    const BandWalker<NQ> w{bat.hist + (size_t)b * bat.T * S, trans, S, hl, hr, (int)threadIdx.x, bg, bat.rowmax + (size_t)b * bat.T};
     lazy::stitch_segments(w, bat.frames[b], bat.T, K, bat.out + (size_t)b * bat.T, arrive + (size_t)item * K, threadIdx.x,
                           grp.stats + 122);
 }
 
 // reach of a matrix: *left = max over finite entries of max(j - i, 0), *right = of max(i - j, 0); grid = S, block = 64;
 // `reach` set to -1, -1 by the caller -- what a matrix without a finite entry leaves
-__global__ __launch_bounds__(64) void band_reach_kernel(const float *__restrict__ trans, int32_t *__restrict__ reach, int S) {
+// (`corner`: what counts as "outside" is the value of trans[0][S - 1], bit for bit -- -inf for log(p), log(tiny) for the
+// log(p + tiny) the reference's evaluation decodes with -- instead of -inf; reach[2] <- its bits)
+__global__ __launch_bounds__(64) void band_reach_kernel(const float *__restrict__ trans, int32_t *__restrict__ reach, int S,
+                                                        int corner) {
     const int j = blockIdx.x, lane = threadIdx.x;
     const float *row = trans + (size_t)j * S;
+    const unsigned outside = corner ? __float_as_uint(trans[S - 1]) : __float_as_uint(-INFINITY);
+    if (corner && j == 0 && lane == 0) reach[2] = (int32_t)outside;
     int left = -1, right = -1;
     for (int i = lane; i < S; i += 64)
-        if (row[i] != -INFINITY) {
+        if (__float_as_uint(row[i]) != outside) {
             left = max(left, max(j - i, 0));
             right = max(right, max(i - j, 0));
         }

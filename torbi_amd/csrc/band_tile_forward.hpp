@@ -22,6 +22,19 @@
 //     own rows -> window, barrier
 // -- two barriers per timestep of ~27 us, nothing else between workgroups or waves.  Arithmetic and results are those of
 // band_forward.hpp (viterbi.cpp:81-104 over the band: -inf candidates never win the strict '>').
+//
+// A CONSTANT outside the band.  The reference's own evaluation does not decode with log(p) but with log(p + tiny)
+// (torbi/evaluate/core.py:97-103 -> torbi/core.py:341-347): its pitch matrix is log(tiny) = -87.34 outside the band, not
+// -inf, and a candidate from outside the band does win when a row's posteriors fall that far (clamped posteriorgram tails).
+// With every entry outside the band equal to ONE value c, the candidates from outside are fl(post[i] + c), and rounding is
+// monotone: their maximum is fl(M + c) with M the largest posterior outside the band.  The workgroup keeps, per item, the
+// previous row's maximum and the lowest / highest state that attains it (LDS atomics in the finish it runs anyway).  For an
+// output (j, item):   fl(rowmax + c) < best of the band          -> nothing outside can win or tie: done (real data: always);
+//                     else, a state attaining rowmax outside j's band -> M = rowmax: best = max(best, fl(rowmax + c)), exact;
+//                     else (the maximum inside the band, yet not enough: in-band entries below c) -> the tile's batch raises
+//                     an alarm and nonfinite::repair_kernel decodes it in the reference's order (never on a pitch matrix).
+// The backtrace (band_forward.hpp, BandWalker) makes the same test with the row maxima this kernel leaves in Batch::rowmax
+// and scans the whole matrix row for the steps where the band alone does not decide.
 #pragma once
 
 #include "band_forward.hpp"
@@ -40,6 +53,7 @@ struct TilePlan {
     int waves, bpw;          // waves per workgroup; blocks per wave
     int w_rows, ig_stride;   // rows of the window (row w holds state w - hl); floats between the item groups' windows
     int w_off, ring_off, misc_off, lds_bytes;
+    float background;        // every entry outside the band (-inf: the band kernels' original contract)
 };
 
 __host__ __device__ inline size_t tile_pack_bytes(int nblk, int Dq4) { return (size_t)nblk * Dq4 * 1024; }
@@ -54,6 +68,7 @@ inline bool make_tile_plan(int S, int hl, int hr, TilePlan &p, int waves_wanted 
     if (S < 64 || S % 4 != 0 || hl < 0 || hr < 0 || hl >= S || hr >= S) return false;
     if (hl + hr + 4 > kMaxWindow) return false;
     p.S = S; p.hl = hl; p.hr = hr;
+    p.background = -INFINITY;
     p.Dq = (hl + hr + 1 + 3) / 4;
     p.Dq4 = (p.Dq + 3) / 4 * 4;
     p.n_jg = S / 4;
@@ -71,7 +86,7 @@ inline bool make_tile_plan(int S, int hl, int hr, TilePlan &p, int waves_wanted 
         p.bpw = (p.nblk + waves - 1) / waves;
         if (p.bpw > (waves == 12 ? 2 : 3)) return false;
         p.misc_off = p.ring_off + waves * kRing * 1024;
-        p.lds_bytes = p.misc_off + 256;
+        p.lds_bytes = p.misc_off + 768;          // frames, offsets, items; row maxima and where they are attained (two rows)
         if (p.lds_bytes <= kLdsBytes) return true;
     }
     return false;
@@ -120,6 +135,12 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
     float *const wq = reinterpret_cast<float *>(lds + pl.w_off);
     int *const sframes = reinterpret_cast<int *>(lds + pl.misc_off);                                 // [16] frames per item (0 past the batch)
     unsigned long long *const sbase = reinterpret_cast<unsigned long long *>(lds + pl.misc_off + 64);  // [16] element offset of the item
+    int *const sitem = reinterpret_cast<int *>(lds + pl.misc_off + 192);                             // [16] item numbers
+    float *const srm = reinterpret_cast<float *>(lds + pl.misc_off + 256);       // [2 rows by parity][16] largest posterior of the row
+    int *const spmin = reinterpret_cast<int *>(lds + pl.misc_off + 384);         // [2][16] lowest state that attains it
+    int *const spmax = reinterpret_cast<int *>(lds + pl.misc_off + 512);         // [2][16] highest
+    const float cbg = pl.background;
+    const bool bg = cbg != -INFINITY;          // (a constant outside the band: see the head of the file)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -144,6 +165,12 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
         }
         sframes[tid] = f;
         sbase[tid] = (unsigned long long)item * (unsigned long long)T * (unsigned long long)S;
+        sitem[tid] = item;
+    }
+    if (tid < 2 * kNI) {
+        srm[tid] = -INFINITY;
+        spmin[tid] = 0x7fffffff;
+        spmax[tid] = -1;
     }
     // rows outside the matrix stay 0: their band entries are -inf
     for (int e = tid; e < 4 * pl.ig_stride; e += nthreads) wq[e] = 0.0f;
@@ -227,7 +254,29 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
         store_row(j4, ok, t, x);
     };
     bool odd = false;               // a NaN / +inf posterior value was produced (nonfinite.hpp)
-    auto finish = [&](int u, const float (&acc)[16]) {
+    bool undecided = false;         // a constant outside the band, and neither test of the head of the file decided an output
+    auto finish = [&](int u, float (&acc)[16], int t) {
+        if (bg && t > 0) {          // the candidates from outside the band: fl(largest posterior out there + c)
+            const int par = (t - 1) & 1;
+            const float4 rm = *reinterpret_cast<const float4 *>(srm + par * kNI + 4 * ig);
+            const int4 lo = *reinterpret_cast<const int4 *>(spmin + par * kNI + 4 * ig);
+            const int4 hi = *reinterpret_cast<const int4 *>(spmax + par * kNI + 4 * ig);
+            const int4 len = *reinterpret_cast<const int4 *>(sframes + 4 * ig);
+            const float bound[4] = {rm.x + cbg, rm.y + cbg, rm.z + cbg, rm.w + cbg};
+            const int los[4] = {lo.x, lo.y, lo.z, lo.w}, his[4] = {hi.x, hi.y, hi.z, hi.w};
+            const bool live[4] = {t < len.x, t < len.y, t < len.z, t < len.w};      // (rows past an item's length are nobody's)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = 4 * jg[u] + k;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool open = bound[c] >= acc[4 * k + c];                       // else: nothing outside wins or ties
+                    const bool outside = los[c] < j - hl || his[c] > j + pl.hr;         // the row's maximum stands outside j's band
+                    acc[4 * k + c] = (open && outside) ? fmaxf(acc[4 * k + c], bound[c]) : acc[4 * k + c];
+                    undecided = undecided || (open && !outside && rowok[u] && live[c]);
+                }
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             v[u][0 + c] = ob[c].x + acc[0 + c];
@@ -237,10 +286,39 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) odd = odd || (rowok[u] && nonfinite::odd(v[u][e]));
+        if (bg && rowok[u]) {       // the largest posterior of row t per item (where it is attained: close_timestep)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float *)(srm + (t & 1) * kNI + 4 * ig + c),
+                                          fmaxf(fmaxf(v[u][c], v[u][4 + c]), fmaxf(v[u][8 + c], v[u][12 + c])), 0, 0, false);
+        }
     };
     auto close_timestep = [&](int t) {
-        if (t + 1 >= fmax) return;
-        barrier();                      // every wave is done with the window of row t - 1
+        if (t + 1 >= fmax) return;          // (the last row's maxima are nobody's input)
+        barrier();                      // every wave is done with the window of row t - 1 (and the row's maxima are complete)
+        if (bg) {
+            const int par = t & 1;
+            const float4 rm = *reinterpret_cast<const float4 *>(srm + par * kNI + 4 * ig);
+            const float top[4] = {rm.x, rm.y, rm.z, rm.w};
+#pragma unroll
+            for (int u = 0; u < BPW; ++u)
+                if (rowok[u]) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (v[u][4 * k + c] == top[c]) {
+                                atomicMin(spmin + par * kNI + 4 * ig + c, 4 * jg[u] + k);
+                                atomicMax(spmax + par * kNI + 4 * ig + c, 4 * jg[u] + k);
+                            }
+                }
+            if (tid < kNI) {            // the row maximum for the backtrace; the other parity's words for row t + 1
+                if (t < sframes[tid]) bat.rowmax[(size_t)sitem[tid] * T + t] = srm[par * kNI + tid];
+                srm[(par ^ 1) * kNI + tid] = -INFINITY;
+                spmin[(par ^ 1) * kNI + tid] = 0x7fffffff;
+                spmax[(par ^ 1) * kNI + tid] = -1;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < BPW; ++u)
             if (rowok[u]) {
@@ -263,7 +341,7 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
 #pragma unroll
             for (int c = 0; c < 4; ++c) first[4 * k + c] = x;
         }
-        finish(u, first);
+        finish(u, first, 0);
     }
     if (nb > 0 && fmax > 1)
         for (int r = 0; r < kRing - 1; ++r) copy_next((unsigned)r);
@@ -310,7 +388,7 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
                 if (q + 3 < Dq && !(BAND_TILE_ABL & 16)) dquad<1>(acc, w, tt, ring_lane, wp + 256);
             }
             TSTAMP(1);
-            finish(u, acc);
+            finish(u, acc, t);
         }
         TSTAMP(2);
         close_timestep(t);
@@ -322,6 +400,7 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
         if (u < nb) store_row(4 * jg[u], rowok[u], fmax - 1, v[u]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (no copy may land in an LDS that is no longer this workgroup's)
     nonfinite::raise(odd, bat.alarm, grp.serial);
+    nonfinite::raise(undecided, bat.alarm + (nonfinite::kBandWord - nonfinite::kAlarmWord), grp.serial);
 #ifdef BAND_STAMP
     if (lane == 0 && blockIdx.x < 1024)
         for (int i = 0; i < kPhases; ++i) g_phase[((size_t)blockIdx.x * kMaxWaves + wave) * kPhases + i] = bacc[i];

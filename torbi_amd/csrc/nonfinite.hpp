@@ -23,7 +23,9 @@
 namespace nonfinite {
 
 constexpr int kAlarmWord = 4;            // of the route record: observations / posterior values
-constexpr int kMatrixWord = 5;           // ... transition matrix / initial vector
+constexpr int kMatrixWord = 5;           // ... transition matrix / initial vector (every item again)
+constexpr int kBandWord = 6;             // ... a band with a constant outside whose tests did not decide (band_tile_forward.hpp):
+                                         //     every item of the batch again
 constexpr int kMaxBatches = 16;
 
 __device__ __forceinline__ bool odd(float x) { return !(x <= 3.402823466e+38f); }        // NaN or +inf (-inf is in contract)
@@ -41,9 +43,10 @@ struct Records {
 // matrix and initial vector: grid = up to 1024 blocks of 256.  `reach_left` >= 0: the caller of the band route promised that
 // trans[j][i] is -inf unless j - reach_left <= i <= j + reach_right (include/torbi_hip.h, torbi_hip_viterbi_decode_banded);
 // the band kernels never read outside it, so an entry there that is NOT -inf -- a stale promise: the matrix was edited
-// behind a cached look -- raises the same alarm, and every item is decoded again on the whole matrix.
+// behind a cached look -- raises the same alarm, and every item is decoded again on the whole matrix.  `background`: what the
+// promise says every entry outside the band is (-inf, or the one constant of band_tile_forward.hpp), compared bit for bit.
 __global__ __launch_bounds__(256) void matrix_kernel(const float *__restrict__ trans, const float *__restrict__ initial, int S,
-                                                     Records recs, int serial, int reach_left, int reach_right) {
+                                                     Records recs, int serial, int reach_left, int reach_right, float background) {
     const size_t n = (size_t)S * S;
     bool seen = false;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void matrix_kernel(const float *__restrict__ t
         seen = seen || odd(x);
         if (reach_left >= 0) {
             const int j = (int)(e / (size_t)S), i = (int)(e - (size_t)j * S);
-            seen = seen || ((i < j - reach_left || i > j + reach_right) && x != -INFINITY);
+            seen = seen || ((i < j - reach_left || i > j + reach_right) && __float_as_uint(x) != __float_as_uint(background));
         }
     }
     if (blockIdx.x == 0)
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) void repair_kernel(RepairJobs jobs, const floa
     int k = 0;
     while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.item0[k + 1]) ++k;
     const int32_t *record = jobs.record[k];
-    const bool matrix = record[kMatrixWord] == serial;
+    const bool matrix = record[kMatrixWord] == serial || record[kBandWord] == serial;
     if (!matrix && record[kAlarmWord] != serial) return;
     const int b = (int)blockIdx.x - jobs.item0[k], T = jobs.T[k];
     int f = jobs.frames[k][b];

@@ -1373,7 +1373,8 @@ inline int backtrace_segments(int items) {
 // Ahead of a decode's forward launches: the matrix and the initial vector; the observations too for the routes whose
 // forward kernels do not look at what they produce (a launch per timestep: generic, held, rows, dense).
 inline hipError_t nonfinite_begin(const HostBatch *hb, int n, const float *trans, const float *init, int S, int cus, hipStream_t s,
-                                  bool scan_observations, int reach_left = -1, int reach_right = -1, bool scan_matrix = true) {
+                                  bool scan_observations, int reach_left = -1, int reach_right = -1, bool scan_matrix = true,
+                                  float background = -INFINITY) {
     const int serial = new_serial();
     if (!scan_matrix) return hipSuccess;            // (the small-state kernels hold the whole matrix: they look themselves)
     nonfinite::Records recs{};
@@ -1381,7 +1382,7 @@ inline hipError_t nonfinite_begin(const HostBatch *hb, int n, const float *trans
     for (int k = 0; k < n; ++k) recs.record[k] = route_record(hb[k].workspace, hb[k].B, hb[k].T, S, cus);
     const size_t cells = (size_t)S * S;
     hipLaunchKernelGGL(nonfinite::matrix_kernel, dim3((unsigned)std::max<size_t>(1, std::min<size_t>(1024, (cells + 2047) / 2048))),
-                       dim3(256), 0, s, trans, init, S, recs, serial, reach_left, reach_right);
+                       dim3(256), 0, s, trans, init, S, recs, serial, reach_left, reach_right, background);
     if (scan_observations)
         for (int k = 0; k < n; ++k) {
             const size_t count = (size_t)hb[k].B * hb[k].T * S;
@@ -1608,10 +1609,12 @@ struct BandChoice {
     band::TilePlan tile;
     bool whole;
     int cap;                // tiles per launch (split form)
+    float background;      // every entry outside the band: -inf, or ONE constant (whole tiles only: band_tile_forward.hpp)
 };
-inline bool choose_band(int S, int hl, int hr, int tiles, int cus, BandChoice &c) {
+inline bool choose_band(int S, int hl, int hr, int tiles, int cus, BandChoice &c, float background = -INFINITY) {
     c = BandChoice{};
-    if (tiles < 1) return false;
+    c.background = background;
+    if (tiles < 1 || background != background || background == INFINITY) return false;
     const char *force = getenv("TORBI_HIP_BAND_FORM");            // experiments: "tile" / "split"
     const char *tw = getenv("TORBI_HIP_TILE_WAVES");              // experiments: 8 / 12 waves per workgroup
     const bool tile_ok = band::make_tile_plan(S, hl, hr, c.tile, tw ? atoi(tw) : 0) && !(force && force[0] == 's');
@@ -1619,8 +1622,10 @@ inline bool choose_band(int S, int hl, int hr, int tiles, int cus, BandChoice &c
         c.whole = true;
         c.pl.S = S; c.pl.hl = hl; c.pl.hr = hr; c.pl.R = 1;
         c.cap = tiles;
+        c.tile.background = background;
         return true;
     }
+    if (background != -INFINITY) return false;        // (the split form knows -inf outside the band only)
     if (!band::make_plan(S, hl, hr, tiles, cus, c.pl)) return false;
     c.cap = std::min(band::tiles_per_launch(c.pl, cus), kMaxGroupTiles);
     return c.cap >= 1;
@@ -1636,7 +1641,7 @@ hipError_t run_band(const HostBatch *hb, int n, const float *trans, const float 
     jobs.ascending = ascending ? 1 : 0;
     grp.n = n;
     {
-        const hipError_t ne = nonfinite_begin(hb, n, trans, init, S, cus, s, false, pl.hl, pl.hr);     // (and the band's promise)
+        const hipError_t ne = nonfinite_begin(hb, n, trans, init, S, cus, s, false, pl.hl, pl.hr, true, choice.background);     // (and the band's promise)
         if (ne != hipSuccess) return ne;
     }
     grp.serial = t_serial;
@@ -1753,10 +1758,12 @@ hipError_t run_band(const HostBatch *hb, int n, const float *trans, const float 
 #define TORBI_BAND_BACKTRACE(NQ_)                                                                                                  \
     if (K > 1) {                                                                                                                   \
         hipLaunchKernelGGL(band::group_segment_band_kernel<NQ_>, dim3(items * K), dim3(64), 0, s, grp, trans, S, pl.hl, pl.hr, K,   \
-                           arrive);                                                                                                \
-        hipLaunchKernelGGL(band::group_stitch_band_kernel<NQ_>, dim3(items), dim3(64), 0, s, grp, trans, S, pl.hl, pl.hr, K, arrive); \
+                           arrive, choice.background);                                                                             \
+        hipLaunchKernelGGL(band::group_stitch_band_kernel<NQ_>, dim3(items), dim3(64), 0, s, grp, trans, S, pl.hl, pl.hr, K, arrive, \
+                           choice.background);                                                                                     \
     } else {                                                                                                                       \
-        hipLaunchKernelGGL(band::group_backtrace_band_kernel<NQ_>, dim3(items), dim3(64), 0, s, grp, trans, S, pl.hl, pl.hr);       \
+        hipLaunchKernelGGL(band::group_backtrace_band_kernel<NQ_>, dim3(items), dim3(64), 0, s, grp, trans, S, pl.hl, pl.hr,        \
+                           choice.background);                                                                                     \
     }
     if (S <= 512) { TORBI_BAND_BACKTRACE(2) }
     else if (S <= 1536) { TORBI_BAND_BACKTRACE(6) }
@@ -1773,7 +1780,8 @@ hipError_t run_band(const HostBatch *hb, int n, const float *trans, const float 
 
 // AUTO takes the band kernel for a promised band when its plan covers the group -- except for shapes a wavefront or a
 // workgroup decodes alone (small_states.hpp) and for the handful of sequences of the held-matrix kernel
-inline bool band_plan_for(const HostBatch *hb, int n, int S, int hl, int hr, int cus, int path, BandChoice &pl) {
+inline bool band_plan_for(const HostBatch *hb, int n, int S, int hl, int hr, int cus, int path, BandChoice &pl,
+                          float background = -INFINITY) {
     if (path != TORBI_HIP_FORWARD_AUTO && path != TORBI_HIP_FORWARD_BAND) return false;
     if (!band_shape(S)) return false;
     int tiles = 0;
@@ -1784,7 +1792,7 @@ inline bool band_plan_for(const HostBatch *hb, int n, int S, int hl, int hr, int
         if (small::supported(S) || small_block_auto((int)std::min(items, 1ll << 30), S, cus)) return false;
         if (n == 1 && held::supported(hb[0].B, S, cus) && held_auto(hb[0].B, S)) return false;
     }
-    return choose_band(S, hl, hr, tiles, cus, pl);
+    return choose_band(S, hl, hr, tiles, cus, pl, background);
 }
 
 // one decode on `s`; optional events bracket the forward and backtrace phases (ev[3]: end of the preparation)
@@ -2055,41 +2063,69 @@ int torbi_hip_viterbi_decode_batches(const torbi_hip_batch *batches, int count, 
 }
 
 
-int torbi_hip_band_reach(const float *transition, int S, int device, void *stream, int *reach_left_out, int *reach_right_out) {
+extern "C++" {
+namespace {
+// `background_out` null: -inf is what counts as outside; else: the matrix's corner entry, whatever it is
+int band_reach_impl(const float *transition, int S, int device, void *stream, int *reach_left_out, int *reach_right_out,
+                    float *background_out) {
     if (!transition || S < 1 || !reach_left_out || !reach_right_out) return TORBI_HIP_EINVAL;
     DeviceGuard guard(device);
     if (guard.err != hipSuccess) return (int)guard.err;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // eight bytes of device scratch per host thread and device, kept for the life of the thread: hipMalloc / hipFree per call
+    // a few bytes of device scratch per host thread and device, kept for the life of the thread: hipMalloc / hipFree per call
     // synchronise the whole device (round-5 advisor) and stall other streams' decodes
     thread_local int32_t *scratch[kMaxDevices] = {};
     if (device < 0 || device >= kMaxDevices) return TORBI_HIP_EINVAL;
     hipError_t e = hipSuccess;
-    if (!scratch[device]) e = hipMalloc(reinterpret_cast<void **>(&scratch[device]), 2 * sizeof(int32_t));
+    if (!scratch[device]) e = hipMalloc(reinterpret_cast<void **>(&scratch[device]), 4 * sizeof(int32_t));
     if (e != hipSuccess) return (int)e;
     int32_t *const dev = scratch[device];
-    int32_t host[2] = {-1, -1};
-    hipLaunchKernelGGL(fill_pair_kernel, dim3(1), dim3(1), 0, s, dev, -1, -1);     // (-1, -1: what a matrix without a finite entry leaves)
-    hipLaunchKernelGGL(band::band_reach_kernel, dim3(S), dim3(64), 0, s, transition, dev, S);
+    int32_t host[3] = {-1, -1, 0};
+    hipLaunchKernelGGL(fill_pair_kernel, dim3(1), dim3(1), 0, s, dev, -1, -1);     // (-1, -1: what a matrix without an entry inside leaves)
+    hipLaunchKernelGGL(band::band_reach_kernel, dim3(S), dim3(64), 0, s, transition, dev, S, background_out ? 1 : 0);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return (int)e;
     *reach_left_out = host[0];
     *reach_right_out = host[1];
+    if (background_out) { union { int32_t i; float f; } bits; bits.i = host[2]; *background_out = bits.f; }
     return TORBI_HIP_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int torbi_hip_band_reach(const float *transition, int S, int device, void *stream, int *reach_left_out, int *reach_right_out) {
+    return band_reach_impl(transition, S, device, stream, reach_left_out, reach_right_out, nullptr);
+}
+
+int torbi_hip_band_reach_over(const float *transition, int S, int device, void *stream, int *reach_left_out, int *reach_right_out,
+                              float *background_out) {
+    if (!background_out) return TORBI_HIP_EINVAL;
+    return band_reach_impl(transition, S, device, stream, reach_left_out, reach_right_out, background_out);
+}
+
+int torbi_hip_band_members_over(int items, int S, int reach_left, int reach_right, float background, int device) {
+    if (items < 1 || S < 1 || reach_left < 0 || reach_right < 0) return TORBI_HIP_EINVAL;
+    BandChoice c;
+    if (!band_shape(S) || !choose_band(S, reach_left, reach_right, band_tiles(items), cu_count(device), c, background)) return 0;
+    return c.pl.R;
 }
 
 int torbi_hip_band_members(int items, int S, int reach_left, int reach_right, int device) {
-    if (items < 1 || S < 1 || reach_left < 0 || reach_right < 0) return TORBI_HIP_EINVAL;
-    BandChoice c;
-    if (!band_shape(S) || !choose_band(S, reach_left, reach_right, band_tiles(items), cu_count(device), c)) return 0;
-    return c.pl.R;
+    return torbi_hip_band_members_over(items, S, reach_left, reach_right, -INFINITY, device);
 }
 
 int torbi_hip_viterbi_decode_banded(const torbi_hip_batch *batches, int count, const float *transition, const float *initial,
                                     int S, int reach_left, int reach_right, int device, void *stream, unsigned flags,
                                     float *phase_ms) {
+    return torbi_hip_viterbi_decode_banded_over(batches, count, transition, initial, S, reach_left, reach_right, -INFINITY, device,
+                                                stream, flags, phase_ms);
+}
+
+int torbi_hip_viterbi_decode_banded_over(const torbi_hip_batch *batches, int count, const float *transition, const float *initial,
+                                         int S, int reach_left, int reach_right, float background, int device, void *stream,
+                                         unsigned flags, float *phase_ms) {
     if (!flags_ok(flags) || count < 0 || count > TORBI_HIP_MAX_BATCHES || S < 1 || reach_left < 0 || reach_right < 0)
         return TORBI_HIP_EINVAL;
     if (count == 0) return TORBI_HIP_OK;
@@ -2109,7 +2145,7 @@ int torbi_hip_viterbi_decode_banded(const torbi_hip_batch *batches, int count, c
     const int path = requested_path(flags);
     bool vec = (reinterpret_cast<uintptr_t>(transition) & 15) == 0;       // (16-byte reads of matrix rows and observation rows)
     for (int k = 0; k < n; ++k) vec = vec && (reinterpret_cast<uintptr_t>(hb[k].obs) & 15) == 0;
-    if (n == 0 || !vec || !band_plan_for(hb, n, S, reach_left, reach_right, cus, path, pl)) {
+    if (n == 0 || !vec || !band_plan_for(hb, n, S, reach_left, reach_right, cus, path, pl, background)) {
         // not a shape of the band kernel: whatever the plain entry point does with it (BAND named: as AUTO)
         unsigned f = flags;
         if (path == TORBI_HIP_FORWARD_BAND) f = (flags & ~(7u << 4)) | TORBI_HIP_PATH_FLAG(TORBI_HIP_FORWARD_AUTO);

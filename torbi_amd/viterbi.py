@@ -72,8 +72,7 @@ def _resolve_path(trans, transition, B, S, device, path, tiles, count=1, items=N
         # a banded matrix (the reference's pitch model, torbi/evaluate/core.py:24-33) whose band the band kernel covers
         # (csrc/band_forward.hpp): every finite cell and no other, the time loop inside one launch.  AUTO leaves the
         # handful of sequences the held-matrix kernel decodes to it.
-        reach = band_reach(trans, transition, S)
-        if reach is not None and _lib.load().torbi_hip_band_members(int(total), S, reach[0], reach[1], index) > 0 \
+        if _band_of(trans, transition, S, total, index) is not None \
                 and (forced == 'band' or not (count == 1 and forward_path(B, S, 'auto', index) == 'held')):
             return 'band'
     if small or forced == 'band':
@@ -237,19 +236,59 @@ def band_reach(trans: torch.Tensor, original: torch.Tensor, states: int):
     return found if found[0] + found[1] + 4 <= BAND_MAX_WINDOW else None
 
 
-def _device_reach(trans: torch.Tensor, original: torch.Tensor, states: int):
-    """(reach_left, reach_right) of a device matrix (torbi_hip_band_reach), looked at once per tensor version."""
+def band_over(trans: torch.Tensor, original: torch.Tensor, states: int):
+    """(reach_left, reach_right, background) of a transition matrix that holds ONE value outside a band -- the reference's
+    evaluation decodes with log(p + tiny), log(tiny) = -87.34 outside the pitch band, not -inf (torbi/evaluate/core.py:97-103 ->
+    torbi/core.py:341-347) --: `background` = the corner entry transition[0][S - 1], the reaches over every other value
+    (include/torbi_hip.h, torbi_hip_band_reach_over); None where the band kernels could not take it.  A matrix that is -inf
+    outside its band answers (reach_left, reach_right, -inf).  One small kernel and a host sync per tensor version."""
+    if states % 4 or not 64 <= states <= BAND_MAX_STATES or not trans.is_cuda or trans.data_ptr() % 16:
+        return None
+    found = _device_look(trans, original, states)
+    left, right, background = max(found[0], 0), max(found[1], 0), found[2]
+    if left + right + 4 > BAND_MAX_WINDOW or background != background or background == float('inf'):
+        return None
+    return left, right, background
+
+
+def _band_of(trans, transition, S, items, index):
+    """What the band route would be told about this matrix for `items` sequences: (reach_left, reach_right, background), or
+    None when the band kernels do not cover it.  -inf outside the band first (both forms of the kernel), then ONE finite
+    constant outside it (whole tiles only)."""
+    lib = _lib.load()
+    reach = band_reach(trans, transition, S)
+    if reach is not None and lib.torbi_hip_band_members(int(items), S, reach[0], reach[1], index) > 0:
+        return reach[0], reach[1], float('-inf')
+    over = band_over(trans, transition, S)
+    if over is not None and over[2] != float('-inf') \
+            and lib.torbi_hip_band_members_over(int(items), S, over[0], over[1], ctypes.c_float(over[2]), index) > 0:
+        return over
+    return None
+
+
+def _device_look(trans: torch.Tensor, original: torch.Tensor, states: int):
+    """(reach_left, reach_right, background) of a device matrix as torbi_hip_band_reach_over answers -- `background` = the
+    corner entry transition[0][S - 1], the reaches over every entry that differs from it bit for bit --, looked at ONCE per
+    tensor version (one small kernel + a host sync) for both questions: -inf outside a band, or one constant."""
     kept = state.notes(original)
-    found = kept.get(('band', states)) if kept is not None else None
+    found = kept.get(('band_over', states)) if kept is not None else None
     if found is None:
-        left, right = ctypes.c_int(0), ctypes.c_int(0)
-        _lib.check(_lib.load().torbi_hip_band_reach(trans.data_ptr(), states, trans.device.index or 0,
-                                                    ctypes.c_void_p(torch.cuda.current_stream(trans.device).cuda_stream),
-                                                    ctypes.byref(left), ctypes.byref(right)), 'torbi_hip_band_reach')
-        found = (left.value, right.value)
+        left, right, background = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_float(0.0)
+        _lib.check(_lib.load().torbi_hip_band_reach_over(trans.data_ptr(), states, trans.device.index or 0,
+                                                         ctypes.c_void_p(torch.cuda.current_stream(trans.device).cuda_stream),
+                                                         ctypes.byref(left), ctypes.byref(right), ctypes.byref(background)),
+                   'torbi_hip_band_reach_over')
+        found = (left.value, right.value, background.value)
         if kept is not None:
-            kept[('band', states)] = found
+            kept[('band_over', states)] = found
     return found
+
+
+def _device_reach(trans: torch.Tensor, original: torch.Tensor, states: int):
+    """(reach_left, reach_right) of a device matrix with -inf as "outside" (torbi_hip_band_reach's answer): a matrix whose
+    corner is not -inf has an entry that is not -inf at distance S - 1."""
+    left, right, background = _device_look(trans, original, states)
+    return (left, right) if background == float('-inf') else (states - 1, states - 1)
 
 
 def tiles_of(batch: int, states: int) -> int:
@@ -351,11 +390,11 @@ def decode(
     if chosen == 'band':
         one = (_lib.Batch * 1)(_lib.Batch(obs.data_ptr(), frames.data_ptr(), indices.data_ptr(), workspace.data_ptr(),
                                           workspace.numel(), B, T))
-        left, right = band_reach(trans, transition, S)
+        left, right, background = _band_of(trans, transition, S, B, index)
         phases = (ctypes.c_float * 6)() if _profile is not None else None
-        _lib.check(lib.torbi_hip_viterbi_decode_banded(one, 1, trans.data_ptr(), init.data_ptr(), S, left, right, index,
-                                                       ctypes.c_void_p(stream), flags, phases),
-                   'torbi_hip_viterbi_decode_banded')
+        _lib.check(lib.torbi_hip_viterbi_decode_banded_over(one, 1, trans.data_ptr(), init.data_ptr(), S, left, right,
+                                                            ctypes.c_float(background), index, ctypes.c_void_p(stream), flags, phases),
+                   'torbi_hip_viterbi_decode_banded_over')
         if _profile is not None:
             _profile[:] = list(phases)
     elif kept is not None:       # the per-call scratch is new every time; the preparation stays with the matrix
@@ -575,10 +614,10 @@ def decode_batches(
     phases = (ctypes.c_float * 6)() if _profile is not None else None
     kept = _kept_preparation(transition, largest, S, chosen, device, index) if own_scratch and chosen != 'band' else None
     if chosen == 'band':
-        left, right = band_reach(trans, transition, S)
-        _lib.check(lib.torbi_hip_viterbi_decode_banded(table, count, trans.data_ptr(), init.data_ptr(), S, left, right, index,
-                                                       ctypes.c_void_p(stream), flags, phases),
-                   'torbi_hip_viterbi_decode_banded')
+        left, right, background = _band_of(trans, transition, S, sum(B for B, _, _ in shapes), index)
+        _lib.check(lib.torbi_hip_viterbi_decode_banded_over(table, count, trans.data_ptr(), init.data_ptr(), S, left, right,
+                                                            ctypes.c_float(background), index, ctypes.c_void_p(stream), flags, phases),
+                   'torbi_hip_viterbi_decode_banded_over')
     elif kept is not None:
         _lib.check(kept.call(device, lambda pointer, size, reuse, filled: lib.torbi_hip_viterbi_decode_batches_prepared(
             table, count, trans.data_ptr(), init.data_ptr(), S, index, ctypes.c_void_p(stream), flags | reuse, phases,
