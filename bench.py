@@ -553,6 +553,8 @@ class Bench:
             'band_single': compact(sec_.get('peaked_banded'), roof(S), **band_exec(sec_.get('peaked_banded'))),
             'band_group': compact(sec_.get('peaked_banded_launch_group'), roof(S),
                                   **band_exec(sec_.get('peaked_banded_launch_group'))),
+            'band_group_evaluation_matrix': compact(sec_.get('evaluation_matrix_launch_group'), roof(S),
+                                                    **band_exec(sec_.get('evaluation_matrix_launch_group'))),
             'uniform': compact(sec_.get('uniform'), HBM_PEAK_GBS * 1e9 / (4 * S + 4)),
         }
         result['roofline']['configs'] = {k: c for k, c in configs.items() if c}
@@ -560,7 +562,8 @@ class Bench:
                                               '4 S + 4) / 8 TB/s; c2 / c3_* / c5 = BASELINE configs[1], [2], [4] (c3_launch_group = the '
                                               'headline value, c3_single_call = ONE decode of ONE batch, c3_every_cell = the dense '
                                               'kernel forced, c3_peaked_dense = posteriorgram-like rows); band_* = the reference\'s pitch '
-                                              'transition (torbi/evaluate/core.py:24-33) on peaked rows; the long notes are under '
+                                              'transition (torbi/evaluate/core.py:24-33) on peaked rows, log(p) (-inf outside the band) '
+                                              'and, *_evaluation_matrix, log(p + tiny) as torbi.evaluate really decodes; the long notes are under '
                                               '"secondary"')
         return result
 
@@ -741,6 +744,24 @@ class Bench:
         sec, _ = self.timed_decodes(lambda: v.decode_batches([peaked] * 8, [frames] * 8, band, init, workspaces=spaces,
                                                              path='resident'), 2)
         record('peaked_banded_launch_group_resident', sec, 8 * B * T, S, 'the same, time-resident kernel forced')
+        # ... and with the matrix the reference's EVALUATION really decodes with: from_files_to_files(transition_file=...,
+        # log_probs=True) takes log(p + tiny) (torbi/core.py:341-347): log(tiny) = -87.34 outside the band, not -inf
+        evaluated = torch.from_numpy(synth.banded_transition(S, args.half_width, tiny=True)).to(dev)
+        prof = []
+        v.decode_batches([peaked] * 8, [frames] * 8, evaluated, init, workspaces=spaces, _profile=prof)
+        sec, _ = self.timed_decodes(lambda: v.decode_batches([peaked] * 8, [frames] * 8, evaluated, init, workspaces=spaces), 2)
+        record('evaluation_matrix_launch_group', sec, 8 * B * T, S,
+               'eight batches of the peaked rows with log(p + tiny) of the pitch transition, as torbi.evaluate calls '
+               'from_files_to_files (torbi/evaluate/core.py:97-103): ONE constant outside the band -- the whole-tile band kernel '
+               'decides every output from the band and the row maximum (csrc/band_tile_forward.hpp); AUTO',
+               {'forward_path': ROUTES[int(prof[3])], 'kernel': v.last_forward_kernel(), 'forward_ms': prof[0],
+                'backtrace_ms': prof[1], 'background': float(evaluated[0, S - 1]),
+                'executed': executed(sec, 8 * B * T, prof[0], spaces[0]),
+                'statistics_gave_up': int(v.scan_stats(spaces[0], B, T, S).cpu()[127])})
+        sec, _ = self.timed_decodes(lambda: v.decode_batches([peaked] * 8, [frames] * 8, evaluated, init, workspaces=spaces,
+                                                             path='resident'), 2)
+        record('evaluation_matrix_launch_group_resident', sec, 8 * B * T, S, 'the same, time-resident kernel forced (AUTO until round 6)')
+        del evaluated
         del peaked, band, spaces
         c = float(torch.tensor(math.log(1.0 / S), dtype=torch.float32))
         sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode_uniform(obs, frames, c, init), 3)

@@ -1892,7 +1892,7 @@ def test_band_launch_group_runs_whole_tiles(waves, monkeypatch):
     got = viterbi.decode_batches(obs_list, frame_list, band, init, _profile=prof)
     torch.cuda.synchronize()
     assert viterbi.ROUTES[int(prof[3])] == 'band' and int(prof[2]) == 1
-    assert 'band_tile_kernel<2, 12>' in viterbi.last_forward_kernel() or (waves and 'band_tile_kernel<3, 8>' in viterbi.last_forward_kernel())
+    assert 'band_tile_kernel<2, 12, false>' in viterbi.last_forward_kernel() or (waves and 'band_tile_kernel<3, 8, false>' in viterbi.last_forward_kernel())
     for k, B in enumerate(sizes):
         dense = torbi_amd.decode(obs_list[k], frame_list[k], band, init, path='dense')
         np.testing.assert_array_equal(got[k].cpu().numpy(), dense.cpu().numpy(), err_msg=f'batch {k}')

@@ -128,7 +128,8 @@ __device__ __forceinline__ void glds16s(const char *base, unsigned voff, unsigne
 #endif
 
 // grid = tiles of the group, block = 64 * pl.waves, dynamic LDS = pl.lds_bytes
-template <int BPW, int NW>
+// BG: ONE constant outside the band instead of -inf (an instance of its own: the -inf instance carries none of its code)
+template <int BPW, int NW, bool BG = false>
 __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan pl, const float *__restrict__ tpack,
                                                                     const float *__restrict__ initial) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
     int *const spmin = reinterpret_cast<int *>(lds + pl.misc_off + 384);         // [2][16] lowest state that attains it
     int *const spmax = reinterpret_cast<int *>(lds + pl.misc_off + 512);         // [2][16] highest
     const float cbg = pl.background;
-    const bool bg = cbg != -INFINITY;          // (a constant outside the band: see the head of the file)
+    constexpr bool bg = BG;                    // (a constant outside the band: see the head of the file)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -258,22 +259,19 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
     auto finish = [&](int u, float (&acc)[16], int t) {
         if (bg && t > 0) {          // the candidates from outside the band: fl(largest posterior out there + c)
             const int par = (t - 1) & 1;
-            const float4 rm = *reinterpret_cast<const float4 *>(srm + par * kNI + 4 * ig);
-            const int4 lo = *reinterpret_cast<const int4 *>(spmin + par * kNI + 4 * ig);
-            const int4 hi = *reinterpret_cast<const int4 *>(spmax + par * kNI + 4 * ig);
-            const int4 len = *reinterpret_cast<const int4 *>(sframes + 4 * ig);
-            const float bound[4] = {rm.x + cbg, rm.y + cbg, rm.z + cbg, rm.w + cbg};
-            const int los[4] = {lo.x, lo.y, lo.z, lo.w}, his[4] = {hi.x, hi.y, hi.z, hi.w};
-            const bool live[4] = {t < len.x, t < len.y, t < len.z, t < len.w};      // (rows past an item's length are nobody's)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int j = 4 * jg[u] + k;
+            for (int c = 0; c < 4; ++c) {          // (an item at a time: four words live, not sixteen)
+                const int it = par * kNI + 4 * ig + c;
+                const float bound = srm[it] + cbg;
+                const int lo = spmin[it], hi = spmax[it];
+                const bool live = t < sframes[4 * ig + c];              // (rows past an item's length are nobody's)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const bool open = bound[c] >= acc[4 * k + c];                       // else: nothing outside wins or ties
-                    const bool outside = los[c] < j - hl || his[c] > j + pl.hr;         // the row's maximum stands outside j's band
-                    acc[4 * k + c] = (open && outside) ? fmaxf(acc[4 * k + c], bound[c]) : acc[4 * k + c];
-                    undecided = undecided || (open && !outside && rowok[u] && live[c]);
+                for (int k = 0; k < 4; ++k) {
+                    const int j = 4 * jg[u] + k;
+                    const bool open = bound >= acc[4 * k + c];                      // else: nothing outside wins or ties
+                    const bool outside = lo < j - hl || hi > j + pl.hr;             // the row's maximum stands outside j's band
+                    acc[4 * k + c] = (open && outside) ? fmaxf(acc[4 * k + c], bound) : acc[4 * k + c];
+                    undecided = undecided || (open && !outside && rowok[u] && live);
                 }
             }
         }

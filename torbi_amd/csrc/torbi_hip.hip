@@ -1710,18 +1710,21 @@ hipError_t run_band(const HostBatch *hb, int n, const float *trans, const float 
         hipLaunchKernelGGL(band::pack_band_kernel, dim3(tp.nblk * tp.Dq4), dim3(64), 0, s, trans, w.tpack, S, tp.hl, tp.hr, tp.Dq,
                            tp.Dq4);
         if (ev) (void)hipEventRecord(ev[3], s);
-#define TORBI_BAND_TILE(BPW_, NW_)                                                                                                \
+#define TORBI_BAND_TILE_AS(BPW_, NW_, BG_)                                                                                         \
         {                                                                                                                         \
-            e = ensure_dynamic_lds(reinterpret_cast<const void *>(&band::band_tile_kernel<BPW_, NW_>), (size_t)tp.lds_bytes);     \
+            e = ensure_dynamic_lds(reinterpret_cast<const void *>(&band::band_tile_kernel<BPW_, NW_, BG_>), (size_t)tp.lds_bytes); \
             if (e != hipSuccess) return e;                                                                                        \
-            TORBI_NOTE_KERNEL("band::band_tile_kernel<" #BPW_ ", " #NW_ ">");                                                     \
-            hipLaunchKernelGGL((band::band_tile_kernel<BPW_, NW_>), dim3(tiles), dim3(64 * tp.waves), (size_t)tp.lds_bytes, s,    \
+            TORBI_NOTE_KERNEL("band::band_tile_kernel<" #BPW_ ", " #NW_ ", " #BG_ ">");                                           \
+            hipLaunchKernelGGL((band::band_tile_kernel<BPW_, NW_, BG_>), dim3(tiles), dim3(64 * tp.waves), (size_t)tp.lds_bytes, s, \
                                grp, tp, w.tpack, init);                                                                          \
         }
+#define TORBI_BAND_TILE(BPW_, NW_)                                                                                                \
+        if (tp.background != -INFINITY) TORBI_BAND_TILE_AS(BPW_, NW_, true) else TORBI_BAND_TILE_AS(BPW_, NW_, false)
         if (tp.bpw == 1) TORBI_BAND_TILE(1, 12)
         else if (tp.waves == 12) TORBI_BAND_TILE(2, 12)
         else if (tp.bpw == 2) TORBI_BAND_TILE(2, 8)
         else TORBI_BAND_TILE(3, 8)
+#undef TORBI_BAND_TILE_AS
 #undef TORBI_BAND_TILE
     } else {
         {

@@ -58,12 +58,17 @@ def lengths(count, lo, hi, seed=0, stream=7):
     return (lo + (u % (hi - lo + 1))).astype(np.int32)
 
 
-def banded_transition(S, half_width, dtype=np.float32):
+def banded_transition(S, half_width, dtype=np.float32, tiny=False):
     """Log of the triangular banded transition the reference's evaluation builds
     (torbi/evaluate/core.py:24-33): clip(w - |x - y|, 0) row-normalised; log(0) = -inf
-    outside the band.  `half_width` plays the role of max_bins_per_frame."""
+    outside the band.  `half_width` plays the role of max_bins_per_frame.
+    tiny: log(p + tiny) in float32 instead -- what the operator really sees when the evaluation calls
+    from_files_to_files(transition_file=..., log_probs=True) (torbi/core.py:341-347): log(tiny) = -87.34 outside the band."""
     x = np.arange(S)
     tri = np.clip(half_width - np.abs(x[:, None] - x[None, :]), 0, None).astype(np.float64)
     tri = tri / tri.sum(axis=1, keepdims=True)
+    if tiny:
+        p = tri.astype(np.float32)
+        return np.log(p + np.finfo(np.float32).tiny).astype(dtype)
     with np.errstate(divide='ignore'):
         return np.log(tri).astype(dtype)
