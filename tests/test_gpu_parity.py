@@ -1636,6 +1636,55 @@ def test_many_file_job_at_1440_states(tmp_path):
         assert np.array_equal(torch.load(outs[k]).numpy(), want), f'file {k} ({lengths[k]} frames)'
 
 
+def test_many_file_job_with_the_pitch_transition_file(tmp_path):
+    """The reference's evaluation as it calls the library (torbi/evaluate/core.py:97-103): a file of pitch transition
+    PROBABILITIES and log_probs=True, i.e. the operator decodes with log(p + tiny) -- log(tiny) outside the band
+    (torbi/core.py:341-347).  2 100 ragged sequences at 1440 states: the launch groups run the whole-tile band kernel with a
+    constant outside the band, every output has its file's length, and 30 files equal the oracle's decode of that file alone."""
+    S, count = 1440, 2100
+    lengths = synth.lengths(count, 20, 60, seed=12).tolist()
+    gen = torch.Generator().manual_seed(12)
+    block = torch.rand(200, S, generator=gen).mul_(6.0)
+    ins, outs = [], []
+    for k, n in enumerate(lengths):
+        f = tmp_path / f'in{k}.pt'
+        start = (37 * k) % 100
+        rows = block[start:start + n].clone()
+        centre = (300 + 7 * k + 3 * torch.arange(n)) % S                       # a peak that wanders: posteriorgram-like
+        rows -= ((torch.arange(S)[None, :] - centre[:, None]).abs().float() / 12.0) ** 2
+        torch.save(rows.log_softmax(-1).clone(), f)
+        ins.append(f)
+        outs.append(tmp_path / f'out{k}.pt')
+    tf = tmp_path / 'transition.pt'
+    x = torch.arange(S)
+    tri = torch.clip(87.2 - (x[:, None] - x[None, :]).abs().float(), 0)
+    torch.save(tri / tri.sum(dim=1, keepdims=True), tf)
+    torbi_amd.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, gpu=0, lengths=lengths)
+    trans = torch.load(tf)
+    # (which kernel a launch group takes depends on how many batches are resident when the device falls idle: whole tiles from
+    # 128 tiles up, clusters below; the same matrix as ONE group of five batches is the band kernel's)
+    dev = torch.device('cuda:0')
+    matrix = torch.log(trans + torch.finfo(torch.float32).tiny).to(dev)
+    rows = [torch.load(ins[k]).to(dev) for k in range(0, 2048)]
+    T = max(r.shape[0] for r in rows)
+    batches = [torch.zeros((512, T, S), device=dev) for _ in range(4)]
+    frames = [torch.tensor(lengths[512 * g:512 * g + 512], dtype=torch.int32, device=dev) for g in range(4)]
+    for k, r in enumerate(rows):
+        batches[k // 512][k % 512, :r.shape[0]] = torch.log(torch.exp(r) + torch.finfo(torch.float32).tiny)
+    prof = []
+    got = viterbi.decode_batches(batches, frames, matrix, torch.full((S,), float(np.log(np.float32(1.0 / S) + np.finfo(np.float32).tiny)),
+                                                                     device=dev), _profile=prof)
+    assert viterbi.ROUTES[int(prof[3])] == 'band' and 'band_tile_kernel<2, 12, true>' in viterbi.last_forward_kernel()
+    for k in range(0, 2048, 97):
+        assert torch.equal(got[k // 512][k % 512, :lengths[k]].cpu(), torch.load(outs[k])), f'file {k}'
+    for k in range(count):
+        a = torch.load(outs[k])
+        assert a.dtype == torch.int32 and a.shape == (lengths[k],)
+    for k in np.random.default_rng(5).choice(count, size=30, replace=False):
+        want = _oracle_for_file(torch.load(ins[k]), trans, S)
+        assert np.array_equal(torch.load(outs[k]).numpy(), want), f'file {k} ({lengths[k]} frames)'
+
+
 @all_paths
 def test_grouped_decode_pipeline_equals_the_oracle():
     """DecodePipeline(group=3): batches are collected and decoded three per launch group; a different model, a
