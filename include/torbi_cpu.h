@@ -8,7 +8,9 @@
  * which torbi.from_probabilities(..., gpu=None) selects (torbi/core.py:147-150) and torbi/viterbi.py:51-52 gives
  * its thread count through global torch state.  This entry point is that operator for callers who ask for the
  * CPU: same result contract as torbi_hip_viterbi_decode (decoded indices bit-identical to the reference CPU
- * operator for inputs without NaN), thread count passed explicitly.
+ * operator, NaN and +inf inputs included: an item that produced a NaN / +inf posterior value -- every item when the
+ * matrix or the initial vector hold one -- is decoded again in the reference's own order of evaluation,
+ * viterbi.cpp:94-100, 218), thread count passed explicitly.
  *
  * It is NOT a fallback: nothing in libtorbi_hip.so or in torbi_amd's GPU paths ever calls it; a GPU request without
  * a usable device raises.  It is also not the test oracle (oracle/ restates the reference's algorithm and cost

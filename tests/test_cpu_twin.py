@@ -79,6 +79,39 @@ def test_twin_equals_the_oracle_on_fresh_inputs(seed):
         assert np.array_equal(twin(obs, frames, trans, init, threads), want), (B, T, S, threads)
 
 
+@pytest.mark.parametrize('kind', ['observation', 'matrix', 'initial', 'final_row', 'inf'])
+@pytest.mark.parametrize('threads', [1, 5])
+def test_twin_follows_the_reference_on_nan_and_inf_inputs(kind, threads):
+    """The reference is deterministic on NaN (a NaN candidate at prev-state 0 is never replaced, one elsewhere never wins,
+    viterbi.cpp:94-100; the final state is ATen's argmax, the first NaN of the last row, :218), a vectorised maximum is not: the
+    twin decodes the items that produced a NaN / +inf posterior value again in the reference's order.  The cases of
+    tests/test_oracle.py (where the oracle is pinned against the reference operator itself) on 20 items, one team and several."""
+    B, T, S = 20, 12, 40
+    obs, trans, init = synth.problem(B, T, S, seed=2100)
+    nan = np.float32('nan')
+    frames = np.clip(synth.lengths(B, 2, T, seed=1), 2, T).astype(np.int32)
+    frames[0] = T
+    if kind == 'observation':
+        obs[0, 3, 5] = nan
+        obs[17, 1, 0] = nan
+    elif kind == 'matrix':
+        trans[7, 0] = nan
+        trans[9, 11] = nan
+    elif kind == 'initial':
+        init[0] = nan
+    elif kind == 'final_row':
+        obs[1, frames[1] - 1, 17] = nan
+        obs[2, 0, :] = nan
+    else:
+        obs[0, 2, 0] = np.inf
+        obs[1, 1, 3] = np.inf
+        trans[6, 0] = -np.inf
+        trans[5, 3] = -np.inf
+    want = oracle.decode(obs, frames, trans, init, num_threads=2)
+    got = torbi_amd.decode_cpu(torch.tensor(obs), torch.tensor(frames), torch.tensor(trans), torch.tensor(init), num_threads=threads)
+    np.testing.assert_array_equal(got.numpy(), want)
+
+
 def test_twin_clamps_lengths_and_fills_the_tail():
     obs, trans, init = synth.problem(3, 10, 7, seed=9)
     got = twin(obs, [4, 0, 99], trans, init)

@@ -7,7 +7,11 @@
 // posterior rows are kept as the (B,T,S) history, and the backpointer -- lowest prev-state attaining the maximum
 // (viterbi.cpp:94-100) -- is recomputed only for the states on the decoded path (viterbi.cpp:140-160 reads exactly
 // those).  Same two roundings per cell in the same order, max is exact, so indices are bit-identical to the reference
-// operator for inputs without NaN.  Not the test oracle (oracle/viterbi_oracle.c restates the reference's own loop
+// operator.  NaN and +inf inputs included: the reference is deterministic there (a NaN candidate at prev-state 0 is never
+// replaced, one elsewhere never wins, viterbi.cpp:94-100; the final state is ATen's argmax: the first NaN, :218), a vectorised
+// maximum is not, so every posterior value produced is looked at (NaN / +inf observations show there) and an item that met
+// one -- every item when the matrix or the initial vector hold one -- is decoded again in the reference's own order of
+// evaluation (faithful_item below; the HIP side does the same, csrc/nonfinite.hpp).  Not the test oracle (oracle/viterbi_oracle.c restates the reference's own loop
 // structure) and not a fallback of the HIP path: torbi_amd calls it only where a caller asks for the CPU (gpu=None).
 #include "torbi_cpu.h"
 #include "file_rows.hpp"
@@ -36,10 +40,12 @@ inline int clamp_frames(int f, int T) { return f < 1 ? 1 : (f > T ? T : f); }
 
 // out[b][j] = obs[b][j] + max_i (post[b][i] + trans[j][i]) for next-states [j0, j1) and NB items.  The item loop is
 // innermost: every 16-float piece of a transition row is loaded once and added to NB posterior rows.
+inline bool odd(float x) { return !(x <= std::numeric_limits<float>::max()); }        // NaN or +inf (-inf is ordinary)
+
 template <int NB>
 __attribute__((target_clones("avx512f", "avx2", "default")))
 void step_rows(const float *const *post, const float *const *obs, float *const *out, const float *trans, int S, int j0,
-               int j1) {
+               int j1, unsigned char *const *flag) {
     const int whole = S / kLanes * kLanes;
     for (int j = j0; j < j1; ++j) {
         const float *tr = trans + (size_t)j * S;
@@ -63,23 +69,58 @@ void step_rows(const float *const *post, const float *const *obs, float *const *
                 const float c = post[b][i] + tr[i];
                 m = c > m ? c : m;
             }
-            out[b][j] = obs[b][j] + m;
+            const float v = obs[b][j] + m;
+            out[b][j] = v;
+            if (odd(v)) __atomic_store_n(flag[b], (unsigned char)1, __ATOMIC_RELAXED);
         }
     }
 }
 
 void step_rows_any(int nb, const float *const *post, const float *const *obs, float *const *out, const float *trans, int S,
-                   int j0, int j1) {
+                   int j0, int j1, unsigned char *const *flag) {
     switch (nb) {
-        case 8: step_rows<8>(post, obs, out, trans, S, j0, j1); break;
-        case 7: step_rows<7>(post, obs, out, trans, S, j0, j1); break;
-        case 6: step_rows<6>(post, obs, out, trans, S, j0, j1); break;
-        case 5: step_rows<5>(post, obs, out, trans, S, j0, j1); break;
-        case 4: step_rows<4>(post, obs, out, trans, S, j0, j1); break;
-        case 3: step_rows<3>(post, obs, out, trans, S, j0, j1); break;
-        case 2: step_rows<2>(post, obs, out, trans, S, j0, j1); break;
-        case 1: step_rows<1>(post, obs, out, trans, S, j0, j1); break;
+        case 8: step_rows<8>(post, obs, out, trans, S, j0, j1, flag); break;
+        case 7: step_rows<7>(post, obs, out, trans, S, j0, j1, flag); break;
+        case 6: step_rows<6>(post, obs, out, trans, S, j0, j1, flag); break;
+        case 5: step_rows<5>(post, obs, out, trans, S, j0, j1, flag); break;
+        case 4: step_rows<4>(post, obs, out, trans, S, j0, j1, flag); break;
+        case 3: step_rows<3>(post, obs, out, trans, S, j0, j1, flag); break;
+        case 2: step_rows<2>(post, obs, out, trans, S, j0, j1, flag); break;
+        case 1: step_rows<1>(post, obs, out, trans, S, j0, j1, flag); break;
         default: break;
+    }
+}
+
+// One item exactly as the reference decodes it (viterbi.cpp:65-108, 140-160, 218-221): scan order, strict '>', int32 trellis,
+// ATen's argmax (the first NaN of the final row, else its first maximum).  `trellis`: [T][S] int32 (the item's history region).
+void faithful_item(const float *obs, int f, const float *trans, const float *initial, int32_t *trellis, int32_t *out, int T,
+                   int S) {
+    std::vector<float> rows((size_t)2 * S);
+    float *cur = rows.data(), *nxt = cur + S;
+    for (int i = 0; i < S; ++i) cur[i] = obs[i] + initial[i];
+    for (int t = 1; t < f; ++t) {
+        for (int j = 0; j < S; ++j) {
+            const float *tr = trans + (size_t)j * S;
+            float best = cur[0] + tr[0];
+            int arg = 0;
+            for (int i = 1; i < S; ++i) {
+                const float c = cur[i] + tr[i];
+                if (c > best) { best = c; arg = i; }
+            }
+            trellis[(size_t)t * S + j] = arg;
+            nxt[j] = obs[(size_t)t * S + j] + best;
+        }
+        std::swap(cur, nxt);
+    }
+    int arg = 0;
+    float best = cur[0];
+    for (int i = 1; i < S; ++i)
+        if (cur[i] > best || (cur[i] != cur[i] && best == best)) { best = cur[i]; arg = i; }
+    for (int t = f - 1; t < T; ++t) out[t] = arg;
+    int index = arg;
+    for (int t = f - 1; t >= 1; --t) {
+        index = trellis[(size_t)t * S + index];
+        out[t - 1] = index;
     }
 }
 
@@ -140,9 +181,10 @@ struct Block {
 
 // the forward pass of one block over next-states [j0, j1) of timestep t (items that have ended are left out)
 inline void block_step(const Block &blk, const int *frames, const float *obs, float *hist, const float *trans, int T, int S,
-                       int t, int j0, int j1) {
+                       int t, int j0, int j1, unsigned char *flags) {
     const float *post[kBlock], *ob[kBlock];
     float *out[kBlock];
+    unsigned char *flag[kBlock];
     int nb = 0;
     for (int k = 0; k < blk.count; ++k) {
         const int b = blk.first + k;
@@ -151,9 +193,10 @@ inline void block_step(const Block &blk, const int *frames, const float *obs, fl
         post[nb] = hist + base + (size_t)(t - 1) * S;
         ob[nb] = obs + base + (size_t)t * S;
         out[nb] = hist + base + (size_t)t * S;
+        flag[nb] = flags + b;
         ++nb;
     }
-    step_rows_any(nb, post, ob, out, trans, S, j0, j1);
+    step_rows_any(nb, post, ob, out, trans, S, j0, j1, flag);
 }
 
 }  // namespace
@@ -184,12 +227,30 @@ int torbi_cpu_viterbi_decode(const float *observation, const int32_t *batch_fram
     }
     const int nblocks = (int)blocks.size();
 
+    // items that met a NaN / +inf (in a posterior value they produced: the observations show there; or in the matrix / the
+    // initial vector: every item) are decoded again in the reference's order once everything else is done
+    std::vector<unsigned char> flagged((size_t)B, 0);
+    unsigned char *const flags = flagged.data();
+    bool odd_matrix = false;
+#pragma omp parallel for num_threads(threads) schedule(static) reduction(|| : odd_matrix)
+    for (int j = 0; j < S; ++j) {
+        const float *tr = transition + (size_t)j * S;
+        bool seen = odd(initial[j]);
+        for (int i = 0; i < S; ++i) seen = seen || odd(tr[i]);
+        odd_matrix = odd_matrix || seen;
+    }
+
     // t = 0: post = obs[0] + initial                                             (viterbi.cpp:72-76)
 #pragma omp parallel for num_threads(threads) schedule(static)
     for (int b = 0; b < B; ++b) {
         const float *o = observation + (size_t)b * T * S;
         float *h = hist + (size_t)b * T * S;
-        for (int i = 0; i < S; ++i) h[i] = o[i] + initial[i];
+        bool seen = odd_matrix;
+        for (int i = 0; i < S; ++i) {
+            h[i] = o[i] + initial[i];
+            seen = seen || odd(h[i]);
+        }
+        if (seen) flags[b] = 1;
     }
 
     // item blocks are dealt to teams of threads; a team of one takes whole blocks through all their timesteps without
@@ -201,7 +262,7 @@ int torbi_cpu_viterbi_decode(const float *observation, const int32_t *batch_fram
         for (int n = 0; n < nblocks; ++n) {
             const Block &blk = blocks[n];
             for (int t = 1; t < blk.longest; ++t)
-                block_step(blk, frames.data(), observation, hist, transition, T, S, t, 0, S);
+                block_step(blk, frames.data(), observation, hist, transition, T, S, t, 0, S, flags);
             for (int k = 0; k < blk.count; ++k) {
                 const int b = blk.first + k;
                 backtrace_item(hist + (size_t)b * T * S, transition, indices_out + (size_t)b * T, frames[b], T, S);
@@ -223,7 +284,7 @@ int torbi_cpu_viterbi_decode(const float *observation, const int32_t *batch_fram
                 for (int n = team; n < nblocks; n += nteams) {
                     const Block &blk = blocks[n];
                     for (int t = 1; t < blk.longest; ++t) {
-                        block_step(blk, frames.data(), observation, hist, transition, T, S, t, j0, j1);
+                        block_step(blk, frames.data(), observation, hist, transition, T, S, t, j0, j1, flags);
                         bar.wait(size, phase);
                     }
                     for (int k = me; k < blk.count; k += size) {
@@ -234,6 +295,11 @@ int torbi_cpu_viterbi_decode(const float *observation, const int32_t *batch_fram
             }
         }
     }
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+    for (int b = 0; b < B; ++b)
+        if (flags[b])
+            faithful_item(observation + (size_t)b * T * S, frames[b], transition, initial,
+                          reinterpret_cast<int32_t *>(hist + (size_t)b * T * S), indices_out + (size_t)b * T, T, S);
     std::free(hist);
     return TORBI_CPU_OK;
 }
