@@ -12,13 +12,16 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 dev = torch.device('cuda:0')
 cases = []
 for (B, T, S, path) in [(512, 300, 1440, 'cluster'), (256, 200, 1440, 'cluster'), (40, 150, 1440, 'cluster'), (128, 120, 4096, 'cluster'),
-                        (300, 100, 2048, 'cluster'), (512, 300, 1440, 'band'), (512, 200, 256, 'auto'), (2048, 100, 128, 'auto')]:
+                        (300, 100, 2048, 'cluster'), (512, 300, 1440, 'band'), (512, 200, 256, 'auto'), (2048, 100, 128, 'auto'),
+                        (2048, 60, 1440, 'band'), (2048, 60, 1440, 'band-tiny'), (2100, 40, 1024, 'band')]:
     init = viterbi.fill_synthetic((S,), synth.STREAM_INITIAL, device=dev)
     obs = viterbi.fill_synthetic((B, T, S), synth.STREAM_OBSERVATION, seed=B + S, device=dev)
-    if path == 'band':
+    if path.startswith('band'):        # (2048+ items: whole tiles -- band_tile_forward.hpp; '-tiny': log(p + tiny), a constant outside the band)
         x = torch.arange(S, device=dev, dtype=torch.float32)
         tri = torch.clamp(87.2 - (x[:, None] - x[None, :]).abs(), min=0)
-        trans = torch.log(tri / tri.sum(1, keepdim=True))
+        p = tri / tri.sum(1, keepdim=True)
+        trans = torch.log(p + torch.finfo(torch.float32).tiny) if path.endswith('tiny') else torch.log(p)
+        path = 'auto' if path.endswith('tiny') else 'band'
     else:
         trans = viterbi.fill_synthetic((S, S), synth.STREAM_TRANSITION, device=dev)
     frames = torch.randint(1, T + 1, (B,), device=dev, dtype=torch.int32)

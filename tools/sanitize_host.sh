@@ -31,6 +31,14 @@ for (B, T, S) in [(1, 3, 3), (3, 40, 17), (20, 30, 70), (9, 25, 360), (17, 12, 1
         rc = lib.torbi_cpu_viterbi_decode(obs.ctypes.data, frames.ctypes.data, trans.ctypes.data, init.ctypes.data,
                                           out.ctypes.data, B, T, S, threads)
         assert rc == 0 and np.array_equal(out, oracle.decode(obs, frames, trans, init, num_threads=2)), (B, T, S, threads)
+    if S > 3:           # items that met a NaN / +inf are decoded again in the reference's order (int32 trellis in the history)
+        obs[0, T // 2, 1] = np.nan
+        obs[B - 1, 0, 0] = np.inf
+        trans[2, 0] = -np.inf
+        out = np.empty((B, T), np.int32)
+        rc = lib.torbi_cpu_viterbi_decode(obs.ctypes.data, frames.ctypes.data, trans.ctypes.data, init.ctypes.data,
+                                          out.ctypes.data, B, T, S, 3)
+        assert rc == 0 and np.array_equal(out, oracle.decode(obs, frames, trans, init, num_threads=2)), (B, T, S, 'nan')
 print('CPU twin under ASan/UBSan: clean, equal to the oracle')
 PY
 rm -rf "$W"
