@@ -16,14 +16,14 @@ centre = torch.randint(0, S, (B, T, 1), device=dev, generator=gen)
 logits -= ((torch.arange(S, device=dev)[None, None, :] - centre).abs().float() / 12.0) ** 2
 peaked = torch.log_softmax(logits, dim=-1).clamp_(min=math.log(torch.finfo(torch.float32).tiny))
 del logits
-band = torch.from_numpy(synth.banded_transition(S, 87.2)).to(dev)
+band = torch.from_numpy(synth.banded_transition(S, 87.2, tiny=bool(os.environ.get('BAND_TILE_TINY')))).to(dev)      # (BAND_TILE_TINY=1: log(p + tiny))
 init = torch.full((S,), math.log(1.0 / S), device=dev)
 frames = torch.full((B,), T, dtype=torch.int32, device=dev)
 spaces = [torch.empty(v.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev) for _ in range(N)]
 best = None
 for _ in range(5):
     prof = []
-    v.decode_batches([peaked] * N, [frames] * N, band, init, workspaces=spaces, path='band', _profile=prof)
+    v.decode_batches([peaked] * N, [frames] * N, band, init, workspaces=spaces, path='auto', _profile=prof)
     best = prof if best is None or prof[0] < best[0] else best
 stats = v.scan_stats(spaces[0], B, T, S)
 ghz = float(stats[120]) / max(float(stats[121]), 1.0) * 0.1
