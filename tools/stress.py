@@ -23,7 +23,8 @@ for c in range(cases):
     if B * T * S * S > 6e9:
         B = max(1, int(6e9 / (T * S * S)))
     obs, trans, init = synth.problem(B, T, S, seed=int(rng.integers(1 << 30)))
-    kind = rng.integers(7)
+    kind = rng.integers(10)
+    background = None
     if kind == 1:      # heavy ties
         obs = np.round(obs / 4) * 4; trans = np.round(trans / 8) * 8
     elif kind == 2:    # random -inf entries
@@ -39,6 +40,22 @@ for c in range(cases):
         centre = rng.integers(0, S, size=(B, T, 1))
         width = float(rng.choice([3.0, 12.0, 40.0]))
         obs = (obs / 4 - ((np.abs(np.arange(S)[None, None, :] - centre)) / width) ** 2).astype(np.float32)
+    elif kind == 7:    # NaN / +inf somewhere (csrc/nonfinite.hpp: the reference's results on every route)
+        for _ in range(int(rng.integers(1, 4))):
+            where = int(rng.integers(4))
+            bad_value = np.float32(rng.choice([np.nan, np.inf]))
+            if where == 0: obs[rng.integers(B), rng.integers(T), rng.integers(S)] = bad_value
+            elif where == 1: trans[rng.integers(S), rng.integers(min(S, 3))] = bad_value
+            elif where == 2: init[rng.integers(min(S, 2))] = bad_value
+            else: obs[rng.integers(B), rng.integers(T), 0] = bad_value
+        trans = np.where(rng.random((S, S)) < 0.05, -np.inf, trans).astype(np.float32)
+    elif kind in (8, 9):   # a band with ONE constant outside it (band_tile_forward.hpp), from "never matters" to "wins everywhere"
+        reach = int(rng.integers(1, max(2, min(S // 4, 120))))
+        background = np.float32(rng.choice([-87.33654, -20.0, -3.0, 1.5]))
+        trans = np.where(np.abs(np.arange(S)[:, None] - np.arange(S)[None, :]) > reach, background, trans).astype(np.float32)
+        if kind == 9:
+            centre = rng.integers(0, S, size=(B, T, 1))
+            obs = (obs / 4 - np.abs(np.arange(S)[None, None, :] - centre) * 1.5).clip(min=-87.0).astype(np.float32)
     frames = rng.integers(1, T + 1, size=B).astype(np.int32)
     want = oracle.decode(obs.astype(np.float32), frames, trans.astype(np.float32), init.astype(np.float32), num_threads=oracle.max_threads())
     args = [torch.as_tensor(np.ascontiguousarray(x)).to(dev) for x in (obs.astype(np.float32), frames, trans.astype(np.float32), init.astype(np.float32))]
@@ -47,9 +64,12 @@ for c in range(cases):
     if not np.array_equal(twin, want):
         bad += 1
         print('MISMATCH', dict(B=B, T=T, S=S, kind=int(kind), path='cpu twin'), int((twin != want).sum()))
-    for path in ('auto', 'dense', 'pruned', 'resident', 'cluster', 'held'):
-        viterbi.set_forward_path(path)
+    for path in ('auto', 'dense', 'pruned', 'resident', 'cluster', 'held') + (('band',) if kind in (3, 8, 9) else ()):
+        viterbi.set_forward_path('auto' if path == 'band' else path)
+        if path == 'band':      # both forms of the band kernel on any number of items ('tile' only for a constant outside the band)
+            os.environ['TORBI_HIP_BAND_FORM'] = 'tile' if (background is not None or c % 2) else 'split'
         got = torbi_amd.decode(*args).cpu().numpy()
+        os.environ.pop('TORBI_HIP_BAND_FORM', None)
         if not np.array_equal(got, want):
             bad += 1
             print('MISMATCH', dict(B=B, T=T, S=S, kind=int(kind), path=path, used=viterbi.forward_path(B, S)), int((got != want).sum()))

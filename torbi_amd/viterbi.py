@@ -272,6 +272,10 @@ def _device_look(trans: torch.Tensor, original: torch.Tensor, states: int):
     tensor version (one small kernel + a host sync) for both questions: -inf outside a band, or one constant."""
     kept = state.notes(original)
     found = kept.get(('band_over', states)) if kept is not None else None
+    if found is None and torch.cuda.is_current_stream_capturing():
+        # (the look synchronises the stream: not while a graph is being captured -- round-5 advisor.  Unknown = not banded:
+        # the routes that do not need a band take the call; look once before capturing to have the band kernels in the graph)
+        return states - 1, states - 1, 0.0
     if found is None:
         left, right, background = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_float(0.0)
         _lib.check(_lib.load().torbi_hip_band_reach_over(trans.data_ptr(), states, trans.device.index or 0,
