@@ -1896,6 +1896,18 @@ def test_auto_takes_the_band_kernel_for_the_pitch_transition():
     assert viterbi.ROUTES[int(prof[3])] == 'band'
     for g, n in zip(group, (B, 100, 17)):
         np.testing.assert_array_equal(g.cpu().numpy(), got_np[:n])
+    # the same ragged batch eight times in one call: 256 tiles = WHOLE tiles (csrc/band_tile_forward.hpp), one forward launch
+    eight = viterbi.decode_batches([peaked] * 8, [frames] * 8, band, init, _profile=prof)
+    assert viterbi.ROUTES[int(prof[3])] == 'band' and int(prof[2]) == 1 and 'band_tile_kernel<2, 12, false>' in viterbi.last_forward_kernel()
+    for g in eight:
+        np.testing.assert_array_equal(g.cpu().numpy(), got_np)
+    # ... and with the matrix the reference's evaluation really decodes with, log(p + tiny): against the dense kernel
+    tiny_band = torch.from_numpy(synth.banded_transition(S, 87.2, tiny=True)).to(dev)
+    eight = viterbi.decode_batches([peaked] * 8, [frames] * 8, tiny_band, init, _profile=prof)
+    assert viterbi.ROUTES[int(prof[3])] == 'band' and 'band_tile_kernel<2, 12, true>' in viterbi.last_forward_kernel()
+    dense = torbi_amd.decode(peaked, frames, tiny_band, init, path='dense').cpu().numpy()
+    for g in eight:
+        np.testing.assert_array_equal(g.cpu().numpy(), dense)
     stats = viterbi.scan_stats(torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev), B, T, S)
     del stats
 
