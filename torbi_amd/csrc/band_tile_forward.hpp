@@ -259,15 +259,17 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
     auto finish = [&](int u, float (&acc)[16], int t) {
         if (bg && t > 0) {          // the candidates from outside the band: fl(largest posterior out there + c)
             const int par = (t - 1) & 1;
+            int ig_ = ig, j0_ = 4 * jg[u];      // (opaque: the addresses and band edges below are made HERE, not kept in
+            asm volatile("" : "+v"(ig_), "+v"(j0_));      //  registers across the scans)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {          // (an item at a time: four words live, not sixteen)
-                const int it = par * kNI + 4 * ig + c;
+                const int it = par * kNI + 4 * ig_ + c;
                 const float bound = srm[it] + cbg;
                 const int lo = spmin[it], hi = spmax[it];
-                const bool live = t < sframes[4 * ig + c];              // (rows past an item's length are nobody's)
+                const bool live = t < sframes[4 * ig_ + c];             // (rows past an item's length are nobody's)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int j = 4 * jg[u] + k;
+                    const int j = j0_ + k;
                     const bool open = bound >= acc[4 * k + c];                      // else: nothing outside wins or ties
                     const bool outside = lo < j - hl || hi > j + pl.hr;             // the row's maximum stands outside j's band
                     acc[4 * k + c] = (open && outside) ? fmaxf(acc[4 * k + c], bound) : acc[4 * k + c];
@@ -285,9 +287,11 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
 #pragma unroll
         for (int e = 0; e < 16; ++e) odd = odd || (rowok[u] && nonfinite::odd(v[u][e]));
         if (bg && rowok[u]) {       // the largest posterior of row t per item (where it is attained: close_timestep)
+            int ig_ = ig;
+            asm volatile("" : "+v"(ig_));
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float *)(srm + (t & 1) * kNI + 4 * ig + c),
+                __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float *)(srm + (t & 1) * kNI + 4 * ig_ + c),
                                           fmaxf(fmaxf(v[u][c], v[u][4 + c]), fmaxf(v[u][8 + c], v[u][12 + c])), 0, 0, false);
         }
     };
@@ -296,18 +300,22 @@ __global__ __launch_bounds__(64 * NW) void band_tile_kernel(Group grp, TilePlan 
         barrier();                      // every wave is done with the window of row t - 1 (and the row's maxima are complete)
         if (bg) {
             const int par = t & 1;
-            const float4 rm = *reinterpret_cast<const float4 *>(srm + par * kNI + 4 * ig);
+            int ig_ = ig;
+            asm volatile("" : "+v"(ig_));
+            const float4 rm = *reinterpret_cast<const float4 *>(srm + par * kNI + 4 * ig_);
             const float top[4] = {rm.x, rm.y, rm.z, rm.w};
 #pragma unroll
             for (int u = 0; u < BPW; ++u)
                 if (rowok[u]) {
+                    int j0_ = 4 * jg[u];
+                    asm volatile("" : "+v"(j0_));
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
 #pragma unroll
                         for (int c = 0; c < 4; ++c)
                             if (v[u][4 * k + c] == top[c]) {
-                                atomicMin(spmin + par * kNI + 4 * ig + c, 4 * jg[u] + k);
-                                atomicMax(spmax + par * kNI + 4 * ig + c, 4 * jg[u] + k);
+                                atomicMin(spmin + par * kNI + 4 * ig_ + c, j0_ + k);
+                                atomicMax(spmax + par * kNI + 4 * ig_ + c, j0_ + k);
                             }
                 }
             if (tid < kNI) {            // the row maximum for the backtrace; the other parity's words for row t + 1
