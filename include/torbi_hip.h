@@ -257,7 +257,8 @@ int torbi_hip_viterbi_decode_batches_prepared(const torbi_hip_batch *batches, in
  * up to 16 members for fewer than 16 tiles), each reach at most a member's share of the states, reach_left + reach_right <= 508.
  *
  * (ABI 15) torbi_hip_band_members answers 1 where the band kernel runs WHOLE tiles: one workgroup per 16-item tile, the band
- * streamed from the L2 (S % 4 == 0, 64 <= S <= 1536), for `items` that give at least every other compute unit a tile.
+ * streamed from the L2 (S % 4 == 0, 64 <= S <= 1536), for `items` that give 5 / 8 of the compute units a tile (every other
+ * unit where the split form does not cover the band).
  *
  * torbi_hip_viterbi_decode_banded: torbi_hip_viterbi_decode_batches for a matrix whose band the caller states -- a
  * PROMISE, verified on the device (ABI 15): an entry outside the band that is not -inf is noticed by the launch that looks

@@ -1618,17 +1618,26 @@ inline bool choose_band(int S, int hl, int hr, int tiles, int cus, BandChoice &c
     const char *force = getenv("TORBI_HIP_BAND_FORM");            // experiments: "tile" / "split"
     const char *tw = getenv("TORBI_HIP_TILE_WAVES");              // experiments: 8 / 12 waves per workgroup
     const bool tile_ok = band::make_tile_plan(S, hl, hr, c.tile, tw ? atoi(tw) : 0) && !(force && force[0] == 's');
-    if (tile_ok && (2 * tiles >= cus || (force && force[0] == 't'))) {
+    // Whole tiles need a tile for (almost) every compute unit to pay: a whole-tile timestep takes ~5 x a split one (36 against
+    // 7.4 us at 1440 states, reach 87) whatever the tile count, a split launch decodes 32 tiles at a time.  Measured, -inf
+    // band, launch groups of 512-item batches (tools/pitch_tiny_probe.py): 4 batches = 128 tiles 56 M whole against 67 M split,
+    // 8 batches 109 M against 72 M; the rates cross near 157 tiles.  Where there is no split form (a constant outside the band;
+    // reaches or state counts it does not cover) the alternative is the cluster form (34-40 M): whole tiles from half the units up.
+    band::Plan split{};
+    const bool split_ok = background == -INFINITY && !(force && force[0] == 't' && tile_ok) && band::make_plan(S, hl, hr, tiles, cus, split) &&
+                          band::tiles_per_launch(split, cus) >= 1;
+    const bool enough = split_ok ? 8 * tiles >= 5 * cus : 2 * tiles >= cus;
+    if (tile_ok && (enough || (force && force[0] == 't'))) {
         c.whole = true;
         c.pl.S = S; c.pl.hl = hl; c.pl.hr = hr; c.pl.R = 1;
         c.cap = tiles;
         c.tile.background = background;
         return true;
     }
-    if (background != -INFINITY) return false;        // (the split form knows -inf outside the band only)
-    if (!band::make_plan(S, hl, hr, tiles, cus, c.pl)) return false;
+    if (!split_ok) return false;                      // (the split form knows -inf outside the band only)
+    c.pl = split;
     c.cap = std::min(band::tiles_per_launch(c.pl, cus), kMaxGroupTiles);
-    return c.cap >= 1;
+    return true;
 }
 
 hipError_t run_band(const HostBatch *hb, int n, const float *trans, const float *init, int S, const BandChoice &choice, int cus,
