@@ -3,7 +3,7 @@
 //
 // Where band_forward.hpp splits a tile over R workgroups so that each member's slab of the band fits its LDS (and pays for
 // it with halo granules, tickets, bounded waits and three barriers per timestep), a launch group that has a tile for
-// every compute unit needs no split: the workgroup keeps the tile's whole window of the previous posterior row in the LDS
+// (most) compute units needs no split: the workgroup keeps the tile's whole window of the previous posterior row in the LDS
 //     W   [4 item groups][S + 4 Dq - 1 rows][4 items]                         103.5 KB at 1440 states, reach 87
 // and STREAMS the band.  The band is packed once per launch, diagonal-major in the order the lanes read it,
 //     tpack [64-next block][dquad q][16 groups of four next-states][4 diagonals][4 next]     1 KiB per (block, dquad)
@@ -18,10 +18,13 @@
 // A lane owns 4 next-states x 4 items (as in the split kernel) for ALL diagonals of a 64-next block, so the waves share no
 // outputs: no merge buffer, no atomics.  A wave scans its blocks one after the other (wave w: blocks w, w + waves), keeps
 // the finished values in registers, and the timestep ends with
-//     observations of row t + 1 asked for, history stores, barrier (every wave is done with the window),
-//     own rows -> window, barrier
-// -- two barriers per timestep of ~27 us, nothing else between workgroups or waves.  Arithmetic and results are those of
-// band_forward.hpp (viterbi.cpp:81-104 over the band: -inf candidates never win the strict '>').
+//     barrier (every wave is done with the window), own rows -> window, barrier
+// -- two barriers per timestep of ~36 us, nothing else between workgroups or waves.  The memory side rides inside the scans:
+// a block's observations of row t are asked for, and its history row t - 1 is stored FROM THE WINDOW (it is still there),
+// in the middle of the block's scan of timestep t, each wave of a SIMD at another dquad.  Arithmetic and results are those
+// of band_forward.hpp (viterbi.cpp:81-104 over the band: -inf candidates never win the strict '>').
+// What binds it (profiles/r06_band_tile_ablations.txt): vector-ALU issue at the clock the power budget delivers -- the
+// dquads alone take 34.7 us per timestep at 2.10 GHz, the whole launch 36.3 at 2.34.
 //
 // A CONSTANT outside the band.  The reference's own evaluation does not decode with log(p) but with log(p + tiny)
 // (torbi/evaluate/core.py:97-103 -> torbi/core.py:341-347): its pitch matrix is log(tiny) = -87.34 outside the band, not
