@@ -2065,6 +2065,30 @@ def test_band_constant_that_the_tests_cannot_decide_is_decoded_in_the_reference_
     np.testing.assert_array_equal(got.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize('case', [(40, 12, 360, 10, None), (130, 7, 724, 30, None), (300, 9, 360, 10, -3.0), (17, 9, 1440, 87, -87.33654)])
+def test_whole_tile_band_launch_leaves_the_posterior_rows_of_the_oracle(case, monkeypatch):
+    """torbi_hip_read_posterior behind a whole-tile band launch (the final rows come from the kernel's registers, every other
+    history row from its window a timestep later): bit-identical to the oracle's posterior rows, -inf and a constant outside
+    the band, one and two blocks per wave, ragged lengths."""
+    monkeypatch.setenv('TORBI_HIP_BAND_FORM', 'tile')
+    B, T, S, reach, c = case
+    obs, trans, init = synth.problem(B, T, S, seed=41)
+    idx = np.arange(S)
+    inside = np.abs(idx[None, :] - idx[:, None]) <= reach
+    trans = np.where(inside, trans, np.float32(-np.inf if c is None else c)).astype(np.float32)
+    frames = np.clip(synth.lengths(B, 1, T, seed=6), 1, T).astype(np.int32)
+    frames[0] = T
+    dev = torch.device('cuda:0')
+    args = [torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)]
+    space = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+    want, want_post = oracle.decode(obs, frames, trans, init, return_posterior=True)
+    got = torbi_amd.decode(*args, workspace=space)
+    assert 'band_tile_kernel' in viterbi.last_forward_kernel()
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    post = viterbi.read_posterior(space, args[1], B, T, S).cpu().numpy()
+    assert np.array_equal(post.view(np.uint32), want_post.view(np.uint32))
+
+
 def test_band_launch_never_holds_more_members_than_are_resident():
     """Round-5 advisor: the members of a tile wait for each other INSIDE a launch, so a launch must not hold more members
     than the chip has units for (a dispatch class of R x ceil(tiles / 8) workgroups runs on one XCD: cus / 8 units).  600
