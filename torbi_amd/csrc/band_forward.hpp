@@ -72,6 +72,8 @@ struct Plan {
     int ig_stride;           // floats between the item groups' windows (== 4 mod 64: conflict-free 16-byte reads)
     int td_off, w_off, m_off, misc_off, lds_bytes;
     int rounds;              // halo granules per thread and timestep
+    float background;        // every entry outside the band: -inf, or ONE constant (band_forward_kernel<true>; the head of
+                             // band_tile_forward.hpp has the rule and its proof)
     // per wave, in dquads.  Before the halo is in the window: [0],[1) and [2],[3) read only the member's own rows (the halo
     // granules are asked for between the two runs) -- the same number of dquads for every wave, so that no wave idles at
     // the barrier in the middle of the timestep; behind it: [4],[5) the wave's other own-row dquads, [6],[7) and [8],[9)
@@ -88,7 +90,10 @@ struct Exchange {
     unsigned long long wait_ticks;       // budget of one wait (100 MHz ticks)
 };
 
-__host__ __device__ inline size_t xchg_tile_bytes(int S) { return (size_t)2 * kNI * (size_t)S * 8 + 256; }
+// (behind the granule planes and the members' XCDs: [2 parities][kMaxR members][16 items] 16-byte records {largest own posterior
+// of the row as an ordered integer, lowest state attaining it, highest, timestep} -- band_forward_kernel<true>)
+constexpr size_t kStatBytes = (size_t)2 * 16 * kNI * 16;
+__host__ __device__ inline size_t xchg_tile_bytes(int S) { return (size_t)2 * kNI * (size_t)S * 8 + 256 + kStatBytes; }
 __host__ __device__ inline size_t xchg_bytes(int B, int S) { return (size_t)((B + kNI - 1) / kNI) * xchg_tile_bytes(S); }
 
 // The plan for `tiles` tiles on `cus` compute units, or false when the band kernel does not cover the shape.  A dispatch
@@ -96,7 +101,7 @@ __host__ __device__ inline size_t xchg_bytes(int B, int S) { return (size_t)((B 
 // once (they wait for each other inside the launch): the plan takes the largest R that fits the XCD's cus / 8 units; when
 // even the smallest R the LDS allows does not, the caller decodes tiles_per_launch(pl, cus) tiles per launch.
 inline int tiles_per_launch(const Plan &pl, int cus) { return pl.R == 1 ? 1 << 30 : 8 * ((cus / 8) / pl.R); }
-inline bool make_plan(int S, int hl, int hr, int tiles, int cus, Plan &pl) {
+inline bool make_plan(int S, int hl, int hr, int tiles, int cus, Plan &pl, float background = -INFINITY) {
     if (S < 64 || S % 4 != 0 || hl < 0 || hr < 0 || hl >= S || hr >= S || tiles < 1) return false;
     if (hl + hr + 4 > kMaxWindow) return false;
     const int Dq = (hl + hr + 1 + 3) / 4;
@@ -106,6 +111,8 @@ inline bool make_plan(int S, int hl, int hr, int tiles, int cus, Plan &pl) {
     for (int R = 1; R <= kMaxR; ++R) {
         Plan p{};
         p.S = S; p.hl = hl; p.hr = hr; p.R = R; p.Dq = Dq;
+        p.background = background;
+        if (background != -INFINITY && R == 1) continue;          // (one member per tile: the whole-tile kernel's case)
         p.n_own = ((S + R - 1) / R + 3) / 4 * 4;
         if (p.n_own > 64 * kMaxBlocks) continue;
         if (R > 1 && ((R - 1) * p.n_own >= S || hl > p.n_own || hr > p.n_own)) break;      // (smaller shares only get worse)
@@ -119,7 +126,7 @@ inline bool make_plan(int S, int hl, int hr, int tiles, int cus, Plan &pl) {
         p.w_off = p.td_off + Dq * p.n_own * 16;
         p.m_off = p.w_off + 4 * p.ig_stride * 4;
         p.misc_off = p.m_off + 16 * p.n_own * 4;
-        p.lds_bytes = p.misc_off + 256;
+        p.lds_bytes = p.misc_off + 256 + (background != -INFINITY ? 512 : 0);      // (+ four 16 x 8-byte key tables)
         if (p.lds_bytes > kLdsBytes) continue;
         p.rounds = R > 1 ? (((hl + 1) / 2 + (hr + 1) / 2) * kNI + 64 * p.waves - 1) / (64 * p.waves) : 0;
         if (p.rounds > kMaxRounds) continue;
@@ -289,7 +296,21 @@ __device__ unsigned long long g_phase[1024 * kMaxWaves * kPhases];
 #define BSTAMP(i)
 #endif
 
+// monotone map float -> unsigned (and back): larger value, larger key; NaNs are the alarm's business (nonfinite.hpp)
+__device__ __forceinline__ unsigned ordered(float v) {
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float unordered(unsigned o) { return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o); }
+
 // grid = tiles of the group x R, block = 64 * pl.waves, dynamic LDS = pl.lds_bytes
+// BG: ONE constant outside the band instead of -inf (band_tile_forward.hpp, head).  A member knows its own rows only: it
+// leaves the largest posterior of every row it finishes and the lowest / highest state attaining it (64-bit keys, one LDS
+// atomic maximum each: {ordered value, ~state} and {ordered value, state}) as one 16-byte record per item in the exchange
+// when the next timestep opens; every member takes all R records of an item in just before the barrier that closes its
+// scans (they were written a timestep's scans ago: the first look finds them), combines them with the same keys, and its
+// finishers decide their outputs as the whole-tile kernel does.  No barrier more than the -inf instance has.
+template <bool BG = false>
 __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp, Exchange ex, Plan pl,
                                                                       const float *__restrict__ trans,
                                                                       const float *__restrict__ initial) {
@@ -300,6 +321,10 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
     int *const sframes = reinterpret_cast<int *>(lds + pl.misc_off);      // [16] frames per item (0 past the batch)
     int *const sitem = sframes + kNI;                                      // [16] item numbers (a valid one past the batch)
     int *const smisc = sitem + kNI;                                        // [0] ticket, [1] gave up waiting
+    // BG: own rows' keys of the row being finished; all members' keys of the row before (lowest / highest state in the low word)
+    unsigned long long *const lkey_lo = reinterpret_cast<unsigned long long *>(lds + pl.misc_off + 256);
+    unsigned long long *const lkey_hi = lkey_lo + kNI, *const gkey_lo = lkey_lo + 2 * kNI, *const gkey_hi = lkey_lo + 3 * kNI;
+    const float cbg = pl.background;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -341,6 +366,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
         }
         sframes[tid] = f;
         sitem[tid] = item;
+        if (BG) lkey_lo[tid] = lkey_hi[tid] = gkey_lo[tid] = gkey_hi[tid] = 0ull;
     }
     // this member's slab of the band, diagonal-major; everything outside the matrix or the band is -inf
     {
@@ -372,6 +398,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
     char *const xtile = ex.xchg[bk] + (size_t)tile * xchg_tile_bytes(S);
     const unsigned xpar = (unsigned)(kNI * S * 8);               // bytes of one parity: [16 items][2 halves][S / 4] granules
     const __amdgpu_buffer_rsrc_t xbuf = buffer_of(xtile, 2u * xpar);
+    const __amdgpu_buffer_rsrc_t sbuf = buffer_of(xtile + 2u * xpar + 256u, (unsigned)kStatBytes);      // (BG: the members' records)
     const int xhalf = (S / 4) * 16;                              // bytes of one half plane of an item
     const int fx_at = fit * 2 * xhalf + (fj >> 2) * 16;          // granule {fj, fj + 1}; {fj + 2, fj + 3} one plane on
     const bool publishes = fin_row && R > 1;
@@ -418,6 +445,20 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
         fw_at[4] = v.y;
         fw_at[8] = v.z;
         fw_at[12] = v.w;
+        if (BG && fin_row) {            // the largest of the four and where: lowest state in one key, highest in the other
+            const float vs[4] = {v.x, v.y, v.z, v.w};
+            int fit_ = fit, fj_ = fj;
+            asm volatile("" : "+v"(fit_), "+v"(fj_));
+            unsigned long long lo = 0ull, hi = 0ull;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long long o = (unsigned long long)ordered(vs[k]) << 32;
+                lo = max(lo, o | (unsigned long long)(0xffffffffu - (unsigned)(fj_ + k)));
+                hi = max(hi, o | (unsigned long long)(unsigned)(fj_ + k));
+            }
+            atomicMax(lkey_lo + fit_, lo);
+            atomicMax(lkey_hi + fit_, hi);
+        }
         return v;
     };
     auto send = [&](int t, const float4 &v, bool more) {
@@ -500,11 +541,22 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
     unsigned long long bacc[kPhases] = {};
     unsigned long long blast = __builtin_readcyclecounter();
 #endif
+    bool undecided = false;            // BG: an output neither test of band_tile_forward.hpp's head decided
     for (int t = 1; t < fmax; ++t) {
         float acc[16];
         float4 w[8];
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = -INFINITY;
+        if (BG && tid < kNI) {          // this member's record of row t - 1 to every member; the key tables start over
+            int it = tid;               // (opaque: addresses made here, not kept in registers across the scans)
+            asm volatile("" : "+v"(it));
+            const unsigned long long lo = lkey_lo[it], hi = lkey_hi[it];
+            const v4u rec = {(unsigned)(lo >> 32), 0xffffffffu - (unsigned)lo, (unsigned)hi, (unsigned)t};
+            const int at = ((((t - 1) & 1) * kMaxR + member) * kNI + it) * 16;
+            if (local) __builtin_amdgcn_raw_buffer_store_b128(rec, sbuf, at, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(rec, sbuf, at, 0, 16);
+            lkey_lo[it] = lkey_hi[it] = gkey_lo[it] = gkey_hi[it] = 0ull;
+        }
         if (BAND_ABL & 16) {
             scan(acc, w, tq0, w0, s0, s3, tq_step);
             scan(acc, w, tq0, w0, s4, s5, tq_step);
@@ -570,6 +622,30 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
                 __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float *)(m_at + e * n_own), acc[e], 0, 0, false);
         }
         BSTAMP(5);
+        if (BG) {                       // every member's record of row t - 1 (written when this timestep opened there)
+            bool lost = false;
+            int e0 = tid;
+            asm volatile("" : "+v"(e0));
+            for (int e = e0; e < R * kNI; e += nthreads) {
+                const int m = e / kNI, it = e - m * kNI;
+                const int at = ((((t - 1) & 1) * kMaxR + m) * kNI + it) * 16;
+                v4u rec;
+                unsigned long long since = 0ull;
+                for (;;) {
+                    rec = __builtin_amdgcn_raw_buffer_load_b128(sbuf, at, 0, 16);
+                    if (rec.w == (unsigned)t || gave_up) break;
+                    const unsigned long long now = wall_clock64();
+                    if (since == 0ull) since = now;
+                    if (now - since >= ex.wait_ticks) { lost = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (rec.w == (unsigned)t) {
+                    atomicMax(gkey_lo + it, ((unsigned long long)rec.x << 32) | (unsigned long long)(0xffffffffu - rec.y));
+                    atomicMax(gkey_hi + it, ((unsigned long long)rec.x << 32) | (unsigned long long)rec.z);
+                }
+            }
+            if (__any(lost)) gave_up = true;
+        }
         if (!(BAND_ABL & 512)) __syncthreads();                // every wave is done with the window; M holds the maxima
         BSTAMP(6);
         if (fin) {
@@ -582,6 +658,25 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
             fm_at[4 * n_own] = -INFINITY;
             fm_at[8 * n_own] = -INFINITY;
             fm_at[12 * n_own] = -INFINITY;
+            if (BG) {                   // the candidates from outside the band: fl(largest posterior out there + c)
+                int fit_ = fit, fj_ = fj;
+                asm volatile("" : "+v"(fit_), "+v"(fj_));
+                const unsigned long long glo = gkey_lo[fit_], ghi = gkey_hi[fit_];
+                const float rm = unordered((unsigned)(glo >> 32));
+                const int pmin = (int)(0xffffffffu - (unsigned)glo), pmax = (int)(unsigned)ghi;
+                const float bound = rm + cbg;
+                float bs[4] = {best.x, best.y, best.z, best.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int j = fj_ + k;
+                    const bool open = bound >= bs[k];                       // else: nothing outside wins or ties
+                    const bool outside = pmin < j - hl || pmax > j + hr;    // a state attaining the row's maximum outside j's band
+                    bs[k] = (open && outside) ? fmaxf(bs[k], bound) : bs[k];
+                    undecided = undecided || (open && !outside && fin_row && t < flen);
+                }
+                best = make_float4(bs[0], bs[1], bs[2], bs[3]);
+                if (member == 0 && fjg == 0 && t - 1 < flen) bat.rowmax[(size_t)sitem[fit_] * T + t - 1] = rm;      // (the backtrace's bound)
+            }
             send(t, settle(best), t + 1 < fmax);
         }
         BSTAMP(7);
@@ -597,6 +692,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
         atomicAdd(&grp.stats[127], 1u);
     }
     nonfinite::raise(odd && fin_row, bat.alarm, grp.serial);
+    if (BG) nonfinite::raise(undecided, bat.alarm + (nonfinite::kBandWord - nonfinite::kAlarmWord), grp.serial);
     if (blockIdx.x == 0 && tid == 0) {
         grp.stats[120] = (unsigned)((clock64() - clock_0) >> 4);
         grp.stats[121] = (unsigned)((wall_clock64() - wall_0) >> 4);
@@ -605,10 +701,13 @@ __global__ __launch_bounds__(64 * kMaxWaves) void band_forward_kernel(Group grp,
 
 // The safety net behind a band launch: a tile whose members gave up waiting is decoded again by ONE workgroup, four
 // items at a time, posterior rows ping-pong in the LDS, no hand-offs.  grid = tiles, block = 1024, LDS = 32 S bytes.
+// (`bg`: the value of every entry outside the band; finite: those candidates are evaluated too, and the rows' maxima go to
+// Batch::rowmax for the backtrace)
 __global__ __launch_bounds__(1024) void band_repair_kernel(Group grp, const unsigned *__restrict__ failed,
                                                            const float *__restrict__ trans, const float *__restrict__ initial,
-                                                           int S, int hl, int hr) {
+                                                           int S, int hl, int hr, float bg) {
     if (failed[blockIdx.x] == 0u) return;
+    __shared__ unsigned rowkey[2][4];        // largest entry of the row being made, per item of the group, as an ordered integer
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float4 *rows = reinterpret_cast<float4 *>(lds);
     __shared__ int sframes[kNI], sitem[kNI];
@@ -627,6 +726,19 @@ __global__ __launch_bounds__(1024) void band_repair_kernel(Group grp, const unsi
         sframes[tid] = f;
         sitem[tid] = item;
     }
+    if (tid < 8) rowkey[tid >> 2][tid & 3] = 0u;
+    const bool finite_bg = bg != -INFINITY;
+    // the row's maxima, for the backtrace's bound (finite background): every thread offers its own, thread bb keeps item bb's
+    auto offer = [&](int t, const float (&top)[4]) {
+        if (finite_bg)
+            for (int bb = 0; bb < 4; ++bb) atomicMax(&rowkey[t & 1][bb], ordered(top[bb]));
+    };
+    auto keep = [&](int t, int g, const int (&len)[4]) {        // (behind the barrier that closes row t)
+        if (finite_bg && tid < 4) {
+            if (t < len[tid]) bat.rowmax[(size_t)sitem[4 * g + tid] * T + t] = unordered(rowkey[t & 1][tid]);
+            rowkey[t & 1][tid] = 0u;
+        }
+    };
     __syncthreads();
     for (int g = 0; g < 4; ++g) {
         size_t at[4];
@@ -637,19 +749,24 @@ __global__ __launch_bounds__(1024) void band_repair_kernel(Group grp, const unsi
             longest = max(longest, len[bb]);
         }
         __syncthreads();
+        float top[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         for (int j = tid; j < S; j += 1024) {
             float v[4];
             for (int bb = 0; bb < 4; ++bb) {
                 v[bb] = bat.obs[at[bb] + j] + initial[j];
                 odd = odd || nonfinite::odd(v[bb]);
+                top[bb] = fmaxf(top[bb], v[bb]);
                 if (len[bb] > 0) bat.hist[at[bb] + j] = v[bb];
             }
             rows[j] = make_float4(v[0], v[1], v[2], v[3]);
         }
+        offer(0, top);
         __syncthreads();
+        keep(0, g, len);
         for (int t = 1; t < longest; ++t) {
             const float4 *cur = rows + (size_t)((t - 1) & 1) * S;
             float4 *nxt = rows + (size_t)(t & 1) * S;
+            for (int bb = 0; bb < 4; ++bb) top[bb] = -INFINITY;
             for (int j = tid; j < S; j += 1024) {
                 float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                 const int lo = max(0, j - hl), hi = min(S - 1, j + hr);
@@ -662,15 +779,27 @@ __global__ __launch_bounds__(1024) void band_repair_kernel(Group grp, const unsi
                     best[2] = fmaxf(best[2], p.z + tv);
                     best[3] = fmaxf(best[3], p.w + tv);
                 }
+                if (bg != -INFINITY)            // a constant outside the band: every candidate out there, one by one
+                    for (int i = 0; i < S; ++i) {
+                        if (i >= lo && i <= hi) { i = hi; continue; }
+                        const float4 p = cur[i];
+                        best[0] = fmaxf(best[0], p.x + bg);
+                        best[1] = fmaxf(best[1], p.y + bg);
+                        best[2] = fmaxf(best[2], p.z + bg);
+                        best[3] = fmaxf(best[3], p.w + bg);
+                    }
                 float v[4];
                 for (int bb = 0; bb < 4; ++bb) {
                     v[bb] = bat.obs[at[bb] + (size_t)t * S + j] + best[bb];
                     odd = odd || nonfinite::odd(v[bb]);
+                    top[bb] = fmaxf(top[bb], v[bb]);
                     if (t < len[bb]) bat.hist[at[bb] + (size_t)t * S + j] = v[bb];
                 }
                 nxt[j] = make_float4(v[0], v[1], v[2], v[3]);
             }
+            offer(t, top);
             __syncthreads();
+            keep(t, g, len);
         }
     }
     nonfinite::raise(odd, bat.alarm, grp.serial);

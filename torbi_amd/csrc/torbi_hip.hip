@@ -1624,7 +1624,7 @@ inline bool choose_band(int S, int hl, int hr, int tiles, int cus, BandChoice &c
     // 8 batches 109 M against 72 M; the rates cross near 157 tiles.  Where there is no split form (a constant outside the band;
     // reaches or state counts it does not cover) the alternative is the cluster form (34-40 M): whole tiles from half the units up.
     band::Plan split{};
-    const bool split_ok = background == -INFINITY && !(force && force[0] == 't' && tile_ok) && band::make_plan(S, hl, hr, tiles, cus, split) &&
+    const bool split_ok = !(force && force[0] == 't' && tile_ok) && band::make_plan(S, hl, hr, tiles, cus, split, background) &&
                           band::tiles_per_launch(split, cus) >= 1;
     const bool enough = split_ok ? 8 * tiles >= 5 * cus : 2 * tiles >= cus;
     if (tile_ok && (enough || (force && force[0] == 't'))) {
@@ -1634,7 +1634,7 @@ inline bool choose_band(int S, int hl, int hr, int tiles, int cus, BandChoice &c
         c.tile.background = background;
         return true;
     }
-    if (!split_ok) return false;                      // (the split form knows -inf outside the band only)
+    if (!split_ok) return false;
     c.pl = split;
     c.cap = std::min(band::tiles_per_launch(c.pl, cus), kMaxGroupTiles);
     return true;
@@ -1741,9 +1741,11 @@ hipError_t run_band(const HostBatch *hb, int n, const float *trans, const float 
             hipLaunchKernelGGL(band::clear_exchange_kernel, dim3((unsigned)blocks, n), dim3(256), 0, s, clear);
         }
         if (ev) (void)hipEventRecord(ev[3], s);
-        e = ensure_dynamic_lds(reinterpret_cast<const void *>(&band::band_forward_kernel), (size_t)pl.lds_bytes);
+        const bool bg = choice.background != -INFINITY;
+        e = bg ? ensure_dynamic_lds(reinterpret_cast<const void *>(&band::band_forward_kernel<true>), (size_t)pl.lds_bytes)
+               : ensure_dynamic_lds(reinterpret_cast<const void *>(&band::band_forward_kernel<false>), (size_t)pl.lds_bytes);
         if (e != hipSuccess) return e;
-        TORBI_NOTE_KERNEL("band::band_forward_kernel");
+        TORBI_NOTE_KERNEL(bg ? "band::band_forward_kernel<true>" : "band::band_forward_kernel<false>");
         // (R > 1: eight dispatch classes of R x ceil(tiles / 8) workgroups each -- band_forward.hpp, membership; a launch
         // never holds more members than one XCD has units for its class: choose_band)
         for (int l = 0; l < nlaunch; ++l) {
@@ -1752,15 +1754,19 @@ hipError_t run_band(const HostBatch *hb, int n, const float *trans, const float 
             ex.control = tickets + 8 * l;
             const int here = ex.tiles - ex.tile0;
             const int grid = pl.R > 1 ? 8 * ((here + 7) / 8) * pl.R : here;
-            hipLaunchKernelGGL(band::band_forward_kernel, dim3(grid), dim3(64 * pl.waves), (size_t)pl.lds_bytes, s, grp, ex, pl,
-                               trans, init);
+            if (bg)
+                hipLaunchKernelGGL(band::band_forward_kernel<true>, dim3(grid), dim3(64 * pl.waves), (size_t)pl.lds_bytes, s, grp, ex,
+                                   pl, trans, init);
+            else
+                hipLaunchKernelGGL(band::band_forward_kernel<false>, dim3(grid), dim3(64 * pl.waves), (size_t)pl.lds_bytes, s, grp, ex,
+                                   pl, trans, init);
         }
         if (pl.R > 1) {          // does nothing unless a member gave up waiting (band_forward.hpp)
             const size_t lds = 32 * (size_t)S;
             e = ensure_dynamic_lds(reinterpret_cast<const void *>(&band::band_repair_kernel), lds);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(band::band_repair_kernel, dim3(tiles), dim3(1024), lds, s, grp, ex.failed, trans, init, S, pl.hl,
-                               pl.hr);
+                               pl.hr, choice.background);
         }
     }
     if (launches) *launches = nlaunch;
