@@ -2125,14 +2125,17 @@ def test_band_launch_never_holds_more_members_than_are_resident():
     np.testing.assert_array_equal(got.cpu().numpy(), torbi_amd.decode(peaked, frames, trans, init, path='dense').cpu().numpy())
 
 
-@pytest.mark.parametrize('shape', [(40, 12, 360, 10), (17, 9, 1440, 87), (130, 7, 724, 30)])
+@pytest.mark.parametrize('shape', [(40, 12, 360, 10), (17, 9, 1440, 87), (130, 7, 724, 30), (40, 12, 360, 10, -3.0), (130, 7, 724, 30, -87.33654)])
 def test_band_launch_that_gives_up_waiting_is_repaired(shape, monkeypatch):
     """The members of a tile wait for each other's halo rows inside the launch; every wait is bounded.  With a budget of 0
     every failed poll gives up: the members flag their tile and band_repair_kernel decodes it again without hand-offs --
     indices and final posterior rows are the oracle's, the give-ups are counted; without the limit nothing gives up."""
-    B, T, S, reach = shape
+    B, T, S, reach = shape[:4]
     obs, _, init = synth.problem(B, T, S, seed=41)
     trans = _banded(S, reach, reach, seed=7)
+    if len(shape) > 4:          # ONE constant outside the band (band_forward_kernel<true>; band_repair_kernel evaluates it too)
+        trans = np.where(np.isneginf(trans), np.float32(shape[4]), trans).astype(np.float32)
+        monkeypatch.setenv('TORBI_HIP_BAND_FORM', 'split')
     frames = np.clip(synth.lengths(B, 1, T, seed=6), 1, T).astype(np.int32)
     frames[0] = T
     dev = torch.device('cuda:0')

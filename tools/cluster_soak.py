@@ -13,7 +13,8 @@ dev = torch.device('cuda:0')
 cases = []
 for (B, T, S, path) in [(512, 300, 1440, 'cluster'), (256, 200, 1440, 'cluster'), (40, 150, 1440, 'cluster'), (128, 120, 4096, 'cluster'),
                         (300, 100, 2048, 'cluster'), (512, 300, 1440, 'band'), (512, 200, 256, 'auto'), (2048, 100, 128, 'auto'),
-                        (2048, 60, 1440, 'band'), (2048, 60, 1440, 'band-tiny'), (2100, 40, 1024, 'band')]:
+                        (2048, 60, 1440, 'band'), (2048, 60, 1440, 'band-tiny'), (2100, 40, 1024, 'band'), (2560, 40, 1440, 'band-tiny'),
+                        (512, 200, 1440, 'band-tiny')]:
     init = viterbi.fill_synthetic((S,), synth.STREAM_INITIAL, device=dev)
     obs = viterbi.fill_synthetic((B, T, S), synth.STREAM_OBSERVATION, seed=B + S, device=dev)
     if path.startswith('band'):        # (2048+ items: whole tiles -- band_tile_forward.hpp; '-tiny': log(p + tiny), a constant outside the band)

@@ -66,8 +66,8 @@ for c in range(cases):
         print('MISMATCH', dict(B=B, T=T, S=S, kind=int(kind), path='cpu twin'), int((twin != want).sum()))
     for path in ('auto', 'dense', 'pruned', 'resident', 'cluster', 'held') + (('band',) if kind in (3, 8, 9) else ()):
         viterbi.set_forward_path('auto' if path == 'band' else path)
-        if path == 'band':      # both forms of the band kernel on any number of items ('tile' only for a constant outside the band)
-            os.environ['TORBI_HIP_BAND_FORM'] = 'tile' if (background is not None or c % 2) else 'split'
+        if path == 'band':      # both forms of the band kernel on any number of items
+            os.environ['TORBI_HIP_BAND_FORM'] = 'tile' if c % 2 else 'split'
         got = torbi_amd.decode(*args).cpu().numpy()
         os.environ.pop('TORBI_HIP_BAND_FORM', None)
         if not np.array_equal(got, want):
