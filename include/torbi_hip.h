@@ -285,7 +285,9 @@ int torbi_hip_viterbi_decode_banded(const torbi_hip_batch *batches, int count, c
  * (csrc/band_tile_forward.hpp; what it cannot decide -- in-band entries BELOW the constant where the row's maximum stands --
  * is decoded again in the reference's order).  The `_over` entry points are the banded ones with `background` = that constant
  * (-inf: identical to them): torbi_hip_band_reach_over takes the matrix's corner entry transition[0][S - 1] for it (bit for
- * bit) and answers the reach over every other value; torbi_hip_band_members_over answers like torbi_hip_band_members (the split
+ * bit) and answers the reach over every other value -- S - 1 / S - 1 ("no band") for a finite constant unless every other
+ * entry lies ABOVE it, as in a pitch matrix: where the band reaches down to the constant, outputs next to a row's maximum
+ * cannot be decided from the maximum alone and the batch would be decoded again every time; torbi_hip_band_members_over answers like torbi_hip_band_members (the split
  * form exchanges its members' row maxima: csrc/band_forward.hpp, band_forward_kernel<true>).
  */
 int torbi_hip_band_reach_over(const float *transition, int S, int device, void *stream, int *reach_left_out, int *reach_right_out,

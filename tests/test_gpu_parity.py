@@ -650,7 +650,7 @@ def test_auto_looks_at_the_transition_once_per_tensor_version():
     band = torch.as_tensor(synth.banded_transition(S, 20.0)).to(dev)
     torbi_amd.decode(args[0], args[1], band, args[3], _profile=prof)
     assert int(prof[3]) == 8                                         # narrow band: the band kernel
-    band.fill_(-1.0)                                                 # same storage, new version
+    band.fill_(-1.0)                                                 # same storage, new version: ONE value everywhere is no band
     torbi_amd.decode(args[0], args[1], band, args[3], _profile=prof)
     assert int(prof[3]) == 5
 
@@ -1962,6 +1962,26 @@ def test_band_launch_group_runs_whole_tiles(waves, monkeypatch):
         np.testing.assert_array_equal(got[k].cpu().numpy()[pick], want, err_msg=f'batch {k}')
 
 
+def _decode_banded_over(obs, frames, trans, init, left, right, background):
+    """torbi_hip_viterbi_decode_banded_over through ctypes with the band and the constant as the caller's promise (BAND named)."""
+    import ctypes
+    from torbi_amd import _lib
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    B, T, S = obs.shape
+    o, f, m, i = (torch.as_tensor(np.ascontiguousarray(x)).to(dev) for x in (obs, frames, trans, init))
+    ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+    out = torch.empty((B, T), dtype=torch.int32, device=dev)
+    one = (_lib.Batch * 1)(_lib.Batch(o.data_ptr(), f.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B, T))
+    phases = (ctypes.c_float * 6)()
+    rc = lib.torbi_hip_viterbi_decode_banded_over(one, 1, m.data_ptr(), i.data_ptr(), S, left, right, ctypes.c_float(background), 0,
+                                                  ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
+                                                  viterbi._path_flag('band'), phases)
+    assert rc == 0
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), viterbi.ROUTES[int(phases[3])], ws
+
+
 @pytest.mark.parametrize('case', [(300, 9, 360, 10, 3, -3.0), (300, 7, 360, 22, 22, -40.0), (272, 8, 1440, 87, 87, -87.33654),
                                   (260, 6, 1024, 5, 60, -1.0), (300, 9, 360, 10, 10, 2.5)])
 @pytest.mark.parametrize('rows', ['random', 'peaked', 'ties'])
@@ -1986,17 +2006,26 @@ def test_band_with_a_constant_outside_matches_the_oracle(case, rows, form, monke
     if rows == 'ties':
         obs, trans, init = np.round(obs * 2) / 2, np.round(trans * 2) / 2, np.round(init)
     trans = np.where(inside, trans, np.float32(c)).astype(np.float32)
-    trans[S // 3, max(0, S // 3 - left):S // 3 + right + 1] = -np.inf        # (inside the band only: the constant stays outside)
+    if rows == 'ties':          # a next-state nothing inside the band leads to (the constant stays outside; AUTO then leaves the matrix alone)
+        trans[S // 3, max(0, S // 3 - left):S // 3 + right + 1] = -np.inf
     frames = np.clip(synth.lengths(B, 1, T, seed=3), 1, T).astype(np.int32)
     frames[0] = T
     want = oracle.decode(obs.astype(np.float32), frames, trans, init, num_threads=oracle.max_threads())
     dev = torch.device('cuda:0')
     args = [torch.as_tensor(np.ascontiguousarray(x)).to(dev) for x in (obs.astype(np.float32), frames, trans, init)]
-    assert viterbi.band_over(args[2], args[2], S) == (left, right, pytest.approx(c))
+    # the entry point with the band and the constant as the caller's promise -- whatever the constant
+    got, route, _ = _decode_banded_over(obs.astype(np.float32), frames, trans, init, left, right, c)
+    assert route == 'band'
+    assert ('band_tile_kernel' if form == 'tile' else 'band_forward_kernel<true>') in viterbi.last_forward_kernel()
+    np.testing.assert_array_equal(got, want)
+    # AUTO takes a finite constant only from a matrix whose every other entry lies above it (a pitch matrix does: log(tiny)
+    # against -10.5 and more inside the band): where the band reaches down to the constant, the outputs next to a row's maximum
+    # cannot be decided from the maximum alone
+    above = bool((trans[inside] > c).all())
+    assert (viterbi.band_over(args[2], args[2], S) == (left, right, pytest.approx(c))) == above
     prof = []
     got = torbi_amd.decode(*args, _profile=prof)
-    assert viterbi.ROUTES[int(prof[3])] == 'band'
-    assert ('band_tile_kernel' if form == 'tile' else 'band_forward_kernel<true>') in viterbi.last_forward_kernel()
+    assert (viterbi.ROUTES[int(prof[3])] == 'band') == above
     np.testing.assert_array_equal(got.cpu().numpy(), want)
 
 
@@ -2063,41 +2092,15 @@ def test_band_constant_that_the_tests_cannot_decide_is_decoded_in_the_reference_
     trans = np.where(inside, trans - 12.0, np.float32(c)).astype(np.float32)       # the band far BELOW the constant
     frames = np.full((B,), T, np.int32)
     want = oracle.decode(obs, frames, trans, init, num_threads=oracle.max_threads())
-    dev = torch.device('cuda:0')
-    args = [torch.as_tensor(np.ascontiguousarray(x)).to(dev) for x in (obs, frames, trans, init)]
     import os
-    os.environ['TORBI_HIP_BAND_FORM'] = 'tile'
-    try:
-        prof = []
-        got = torbi_amd.decode(*args, _profile=prof)
-    finally:
-        del os.environ['TORBI_HIP_BAND_FORM']
-    assert viterbi.ROUTES[int(prof[3])] == 'band'
-    np.testing.assert_array_equal(got.cpu().numpy(), want)
-
-
-@pytest.mark.parametrize('case', [(40, 12, 360, 10, None), (130, 7, 724, 30, None), (300, 9, 360, 10, -3.0), (17, 9, 1440, 87, -87.33654)])
-def test_whole_tile_band_launch_leaves_the_posterior_rows_of_the_oracle(case, monkeypatch):
-    """torbi_hip_read_posterior behind a whole-tile band launch (the final rows come from the kernel's registers, every other
-    history row from its window a timestep later): bit-identical to the oracle's posterior rows, -inf and a constant outside
-    the band, one and two blocks per wave, ragged lengths."""
-    monkeypatch.setenv('TORBI_HIP_BAND_FORM', 'tile')
-    B, T, S, reach, c = case
-    obs, trans, init = synth.problem(B, T, S, seed=41)
-    idx = np.arange(S)
-    inside = np.abs(idx[None, :] - idx[:, None]) <= reach
-    trans = np.where(inside, trans, np.float32(-np.inf if c is None else c)).astype(np.float32)
-    frames = np.clip(synth.lengths(B, 1, T, seed=6), 1, T).astype(np.int32)
-    frames[0] = T
-    dev = torch.device('cuda:0')
-    args = [torch.as_tensor(x).to(dev) for x in (obs, frames, trans, init)]
-    space = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
-    want, want_post = oracle.decode(obs, frames, trans, init, return_posterior=True)
-    got = torbi_amd.decode(*args, workspace=space)
-    assert 'band_tile_kernel' in viterbi.last_forward_kernel()
-    np.testing.assert_array_equal(got.cpu().numpy(), want)
-    post = viterbi.read_posterior(space, args[1], B, T, S).cpu().numpy()
-    assert np.array_equal(post.view(np.uint32), want_post.view(np.uint32))
+    for form in ('tile', 'split'):
+        os.environ['TORBI_HIP_BAND_FORM'] = form
+        try:
+            got, route, ws = _decode_banded_over(obs, frames, trans, init, reach, reach, c)
+        finally:
+            del os.environ['TORBI_HIP_BAND_FORM']
+        assert route == 'band', form
+        np.testing.assert_array_equal(got, want, err_msg=form)
 
 
 def test_band_launch_never_holds_more_members_than_are_resident():
@@ -2125,7 +2128,7 @@ def test_band_launch_never_holds_more_members_than_are_resident():
     np.testing.assert_array_equal(got.cpu().numpy(), torbi_amd.decode(peaked, frames, trans, init, path='dense').cpu().numpy())
 
 
-@pytest.mark.parametrize('shape', [(40, 12, 360, 10), (17, 9, 1440, 87), (130, 7, 724, 30), (40, 12, 360, 10, -3.0), (130, 7, 724, 30, -87.33654)])
+@pytest.mark.parametrize('shape', [(40, 12, 360, 10), (17, 9, 1440, 87), (130, 7, 724, 30), (40, 12, 360, 10, -40.0), (130, 7, 724, 30, -87.33654)])
 def test_band_launch_that_gives_up_waiting_is_repaired(shape, monkeypatch):
     """The members of a tile wait for each other's halo rows inside the launch; every wait is bounded.  With a budget of 0
     every failed poll gives up: the members flag their tile and band_repair_kernel decodes it again without hand-offs --

@@ -934,12 +934,17 @@ __global__ __launch_bounds__(64) void band_reach_kernel(const float *__restrict_
     const float *row = trans + (size_t)j * S;
     const unsigned outside = corner ? __float_as_uint(trans[S - 1]) : __float_as_uint(-INFINITY);
     if (corner && j == 0 && lane == 0) reach[2] = (int32_t)outside;
+    const float cv = __uint_as_float(outside);
     int left = -1, right = -1;
-    for (int i = lane; i < S; i += 64)
+    bool below = false;                // an entry BELOW the corner value (the constant's rule wants the band above it)
+    for (int i = lane; i < S; i += 64) {
+        below = below || row[i] < cv;
         if (__float_as_uint(row[i]) != outside) {
             left = max(left, max(j - i, 0));
             right = max(right, max(i - j, 0));
         }
+    }
+    if (corner && __any(below) && lane == 0) reach[3] = 1;
     left = -wavered::wave_min_i32(-left);
     right = -wavered::wave_min_i32(-right);
     if (lane == 0 && left >= 0) {

@@ -1626,7 +1626,10 @@ inline bool choose_band(int S, int hl, int hr, int tiles, int cus, BandChoice &c
     band::Plan split{};
     const bool split_ok = !(force && force[0] == 't' && tile_ok) && band::make_plan(S, hl, hr, tiles, cus, split, background) &&
                           band::tiles_per_launch(split, cus) >= 1;
-    const bool enough = split_ok ? 8 * tiles >= 5 * cus : 2 * tiles >= cus;
+    // (a split launch decodes `per` tiles in ~1.6 / R of a whole-tile timestep: whole tiles once the split launches of the group
+    // add up to more -- 8 * launches >= 5 * R, which is 8 * tiles >= 5 * CUs for groups that fill their launches)
+    const int per = split_ok ? std::max(1, std::min(band::tiles_per_launch(split, cus), kMaxGroupTiles)) : 1;
+    const bool enough = split_ok ? 8 * ((tiles + per - 1) / per) >= 5 * split.R : 2 * tiles >= cus;
     if (tile_ok && (enough || (force && force[0] == 't'))) {
         c.whole = true;
         c.pl.S = S; c.pl.hl = hl; c.pl.hr = hr; c.pl.R = 1;
@@ -2098,8 +2101,9 @@ int band_reach_impl(const float *transition, int S, int device, void *stream, in
     if (!scratch[device]) e = hipMalloc(reinterpret_cast<void **>(&scratch[device]), 4 * sizeof(int32_t));
     if (e != hipSuccess) return (int)e;
     int32_t *const dev = scratch[device];
-    int32_t host[3] = {-1, -1, 0};
+    int32_t host[4] = {-1, -1, 0, 0};
     hipLaunchKernelGGL(fill_pair_kernel, dim3(1), dim3(1), 0, s, dev, -1, -1);     // (-1, -1: what a matrix without an entry inside leaves)
+    hipLaunchKernelGGL(fill_pair_kernel, dim3(1), dim3(1), 0, s, dev + 2, 0, 0);
     hipLaunchKernelGGL(band::band_reach_kernel, dim3(S), dim3(64), 0, s, transition, dev, S, background_out ? 1 : 0);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, s);
@@ -2107,7 +2111,15 @@ int band_reach_impl(const float *transition, int S, int device, void *stream, in
     if (e != hipSuccess) return (int)e;
     *reach_left_out = host[0];
     *reach_right_out = host[1];
-    if (background_out) { union { int32_t i; float f; } bits; bits.i = host[2]; *background_out = bits.f; }
+    if (background_out) {
+        union { int32_t i; float f; } bits;
+        bits.i = host[2];
+        *background_out = bits.f;
+        // a FINITE constant is taken only from matrices whose every other entry lies ABOVE it (a pitch matrix: log(tiny) against
+        // at least -10.5 inside the band) and that have such entries: where the band reaches down to the constant, the outputs
+        // next to a row's maximum cannot be decided from the maximum alone, and the launch would be decoded again every time
+        if (bits.f != -INFINITY && (host[3] != 0 || host[0] < 0)) *reach_left_out = *reach_right_out = S - 1;
+    }
     return TORBI_HIP_OK;
 }
 }  // namespace
