@@ -708,8 +708,8 @@ def test_band_plan_covers_the_reference_pitch_band_and_says_so_without_a_gpu():
     members = lambda items, S, left, right: lib.torbi_hip_band_members(items, S, left, right, 0)
     assert members(512, 1440, 87, 87) == 8                      # 32 tiles x 8 = one workgroup per compute unit
     assert members(4096, 1440, 87, 87) == 1                     # a launch group of eight batches: WHOLE tiles (band_tile_forward.hpp)
-    assert members(2560, 1440, 87, 87) == 1 and members(2544, 1440, 87, 87) == 8       # ... from 5 / 8 of a tile per unit up (below,
-                                                                # 32 tiles at a time in the split form decode more per second)
+    assert members(2064, 1440, 87, 87) == 1 and members(2048, 1440, 87, 87) == 8       # ... once the split form would need five
+                                                                # launches of 32 tiles (5 x 7.4 us against 36 us a timestep); four: split
     assert members(4096, 1440, 250, 250) == 1 and members(4096, 1440, 255, 255) == 0   # (the backtrace's window: 512 prev-states)
     assert members(2048, 1440, 250, 250) == 1 and members(2032, 1440, 250, 250) == 0   # no split form for this reach: whole tiles
                                                                                        # from half a tile per unit up, nothing below
