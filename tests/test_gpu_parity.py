@@ -1546,6 +1546,15 @@ def test_many_file_job_every_file_equals_the_oracle(tmp_path, monkeypatch):
     torbi_amd.from_files_to_files(ins, outs2, transition_file=tf, log_probs=True, gpu=0, lengths=lengths)
     for a, b in zip(outs, outs2):
         assert torch.equal(torch.load(a), torch.load(b))
+    # the host link's ring of pinned chunks (core.py::_Staging.upload_rows): chunks of a few rows (a 512-file batch in ~90
+    # pieces through three chunks), chunks smaller than ONE row (a chunk per row), and whole-batch pinned slabs instead
+    for chunk_bytes, chunks in ((1 << 20, 3), (1 << 12, 2), (1 << 28, 0)):
+        monkeypatch.setattr(torbi_amd.core, 'RING_CHUNK_BYTES', chunk_bytes)
+        monkeypatch.setattr(torbi_amd.core, 'RING_CHUNKS', chunks)
+        outs3 = [tmp_path / f'ring{k}.pt' for k in range(count)]
+        torbi_amd.from_files_to_files(ins, outs3, transition_file=tf, log_probs=True, gpu=0)
+        for a, b in zip(outs, outs3):
+            assert torch.equal(torch.load(a), torch.load(b)), (chunk_bytes, chunks)
 
 
 @pytest.mark.parametrize('count', [600, pytest.param(2100, marks=pytest.mark.slow)])

@@ -34,6 +34,10 @@ SAVE_THREADS = 2
 # (20 000 files: 1.3 s against 4.4 s for the first call) at the price of those gigabytes staying out of torch's caching
 # allocator until `release_job_memory()`.
 KEEP_JOB_MEMORY = os.environ.get('TORBI_KEEP_JOB_MEMORY', '0') != '0'
+# The file batches of a GPU job cross the host link through a ring of RING_CHUNKS pinned chunks of RING_CHUNK_BYTES (powers
+# of two: the pinned allocator rounds up to one), not through whole-batch pinned slabs; 0 chunks = whole-batch slabs.
+RING_CHUNKS = int(os.environ.get('TORBI_RING_CHUNKS', '4'))
+RING_CHUNK_BYTES = int(os.environ.get('TORBI_RING_CHUNK_MB', '256')) << 20
 
 
 def _compute_device(gpu):
@@ -349,6 +353,10 @@ def from_dataloader(
         stage = _Staging(torch.device('cuda', gpu))
         if log_probs and hasattr(dataloader, 'stage') and getattr(dataloader, 'pin_memory', False):
             dataloader.stage = stage.upload           # (fastio.FileBatches: copies start in the assembling threads)
+            if RING_CHUNKS > 0 and hasattr(dataloader, 'stage_rows'):
+                dataloader.stage_rows = stage.upload_rows        # ... chunk by chunk through a small pinned ring
+            if hasattr(dataloader, 'start'):
+                dataloader.start()                    # the first batches are read while the transition matrix is prepared
         if transition is not None:
             # the one look at the transition matrix that costs a host sync (torbi_amd.viterbi._choose_path) happens now,
             # while the device is idle, not at the first launch group with several batches' copies queued behind it
@@ -491,6 +499,34 @@ class _Staging:
         staged.torbi_copied = copied
         staged.torbi_device_slab = slab
         staged.torbi_keep = (observation, lengths)       # (pinned sources stay alive until the copy has been issued)
+        return staged
+
+    def upload_rows(self, shape, batch_frames, fill):
+        """`upload` for a batch that has not been read yet (fastio.FileBatches.stage_rows): `fill(address, first, k)` reads
+        rows first .. first + k - 1 to `address`.  The rows pass through a ring of RING_CHUNKS pinned chunks of
+        RING_CHUNK_BYTES, each copied to its place in the pooled device slab as soon as it has been read."""
+        count, longest, states = shape
+        row_bytes = 4 * longest * states
+        nbytes = count * row_bytes
+        slab = self.pool.take(nbytes)
+        staged = slab[:nbytes].view(torch.float32).view(shape)
+        lengths = batch_frames.to(torch.int32).pin_memory()
+        with torch.cuda.stream(self.copy):
+            staged.torbi_lengths = lengths.to(self.device, non_blocking=True)
+        per = max(1, RING_CHUNK_BYTES // row_bytes)
+        copied = None
+        for first in range(0, count, per):
+            k = min(per, count - first)
+            chunk = self.host_pool.take(max(RING_CHUNK_BYTES, k * row_bytes), limit=RING_CHUNKS, exact=True)
+            fill(chunk.data_ptr(), first, k)
+            with torch.cuda.stream(self.copy):
+                slab[first * row_bytes:(first + k) * row_bytes].copy_(chunk[:k * row_bytes], non_blocking=True)
+                copied = torch.cuda.Event()
+                copied.record(self.copy)
+            self.host_pool.give(chunk, copied)           # refilled once its copy has left
+        staged.torbi_copied = copied
+        staged.torbi_device_slab = slab
+        staged.torbi_keep = (lengths,)
         return staged
 
     def decode(self, observation, batch_frames, transition, initial, gpu, num_threads, pipe, model):

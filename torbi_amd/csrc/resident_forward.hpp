@@ -98,7 +98,9 @@ constexpr int kMaxTop = 4;               // list entries per item a member publi
 // critical path.  Four slots by timestep: row t goes to slot t % 4 and, behind the workgroup barrier of
 // timestep t, every wave resets the slot row t - 2 went to -- which every member finished reading before it sent row t - 1,
 // which this member has taken -- two timesteps before the next use ((t + 2) % 4), with that timestep's observation loads
-// (issued behind the reset, awaited before any output exists: vmcnt counts in order) between the two.
+// (issued behind the reset, awaited before any output exists: vmcnt counts in order) between the two.  The assumption
+// (gfx9: ONE vmcnt for loads and stores, decremented in issue order) is pinned by tools/cluster_soak.py: every decode
+// against the dense route's, 105 842 decodes on two streams without a mismatch (profiles/r06_soak_stress.txt).
 // (An input that makes the recurrence produce this very NaN -- NaNs are out of contract -- runs into the bounded wait and is
 // decoded again by the repair launch, like any cluster that cannot complete.)
 constexpr unsigned kAbsentBits = 0x7fd5a5a5u;

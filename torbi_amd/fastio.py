@@ -273,10 +273,20 @@ class FileBatches:
         # place -- the many-file driver starts the host-to-device copy here, so that copies are queued as soon as batches
         # exist, not when the consuming thread next comes round (torbi_amd/core.py::_Staging.upload)
         self.stage = None
+        # ... or, in its place: called with ((rows, longest, states), batch_frames, fill) BEFORE anything is read; calls
+        # fill(address, first, k) for the pieces it wants (rows first .. first + k - 1 read to `address`, padded like
+        # collate.py:24-31) and returns what is yielded (torbi_amd/core.py::_Staging.upload_rows: a ring of pinned chunks)
+        self.stage_rows = None
         self._window = None
         self.timings = [] if os.environ.get('TORBI_FILE_TIMINGS') else None     # (open + headers, slab, native read, bytes)
         # descriptors of `producers + ahead` batches are open at once (+ the savers' and the interpreter's own)
-        _reserve_descriptors(self.batch_size * (self.producers + self.ahead + 1) + 256)
+        # (in a thread of its own: the one expansion waits for an RCU grace period -- 0.13 s on the GPU box's 256 logical
+        # CPUs -- while the calling thread prepares the transition matrix and the job's streams; an open() that needs the
+        # larger table waits for it in the kernel, every other one goes ahead)
+        threading.Thread(target=_reserve_descriptors, args=(self.batch_size * (self.producers + self.ahead + 1) + 256,),
+                         name='torbi-descriptor-table', daemon=True).start()
+        self._workers = None
+        self._groups = None
 
     def more_ready(self):
         """True while the batch after the one just yielded is already assembled (or the job is over).  The many-file
@@ -306,6 +316,8 @@ class FileBatches:
             longest = max(entry[1] for entry in opened)
             row_bytes = 4 * longest * states
             t1 = time.perf_counter()
+            if self.stage_rows is not None and self.pin_memory:
+                return self._assemble_through_ring(files, opened, count, longest, states, t0, t1)
             if self.pin_memory:
                 # a pinned slab of the process-wide pool (torbi_amd/slabs.py): the consumer hands it back with the event of
                 # its host-to-device copy (`observation.torbi_slab`); one that never does just lets it be collected
@@ -347,22 +359,69 @@ class FileBatches:
             for entry in opened:
                 os.close(entry[0])
 
+    def _assemble_through_ring(self, files, opened, count, longest, states, t0, t1):
+        """The batch goes to the device in pieces of RING_CHUNK_BYTES: rows are read into a pinned chunk of a small ring and
+        copied from there (`stage_rows`: torbi_amd/core.py::_Staging.upload_rows), the chunk returns to the ring behind its
+        copy.  The first job of a process pins 1.5 GB instead of three or four whole-batch slabs (2.7 GB asked, 4 GB pinned
+        each: the host allocator rounds to powers of two), and a batch's copy starts when its first chunk has been read."""
+        import time
+        row_bytes = 4 * longest * states
+        fds = np.array([entry[0] for entry in opened], dtype=np.int32)
+        frames = np.array([entry[1] for entry in opened], dtype=np.int64)
+        offsets = np.array([entry[3] for entry in opened], dtype=np.int64)
+        sizes = 4 * states * frames
+        zeros = row_bytes - sizes
+        read_rows, _ = _lib.host_io(self.gpu)
+        spent = [0.0]
+
+        def fill(address, first, k):
+            rows = address + row_bytes * np.arange(k, dtype=np.int64)
+            part = slice(first, first + k)
+            f, o, b, z = (np.ascontiguousarray(a[part]) for a in (fds, offsets, sizes, zeros))
+            error = ctypes.c_int(0)
+            t = time.perf_counter()
+            with self._read_lock:          # one native read at a time, with every reader thread (see _assemble)
+                code = read_rows(f.ctypes.data, o.ctypes.data, b.ctypes.data, rows.ctypes.data, z.ctypes.data, k,
+                                 max(1, min(self.threads, k)), ctypes.byref(error))
+            spent[0] += time.perf_counter() - t
+            if code <= -100:
+                raise OSError(error.value, f'could not read {files[first - (code + 100)]} in full')
+            _lib.check_io(code, 'read_rows')
+
+        batch_frames = torch.from_numpy(frames.copy())
+        observation = self.stage_rows((count, longest, states), batch_frames, fill)
+        if self.timings is not None:
+            self.timings.append((t1 - t0, time.perf_counter() - t1 - spent[0], spent[0], count * row_bytes))
+        return observation, batch_frames, [1] * count, tuple(files)
+
+    def start(self):
+        """Begin assembling the first batches now (the iterator would at its first `next`): the many-file driver calls this
+        once `stage` / `stage_rows` are set and prepares the transition matrix meanwhile."""
+        import collections
+        from concurrent.futures import ThreadPoolExecutor
+        if self._workers is not None:
+            return
+        groups = self._groups = iter([self.input_files[k:k + self.batch_size]
+                                      for k in range(0, len(self.input_files), self.batch_size)])
+        workers = self._workers = ThreadPoolExecutor(max_workers=self.producers, thread_name_prefix='torbi-file-batches')
+        window = self._window = collections.deque()
+        for _ in range(self.ahead + self.producers - 1):
+            files = next(groups, None)
+            if files is not None:
+                window.append(workers.submit(self._assemble, files))
+
     def __iter__(self):
         """Batches in order, assembled by `producers` threads that take alternate batches (a batch's Python side -- 512
         opens, header reads and closes under the interpreter lock, 10-15 ms -- then hides behind the native copy of the
         other one), at most `ahead` + `producers` batches ahead of the consumer."""
-        import collections
-        from concurrent.futures import ThreadPoolExecutor
-        groups = iter([self.input_files[k:k + self.batch_size] for k in range(0, len(self.input_files), self.batch_size)])
-        workers = ThreadPoolExecutor(max_workers=self.producers, thread_name_prefix='torbi-file-batches')
-        window = self._window = collections.deque()
+        self.start()
+        groups, workers, window = self._groups, self._workers, self._window
+        self._groups = self._workers = None
         try:
             def submit():
                 files = next(groups, None)
                 if files is not None:
                     window.append(workers.submit(self._assemble, files))
-            for _ in range(self.ahead + self.producers - 1):
-                submit()
             while window:
                 item = window.popleft().result()         # (an exception of the worker surfaces here)
                 submit()

@@ -37,7 +37,7 @@ class SlabPool:
                 still.append((slab, event))
         self._busy = still
 
-    def take(self, nbytes: int, limit: Optional[int] = None) -> torch.Tensor:
+    def take(self, nbytes: int, limit: Optional[int] = None, exact: bool = False) -> torch.Tensor:
         """A slab of at least `nbytes` bytes: the smallest free one that fits, else a new allocation (sized generously,
         so that the slightly larger batch that follows fits as well).  With `limit`, a pool that already holds that
         many slabs waits for one in use to come back instead of growing (pinning a few GB costs more than the wait);
@@ -63,7 +63,9 @@ class SlabPool:
             if waiting_for is None:
                 break
             waiting_for.synchronize()
-        size = (nbytes + nbytes // 8 + (1 << 20) - 1) >> 20 << 20
+        # (`exact`: the caller asks for one size again and again -- the pinned allocator rounds what it is asked for up
+        # to a power of two, so a generous 288 MB would pin 512)
+        size = nbytes if exact else (nbytes + nbytes // 8 + (1 << 20) - 1) >> 20 << 20
         if self.device is None:
             slab = torch.empty((size,), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
         else:
