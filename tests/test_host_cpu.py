@@ -699,6 +699,45 @@ def test_slab_pool_stops_counting_slabs_that_were_dropped():
     assert pool._out == 0
 
 
+def test_ring_of_staging_chunks_reads_a_batch_in_pieces(tmp_path):
+    """torbi_amd/fastio.py::FileBatches.stage_rows (the many-file job's ring of pinned chunks, core.py::_Staging.upload_rows):
+    the batch is handed over BEFORE it is read, the stage asks for its rows piece by piece; pieces of any size -- here three
+    rows at a time into one small buffer -- assemble the rows `collate` would have built (collate.py:24-31), and the pool
+    hands out chunks of exactly the size asked for (the pinned allocator rounds up to powers of two)."""
+    import ctypes
+    from torbi_amd import fastio, slabs
+    gen = torch.Generator().manual_seed(3)
+    lengths = [5, 9, 2, 7, 9, 1, 4]
+    files = []
+    for k, n in enumerate(lengths):
+        files.append(tmp_path / f'{k}.pt')
+        torch.save(torch.rand(n, 12, generator=gen), files[-1])
+    batches = fastio.open_batches(files, 7, pin_memory=True, gpu=False)
+    assert batches is not None
+    asked = []
+
+    def stage_rows(shape, batch_frames, fill):
+        count, longest, states = shape
+        out = torch.full(shape, float('nan'))
+        piece = torch.empty((3, longest, states))
+        for first in range(0, count, 3):
+            k = min(3, count - first)
+            fill(piece.data_ptr(), first, k)
+            asked.append((first, k))
+            out[first:first + k] = piece[:k]
+        return out
+    batches.stage_rows = stage_rows
+    (observation, frames, chunks, names), = list(batches)
+    assert asked == [(0, 3), (3, 3), (6, 1)] and frames.tolist() == lengths and observation.shape == (7, 9, 12)
+    for k, n in enumerate(lengths):
+        assert torch.equal(observation[k, :n], torch.load(files[k])) and not observation[k, n:].any()
+    pool = slabs.SlabPool(None)
+    chunk = pool.take(1 << 16, limit=2, exact=True)
+    assert chunk.numel() == 1 << 16
+    pool.give(chunk)
+    assert pool.take(1 << 16, limit=2, exact=True) is chunk
+
+
 def test_band_plan_covers_the_reference_pitch_band_and_says_so_without_a_gpu():
     """torbi_hip_band_members (include/torbi_hip.h): members per 16-item tile of the band kernel, 0 where it does not cover the
     shape.  The plan is host arithmetic (LDS budget of a member: its slab of the band + window + merge buffer within 160 KB;

@@ -12,6 +12,9 @@ Orders simulated, dquads walked per wave and timestep (of Dq = 44):
     ltr        left to right as today; window bound = the item's suffix maximum (one scan per row and item)
     ltr-exact  ... bound = the maximum over exactly the rows the lane still reads (what no cheaper bound can beat)
     ltr-oracle ... stop when every output HAS its final value (no bound at all: the floor of any left-to-right scheme)
+    ltr-16     what the kernel's LDS has room for: suffix maxima per granule of 16 rows, a look every 4 dquads;
+               busiest-SIMD: the timestep this gives (12 waves x 2 blocks on 4 SIMDs, the busiest SIMD's sum) -- before the
+               cost of the suffix pass (~4 %) and of the looks (~5 %)
     out        centre -> right edge, then centre -> left edge (two monotone walks, each with its own stop),
                suffix / prefix maxima
     out-exact, out-oracle   as above
@@ -70,13 +73,18 @@ def simulate(kind, B, T, seed=7):
     post = obs[:, 0, :] + init[None, :]
     pad = 4 * DQ
     nblk = (S // 4 + 15) // 16
-    walked = {k: [] for k in ('ltr', 'ltr-exact', 'ltr-oracle', 'out', 'out-exact', 'out-oracle')}
+    walked = {k: [] for k in ('ltr', 'ltr-exact', 'ltr-oracle', 'out', 'out-exact', 'out-oracle', 'ltr-16')}
+    simd_full, simd_walk = [], []       # 'ltr-16' per tile and timestep: dquads of the busiest SIMD, all / walked
     cq = DQ // 2                    # first dquad of the walk to the right
     for t in range(1, T):
         # window of the previous row, padded: W[b][w] = post[b][w - HL]; outside the matrix -inf (never wins, never bounds)
         W = np.full((B, S + pad + 8), -np.inf, np.float32)
         W[:, HL:HL + S] = post
         suf = np.maximum.accumulate(W[:, ::-1], axis=1)[:, ::-1]          # max of rows >= w
+        # what fits the kernel's LDS beside window and rings (5.8 KB): the suffix maximum per GRANULE of 16 rows (from the
+        # granule's first row on), looked at every 4 dquads
+        suf16 = suf[:, (np.arange(W.shape[1]) // 16) * 16]
+        per_tile = np.zeros((B // 16, nblk), np.int64)
         pre = np.maximum.accumulate(W, axis=1)                           # max of rows <= w
         new = np.empty_like(post)
         for blk in range(nblk):
@@ -102,6 +110,11 @@ def simulate(kind, B, T, seed=7):
                 b_suf = suf[b][:, first_row] + rem_t[None, None, :]
                 done = (b_suf <= run).all(axis=(0, 1))
                 walked['ltr'].append(int(np.argmax(done)) + 1 if done.any() else DQ)
+                looks = np.arange(3, DQ, 4)                               # behind dquads 3, 7, ...
+                d16 = (suf16[b][:, first_row[:, looks]] + rem_t[None, None, looks] <= run[:, :, looks]).all(axis=(0, 1))
+                n16 = int(looks[int(np.argmax(d16))]) + 1 if d16.any() else DQ
+                walked['ltr-16'].append(n16)
+                per_tile[tile, blk] = n16
                 # exact window maximum of the rows still to come
                 ex = np.full((16, nj, DQ), -np.inf, np.float32)
                 for q in range(DQ - 1):
@@ -150,8 +163,15 @@ def simulate(kind, B, T, seed=7):
                 else:
                     n_l = 0
                 walked['out-oracle'].append(n_r + n_l)
+        # the kernel's timestep: 12 waves x 2 blocks, wave w on SIMD w % 4 -- the busiest SIMD's dquads
+        simd_of = (np.arange(nblk) // 2) % 4
+        for tile in range(B // 16):
+            simd_walk.append(max(int(per_tile[tile, simd_of == s_].sum()) for s_ in range(4)))
+            simd_full.append(max(int((simd_of == s_).sum()) * DQ for s_ in range(4)))
         post = obs[:, t, :] + new
-    return {k: float(np.mean(v)) for k, v in walked.items()}
+    out = {k: float(np.mean(v)) for k, v in walked.items()}
+    out['busiest-SIMD'] = DQ * float(np.sum(simd_walk)) / float(np.sum(simd_full))      # (as dquads of 44, for the same print)
+    return out
 
 
 if __name__ == '__main__':
