@@ -257,8 +257,9 @@ int torbi_hip_viterbi_decode_batches_prepared(const torbi_hip_batch *batches, in
  * up to 16 members for fewer than 16 tiles), each reach at most a member's share of the states, reach_left + reach_right <= 508.
  *
  * (ABI 15) torbi_hip_band_members answers 1 where the band kernel runs WHOLE tiles: one workgroup per 16-item tile, the band
- * streamed from the L2 (S % 4 == 0, 64 <= S <= 1536), for `items` that give 5 / 8 of the compute units a tile (every other
- * unit where the split form does not cover the band).
+ * streamed from the L2 (S % 4 == 0, 64 <= S <= 1536), once the split form's launches of resident-sized pieces would add up to
+ * more (8 * launches >= 5 * members; at 1440 states: from 129 tiles = 2 064 items), or for every other unit a tile where
+ * the split form does not cover the band.
  *
  * torbi_hip_viterbi_decode_banded: torbi_hip_viterbi_decode_batches for a matrix whose band the caller states -- a
  * PROMISE, verified on the device (ABI 15): an entry outside the band that is not -inf is noticed by the launch that looks
