@@ -13,7 +13,6 @@ indices as the reference's Python" (tests/golden/golden_api.npz), not oracle equ
 The entropy is evaluated with the reference's own expression on the host (torch CPU ops, same operand layout), so
 frames that sit near the threshold fall on the same side as upstream.
 """
-import math
 from typing import List, Optional
 
 import torch

@@ -12,7 +12,7 @@ import torch
 
 from . import data as _data
 from . import timer
-from .viterbi import decode, decode_uniform, epsilon_clamp_, log_epsilon_clamp, uniform_supported, _version_of
+from .viterbi import decode, decode_uniform, epsilon_clamp_, log_epsilon_clamp, uniform_supported
 
 # reference torbi/config/defaults.py:80,83
 BATCH_SIZE = 512

@@ -20,7 +20,6 @@ import ctypes
 import io
 import os
 import pickle
-import queue
 import struct
 import threading
 import zipfile

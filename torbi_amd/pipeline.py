@@ -15,7 +15,7 @@ independent, which buys two things here:
 valid once `wait(indices)` / `synchronize()` returns (or on the stream the pipeline used, for callers that
 chain more GPU work).
 """
-from typing import Callable, List, Optional, Tuple
+from typing import Callable, List, Optional
 
 import torch
 
