@@ -1798,6 +1798,49 @@ def test_auto_leaves_the_time_resident_kernel_when_nothing_is_pruned():
         assert routes[0] == 3 and routes[-1] == later, (name, routes)
 
 
+@pytest.mark.parametrize('case', [(1, 40, 1440, None), (9, 30, 360, None), (300, 25, 64, None), (300, 20, 200, None),
+                                  (70, 24, 1440, None), (520, 12, 1440, None), (140, 15, 2052, None), (300, 16, 1440, (87, 87)),
+                                  (2080, 8, 1440, (87, 87))])
+def test_decode_captures_into_a_hip_graph_and_replays_on_new_observations(case):
+    """A decode with a caller-owned workspace is a fixed sequence of launches on the caller's stream: torch.cuda.graph captures
+    it on every route (one sequence, a handful, small state counts, clusters, whole tiles, both band forms -- the in-launch
+    exchanges start from memset nodes), and a replay on NEW observations in the captured buffers decodes those: equal to the
+    oracle.  (Eager calls first: the one look at the matrix that synchronises is not taken while capturing, nor are the
+    routing statistics read or written.)"""
+    B, T, S, band = case
+    obs, trans, init = synth.problem(B, T, S, seed=B + S)
+    if band is not None:
+        trans = _banded(S, *band, seed=3)
+    obs2 = synth.problem(B, T, S, seed=B + S + 1)[0]
+    frames = synth.lengths(B, 1, T)
+    frames[0] = T
+    dev = torch.device('cuda:0')
+    tobs, tframes, ttrans, tinit = (torch.as_tensor(np.ascontiguousarray(x)).to(dev) for x in (obs, frames.astype(np.int32), trans, init))
+    ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
+    for _ in range(2):
+        eager = torbi_amd.decode(tobs, tframes, ttrans, tinit, workspace=ws).clone()
+    def reference(o):               # the oracle; the largest shapes against the per-timestep dense route (itself oracle-tested)
+        if B * T * S * S < 6e9:
+            return oracle.decode(o, frames, trans, init)
+        return torbi_amd.decode(torch.as_tensor(o).to(dev), tframes, ttrans, tinit, path='dense').cpu().numpy()
+    want = reference(obs)
+    np.testing.assert_array_equal(eager.cpu().numpy(), want)
+    side = torch.cuda.Stream(device=dev)
+    graph = torch.cuda.CUDAGraph()
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            out = torbi_amd.decode(tobs, tframes, ttrans, tinit, workspace=ws)
+    graph.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+    tobs.copy_(torch.as_tensor(obs2))
+    graph.replay()
+    graph.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), reference(obs2))
+
+
 # ---- the band kernel (csrc/band_forward.hpp): banded transition matrices, the time loop inside one launch ----------------
 
 def _banded(S, left, right, seed=0):

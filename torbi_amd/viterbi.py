@@ -129,6 +129,12 @@ DENSE_PROBE_AT_MOST = 48        # (flat data for good: one call in 48 pays for t
 _depth_lock = threading.Lock()  # host threads that share one transition tensor share its record
 
 
+def _capturing() -> bool:
+    """The current stream is being captured into a HIP graph (torch.cuda.graph): nothing that waits for or asks about
+    the device may run."""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 def _depth_record(transition: torch.Tensor, states: int):
     """[scan depth of time-resident launches with this matrix in list blocks per wave pass, on the scale of a three-seed
     launch (None until known), pending sample (pinned stats, event, seeds per item of that launch) or None, calls between
@@ -148,7 +154,9 @@ def _known_depth(transition: torch.Tensor, states: int):
         return None
     with _depth_lock:
         pending = known[1]
-        if pending is not None and pending[1].query():
+        # (no event query while the stream is being captured into a HIP graph: it would invalidate the capture; the
+        # graph then replays the route that what is known so far chooses)
+        if pending is not None and not _capturing() and pending[1].query():
             stats, _, seeds = pending
             if int(stats[64:120].sum()) > 0:
                 sample = critical_blocks(stats) / (ONE_SEED_DEPTH if seeds == 1 else 1.0)
@@ -212,7 +220,7 @@ def _watch_resident(transition, workspace, batch, frames, states, seeds=3) -> No
     host memory (asynchronously; folded in by a later call, never waited for) -- unless the previous sample is still on its
     way.  `seeds`: what the launch kept per item."""
     known = _depth_record(transition, states)
-    if known is None:
+    if known is None or _capturing():       # (a sample copied by a graph's replays would never be looked at: its event is a node)
         return
     with _depth_lock:
         if known[1] is not None:
