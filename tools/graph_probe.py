@@ -23,7 +23,9 @@ def run(B, T, S, band=False):
     ws = torch.empty(viterbi.workspace_bytes(B, T, S), dtype=torch.uint8, device=dev)
     for _ in range(3):                       # eager first: routing decided, preparation done, the look at the matrix taken
         want = torbi_amd.decode(obs, frames, trans, init, workspace=ws)
-    want_other = torbi_amd.decode(other, frames, trans, init, workspace=ws).clone()
+    prof = []
+    want_other = torbi_amd.decode(other, frames, trans, init, workspace=ws, _profile=prof).clone()
+    route = viterbi.ROUTES[int(prof[3])]
     want = want.clone()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -55,7 +57,7 @@ def run(B, T, S, band=False):
         graph.replay()
     torch.cuda.synchronize()
     replay = (time.perf_counter() - t0) / 20
-    print(f'{B} x {T} x {S}{" band" if band else ""}: route {viterbi.forward_path(B, S)}; eager {eager * 1e3:.3f} ms, replay {replay * 1e3:.3f} ms; '
+    print(f'{B} x {T} x {S}{" band" if band else ""}: route {route}; eager {eager * 1e3:.3f} ms, replay {replay * 1e3:.3f} ms; '
           f'replay == eager: {same}, on new observations: {same_other}', flush=True)
 
 
