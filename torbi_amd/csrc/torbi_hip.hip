@@ -449,8 +449,16 @@ std::mutex g_marks_mutex;
 std::vector<StreamMark> g_marks[kMaxDevices];
 constexpr size_t kMaxMarks = 64;
 
+// `s` is being captured into a HIP graph: nothing may be asked of an event (hipEventQuery invalidates a capture), and an
+// event recorded now becomes a node of the graph that no later query may name
+inline bool capturing(hipStream_t s) {
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &status) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return status != hipStreamCaptureStatusNone;
+}
+
 inline void mark_decode_end(int device, hipStream_t s) {
-    if (device < 0 || device >= kMaxDevices) return;
+    if (device < 0 || device >= kMaxDevices || capturing(s)) return;
     std::lock_guard<std::mutex> hold(g_marks_mutex);
     auto &marks = g_marks[device];
     StreamMark *slot = nullptr;
@@ -472,7 +480,9 @@ inline void mark_decode_end(int device, hipStream_t s) {
 }
 
 inline bool other_streams_busy(int device, hipStream_t s) {
-    if (device < 0 || device >= kMaxDevices) return false;
+    // (while capturing: what the replays will run beside is unknown anyway; the held kernel's bounded waits and its
+    // repair launch cover a busy device)
+    if (device < 0 || device >= kMaxDevices || capturing(s)) return false;
     std::lock_guard<std::mutex> hold(g_marks_mutex);
     for (auto &m : g_marks[device])
         if (m.stream != s) {
