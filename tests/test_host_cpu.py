@@ -731,6 +731,18 @@ def test_ring_of_staging_chunks_reads_a_batch_in_pieces(tmp_path):
     assert asked == [(0, 3), (3, 3), (6, 1)] and frames.tolist() == lengths and observation.shape == (7, 9, 12)
     for k, n in enumerate(lengths):
         assert torch.equal(observation[k, :n], torch.load(files[k])) and not observation[k, n:].any()
+    # a file that shrinks between the header look and its piece's read: the short read names THAT file
+    shrunk = fastio.open_batches(files, 7, pin_memory=True, gpu=False)
+
+    def shrink_then_read(shape, batch_frames, fill):
+        piece = torch.empty((3, shape[1], shape[2]))
+        fill(piece.data_ptr(), 0, 3)
+        with open(files[4], 'r+b') as handle:
+            handle.truncate(fastio.payload(files[4])[2] + 4 * 12 * 2)          # two of its nine frames left
+        fill(piece.data_ptr(), 3, 3)
+    shrunk.stage_rows = shrink_then_read
+    with pytest.raises(OSError, match='4.pt'):
+        list(shrunk)
     pool = slabs.SlabPool(None)
     chunk = pool.take(1 << 16, limit=2, exact=True)
     assert chunk.numel() == 1 << 16
