@@ -382,7 +382,8 @@ int torbi_hip_epsilon_clamp(float *x, uint64_t count, int device, void *stream);
 /*
  * The same for PROBABILITY inputs: out <- log(exp(log(p)) + FLT_MIN), i.e. upstream's torch.log(observation)
  * (torbi/core.py:189-191, out of place) and the clamp behind it in one pass instead of four.  `probabilities`
- * is not written; both pointers 16-byte aligned.
+ * is not written unless `out` == `probabilities` (in place: the many-file driver's own copies of its files); both
+ * pointers 16-byte aligned.
  */
 int torbi_hip_log_epsilon_clamp(const float *probabilities, float *out, uint64_t count, int device, void *stream);
 

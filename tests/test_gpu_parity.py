@@ -1557,6 +1557,47 @@ def test_many_file_job_every_file_equals_the_oracle(tmp_path, monkeypatch):
             assert torch.equal(torch.load(a), torch.load(b)), (chunk_bytes, chunks)
 
 
+def test_many_file_job_on_probability_files(tmp_path, monkeypatch):
+    """The reference's DEFAULT call -- files of probabilities, log_probs=False (core.py:310-318) -- takes the same staged
+    route as log-probability files: rows through the ring of pinned chunks into a pooled device slab, log() and the epsilon
+    round trip (core.py:189-197) as ONE pass in place there.  Every output equals the reference loader's (torch.load +
+    collate + from_probabilities' own log / clamp) and whole-batch staging's; every 9th file equals the oracle's decode of that
+    file alone; the default uniform model (no transition file) likewise."""
+    import math
+    S, count = 256, 700
+    lengths = synth.lengths(count, 20, 120, seed=11).tolist()
+    gen = torch.Generator().manual_seed(11)
+    block = torch.rand(300, S, generator=gen).mul_(6.0).softmax(-1)
+    block[:, 5] = 0.0                                       # (probability zero: log -> -inf -> log(tiny) behind the round trip)
+    ins = []
+    for k, n in enumerate(lengths):
+        ins.append(tmp_path / f'in{k}.pt')
+        torch.save(block[(13 * k) % 150:(13 * k) % 150 + n].roll(k, dims=1).clone(), ins[-1])
+    tf = tmp_path / 'transition.pt'
+    trans = torch.rand(S, S, generator=gen).mul_(4.0).softmax(-1)
+    trans[trans < 0.001] = 0.0                              # (-inf entries for the operator)
+    torch.save(trans, tf)
+    tiny = torch.finfo(torch.float32).tiny
+    init = np.full((S,), math.log(1. / S + tiny), dtype=np.float32)
+    for model in (dict(transition_file=tf), dict()):
+        outs = [tmp_path / f'out{k}.pt' for k in range(count)]
+        torbi_amd.from_files_to_files(ins, outs, log_probs=False, gpu=0, **model)
+        want = [torch.load(f) for f in outs]
+        log_trans = torch.log(trans).numpy() if model else np.full((S, S), np.float32(math.log(1. / S)), dtype=np.float32)
+        for k in range(0, count, 9):
+            x = torch.log(torch.load(ins[k]).to('cuda:0'))
+            x = torch.log(torch.exp(x) + tiny).cpu().numpy()[None]
+            assert np.array_equal(want[k].numpy(), oracle.decode(x, [lengths[k]], log_trans, init)[0]), (bool(model), k)
+        with monkeypatch.context() as patch:
+            patch.setattr(torbi_amd.core, 'RING_CHUNKS', 0)
+            torbi_amd.from_files_to_files(ins, outs, log_probs=False, gpu=0, lengths=lengths, **model)
+            assert all(torch.equal(torch.load(f), w) for f, w in zip(outs, want)), bool(model)
+        with monkeypatch.context() as patch:
+            patch.setattr(torbi_amd.core, 'DIRECT_FILE_IO', False)
+            torbi_amd.from_files_to_files(ins, outs, log_probs=False, gpu=0, **model)
+            assert all(torch.equal(torch.load(f), w) for f, w in zip(outs, want)), bool(model)
+
+
 @pytest.mark.parametrize('count', [600, pytest.param(2100, marks=pytest.mark.slow)])
 def test_many_file_job_through_the_reference_loader(tmp_path, monkeypatch, count):
     """The same ragged job with the reference's host path (torch.load + collate in a DataLoader, saves on the calling

@@ -14,7 +14,8 @@ lengths = synth.lengths(files, 100, 900).tolist()
 folder = tempfile.mkdtemp(prefix='torbi_job_', dir='/dev/shm')
 try:
     gen = torch.Generator().manual_seed(1)
-    block = torch.rand(900, S, generator=gen).log_softmax(-1)
+    probs = bool(os.environ.get('PROBS'))              # files of probabilities, log_probs=False: the reference's default call
+    block = torch.rand(900, S, generator=gen).softmax(-1) if probs else torch.rand(900, S, generator=gen).log_softmax(-1)
     ins, outs = [], []
     for k, n in enumerate(lengths):
         f = os.path.join(folder, f'in{k}.pt'); torch.save(torch.roll(block, k, dims=0)[:n].clone(), f)
@@ -39,7 +40,7 @@ try:
         prof = cProfile.Profile()
         t0 = time.perf_counter()
         prof.enable()
-        torbi_amd.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, lengths=lengths, gpu=0, num_workers=threads)
+        torbi_amd.from_files_to_files(ins, outs, transition_file=tf, log_probs=not probs, lengths=lengths, gpu=0, num_workers=threads)
         torch.cuda.synchronize()
         prof.disable()
         dt = time.perf_counter() - t0

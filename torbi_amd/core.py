@@ -37,6 +37,9 @@ KEEP_JOB_MEMORY = os.environ.get('TORBI_KEEP_JOB_MEMORY', '0') != '0'
 # The file batches of a GPU job cross the host link through a ring of RING_CHUNKS pinned chunks of RING_CHUNK_BYTES (powers
 # of two: the pinned allocator rounds up to one), not through whole-batch pinned slabs; 0 chunks = whole-batch slabs.
 RING_CHUNKS = int(os.environ.get('TORBI_RING_CHUNKS', '4'))
+# probability files (log_probs=False, the reference's default) take the staged route too: log() + epsilon round trip as one
+# pass in place in the device slab; False = pinned batch -> from_probabilities' own device move, log and clamp (rounds 2-5)
+STAGE_PROBABILITIES = os.environ.get('TORBI_STAGE_PROBABILITIES', '1') != '0'
 RING_CHUNK_BYTES = int(os.environ.get('TORBI_RING_CHUNK_MB', '256')) << 20
 
 
@@ -106,7 +109,8 @@ def from_probabilities(
     gpu: Optional[int] = None,
     num_threads: Optional[int] = 1,
     _pipeline=None,
-    _model: Optional[dict] = None
+    _model: Optional[dict] = None,
+    _prepared: bool = False
 ) -> torch.Tensor:
     """Viterbi-decode a batch of per-frame state distributions on HIP device `gpu` (or on the CPU: `gpu=None`).
 
@@ -175,8 +179,10 @@ def from_probabilities(
 
     # Ensure observation probabilities are in log space (core.py:189-191).  Probabilities that already live on the
     # compute device go through log() and the epsilon round trip below in one pass (same values, tested bitwise)
-    clamped = None
-    if not log_probs:
+    # (`_prepared`, the many-file driver: the batch is on the device, float32, and has been through both steps already --
+    # in place in its staging slab, _Staging.decode)
+    clamped = observation if _prepared else None
+    if not log_probs and not _prepared:
         if observation.device == device:
             clamped = log_epsilon_clamp(observation)
         if clamped is None:
@@ -351,7 +357,7 @@ def from_dataloader(
     if gpu is not None and torch.cuda.is_available():
         pipe, give_back = _job_pipeline(torch.device('cuda', gpu))
         stage = _Staging(torch.device('cuda', gpu))
-        if log_probs and hasattr(dataloader, 'stage') and getattr(dataloader, 'pin_memory', False):
+        if (log_probs or STAGE_PROBABILITIES) and hasattr(dataloader, 'stage') and getattr(dataloader, 'pin_memory', False):
             dataloader.stage = stage.upload           # (fastio.FileBatches: copies start in the assembling threads)
             if RING_CHUNKS > 0 and hasattr(dataloader, 'stage_rows'):
                 dataloader.stage_rows = stage.upload_rows        # ... chunk by chunk through a small pinned ring
@@ -388,10 +394,11 @@ def from_dataloader(
     starved = getattr(dataloader, 'more_ready', None)
     try:
         for observation, batch_frames, batch_chunks, input_filenames in dataloader:
-            if stage is not None and stage.takes(observation, log_probs):
-                # log-probabilities in pinned memory: copy on the copy stream into a pooled device slab, epsilon round
-                # trip (core.py:193-197) on the preparation stream, decode on the pipeline's streams
-                indices = stage.decode(observation, batch_frames, transition, initial, gpu, num_threads, pipe, model)
+            if stage is not None and (log_probs or STAGE_PROBABILITIES) and stage.takes(observation):
+                # a float32 batch in pinned memory (or already on its way): copy on the copy stream into a pooled device
+                # slab, log() unless `log_probs` + epsilon round trip (core.py:189-197) on the preparation stream, decode
+                # on the pipeline's streams
+                indices = stage.decode(observation, batch_frames, transition, initial, gpu, num_threads, pipe, model, log_probs)
             else:
                 indices = from_probabilities(
                     observation=observation,
@@ -474,10 +481,10 @@ class _Staging:
         self.copy, self.prep = streams
 
     @staticmethod
-    def takes(observation, log_probs) -> bool:
-        return log_probs and (hasattr(observation, 'torbi_copied') or (
+    def takes(observation) -> bool:
+        return hasattr(observation, 'torbi_copied') or (
             observation.device.type == 'cpu' and observation.dtype == torch.float32 and observation.is_contiguous()
-            and observation.is_pinned()))
+            and observation.is_pinned())
 
     def upload(self, observation, batch_frames):
         """Start the host-to-device copy of a pinned batch (any thread: the reader's assembling threads call this as soon
@@ -529,16 +536,27 @@ class _Staging:
         staged.torbi_keep = (lengths,)
         return staged
 
-    def decode(self, observation, batch_frames, transition, initial, gpu, num_threads, pipe, model):
+    def decode(self, observation, batch_frames, transition, initial, gpu, num_threads, pipe, model, log_probs=True):
         staged = observation if hasattr(observation, 'torbi_copied') else self.upload(observation, batch_frames)
         slab, copied = staged.torbi_device_slab, staged.torbi_copied
         self.prep.wait_event(copied)
         with torch.cuda.stream(self.prep):
-            # (from_probabilities: already on the device, float32, log_probs -> epsilon round trip in place, then the
-            # pipeline, whose side stream waits for the readiness event recorded on the stream that is current here)
+            # (from_probabilities: already on the device, float32; log-probabilities -> epsilon round trip in place;
+            # probabilities -> log() and the round trip as ONE pass, in place in the slab -- the batch is this job's own
+            # copy of the files -- instead of a fresh 1.5-2.7 GB tensor per batch; then the pipeline, whose side stream
+            # waits for the readiness event recorded on the stream that is current here.  Probabilities with the default
+            # uniform model go as they are: from_probabilities decodes them in one pass, log() included.)
+            prepared = False
+            if not log_probs and transition is not None and staged.data_ptr() % 16 == 0:
+                from . import _lib
+                import ctypes
+                _lib.check(_lib.load().torbi_hip_log_epsilon_clamp(
+                    staged.data_ptr(), staged.data_ptr(), staged.numel(), self.device.index or 0,
+                    ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), 'torbi_hip_log_epsilon_clamp')
+                prepared = True
             indices = from_probabilities(observation=staged, batch_frames=staged.torbi_lengths, transition=transition,
-                                         initial=initial, log_probs=True, gpu=gpu, num_threads=num_threads,
-                                         _pipeline=pipe, _model=model)
+                                         initial=initial, log_probs=log_probs, gpu=gpu, num_threads=num_threads,
+                                         _pipeline=pipe, _model=model, _prepared=prepared)
         if pipe is not None and model.get('uniform') is None:
             pipe.when_done(indices, lambda event, slab=slab: self.pool.give(slab, event))
         else:

@@ -351,9 +351,9 @@ __global__ __launch_bounds__(256) void epsilon_clamp_kernel(float *__restrict__ 
 }
 
 // y = log(exp(log(p)) + tiny): the log() of probability inputs (torbi/core.py:189-191) and the epsilon clamp behind it
-// (core.py:193-197) in one pass, out of place like upstream's torch.log
-__global__ __launch_bounds__(256) void log_epsilon_clamp_kernel(const float *__restrict__ p, float *__restrict__ y,
-                                                                uint64_t count) {
+// (core.py:193-197) in one pass, out of place like upstream's torch.log -- or in place (y == p: every element is read and
+// written by one thread; the many-file driver's staged batches)
+__global__ __launch_bounds__(256) void log_epsilon_clamp_kernel(const float *p, float *y, uint64_t count) {
     const float tiny = 1.17549435e-38f;
     const uint64_t n4 = count / 4;
     const float4 *p4 = reinterpret_cast<const float4 *>(p);
