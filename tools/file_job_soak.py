@@ -17,7 +17,8 @@ folder = tempfile.mkdtemp(prefix='torbi_soak_', dir='/dev/shm')
 rng = random.Random(5)
 try:
     gen = torch.Generator().manual_seed(1)
-    block = torch.rand(300, S, generator=gen).log_softmax(-1)
+    probs = bool(os.environ.get('PROBS'))          # files of probabilities, log_probs=False (the reference's default call)
+    block = torch.rand(300, S, generator=gen).softmax(-1) if probs else torch.rand(300, S, generator=gen).log_softmax(-1)
     ins = []
     for k, n in enumerate(lengths):
         f = os.path.join(folder, f'in{k}.pt')
@@ -27,13 +28,13 @@ try:
     torch.save(torch.rand(S, S, generator=gen).mul_(4.0).softmax(-1), tf)
     first = [os.path.join(folder, f'first{k}.pt') for k in range(files)]
     core.RING_CHUNKS = 0
-    torbi_amd.from_files_to_files(ins, first, transition_file=tf, log_probs=True, gpu=0)
+    torbi_amd.from_files_to_files(ins, first, transition_file=tf, log_probs=not probs, gpu=0)
     want = [torch.load(f) for f in first]
     # the first run against single decodes of some files on the dense route
-    trans = torch.log(torch.load(tf) + torch.finfo(torch.float32).tiny).cuda()
+    trans = (torch.log(torch.load(tf)) if probs else torch.log(torch.load(tf) + torch.finfo(torch.float32).tiny)).cuda()
     init = torch.full((S,), float(torch.log(torch.tensor(1.0 / S) + torch.finfo(torch.float32).tiny))).cuda()
     for k in range(0, files, 97):
-        x = torch.load(ins[k]).cuda()
+        x = torch.log(torch.load(ins[k]).cuda()) if probs else torch.load(ins[k]).cuda()
         x = torch.log(torch.exp(x) + torch.finfo(torch.float32).tiny)[None]
         got = torbi_amd.decode(x, torch.tensor([lengths[k]], dtype=torch.int32, device='cuda'), trans, init, path='dense')[0].cpu()
         assert torch.equal(got[:lengths[k]], want[k]), k
@@ -44,7 +45,7 @@ try:
         core.BATCH_SIZE = rng.choice([512, 512, 200, 64])
         core.KEEP_JOB_MEMORY = rng.random() < 0.5
         outs = [os.path.join(folder, f'out{k}.pt') for k in range(files)]
-        torbi_amd.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, gpu=0, num_workers=rng.choice([2, 8, 16, 32]),
+        torbi_amd.from_files_to_files(ins, outs, transition_file=tf, log_probs=not probs, gpu=0, num_workers=rng.choice([2, 8, 16, 32]),
                                       lengths=lengths if rng.random() < 0.5 else None)
         for k, f in enumerate(outs):
             if not torch.equal(torch.load(f), want[k]):
