@@ -1497,6 +1497,38 @@ def test_from_probabilities_equals_the_reference_outputs():
     np.testing.assert_array_equal(got.cpu().numpy(), API['probs/indices_log'])
 
 
+def test_a_large_host_batch_of_probabilities_is_logged_like_upstream(monkeypatch):
+    """core.py:189-191: upstream takes log() of the observation where it lives, BEFORE the device move -- a host batch is
+    logged by the host.  Large float32 host batches take that log into a pooled pinned buffer (core._host_log): the same
+    torch kernel, so the decode equals the one of `torch.log(x)` handed over as log-probabilities; the caller's tensor is
+    left alone; the buffer goes back to the pool and is reused by the next call; a small batch and a float64 batch go the
+    plain way and give the same indices."""
+    from torbi_amd import core, slabs
+    monkeypatch.setattr(core, 'HOST_LOG_POOL_BYTES', 1 << 16)
+    B, T, S = 24, 30, 360
+    gen = torch.Generator().manual_seed(5)
+    probs = torch.rand(B, T, S, generator=gen).mul_(5.0).softmax(-1)
+    probs[:, :, 7] = 0.0
+    trans = torch.rand(S, S, generator=gen).mul_(4.0).softmax(-1)
+    frames = torch.as_tensor(synth.lengths(B, 1, T).astype(np.int32))
+    keep = probs.clone()
+    want = torbi_amd.from_probabilities(torch.log(probs), frames, torch.log(trans), log_probs=True, gpu=0).cpu()
+    held = slabs.pool(None).held_bytes()
+    got = torbi_amd.from_probabilities(probs, frames, trans, gpu=0).cpu()
+    assert torch.equal(got, want) and torch.equal(probs, keep)
+    torch.cuda.synchronize()
+    grown = slabs.pool(None).held_bytes()
+    assert grown >= held + probs.numel() * 4 or held >= probs.numel() * 4          # the pooled buffer came back
+    again = torbi_amd.from_probabilities(probs, frames, trans, gpu=0).cpu()
+    torch.cuda.synchronize()
+    assert torch.equal(again, want) and slabs.pool(None).held_bytes() == grown    # ... and was used again
+    monkeypatch.setattr(core, 'HOST_LOG_POOL_BYTES', 1 << 40)
+    assert torch.equal(torbi_amd.from_probabilities(probs, frames, trans, gpu=0).cpu(), want)
+    assert torch.equal(torbi_amd.from_probabilities(probs[:, ::2], frames.clamp(max=15), trans, gpu=0).cpu(),
+                       torbi_amd.from_probabilities(torch.log(probs[:, ::2]), frames.clamp(max=15), torch.log(trans),
+                                                    log_probs=True, gpu=0).cpu())
+
+
 # ---- BASELINE configs[3] scaled down: a ragged many-file job through from_files_to_files ---------------------
 
 def _ragged_job(tmp_path, count, S, seed, shortest=100, longest=900):
