@@ -861,6 +861,11 @@ class Bench:
         try:
             # configs[3] from files to files (4 096 sequences: torch.save()d inputs in /dev/shm -> one output file each)
             out['c4_files_end_to_end'] = self.c4_end_to_end(4096)
+            # the reference's DEFAULT call: files of probabilities, log_probs=False -- staged like the others, log() and the
+            # epsilon round trip as one pass in place in the device slab (a smaller job: the files are written once more)
+            record = self.c4_end_to_end(1024, probabilities=True)
+            out['c4_files_of_probabilities'] = {k: record[k] for k in ('value', 'unit', 'seconds', 'first_call_seconds', 'sequences',
+                                                                        'files_hold', 'gb_per_s_from_files')}
         except (OSError, RuntimeError) as exc:
             out['c4_files_end_to_end'] = {'value': None, 'note': f'not measured: {exc}'}
         return out
@@ -968,8 +973,9 @@ class Bench:
         del pool, batches
         return record
 
-    def c4_end_to_end(self, files):
-        """torch.save()d inputs -> from_files_to_files -> torch.save()d outputs on this rank's share."""
+    def c4_end_to_end(self, files, probabilities=False):
+        """torch.save()d inputs -> from_files_to_files -> torch.save()d outputs on this rank's share.  `probabilities`: the
+        files hold probabilities and the call is the reference's default (log_probs=False, torbi/core.py:310-318)."""
         import shutil
         import tempfile
         torch, synth = self.torch, self.synth
@@ -980,7 +986,8 @@ class Bench:
         try:
             ins, outs = [], []
             gen = torch.Generator().manual_seed(1)
-            block = torch.rand(900, S, generator=gen).log_softmax(-1)
+            block = torch.rand(900, S, generator=gen)
+            block = block.softmax(-1) if probabilities else block.log_softmax(-1)
             for k, n in enumerate(lengths):
                 f = os.path.join(folder, f'in{k}.pt')
                 if self.rank == 0:
@@ -1009,8 +1016,8 @@ class Bench:
             for _ in range(2):      # first call: pinned host blocks, device scratch and code objects are new
                 self.fence()
                 t0 = time.perf_counter()
-                self.distributed.from_files_to_files(ins, outs, transition_file=tf, log_probs=True, lengths=lengths,
-                                                     num_workers=workers)
+                self.distributed.from_files_to_files(ins, outs, transition_file=tf, log_probs=not probabilities,
+                                                     lengths=lengths, num_workers=workers)
                 self.fence()
                 seconds.append(self.max_over_ranks(time.perf_counter() - t0))
             elapsed = seconds[-1]
@@ -1021,7 +1028,7 @@ class Bench:
             return {'value': sum(lengths) / elapsed, 'unit': 'timesteps/s', 'seconds': elapsed,
                     'first_call_seconds': seconds[0], 'first_call_over_steady': seconds[0] / elapsed,
                     'inputs_read_once_by_another_process_before_timing': preread, 'sequences': files,
-                    'outputs_written': ok,
+                    'outputs_written': ok, 'files_hold': 'probabilities (log_probs=False)' if probabilities else 'log-probabilities',
                     'reader_threads': workers,
                     'host_path': 'direct reader (payloads pread into pinned batch rows by native threads, outputs from '
                                  'a prebuilt container image)' if direct else 'torch.load + collate in DataLoader workers, torch.save',
