@@ -112,7 +112,7 @@ def _host_log(observation: torch.Tensor) -> torch.Tensor:
     behind it -- 512 x 500 x 1440: 398 -> ~65 ms per call."""
     nbytes = observation.numel() * 4
     if (observation.device.type != 'cpu' or observation.dtype != torch.float32 or nbytes < HOST_LOG_POOL_BYTES
-            or not torch.cuda.is_available()):
+            or observation.requires_grad or not torch.cuda.is_available()):          # (`out=` is not for tensors in a graph)
         return torch.log(observation)
     from . import slabs
     slab = slabs.pool(None).take(nbytes, limit=2)
